@@ -1,0 +1,159 @@
+// G1 point arithmetic for the MSM kernels, over fp28::Fe.
+// XYZZ coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2) exactly as the reference's
+// bucket type P1XYZZ (kzg/src/msm/pippenger_utils.rs:5-12); the formulas are EFD
+// madd-2008-s / add-2008-s / dbl-2008-s-1, the same ones p1_dadd_affine / p1_dadd
+// restate (pippenger_utils.rs:90-210), with the same exceptional cases
+// (infinity, P == Q -> double, P == -Q -> infinity).
+//
+// Value bounds carried between calls (see fp28.cuh): X < 10p, Y < 6p, ZZ, ZZZ < 2p.
+#pragma once
+#include "fp28.cuh"
+
+namespace g1 {
+using fp28::Fe;
+
+struct Xyzz {
+    Fe x, y, zzz, zz;
+};
+
+// table / input point, 128-byte slot: x, y in fp28 form (Montgomery 2^392, canonical value),
+// flags bit0 = point at infinity
+struct alignas(16) AffPt {
+    Fe x, y;
+    ff::u32 flags, pad[3];
+};
+static_assert(sizeof(AffPt) == 128, "AffPt slot");
+static_assert(sizeof(Xyzz) == 224, "Xyzz size");
+
+FF_HD void set_inf(Xyzz& p) {
+    p.x = fp28::zero();
+    p.y = fp28::zero();
+    p.zzz = fp28::zero();
+    p.zz = fp28::zero();
+}
+FF_HD bool is_inf(const Xyzz& p) { return fp28::is_zero_limbs(p.zz); }
+
+FF_HD void set_affine(Xyzz& p, const Fe& x, const Fe& y) {
+    p.x = x;
+    p.y = y;
+    p.zzz = fp28::one();
+    p.zz = fp28::one();
+}
+
+// 2 * (x2, y2)  (mdbl-2008-s-1)
+FF_HD void dbl_affine(Xyzz& out, const Fe& x2, const Fe& y2) {
+    using namespace fp28;
+    Fe u = addn(y2, y2);
+    Fe zz = sqr(u);
+    Fe zzz = mul(zz, u);
+    Fe s = mul(x2, zz);
+    Fe m = sqr(x2);
+    Fe m3 = addn(add(m, m), m);
+    Fe x3 = sub<8>(sqr(m3), addn(s, s));
+    Fe y3 = sub<4>(mul(m3, sub<16>(s, x3)), mul(zzz, y2));
+    out.x = x3;
+    out.y = y3;
+    out.zz = zz;
+    out.zzz = zzz;
+}
+
+// acc = 2 * acc (dbl-2008-s-1); acc != infinity
+FF_HD void dbl(Xyzz& acc) {
+    using namespace fp28;
+    Fe u = addn(acc.y, acc.y);
+    Fe v = sqr(u);
+    Fe w = mul(v, u);
+    Fe s = mul(acc.x, v);
+    Fe m = sqr(acc.x);
+    Fe m3 = addn(add(m, m), m);
+    Fe x3 = sub<8>(sqr(m3), addn(s, s));
+    Fe y3 = sub<4>(mul(m3, sub<16>(s, x3)), mul(w, acc.y));
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = mul(acc.zz, v);
+    acc.zzz = mul(acc.zzz, w);
+}
+
+// acc += (x2, y2), affine point not at infinity; y2 already carries the sign
+// (the caller passes 2p - y for a subtraction).  madd-2008-s.
+FF_HD void madd(Xyzz& acc, const Fe& x2, const Fe& y2) {
+    using namespace fp28;
+    if (is_inf(acc)) {
+        set_affine(acc, x2, y2);
+        return;
+    }
+    Fe p = sub<16>(mul(x2, acc.zz), acc.x);
+    Fe r = sub<16>(mul(y2, acc.zzz), acc.y);
+    if (is_zero_mod_p(p)) {
+        if (is_zero_mod_p(r)) dbl_affine(acc, x2, y2);
+        else set_inf(acc);
+        return;
+    }
+    Fe pp = sqr(p);
+    Fe ppp = mul(p, pp);
+    Fe q = mul(acc.x, pp);
+    Fe x3 = sub<8>(sqr(r), addn(add(q, q), ppp));
+    Fe y3 = sub<4>(mul(r, sub<16>(q, x3)), mul(acc.y, ppp));
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = mul(acc.zz, pp);
+    acc.zzz = mul(acc.zzz, ppp);
+}
+
+// acc += b   (add-2008-s)
+FF_HD void dadd(Xyzz& acc, const Xyzz& b) {
+    using namespace fp28;
+    if (is_inf(b)) return;
+    if (is_inf(acc)) {
+        acc = b;
+        return;
+    }
+    Fe u = mul(acc.x, b.zz);
+    Fe s = mul(acc.y, b.zzz);
+    Fe p = sub<4>(mul(b.x, acc.zz), u);
+    Fe r = sub<4>(mul(b.y, acc.zzz), s);
+    if (is_zero_mod_p(p)) {
+        if (is_zero_mod_p(r)) dbl(acc);
+        else set_inf(acc);
+        return;
+    }
+    Fe pp = sqr(p);
+    Fe ppp = mul(p, pp);
+    Fe q = mul(u, pp);
+    Fe x3 = sub<8>(sqr(r), addn(add(q, q), ppp));
+    Fe y3 = sub<4>(mul(r, sub<16>(q, x3)), mul(s, ppp));
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = mul(mul(acc.zz, b.zz), pp);
+    acc.zzz = mul(mul(acc.zzz, b.zzz), ppp);
+}
+
+// acc = k * acc for a small public integer k (double-and-add, MSB first)
+FF_HD void mul_small(Xyzz& acc, ff::u32 k) {
+    if (k == 0 || is_inf(acc)) {
+        set_inf(acc);
+        return;
+    }
+    Xyzz base = acc;
+    int top = 31;
+    while (!((k >> top) & 1)) --top;
+    for (int b = top - 1; b >= 0; --b) {
+        if (!is_inf(acc)) dbl(acc);
+        if ((k >> b) & 1) dadd(acc, base);
+    }
+}
+
+// Jacobian (X*ZZ, Y*ZZZ, ZZ) in blst layout (pippenger_utils.rs:84-88); infinity -> all-zero
+FF_HD void to_blst_jacobian(ff::Fp out[3], const Xyzz& p) {
+    if (is_inf(p)) {
+        out[0] = ff::Fp::zero();
+        out[1] = ff::Fp::zero();
+        out[2] = ff::Fp::zero();
+        return;
+    }
+    out[0] = fp28::to_blst(fp28::mul(p.x, p.zz));
+    out[1] = fp28::to_blst(fp28::mul(p.y, p.zzz));
+    out[2] = fp28::to_blst(p.zz);
+}
+
+}  // namespace g1

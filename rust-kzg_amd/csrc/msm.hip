@@ -1,0 +1,591 @@
+// MI355X-native Pippenger MSM over BLS12-381 G1 — kernels + host driver behind the
+// sppark-compatible boundary (include/kzg_mi355x.h, B1).
+//
+// Shape of the computation (one "set" = one bucket array):
+//   prepared handle : fixed-base table rows  T[j][i] = 2^(c*j) * P_i  (built once in prepare_msm,
+//                     the reference's BGMW idea, kzg/src/msm/bgmw.rs:206-227) so that all
+//                     ceil(255/c) signed windows of a scalar share ONE bucket set and the result
+//                     needs no doublings.  nsets = nbatch.
+//   unprepared call : classic windowed Pippenger, one bucket set per window, Horner at the end.
+//                     nsets = windows.
+//   k_digits   : scalar -> signed c-bit digits, per-bucket histogram (global atomics)
+//   k_scan     : exclusive scan of the histogram per set
+//   k_scatter  : counting-sort of (point index | sign) by bucket
+//   k_accum    : one lane per bucket, chain of XYZZ mixed adds over its sorted run
+//   k_reduce   : one lane per 32-bucket segment: running-sum trick + small scalar multiple
+//   k_setsum   : one workgroup per set, LDS tree sum of the segment results
+//   k_final    : Horner over windows (unprepared), convert to blst Jacobian
+// All arithmetic is integer VALU (v_mad_u64_u32); there is no MFMA-shaped work here.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kzg_mi355x.h"
+#include "g1_28.cuh"
+#include "msm_internal.h"
+
+using ff::u32;
+using ff::u64;
+using g1::AffPt;
+using g1::Xyzz;
+
+namespace {
+
+constexpr int SEG = 32;  // buckets per k_reduce lane
+
+// ---------------------------------------------------------------- helpers
+struct HipErr {
+    hipError_t e;
+    const char* what;
+};
+#define HIP_TRY(x)                                  \
+    do {                                            \
+        hipError_t _e = (x);                        \
+        if (_e != hipSuccess) throw HipErr{_e, #x}; \
+    } while (0)
+
+RustError ok_error() { return RustError{0, nullptr}; }
+RustError make_error(int code, const std::string& msg) {
+    char* m = (char*)malloc(msg.size() + 1);
+    if (m) memcpy(m, msg.c_str(), msg.size() + 1);
+    return RustError{code, m};
+}
+
+// ---------------------------------------------------------------- kernels
+
+// blst affine (2 x 12 u32, Montgomery 2^384) -> table slot (fp28, Montgomery 2^392)
+__global__ void __launch_bounds__(256) k_points_in(AffPt* __restrict__ dst, const ff::Fp* __restrict__ src, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ff::Fp x = src[2 * i], y = src[2 * i + 1];
+    AffPt o;
+    o.flags = (x.is_zero() && y.is_zero()) ? 1u : 0u;
+    o.pad[0] = o.pad[1] = o.pad[2] = 0;
+    // canonical residues, so that y and 2p - y are both valid normalized inputs
+    o.x = fp28::canon(fp28::from_blst(x));
+    o.y = fp28::canon(fp28::from_blst(y));
+    dst[i] = o;
+}
+
+// a^(p-2) in fp28 (Fermat); only used while building tables
+__device__ fp28::Fe fe_inverse(const fp28::Fe& a) {
+    fp28::Fe r = fp28::one();
+    bool started = false;
+    for (int i = 11; i >= 0; --i) {
+        u32 e = ff::FpParams::p(i);
+        if (i == 0) e -= 2;
+        for (int b = 31; b >= 0; --b) {
+            if (started) r = fp28::sqr(r);
+            if ((e >> b) & 1) {
+                r = started ? fp28::mul(r, a) : a;
+                started = true;
+            }
+        }
+    }
+    return r;
+}
+
+// table rows j = 1..rows-1:  T[j][i] = 2^c * T[j-1][i], kept affine (one inversion per entry)
+__global__ void __launch_bounds__(128) k_table_rows(AffPt* __restrict__ table, size_t n, int rows, int c) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    AffPt cur = table[i];
+    for (int j = 1; j < rows; ++j) {
+        AffPt nxt;
+        nxt.flags = cur.flags;
+        nxt.pad[0] = nxt.pad[1] = nxt.pad[2] = 0;
+        if (cur.flags & 1) {
+            nxt.x = fp28::zero();
+            nxt.y = fp28::zero();
+        } else {
+            Xyzz acc;
+            g1::dbl_affine(acc, cur.x, cur.y);
+            bool inf = false;
+            for (int k = 1; k < c; ++k) {
+                if (fp28::is_zero_mod_p(acc.y)) {  // order-2 point: doubling gives infinity
+                    inf = true;
+                    break;
+                }
+                g1::dbl(acc);
+            }
+            if (inf || g1::is_inf(acc)) {
+                nxt.flags = 1;
+                nxt.x = fp28::zero();
+                nxt.y = fp28::zero();
+            } else {
+                fp28::Fe zi = fe_inverse(fp28::mul(acc.zz, acc.zzz));  // 1/(ZZ*ZZZ)
+                fp28::Fe izz = fp28::mul(zi, acc.zzz), izzz = fp28::mul(zi, acc.zz);
+                nxt.x = fp28::canon(fp28::mul(acc.x, izz));
+                nxt.y = fp28::canon(fp28::mul(acc.y, izzz));
+            }
+        }
+        table[(size_t)j * n + i] = nxt;
+        cur = nxt;
+    }
+}
+
+struct DigitParams {
+    size_t n;        // points per MSM
+    size_t nbatch;   // MSMs in this launch
+    int c;           // window bits
+    int nwin;        // windows per scalar
+    int prepared;    // 1: all windows share one bucket set
+    int mont;        // scalars are Montgomery blst_fr
+    size_t nb;       // buckets per set = 2^(c-1)
+    size_t row_stride;  // prepared: points per table row
+};
+
+// canonical 256-bit scalar (8 x u32) -> signed digit of window w, carrying from below
+__device__ __forceinline__ void load_scalar(u32 s[8], const u32* __restrict__ scalars, size_t idx, int mont) {
+    ff::Fr f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f.v[k] = scalars[idx * 8 + k];
+    if (mont) f = ff::from_mont(f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = f.v[k];
+}
+
+__device__ __forceinline__ u32 window_bits(const u32 s[8], int bit, int c) {
+    // c <= 24 bits starting at `bit` (bits above 255 read as zero)
+    int w = bit >> 5, sh = bit & 31;
+    u64 two = 0;
+    if (w < 8) two = s[w];
+    if (w + 1 < 8) two |= (u64)s[w + 1] << 32;
+    return (u32)(two >> sh) & ((1u << c) - 1);
+}
+
+// pass 0: histogram; pass 1: scatter (recomputes the digits instead of storing them)
+template <int PASS>
+__global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __restrict__ scalars,
+                                                const AffPt* __restrict__ pts, u32* __restrict__ counts,
+                                                const u32* __restrict__ offsets, u32* __restrict__ sorted,
+                                                size_t set_cap) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.n * P.nbatch) return;
+    size_t b = t / P.n, i = t % P.n;
+    if (pts[i].flags & 1) return;  // infinity base contributes nothing (rows share the flag)
+    u32 s[8];
+    load_scalar(s, scalars, t, P.mont);
+    u32 carry = 0;
+    const u32 half = 1u << (P.c - 1);
+    for (int w = 0; w < P.nwin; ++w) {
+        u32 d = window_bits(s, w * P.c, P.c) + carry;
+        u32 neg = 0;
+        carry = 0;
+        if (d > half) {
+            d = (1u << P.c) - d;
+            neg = 1;
+            carry = 1;
+        }
+        if (d == 0) continue;
+        size_t set = P.prepared ? b : b * P.nwin + w;
+        size_t slot = set * P.nb + (d - 1);
+        if (PASS == 0) {
+            atomicAdd(&counts[slot], 1u);
+        } else {
+            u32 pos = offsets[set * (P.nb + 1) + (d - 1)] + atomicAdd(&counts[slot], 1u);
+            u32 pidx = P.prepared ? (u32)((size_t)w * P.row_stride + i) : (u32)i;
+            sorted[set * set_cap + pos] = pidx | (neg << 31);
+        }
+    }
+}
+
+// exclusive scan of counts[set][0..nb) -> offsets[set][0..nb]; zeroes counts for the scatter pass
+__global__ void __launch_bounds__(1024) k_scan(u32* __restrict__ counts, u32* __restrict__ offsets, size_t nb) {
+    __shared__ u32 wsum[16];
+    __shared__ u32 base_s;
+    size_t set = blockIdx.x;
+    u32* cnt = counts + set * nb;
+    u32* off = offsets + set * (nb + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (size_t start = 0; start < nb; start += 1024) {
+        size_t k = start + threadIdx.x;
+        u32 v = k < nb ? cnt[k] : 0;
+        if (k < nb) cnt[k] = 0;
+        u32 x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            u32 y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        u32 wbase = 0;
+        for (int w2 = 0; w2 < wave; ++w2) wbase += wsum[w2];
+        u32 base = base_s;
+        if (k < nb) off[k] = base + wbase + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) base_s = base + wbase + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[nb] = base_s;
+}
+
+// one lane per bucket: sum of its sorted run
+__global__ void __launch_bounds__(256) k_accum(const u32* __restrict__ offsets, const u32* __restrict__ sorted,
+                                               const AffPt* __restrict__ pts, Xyzz* __restrict__ buckets, size_t nb,
+                                               size_t nsets, size_t set_cap) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb * nsets) return;
+    size_t set = t / nb, bk = t % nb;
+    const u32* off = offsets + set * (nb + 1);
+    u32 beg = off[bk], end = off[bk + 1];
+    const u32* run = sorted + set * set_cap;
+    Xyzz acc;
+    g1::set_inf(acc);
+    for (u32 k = beg; k < end; ++k) {
+        u32 e = run[k];
+        const AffPt* p = pts + (e & 0x7fffffffu);
+        fp28::Fe x = p->x, y = p->y;
+        if (e >> 31) y = fp28::neg<2>(y);
+        g1::madd(acc, x, y);
+    }
+    buckets[t] = acc;
+}
+
+// one lane per SEG consecutive buckets: contribution sum_{k in seg} k * B_k
+__global__ void __launch_bounds__(128) k_reduce(const Xyzz* __restrict__ buckets, Xyzz* __restrict__ segout, size_t nb,
+                                                size_t nsets) {
+    const size_t nseg = (nb + SEG - 1) / SEG;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseg * nsets) return;
+    size_t set = t / nseg, sg = t % nseg;
+    const Xyzz* bk = buckets + set * nb;
+    size_t lo = sg * SEG, hi = lo + SEG < nb ? lo + SEG : nb;  // bucket k (0-based) has weight k+1
+    Xyzz run, tot;
+    g1::set_inf(run);
+    g1::set_inf(tot);
+    for (size_t k = hi; k-- > lo;) {
+        Xyzz b = bk[k];
+        g1::dadd(run, b);
+        g1::dadd(tot, run);
+    }
+    // tot = sum (k-lo+1) B_k ;  add lo * sum B_k
+    if (lo != 0) {
+        g1::mul_small(run, (u32)lo);
+        g1::dadd(tot, run);
+    }
+    segout[t] = tot;
+}
+
+// one workgroup per set: sum of its nseg segment results
+__global__ void __launch_bounds__(256) k_setsum(const Xyzz* __restrict__ segout, Xyzz* __restrict__ setout, size_t nseg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Xyzz* sh = reinterpret_cast<Xyzz*>(smem);
+    size_t set = blockIdx.x;
+    const Xyzz* in = segout + set * nseg;
+    Xyzz acc;
+    g1::set_inf(acc);
+    for (size_t k = threadIdx.x; k < nseg; k += blockDim.x) {
+        Xyzz b = in[k];
+        g1::dadd(acc, b);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int stride = blockDim.x / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) {
+            Xyzz b = sh[threadIdx.x + stride];
+            g1::dadd(acc, b);
+            sh[threadIdx.x] = acc;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) setout[set] = acc;
+}
+
+// one lane per MSM: Horner over windows (unprepared) and conversion to blst Jacobian
+__global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ setout, ff::Fp* __restrict__ out, size_t nbatch,
+                                              int nwin, int c, int prepared) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbatch) return;
+    Xyzz acc;
+    if (prepared) {
+        acc = setout[b];
+    } else {
+        g1::set_inf(acc);
+        for (int w = nwin - 1; w >= 0; --w) {
+            if (!g1::is_inf(acc))
+                for (int k = 0; k < c; ++k) {
+                    if (fp28::is_zero_mod_p(acc.y)) {
+                        g1::set_inf(acc);
+                        break;
+                    }
+                    g1::dbl(acc);
+                }
+            Xyzz r = setout[b * nwin + w];
+            g1::dadd(acc, r);
+        }
+    }
+    ff::Fp j[3];
+    g1::to_blst_jacobian(j, acc);
+    out[3 * b] = j[0];
+    out[3 * b + 1] = j[1];
+    out[3 * b + 2] = j[2];
+}
+
+// ---------------------------------------------------------------- host side
+
+int choose_window(size_t n, bool prepared) {
+    // minimise adds: prepared  n*ceil(256/c) + 3*2^(c-1);  unprepared  ceil(256/c) * (n + 3*2^(c-1))
+    int best = 2;
+    double best_cost = 1e300;
+    for (int c = 2; c <= 22; ++c) {
+        double w = 255 / c + 1, nb = (double)((size_t)1 << (c - 1));
+        double cost = prepared ? w * (double)n + 3.0 * nb : w * ((double)n + 3.0 * nb);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    return best;
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n) {
+        if (n <= cap) return;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+        cap = n;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Workspace {
+    DevBuf<u32> counts, offsets, sorted, scalars;
+    DevBuf<Xyzz> buckets, segout, setout;
+    DevBuf<ff::Fp> out;
+    void release() {
+        counts.release();
+        offsets.release();
+        sorted.release();
+        scalars.release();
+        buckets.release();
+        segout.release();
+        setout.release();
+        out.release();
+    }
+};
+
+}  // namespace
+
+struct kzgamd::MsmContext {
+    std::mutex mu;
+    int device = 0;
+    size_t n = 0;
+    bool prepared = false;
+    int c = 0, rows = 0;
+    size_t nb = 0;
+    DevBuf<AffPt> table;  // rows x n (prepared) or n
+    Workspace ws;
+    hipStream_t stream = nullptr;
+    ~MsmContext() {
+        table.release();
+        ws.release();
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace kzgamd {
+
+static void require_device() {
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0) throw HipErr{e == hipSuccess ? hipErrorNoDevice : e, "no gfx950 device visible"};
+}
+
+// uploads points (host or device pointer), builds the fixed-base rows when `prepare`
+MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare) {
+    require_device();
+    auto* ctx = new MsmContext();
+    try {
+        HIP_TRY(hipGetDevice(&ctx->device));
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->n = n;
+        ctx->prepared = prepare;
+        ctx->c = choose_window(n, prepare);
+        ctx->rows = prepare ? (255 / ctx->c + 1) : 1;
+        ctx->nb = (size_t)1 << (ctx->c - 1);
+        ctx->table.ensure((size_t)ctx->rows * n);
+        DevBuf<ff::Fp> staging;
+        const ff::Fp* src = (const ff::Fp*)points;
+        if (!points_on_device) {
+            staging.ensure(2 * n);
+            HIP_TRY(hipMemcpyAsync(staging.p, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
+            src = staging.p;
+        }
+        hipLaunchKernelGGL(k_points_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->table.p, src, n);
+        if (prepare && ctx->rows > 1)
+            hipLaunchKernelGGL(k_table_rows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, ctx->table.p, n,
+                               ctx->rows, ctx->c);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        staging.release();
+    } catch (...) {
+        delete ctx;
+        throw;
+    }
+    return ctx;
+}
+
+void msm_destroy(MsmContext* ctx) { delete ctx; }
+
+// enqueue nbatch MSMs over the first npoints bases; d_scalars / d_out device pointers
+void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npoints, size_t nbatch, int mont,
+                 hipStream_t stream) {
+    if (npoints > ctx->n) throw HipErr{hipErrorInvalidValue, "npoints exceeds the prepared size"};
+    if (nbatch == 0) return;
+    const int c = ctx->c;
+    const int nwin = 255 / c + 1;
+    const size_t nb = ctx->nb;
+    const size_t nsets = ctx->prepared ? nbatch : nbatch * (size_t)nwin;
+    const size_t set_cap = ctx->prepared ? npoints * (size_t)nwin : npoints;
+    const size_t nseg = (nb + SEG - 1) / SEG;
+    if (npoints == 0) {
+        HIP_TRY(hipMemsetAsync(d_out, 0, nbatch * 144, stream));
+        return;
+    }
+    if (set_cap >= ((size_t)1 << 31) || nsets * nb >= ((size_t)1 << 40)) throw HipErr{hipErrorInvalidValue, "MSM too large"};
+    Workspace& ws = ctx->ws;
+    ws.counts.ensure(nsets * nb);
+    ws.offsets.ensure(nsets * (nb + 1));
+    ws.sorted.ensure(nsets * set_cap);
+    ws.buckets.ensure(nsets * nb);
+    ws.segout.ensure(nsets * nseg);
+    ws.setout.ensure(nsets);
+    DigitParams P{npoints, nbatch, c, nwin, ctx->prepared ? 1 : 0, mont, nb, ctx->n};
+    HIP_TRY(hipMemsetAsync(ws.counts.p, 0, nsets * nb * sizeof(u32), stream));
+    const unsigned gdig = (unsigned)((npoints * nbatch + 255) / 256);
+    hipLaunchKernelGGL(k_digits<0>, dim3(gdig), dim3(256), 0, stream, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
+                       (const u32*)nullptr, (u32*)nullptr, set_cap);
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)nsets), dim3(1024), 0, stream, ws.counts.p, ws.offsets.p, nb);
+    hipLaunchKernelGGL(k_digits<1>, dim3(gdig), dim3(256), 0, stream, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
+                       (const u32*)ws.offsets.p, ws.sorted.p, set_cap);
+    hipLaunchKernelGGL(k_accum, dim3((unsigned)((nsets * nb + 255) / 256)), dim3(256), 0, stream, (const u32*)ws.offsets.p,
+                       (const u32*)ws.sorted.p, (const AffPt*)ctx->table.p, ws.buckets.p, nb, nsets, set_cap);
+    hipLaunchKernelGGL(k_reduce, dim3((unsigned)((nsets * nseg + 127) / 128)), dim3(128), 0, stream,
+                       (const Xyzz*)ws.buckets.p, ws.segout.p, nb, nsets);
+    hipLaunchKernelGGL(k_setsum, dim3((unsigned)nsets), dim3(256), 256 * sizeof(Xyzz), stream, (const Xyzz*)ws.segout.p,
+                       ws.setout.p, nseg);
+    hipLaunchKernelGGL(k_final, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)ws.setout.p,
+                       (ff::Fp*)d_out, nbatch, nwin, c, ctx->prepared ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+}
+
+// host buffers in, host buffers out
+void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoints, size_t nbatch) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    ctx->ws.scalars.ensure(nbatch * npoints * 8 + 8);
+    ctx->ws.out.ensure(nbatch * 3 + 3);
+    if (npoints * nbatch)
+        HIP_TRY(hipMemcpyAsync(ctx->ws.scalars.p, scalars, nbatch * npoints * 32, hipMemcpyHostToDevice, ctx->stream));
+    msm_enqueue(ctx, ctx->ws.out.p, ctx->ws.scalars.p, npoints, nbatch, 1, ctx->stream);
+    HIP_TRY(hipMemcpyAsync(out, ctx->ws.out.p, nbatch * 144, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+}
+
+}  // namespace kzgamd
+
+// ---------------------------------------------------------------- C ABI (B1)
+using kzgamd::MsmContext;
+
+template <class F>
+static RustError guarded(F&& f) {
+    try {
+        f();
+        return ok_error();
+    } catch (const HipErr& e) {
+        return make_error((int)e.e ? (int)e.e : 1, std::string(e.what) + ": " + hipGetErrorString(e.e));
+    } catch (const std::exception& e) {
+        return make_error(1, e.what());
+    }
+}
+
+extern "C" void* prepare_msm(const blst_p1_affine points[], size_t npoints) {
+    try {
+        if (!points || npoints == 0) return nullptr;
+        return kzgamd::msm_create(points, npoints, false, true);
+    } catch (const HipErr& e) {
+        fprintf(stderr, "kzg_mi355x: prepare_msm failed: %s: %s\n", e.what, hipGetErrorString(e.e));
+        return nullptr;
+    } catch (...) {
+        return nullptr;
+    }
+}
+
+extern "C" void free_msm(void* msm) {
+    if (msm) kzgamd::msm_destroy((MsmContext*)msm);
+}
+
+extern "C" RustError mult_pippenger_prepared(void* msm, blst_p1* out, size_t npoints, const blst_fr scalars[]) {
+    if (!msm || !out) return make_error(1, "mult_pippenger_prepared: null handle or output");
+    return guarded([&] { kzgamd::msm_run_host((MsmContext*)msm, out, scalars, npoints, 1); });
+}
+
+extern "C" RustError mult_pippenger_prepared_batch(void* msm, blst_p1 out[], size_t npoints, size_t nbatch,
+                                                   const blst_fr scalars[]) {
+    if (!msm || !out) return make_error(1, "mult_pippenger_prepared_batch: null handle or output");
+    return guarded([&] { kzgamd::msm_run_host((MsmContext*)msm, out, scalars, npoints, nbatch); });
+}
+
+extern "C" RustError mult_pippenger(blst_p1* out, const blst_p1_affine points[], size_t npoints, const blst_fr scalars[]) {
+    if (!out) return make_error(1, "mult_pippenger: null output");
+    return guarded([&] {
+        if (npoints == 0) {
+            memset(out, 0, sizeof *out);
+            return;
+        }
+        MsmContext* ctx = kzgamd::msm_create(points, npoints, false, false);
+        try {
+            kzgamd::msm_run_host(ctx, out, scalars, npoints, 1);
+        } catch (...) {
+            kzgamd::msm_destroy(ctx);
+            throw;
+        }
+        kzgamd::msm_destroy(ctx);
+    });
+}
+
+extern "C" RustError kzgamd_msm_prepared_batch_device(void* msm, void* d_out, const void* d_scalars, size_t npoints,
+                                                      size_t nbatch, int scalars_mont, void* stream) {
+    if (!msm) return make_error(1, "null handle");
+    return guarded([&] {
+        MsmContext* ctx = (MsmContext*)msm;
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        kzgamd::msm_enqueue(ctx, d_out, d_scalars, npoints, nbatch, scalars_mont, (hipStream_t)stream);
+    });
+}
+
+extern "C" int kzgamd_msm_info(void* msm, int* window_bits, int* rows, size_t* nbuckets, size_t* npoints) {
+    if (!msm) return 1;
+    MsmContext* ctx = (MsmContext*)msm;
+    if (window_bits) *window_bits = ctx->c;
+    if (rows) *rows = ctx->rows;
+    if (nbuckets) *nbuckets = ctx->nb;
+    if (npoints) *npoints = ctx->n;
+    return 0;
+}
+
+extern "C" int kzgamd_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+extern "C" const char* kzgamd_version(void) { return "kzg_mi355x 0.1 (gfx950)"; }

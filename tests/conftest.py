@@ -61,3 +61,22 @@ def oracle_settings(oracle, trusted_setup_text):
     rc, s = oracle.load_settings(trusted_setup_text)
     assert rc == 0
     return s
+
+
+def load_package():
+    """import rust-kzg_amd/ (hyphenated directory) under the module name rust_kzg_amd"""
+    import importlib.util
+
+    if "rust_kzg_amd" in sys.modules:
+        return sys.modules["rust_kzg_amd"]
+    path = os.path.join(ROOT, "rust-kzg_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location("rust_kzg_amd", path, submodule_search_locations=[os.path.dirname(path)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["rust_kzg_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def kzg():
+    return load_package()

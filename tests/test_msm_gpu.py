@@ -1,0 +1,175 @@
+"""MSM parity on the GPU: HIP Pippenger (through the C-ABI, B1) vs the CPU oracle.
+Mirrors the reference's MSM tests (kzg-bench/src/tests/bls12_381.rs:184-387) and the fuzz
+invariant (fuzz/src/lib.rs:81-96: every MSM variant == sequential Pippenger bytes)."""
+import ctypes as C
+import random
+
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+
+def gen_points(L, n, rnd, base=None):
+    g = O.G1()
+    L.og1_generator(C.byref(g))
+    pts = (O.G1Affine * max(n, 1))()
+    for i in range(n):
+        t = O.G1()
+        kf = O.fr_from_int(rnd.randrange(1, O.R))
+        L.og1_mul(C.byref(t), C.byref(g), C.byref(kf))
+        L.og1_to_affine(C.byref(pts[i]), C.byref(t))
+    return pts
+
+
+def compressed(L, p):
+    buf = C.create_string_buffer(48)
+    L.og1_compress(buf, C.byref(p))
+    return buf.raw
+
+
+def as_oracle_g1(p1):
+    g = O.G1()
+    C.memmove(C.byref(g), C.byref(p1), 144)
+    return g
+
+
+def check(L, kzg, pts, sc, n, prepared=None, unprepared=True):
+    exp = O.G1()
+    L.omsm_affine(C.byref(exp), pts, sc, n)
+    want = compressed(L, exp)
+    if prepared is not None:
+        got = as_oracle_g1(kzg.multi_scalar_mult_prepared(prepared, sc, n))
+        assert compressed(L, got) == want
+    if unprepared and n > 0:
+        got = as_oracle_g1(kzg.multi_scalar_mult(pts, sc, n))
+        assert compressed(L, got) == want
+    return want
+
+
+def test_small_sizes_with_and_without_precomputation(oracle, kzg):
+    # every n in a range, output buffer semantics (bls12_381.rs:314-387)
+    L = oracle.lib()
+    rnd = random.Random(11)
+    pts = gen_points(L, 130, rnd)
+    sc = O.fr_array([rnd.randrange(O.R) for _ in range(130)])
+    h = kzg.prepare_multi_scalar_mult(pts, 130)
+    for n in list(range(1, 20)) + [31, 32, 33, 64, 100, 128, 130]:
+        check(L, kzg, pts, sc, n, prepared=h)
+    h.close()
+
+
+def test_edge_scalars_and_points(oracle, kzg):
+    L = oracle.lib()
+    rnd = random.Random(12)
+    n = 96
+    pts = gen_points(L, n, rnd)
+    vals = [rnd.randrange(O.R) for _ in range(n)]
+    for i in range(0, n, 7):
+        vals[i] = 0                      # ~10% zero scalars (bls12_381.rs:265-311)
+    vals[1], vals[2], vals[3] = 1, O.R - 1, O.R - 2
+    vals[4] = (1 << 254)                 # top bits
+    vals[5] = (1 << 255) % O.R
+    for i in range(5, n, 9):
+        pts[i] = O.G1Affine()            # infinity points
+    pts[10] = pts[11]                    # equal points (doubling inside a bucket when digits agree)
+    vals[10] = vals[11]
+    pts[20] = pts[21]
+    vals[20] = O.R - vals[21]            # P and -P with equal digits -> cancels to infinity in a bucket
+    sc = O.fr_array(vals)
+    h = kzg.prepare_multi_scalar_mult(pts, n)
+    check(L, kzg, pts, sc, n, prepared=h)
+    # all-equal scalars, all-zero scalars, all-same point
+    sc2 = O.fr_array([vals[7]] * n)
+    check(L, kzg, pts, sc2, n, prepared=h)
+    sc0 = O.fr_array([0] * n)
+    got = check(L, kzg, pts, sc0, n, prepared=h)
+    assert got == b"\xc0" + bytes(47)
+    h.close()
+    same = (O.G1Affine * n)(*[pts[0]] * n)
+    hs = kzg.prepare_multi_scalar_mult(same, n)
+    check(L, kzg, same, sc, n, prepared=hs)
+    check(L, kzg, same, sc2, n, prepared=hs)
+    hs.close()
+
+
+def test_sum_of_multiples_of_generator(oracle, kzg):
+    # sum (i+1)*G with scalars (i+1), n = 255 (bls12_381.rs:184-219)
+    L = oracle.lib()
+    n = 255
+    g = O.G1()
+    L.og1_generator(C.byref(g))
+    pts = (O.G1Affine * n)()
+    acc = O.G1()
+    L.og1_generator(C.byref(acc))
+    for i in range(n):
+        L.og1_to_affine(C.byref(pts[i]), C.byref(acc))
+        L.og1_add_or_dbl(C.byref(acc), C.byref(acc), C.byref(g))
+    sc = O.fr_array([i + 1 for i in range(n)])
+    h = kzg.prepare_multi_scalar_mult(pts, n)
+    got = check(L, kzg, pts, sc, n, prepared=h)
+    tot = O.fr_from_int(sum((i + 1) ** 2 for i in range(n)))
+    e = O.G1()
+    L.og1_mul(C.byref(e), C.byref(g), C.byref(tot))
+    assert compressed(L, e) == got
+    h.close()
+
+
+def test_trusted_setup_4096_random_scalars_and_batch(oracle, oracle_settings, kzg):
+    # BASELINE configs[1]: n=4096 random Fr x trusted-setup Lagrange points
+    L = oracle.lib()
+    rnd = random.Random(1)
+    n = 4096
+    pts = oracle_settings.g1_lagrange_brp
+    h = kzg.prepare_multi_scalar_mult(pts, n)
+    info = h.info()
+    assert info["npoints"] == n and info["rows"] == 255 // info["window_bits"] + 1
+    nb = 3
+    vals = [rnd.randrange(O.R) for _ in range(nb * n)]
+    sc = O.fr_array(vals)
+    outs = kzg.multi_scalar_mult_prepared_batch(h, sc, n, nb)
+    for b in range(nb):
+        scb = (O.Fr * n).from_buffer(sc, b * n * 32)
+        exp = O.G1()
+        L.omsm_affine(C.byref(exp), pts, scb, n)
+        assert compressed(L, as_oracle_g1(outs[b])) == compressed(L, exp)
+    # unprepared path on the same inputs, and a shorter MSM on the prepared handle
+    scb = (O.Fr * n).from_buffer(sc, 0)
+    check(L, kzg, pts, scb, n, prepared=h)
+    check(L, kzg, pts, scb, 1000, prepared=h, unprepared=False)
+    h.close()
+
+
+def test_linearity_property_large(oracle, kzg):
+    # size-independent property at n = 2^16: MSM(s) + MSM(t) == MSM(s + t); points = 16 distinct
+    # oracle-checked points tiled (every bucket sees repeated points -> doubling path exercised)
+    L = oracle.lib()
+    rnd = random.Random(5)
+    n = 1 << 16
+    base = gen_points(L, 16, rnd)
+    pts = (O.G1Affine * n)()
+    for i in range(n):
+        pts[i] = base[i % 16]
+    s = [rnd.randrange(O.R) for _ in range(n)]
+    t = [rnd.randrange(O.R) for _ in range(n)]
+    import numpy as np
+
+    def fr_bulk(vals):
+        # Montgomery limbs via python ints (R = 2^256)
+        arr = (O.Fr * len(vals))()
+        raw = b"".join(((v << 256) % O.R).to_bytes(32, "little") for v in vals)
+        C.memmove(arr, raw, len(raw))
+        return arr
+
+    a = as_oracle_g1(kzg.multi_scalar_mult(pts, fr_bulk(s), n))
+    b = as_oracle_g1(kzg.multi_scalar_mult(pts, fr_bulk(t), n))
+    c = as_oracle_g1(kzg.multi_scalar_mult(pts, fr_bulk([(x + y) % O.R for x, y in zip(s, t)]), n))
+    ab = O.G1()
+    L.og1_add_or_dbl(C.byref(ab), C.byref(a), C.byref(b))
+    assert compressed(L, ab) == compressed(L, c)
+    # closed form: sum_i s_i * base[i%16] = sum_j (sum_{i%16==j} s_i) * base[j]
+    folded = O.fr_array([sum(s[j::16]) % O.R for j in range(16)])
+    e = O.G1()
+    L.omsm_affine(C.byref(e), base, folded, 16)
+    assert compressed(L, e) == compressed(L, a)
