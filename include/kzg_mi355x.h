@@ -52,6 +52,10 @@ RustError kzgamd_msm_prepared_batch_device(void *msm, void *d_out, const void *d
                                            size_t nbatch, int scalars_mont, void *stream);
 /* introspection for benches/tests: window bits, table rows, buckets of a handle */
 int kzgamd_msm_info(void *msm, int *window_bits, int *rows, size_t *nbuckets, size_t *npoints);
+/* HIP-event timing of the bucket-accumulation kernel (k_accum) and of the whole enqueue, recorded on
+ * the launch stream of the most recent enqueue; get returns non-zero until a profiled enqueue has run */
+int kzgamd_msm_set_profile(void *msm, int on);
+int kzgamd_msm_get_profile(void *msm, float *accum_ms, float *total_ms);
 
 /* ------------------------------------------------------------------------------------------
  * B2 — NTT plug-in.  Replaces FFTFr::fft_fr / DASExtension::das_fft_extension for FsFFTSettings
@@ -85,28 +89,54 @@ typedef struct { uint8_t bytes[BYTES_PER_BLOB]; } Blob;
 typedef Bytes48 KZGCommitment;
 typedef Bytes48 KZGProof;
 
-/* Opaque settings: device-resident fixed-base tables + roots (the reference keeps the GPU table
- * behind an opaque pointer too: kzg/src/msm/sppark.rs:5-22). */
-typedef struct KzgAmdSettings KzgAmdSettings;
+typedef struct { uint8_t opaque[288]; } blst_p2;       /* 3 x Fp2, never dereferenced by this library */
 
-C_KZG_RET kzgamd_load_trusted_setup(KzgAmdSettings **out, const uint8_t *g1_monomial_bytes, size_t n1m,
-                                    const uint8_t *g1_lagrange_bytes, size_t n1l,
-                                    const uint8_t *g2_monomial_bytes, size_t n2);           /* eip_4844.rs:180-222 */
-C_KZG_RET kzgamd_load_trusted_setup_file(KzgAmdSettings **out, FILE *in);                     /* eip_4844.rs:227-269 */
-void kzgamd_free_trusted_setup(KzgAmdSettings *s);                                             /* eip_4844.rs:296-378 */
-C_KZG_RET kzgamd_blob_to_kzg_commitment(KZGCommitment *out, const Blob *blob, const KzgAmdSettings *s); /* :163-175 */
-C_KZG_RET kzgamd_compute_kzg_proof(KZGProof *proof_out, Bytes32 *y_out, const Blob *blob, const Bytes32 *z_bytes,
-                                   const KzgAmdSettings *s);                                   /* :476-496 */
-C_KZG_RET kzgamd_compute_blob_kzg_proof(KZGProof *out, const Blob *blob, const Bytes48 *commitment_bytes,
-                                        const KzgAmdSettings *s);                              /* :274-291 */
-C_KZG_RET kzgamd_compute_challenge(Bytes32 *out, const Blob *blob, const Bytes48 *commitment_bytes); /* :501-514 */
-/* batched forms (new API, BASELINE.json configs[4]); per-blob results equal the single calls */
-C_KZG_RET kzgamd_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blobs, size_t n, const KzgAmdSettings *s);
+/* Same layout as the reference's CKZGSettings (kzg/src/eth/c_bindings.rs:55-108).  The host arrays are
+ * owned by the library and freed by free_trusted_setup; the device-resident state (fixed-base MSM table)
+ * is found through a registry keyed by g1_values_lagrange_brp, as the reference does for its tables
+ * (kzg/src/eip_4844.rs:64-146).  g2_values_monomial / x_ext_fft_columns / tables stay NULL: pairing
+ * (verify_*) and FK20 are outside this library's path. */
+typedef struct {
+    blst_fr *roots_of_unity;          /* 8193 */
+    blst_fr *brp_roots_of_unity;      /* 8192 */
+    blst_fr *reverse_roots_of_unity;  /* 8193 */
+    blst_p1 *g1_values_monomial;      /* 4096 */
+    blst_p1 *g1_values_lagrange_brp;  /* 4096 */
+    blst_p2 *g2_values_monomial;      /* NULL */
+    blst_p1 **x_ext_fft_columns;      /* NULL */
+    blst_p1_affine **tables;          /* NULL */
+    size_t wbits;
+    size_t scratch_size;
+} CKZGSettings;
+
+/* Exact c-kzg-4844 names and signatures, as exported by blst/src/eip_4844.rs. */
+C_KZG_RET load_trusted_setup(CKZGSettings *out, const uint8_t *g1_monomial_bytes, uint64_t num_g1_monomial_bytes,
+                             const uint8_t *g1_lagrange_bytes, uint64_t num_g1_lagrange_bytes,
+                             const uint8_t *g2_monomial_bytes, uint64_t num_g2_monomial_bytes,
+                             uint64_t precompute);                                             /* eip_4844.rs:180-222 */
+C_KZG_RET load_trusted_setup_file(CKZGSettings *out, FILE *in);                                /* eip_4844.rs:227-269 */
+void free_trusted_setup(CKZGSettings *s);                                                      /* eip_4844.rs:296-378 */
+C_KZG_RET blob_to_kzg_commitment(KZGCommitment *out, const Blob *blob, const CKZGSettings *s); /* eip_4844.rs:163-175 */
+C_KZG_RET compute_kzg_proof(KZGProof *proof_out, Bytes32 *y_out, const Blob *blob, const Bytes32 *z_bytes,
+                            const CKZGSettings *s);                                            /* eip_4844.rs:476-496 */
+C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, const Bytes48 *commitment_bytes,
+                                 const CKZGSettings *s);                                       /* eip_4844.rs:274-291 */
+/* helper exported by the reference for the test-suite (eip_4844.rs:501-514) */
+C_KZG_RET compute_challenge(Bytes32 *out, const Blob *blob, const Bytes48 *commitment_bytes);
+
+/* Batched forms (new API; BASELINE.json configs[4] names a compute_blob_kzg_proof_batch the reference
+ * does not have — its closest behaviour is a host loop, kzg-bench/src/benches/eip_4844.rs:56-60).
+ * Per-blob results equal the single-blob calls; any invalid blob fails the whole call (BadArgs). */
+C_KZG_RET kzgamd_blob_to_kzg_commitment_batch(KZGCommitment *out, const Blob *blobs, size_t n, const CKZGSettings *s);
 C_KZG_RET kzgamd_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n,
-                                              const KzgAmdSettings *s);
-/* device-resident commit: d_blobs = n x 131072 bytes, d_out = n x 48 bytes, d_status = n x int32 (0 ok, 1 bad blob) */
-C_KZG_RET kzgamd_blob_to_kzg_commitment_device(void *d_out, void *d_status, const void *d_blobs, size_t n,
-                                               const KzgAmdSettings *s, void *stream);
+                                              const CKZGSettings *s);
+/* Device-resident commit, enqueued on `stream` without synchronising: d_blobs = n x 131072 B,
+ * d_out = n x 48 B, d_status = n x int32 (0 ok, 1 blob has an element >= r),
+ * d_scratch = n x 131072 B of workspace. */
+C_KZG_RET kzgamd_blob_to_kzg_commitment_device(void *d_out, void *d_status, void *d_scratch, const void *d_blobs,
+                                               size_t n, const CKZGSettings *s, void *stream);
+/* the prepared-MSM handle behind a settings object (for kzgamd_msm_* calls) */
+void *kzgamd_settings_msm_handle(const CKZGSettings *s);
 
 /* library / device info */
 int kzgamd_device_count(void);

@@ -50,8 +50,24 @@ _lib = None
 # every symbol include/kzg_mi355x.h declares; tests check the library exports all of them
 EXPORTS = [
     "prepare_msm", "mult_pippenger_prepared", "mult_pippenger", "free_msm", "mult_pippenger_prepared_batch",
-    "kzgamd_msm_prepared_batch_device", "kzgamd_msm_info", "kzgamd_device_count", "kzgamd_version",
+    "kzgamd_msm_prepared_batch_device", "kzgamd_msm_info", "kzgamd_msm_set_profile", "kzgamd_msm_get_profile",
+    "kzgamd_device_count", "kzgamd_version",
+    "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
+    "kzgamd_blob_to_kzg_commitment_batch", "kzgamd_blob_to_kzg_commitment_device", "kzgamd_settings_msm_handle",
 ]
+
+
+class CKZGSettings(C.Structure):
+    """kzg/src/eth/c_bindings.rs:55-108"""
+    _fields_ = [("roots_of_unity", C.c_void_p), ("brp_roots_of_unity", C.c_void_p),
+                ("reverse_roots_of_unity", C.c_void_p), ("g1_values_monomial", C.c_void_p),
+                ("g1_values_lagrange_brp", C.c_void_p), ("g2_values_monomial", C.c_void_p),
+                ("x_ext_fft_columns", C.c_void_p), ("tables", C.c_void_p), ("wbits", C.c_size_t),
+                ("scratch_size", C.c_size_t)]
+
+
+C_KZG_OK, C_KZG_BADARGS, C_KZG_ERROR, C_KZG_MALLOC = 0, 1, 2, 3
+BYTES_PER_BLOB = 131072
 
 
 def lib():
@@ -79,6 +95,26 @@ def lib():
     L.kzgamd_msm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(sz), C.POINTER(sz)]
     L.kzgamd_device_count.restype = C.c_int
     L.kzgamd_version.restype = C.c_char_p
+    L.kzgamd_msm_set_profile.restype = C.c_int
+    L.kzgamd_msm_set_profile.argtypes = [vp, C.c_int]
+    L.kzgamd_msm_get_profile.restype = C.c_int
+    L.kzgamd_msm_get_profile.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    sp = C.POINTER(CKZGSettings)
+    L.load_trusted_setup.restype = C.c_int
+    L.load_trusted_setup.argtypes = [sp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64,
+                                     C.c_uint64]
+    L.load_trusted_setup_file.restype = C.c_int
+    L.load_trusted_setup_file.argtypes = [sp, vp]
+    L.free_trusted_setup.restype = None
+    L.free_trusted_setup.argtypes = [sp]
+    L.blob_to_kzg_commitment.restype = C.c_int
+    L.blob_to_kzg_commitment.argtypes = [vp, vp, sp]
+    L.kzgamd_blob_to_kzg_commitment_batch.restype = C.c_int
+    L.kzgamd_blob_to_kzg_commitment_batch.argtypes = [vp, vp, sz, sp]
+    L.kzgamd_blob_to_kzg_commitment_device.restype = C.c_int
+    L.kzgamd_blob_to_kzg_commitment_device.argtypes = [vp, vp, vp, vp, sz, sp, vp]
+    L.kzgamd_settings_msm_handle.restype = vp
+    L.kzgamd_settings_msm_handle.argtypes = [sp]
     _lib = L
     return L
 
@@ -154,3 +190,105 @@ def msm_prepared_batch_device(msm, d_out, d_scalars, npoints, nbatch, scalars_mo
 
 def device_count():
     return lib().kzgamd_device_count()
+
+
+# ---------------------------------------------------------------- c-kzg-4844 surface (B3)
+_libc = None
+
+
+def _fopen(path):
+    global _libc
+    if _libc is None:
+        _libc = C.CDLL(None)
+        _libc.fopen.restype = C.c_void_p
+        _libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+        _libc.fclose.argtypes = [C.c_void_p]
+    f = _libc.fopen(os.fsencode(path), b"r")
+    if not f:
+        raise FileNotFoundError(path)
+    return f
+
+
+class KZGSettings:
+    """Owns a CKZGSettings loaded through the library's own load_trusted_setup(_file)."""
+
+    def __init__(self):
+        self.c = CKZGSettings()
+        self.loaded = False
+
+    @classmethod
+    def from_file(cls, path):
+        self = cls()
+        f = _fopen(path)
+        try:
+            rc = lib().load_trusted_setup_file(C.byref(self.c), f)
+        finally:
+            _libc.fclose(f)
+        if rc != C_KZG_OK:
+            raise KzgAmdError("load_trusted_setup_file: C_KZG_RET %d" % rc)
+        self.loaded = True
+        return self
+
+    @classmethod
+    def from_bytes(cls, g1_monomial, g1_lagrange, g2_monomial):
+        self = cls()
+        rc = lib().load_trusted_setup(C.byref(self.c), g1_monomial, len(g1_monomial), g1_lagrange, len(g1_lagrange),
+                                      g2_monomial, len(g2_monomial), 0)
+        if rc != C_KZG_OK:
+            raise KzgAmdError("load_trusted_setup: C_KZG_RET %d" % rc)
+        self.loaded = True
+        return self
+
+    def msm_handle(self):
+        return lib().kzgamd_settings_msm_handle(C.byref(self.c))
+
+    def g1_lagrange_brp(self):
+        return (BlstP1 * 4096).from_address(self.c.g1_values_lagrange_brp)
+
+    def close(self):
+        if self.loaded:
+            lib().free_trusted_setup(C.byref(self.c))
+            self.loaded = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def blob_to_kzg_commitment(blob: bytes, settings: KZGSettings) -> bytes:
+    """blst/src/eip_4844.rs:163-175; raises KzgAmdError on C_KZG_BADARGS."""
+    if len(blob) != BYTES_PER_BLOB:
+        raise KzgAmdError("blob_to_kzg_commitment: C_KZG_RET %d" % C_KZG_BADARGS)
+    out = C.create_string_buffer(48)
+    rc = lib().blob_to_kzg_commitment(out, blob, C.byref(settings.c))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("blob_to_kzg_commitment: C_KZG_RET %d" % rc)
+    return out.raw
+
+
+def blob_to_kzg_commitment_batch(blobs: bytes, n: int, settings: KZGSettings):
+    out = C.create_string_buffer(48 * n)
+    rc = lib().kzgamd_blob_to_kzg_commitment_batch(out, blobs, n, C.byref(settings.c))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("kzgamd_blob_to_kzg_commitment_batch: C_KZG_RET %d" % rc)
+    return [out.raw[48 * i:48 * i + 48] for i in range(n)]
+
+
+def blob_to_kzg_commitment_device(d_out, d_status, d_scratch, d_blobs, n, settings, stream=0):
+    rc = lib().kzgamd_blob_to_kzg_commitment_device(C.c_void_p(d_out), C.c_void_p(d_status), C.c_void_p(d_scratch),
+                                                    C.c_void_p(d_blobs), n, C.byref(settings.c), C.c_void_p(stream))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("kzgamd_blob_to_kzg_commitment_device: C_KZG_RET %d" % rc)
+
+
+def msm_set_profile(handle, on=True):
+    lib().kzgamd_msm_set_profile(C.c_void_p(handle), 1 if on else 0)
+
+
+def msm_get_profile(handle):
+    a, t = C.c_float(), C.c_float()
+    if lib().kzgamd_msm_get_profile(C.c_void_p(handle), C.byref(a), C.byref(t)) != 0:
+        return None
+    return a.value, t.value

@@ -1,0 +1,432 @@
+// c-kzg-4844 surface (B3) for the proving path, MI355X-native.
+// Replaces blst/src/eip_4844.rs:160-530 + the generic protocol code it calls
+// (kzg/src/eip_4844.rs).  The CKZGSettings struct has the reference's layout
+// (kzg/src/eth/c_bindings.rs:55-108); the device-resident state (fixed-base MSM table,
+// roots) hangs off a registry keyed by the settings' g1_values_lagrange_brp pointer —
+// the same trick the reference uses for its precomputation tables
+// (PrecomputationTableManager, kzg/src/eip_4844.rs:64-146).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kzg_mi355x.h"
+#include "ckzg_internal.h"
+#include "fr_host.h"
+#include "g1_io.cuh"
+#include "msm_internal.h"
+#include "sha256.h"
+
+using ff::u32;
+using ff::u64;
+using g1::AffPt;
+
+namespace {
+
+struct CkErr {
+    C_KZG_RET rc;
+    std::string what;
+};
+#define CK_HIP(x)                                                                         \
+    do {                                                                                  \
+        hipError_t _e = (x);                                                              \
+        if (_e != hipSuccess) throw CkErr{C_KZG_ERROR, std::string(#x) + ": " + hipGetErrorString(_e)}; \
+    } while (0)
+#define CK_REQUIRE(cond, msg)                      \
+    do {                                           \
+        if (!(cond)) throw CkErr{C_KZG_BADARGS, msg}; \
+    } while (0)
+
+constexpr size_t N = FIELD_ELEMENTS_PER_BLOB;
+constexpr size_t NUM_G2 = 65;
+
+// ---------------------------------------------------------------- kernels
+
+__global__ void __launch_bounds__(128) k_uncompress(AffPt* __restrict__ out, int* __restrict__ bad,
+                                                    const unsigned char* __restrict__ in, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned char buf[48];
+    for (int k = 0; k < 48; ++k) buf[k] = in[48 * i + k];
+    AffPt p;
+    if (!g1io::uncompress(p, buf)) atomicAdd(bad, 1);
+    out[i] = p;
+}
+
+// AffPt -> blst_p1 (Jacobian, Z = one; infinity = all-zero) for the CKZGSettings arrays
+__global__ void __launch_bounds__(256) k_affpt_to_blst_p1(ff::Fp* __restrict__ out, const AffPt* __restrict__ in, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    AffPt p = in[i];
+    if (p.flags & 1) {
+        out[3 * i] = ff::Fp::zero();
+        out[3 * i + 1] = ff::Fp::zero();
+        out[3 * i + 2] = ff::Fp::zero();
+    } else {
+        out[3 * i] = fp28::to_blst(p.x);
+        out[3 * i + 1] = fp28::to_blst(p.y);
+        out[3 * i + 2] = ff::Fp::one();
+    }
+}
+
+// blob bytes (4096 x 32 B big-endian) -> canonical little-endian scalars; status[b] = 1 if any element >= r
+// (bytes_to_blob / FsFr::from_bytes, kzg/src/eip_4844.rs:867-880, blst/src/types/fr.rs:64-86)
+__global__ void __launch_bounds__(256) k_blob_to_scalars(u32* __restrict__ out, int* __restrict__ status,
+                                                         const u32* __restrict__ blobs, size_t nblobs) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblobs * N) return;
+    u32 w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = __builtin_bswap32(blobs[t * 8 + (7 - k)]);
+    // w >= r ?
+    u64 borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        u64 d = (u64)w[k] - ff::FrParams::p(k) - borrow;
+        borrow = (d >> 32) & 1;
+    }
+    if (!borrow) status[t / N] = 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[t * 8 + k] = w[k];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- settings object
+struct KzgAmdSettings {
+    int device = 0;
+    kzgamd::MsmContext* msm = nullptr;  // prepared over g1_lagrange_brp
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    // staging for the host-buffer entry points
+    unsigned char* d_blobs = nullptr;
+    u32* d_scalars = nullptr;
+    int* d_status = nullptr;
+    unsigned char* d_out = nullptr;
+    size_t cap_blobs = 0;
+    std::vector<ff::Fr> brp_roots;  // brp_roots_of_unity[0..8192) (host copy, Montgomery)
+    ~KzgAmdSettings() {
+        if (msm) kzgamd::msm_destroy(msm);
+        if (d_blobs) (void)hipFree(d_blobs);
+        if (d_scalars) (void)hipFree(d_scalars);
+        if (d_status) (void)hipFree(d_status);
+        if (d_out) (void)hipFree(d_out);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    void ensure(size_t nblobs) {
+        if (nblobs <= cap_blobs) return;
+        if (d_blobs) (void)hipFree(d_blobs);
+        if (d_scalars) (void)hipFree(d_scalars);
+        if (d_status) (void)hipFree(d_status);
+        if (d_out) (void)hipFree(d_out);
+        d_blobs = nullptr;
+        d_scalars = nullptr;
+        d_status = nullptr;
+        d_out = nullptr;
+        cap_blobs = 0;
+        CK_HIP(hipMalloc(&d_blobs, nblobs * BYTES_PER_BLOB));
+        CK_HIP(hipMalloc(&d_scalars, nblobs * BYTES_PER_BLOB));
+        CK_HIP(hipMalloc(&d_status, nblobs * sizeof(int)));
+        CK_HIP(hipMalloc(&d_out, nblobs * 48));
+        cap_blobs = nblobs;
+    }
+};
+
+namespace {
+
+std::mutex g_registry_mu;
+std::map<const void*, KzgAmdSettings*> g_registry;
+
+KzgAmdSettings* lookup(const CKZGSettings* s) {
+    if (!s || !s->g1_values_lagrange_brp) return nullptr;
+    std::lock_guard<std::mutex> lk(g_registry_mu);
+    auto it = g_registry.find(s->g1_values_lagrange_brp);
+    return it == g_registry.end() ? nullptr : it->second;
+}
+
+size_t reverse_bits(size_t v, unsigned bits) {
+    size_t r = 0;
+    for (unsigned b = 0; b < bits; ++b)
+        if (v & ((size_t)1 << b)) r |= (size_t)1 << (bits - 1 - b);
+    return r;
+}
+
+// ---- trusted setup text (kzg/src/eip_4844.rs:151-228) ----
+bool is_ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+int hexval(unsigned char c) {
+    if (c >= '0' && c <= '9') return c - '0';
+    if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+    if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+    return -1;
+}
+bool scan_number(const std::string& s, size_t& off, size_t& out) {
+    while (off < s.size() && is_ws((unsigned char)s[off])) ++off;
+    if (off >= s.size()) return false;
+    size_t start = off;
+    while (off < s.size() && s[off] >= '0' && s[off] <= '9') ++off;
+    if (off >= s.size() || off == start || off - start > 18) return false;
+    out = 0;
+    for (size_t i = start; i < off; ++i) out = out * 10 + (size_t)(s[i] - '0');
+    return true;
+}
+bool scan_hex_byte(const std::string& s, size_t& off, uint8_t& out) {
+    while (off < s.size() && is_ws((unsigned char)s[off])) ++off;
+    if (off >= s.size()) return false;
+    int hi = hexval((unsigned char)s[off]);
+    if (hi < 0) return false;
+    if (off + 1 < s.size() && hexval((unsigned char)s[off + 1]) >= 0) {
+        out = (uint8_t)(hi * 16 + hexval((unsigned char)s[off + 1]));
+        off += 2;
+    } else {
+        out = (uint8_t)hi;
+        off += 1;
+    }
+    return true;
+}
+void parse_setup_text(const std::string& text, std::vector<uint8_t>& g1_mono, std::vector<uint8_t>& g1_lag,
+                      std::vector<uint8_t>& g2_mono) {
+    size_t off = 0, n1 = 0, n2 = 0;
+    CK_REQUIRE(scan_number(text, off, n1) && n1 == N, "Incorrect trusted setup format");
+    CK_REQUIRE(scan_number(text, off, n2) && n2 == NUM_G2, "Incorrect trusted setup format");
+    g1_lag.resize(48 * N);
+    g2_mono.resize(96 * NUM_G2);
+    g1_mono.resize(48 * N);
+    for (auto& b : g1_lag) CK_REQUIRE(scan_hex_byte(text, off, b), "Incorrect trusted setup format");
+    for (auto& b : g2_mono) CK_REQUIRE(scan_hex_byte(text, off, b), "Incorrect trusted setup format");
+    for (auto& b : g1_mono) CK_REQUIRE(scan_hex_byte(text, off, b), "Incorrect trusted setup format");
+}
+
+template <class T>
+T* leak_array(size_t n) {
+    T* p = (T*)calloc(n, sizeof(T));
+    if (!p) throw CkErr{C_KZG_MALLOC, "out of memory"};
+    return p;
+}
+
+void zero_settings(CKZGSettings* out) { memset(out, 0, sizeof *out); }
+
+void free_host_arrays(CKZGSettings* s) {
+    free(s->roots_of_unity);
+    free(s->brp_roots_of_unity);
+    free(s->reverse_roots_of_unity);
+    free(s->g1_values_monomial);
+    free(s->g1_values_lagrange_brp);
+    free(s->g2_values_monomial);
+    zero_settings(s);
+}
+
+// load_trusted_setup_rust (kzg/src/eip_4844.rs:1022-1086) with the G1 work on the device
+void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint8_t* g1_lag, size_t n1l,
+               const uint8_t* g2_mono, size_t n2) {
+    CK_REQUIRE(n1m / 48 == N && n1m % 48 == 0, "Invalid number of G1 points");
+    CK_REQUIRE(n1l / 48 == N && n1l % 48 == 0, "Invalid number of G1 points");
+    CK_REQUIRE(n2 / 96 == NUM_G2 && n2 % 96 == 0, "Invalid number of G2 points");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw CkErr{C_KZG_ERROR, "no gfx950 device visible"};
+    // G2 points are only consumed by the pairing-based verifiers, which are outside this
+    // library's path; the encoding flags are sanity-checked, the points are not decoded.
+    for (size_t i = 0; i < NUM_G2; ++i) CK_REQUIRE((g2_mono[96 * i] & 0x80) != 0, "Invalid G2 point");
+
+    auto* dev = new KzgAmdSettings();
+    unsigned char* d_bytes = nullptr;
+    AffPt* d_pts = nullptr;
+    int* d_bad = nullptr;
+    ff::Fp* d_p1 = nullptr;
+    try {
+        CK_HIP(hipGetDevice(&dev->device));
+        CK_HIP(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
+        // bytes: [0,N) monomial, [N,2N) Lagrange in bit-reversed order (reverse_bit_order, eip_4844.rs:1070)
+        std::vector<uint8_t> stage(2 * N * 48);
+        memcpy(stage.data(), g1_mono, N * 48);
+        for (size_t i = 0; i < N; ++i) memcpy(&stage[(N + i) * 48], g1_lag + 48 * reverse_bits(i, 12), 48);
+        CK_HIP(hipMalloc(&d_bytes, stage.size()));
+        CK_HIP(hipMalloc(&d_pts, 2 * N * sizeof(AffPt)));
+        CK_HIP(hipMalloc(&d_bad, sizeof(int)));
+        CK_HIP(hipMalloc(&d_p1, 2 * N * 144));
+        CK_HIP(hipMemcpyAsync(d_bytes, stage.data(), stage.size(), hipMemcpyHostToDevice, dev->stream));
+        CK_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), dev->stream));
+        hipLaunchKernelGGL(k_uncompress, dim3((unsigned)((2 * N + 127) / 128)), dim3(128), 0, dev->stream, d_pts, d_bad,
+                           d_bytes, 2 * N);
+        hipLaunchKernelGGL(k_affpt_to_blst_p1, dim3((unsigned)((2 * N + 255) / 256)), dim3(256), 0, dev->stream, d_p1,
+                           d_pts, 2 * N);
+        int bad = 0;
+        CK_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, dev->stream));
+        CK_HIP(hipStreamSynchronize(dev->stream));
+        CK_REQUIRE(bad == 0, "Invalid G1 point in trusted setup");
+
+        out->g1_values_monomial = leak_array<blst_p1>(N);
+        out->g1_values_lagrange_brp = leak_array<blst_p1>(N);
+        CK_HIP(hipMemcpy(out->g1_values_monomial, d_p1, N * 144, hipMemcpyDeviceToHost));
+        CK_HIP(hipMemcpy(out->g1_values_lagrange_brp, d_p1 + 3 * N, N * 144, hipMemcpyDeviceToHost));
+
+        // fixed-base MSM table over the bit-reversed Lagrange points (FsKZGSettings::new ->
+        // prepare_msm, blst/src/types/kzg_settings.rs:109-123)
+        dev->msm = kzgamd::msm_create(d_pts + N, N, true, true, true);
+
+        // Lagrange-form sanity check.  The reference compares two pairings
+        // (is_trusted_setup_in_lagrange_form, eip_4844.rs:1005-1020); the pairing is outside this
+        // path, so the equivalent group identity is used instead: the Lagrange basis sums to one,
+        // i.e. sum_i L_i(tau)*G == G == g1_monomial[0].  A monomial-form file fails it.
+        {
+            std::vector<ff::Fr> ones(N, ff::Fr::one());
+            blst_p1 sum;
+            kzgamd::msm_run_host(dev->msm, &sum, ones.data(), N, 1);
+            CK_REQUIRE(kzgamd::host_p1_equal(&sum, &out->g1_values_monomial[0]), "Trusted setup is not in Lagrange form");
+        }
+
+        // FsFFTSettings::new(13) (blst/src/types/fft_settings.rs:30-58)
+        const size_t W = 2 * N;
+        out->roots_of_unity = leak_array<blst_fr>(W + 1);
+        out->reverse_roots_of_unity = leak_array<blst_fr>(W + 1);
+        out->brp_roots_of_unity = leak_array<blst_fr>(W);
+        std::vector<ff::Fr> roots;
+        kzgamd::expand_roots(roots, 13);
+        dev->brp_roots.resize(W);
+        for (size_t i = 0; i <= W; ++i) {
+            memcpy(&out->roots_of_unity[i], &roots[i], 32);
+            memcpy(&out->reverse_roots_of_unity[i], &roots[W - i], 32);
+        }
+        for (size_t i = 0; i < W; ++i) {
+            dev->brp_roots[i] = roots[reverse_bits(i, 13)];
+            memcpy(&out->brp_roots_of_unity[i], &dev->brp_roots[i], 32);
+        }
+        // g2_values_monomial / x_ext_fft_columns / tables stay NULL: pairing and FK20 state are not
+        // part of this path (blst/src/eip_4844.rs:140-142 leaves tables/wbits/scratch_size empty too)
+        (void)hipFree(d_bytes);
+        (void)hipFree(d_pts);
+        (void)hipFree(d_bad);
+        (void)hipFree(d_p1);
+        std::lock_guard<std::mutex> lk(g_registry_mu);
+        g_registry[out->g1_values_lagrange_brp] = dev;
+    } catch (...) {
+        if (d_bytes) (void)hipFree(d_bytes);
+        if (d_pts) (void)hipFree(d_pts);
+        if (d_bad) (void)hipFree(d_bad);
+        if (d_p1) (void)hipFree(d_p1);
+        delete dev;
+        free_host_arrays(out);
+        throw;
+    }
+}
+
+// device pipeline: blobs (device) -> 48-byte commitments (device)
+void commit_enqueue(KzgAmdSettings* dev, void* d_out, int* d_status, const void* d_blobs, u32* d_scalars, size_t n,
+                    hipStream_t stream) {
+    CK_HIP(hipMemsetAsync(d_status, 0, n * sizeof(int), stream));
+    hipLaunchKernelGGL(k_blob_to_scalars, dim3((unsigned)((n * N + 255) / 256)), dim3(256), 0, stream, d_scalars, d_status,
+                       (const u32*)d_blobs, n);
+    kzgamd::msm_lock(dev->msm);
+    try {
+        kzgamd::msm_enqueue(dev->msm, d_out, d_scalars, N, n, 0, stream, kzgamd::OUT_COMPRESSED);
+    } catch (...) {
+        kzgamd::msm_unlock(dev->msm);
+        throw;
+    }
+    kzgamd::msm_unlock(dev->msm);
+}
+
+template <class F>
+C_KZG_RET guarded(F&& f) {
+    try {
+        f();
+        return C_KZG_OK;
+    } catch (const CkErr& e) {
+        if (getenv("KZGAMD_DEBUG")) fprintf(stderr, "kzg_mi355x: %s\n", e.what.c_str());
+        return e.rc == C_KZG_MALLOC ? C_KZG_MALLOC : C_KZG_BADARGS;  // the reference maps every failure to BadArgs
+    } catch (const std::bad_alloc&) {
+        return C_KZG_MALLOC;
+    } catch (...) {
+        return C_KZG_BADARGS;
+    }
+}
+
+}  // namespace
+
+KzgAmdSettings* kzgamd::device_settings(const CKZGSettings* s) { return lookup(s); }
+
+// ---------------------------------------------------------------- C ABI (B3)
+
+extern "C" C_KZG_RET load_trusted_setup(CKZGSettings* out, const uint8_t* g1_monomial_bytes, uint64_t num_g1_monomial_bytes,
+                                        const uint8_t* g1_lagrange_bytes, uint64_t num_g1_lagrange_bytes,
+                                        const uint8_t* g2_monomial_bytes, uint64_t num_g2_monomial_bytes,
+                                        uint64_t precompute) {
+    (void)precompute;
+    if (!out) return C_KZG_BADARGS;
+    zero_settings(out);
+    if (!g1_monomial_bytes || !g1_lagrange_bytes || !g2_monomial_bytes) return C_KZG_BADARGS;
+    return guarded([&] {
+        load_impl(out, g1_monomial_bytes, num_g1_monomial_bytes, g1_lagrange_bytes, num_g1_lagrange_bytes, g2_monomial_bytes,
+                  num_g2_monomial_bytes);
+    });
+}
+
+extern "C" C_KZG_RET load_trusted_setup_file(CKZGSettings* out, FILE* in) {
+    if (!out) return C_KZG_BADARGS;
+    zero_settings(out);
+    if (!in) return C_KZG_BADARGS;
+    return guarded([&] {
+        std::string buf(1024 * 1024, '\0');  // the reference reads at most 1 MiB (blst/src/eip_4844.rs:244-246)
+        size_t len = fread(&buf[0], 1, buf.size(), in);
+        buf.resize(len);
+        std::vector<uint8_t> g1m, g1l, g2m;
+        parse_setup_text(buf, g1m, g1l, g2m);
+        load_impl(out, g1m.data(), g1m.size(), g1l.data(), g1l.size(), g2m.data(), g2m.size());
+    });
+}
+
+extern "C" void free_trusted_setup(CKZGSettings* s) {
+    if (!s) return;
+    KzgAmdSettings* dev = nullptr;
+    if (s->g1_values_lagrange_brp) {
+        std::lock_guard<std::mutex> lk(g_registry_mu);
+        auto it = g_registry.find(s->g1_values_lagrange_brp);
+        if (it != g_registry.end()) {
+            dev = it->second;
+            g_registry.erase(it);
+        }
+    }
+    delete dev;
+    free_host_arrays(s);
+}
+
+extern "C" C_KZG_RET kzgamd_blob_to_kzg_commitment_batch(KZGCommitment* out, const Blob* blobs, size_t n,
+                                                         const CKZGSettings* s) {
+    if (!out || !blobs) return C_KZG_BADARGS;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    if (n == 0) return C_KZG_OK;
+    return guarded([&] {
+        std::lock_guard<std::mutex> lk(dev->mu);
+        CK_HIP(hipSetDevice(dev->device));
+        dev->ensure(n);
+        CK_HIP(hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream));
+        commit_enqueue(dev, dev->d_out, dev->d_status, dev->d_blobs, dev->d_scalars, n, dev->stream);
+        std::vector<int> status(n);
+        CK_HIP(hipMemcpyAsync(status.data(), dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
+        CK_HIP(hipMemcpyAsync(out, dev->d_out, n * 48, hipMemcpyDeviceToHost, dev->stream));
+        CK_HIP(hipStreamSynchronize(dev->stream));
+        for (size_t i = 0; i < n; ++i) CK_REQUIRE(status[i] == 0, "Invalid scalar");
+    });
+}
+
+extern "C" C_KZG_RET blob_to_kzg_commitment(KZGCommitment* out, const Blob* blob, const CKZGSettings* s) {
+    return kzgamd_blob_to_kzg_commitment_batch(out, blob, 1, s);
+}
+
+extern "C" C_KZG_RET kzgamd_blob_to_kzg_commitment_device(void* d_out, void* d_status, void* d_scratch, const void* d_blobs,
+                                                          size_t n, const CKZGSettings* s, void* stream) {
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev || !d_out || !d_status || !d_scratch || !d_blobs) return C_KZG_BADARGS;
+    if (n == 0) return C_KZG_OK;
+    return guarded([&] { commit_enqueue(dev, d_out, (int*)d_status, d_blobs, (u32*)d_scratch, n, (hipStream_t)stream); });
+}
+
+extern "C" void* kzgamd_settings_msm_handle(const CKZGSettings* s) {
+    KzgAmdSettings* dev = lookup(s);
+    return dev ? (void*)dev->msm : nullptr;
+}

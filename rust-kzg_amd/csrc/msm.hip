@@ -26,7 +26,7 @@
 #include <vector>
 
 #include "../../include/kzg_mi355x.h"
-#include "g1_28.cuh"
+#include "g1_io.cuh"
 #include "msm_internal.h"
 
 using ff::u32;
@@ -301,8 +301,8 @@ __global__ void __launch_bounds__(256) k_setsum(const Xyzz* __restrict__ segout,
 }
 
 // one lane per MSM: Horner over windows (unprepared) and conversion to blst Jacobian
-__global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ setout, ff::Fp* __restrict__ out, size_t nbatch,
-                                              int nwin, int c, int prepared) {
+__global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ setout, void* __restrict__ out_v, size_t nbatch,
+                                              int nwin, int c, int prepared, int out_mode) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbatch) return;
     Xyzz acc;
@@ -323,11 +323,27 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ setout, f
             g1::dadd(acc, r);
         }
     }
+    if (out_mode == kzgamd::OUT_COMPRESSED) {
+        unsigned char buf[48];
+        g1io::compress(buf, acc);
+        u32* o = (u32*)out_v + 12 * b;
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            o[k] = (u32)buf[4 * k] | ((u32)buf[4 * k + 1] << 8) | ((u32)buf[4 * k + 2] << 16) | ((u32)buf[4 * k + 3] << 24);
+        return;
+    }
+    ff::Fp* out = (ff::Fp*)out_v;
     ff::Fp j[3];
     g1::to_blst_jacobian(j, acc);
     out[3 * b] = j[0];
     out[3 * b + 1] = j[1];
     out[3 * b + 2] = j[2];
+}
+
+// device copy of already-converted table slots (row 0)
+__global__ void __launch_bounds__(256) k_copy_affpt(AffPt* __restrict__ dst, const AffPt* __restrict__ src, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 
 // ---------------------------------------------------------------- host side
@@ -394,9 +410,14 @@ struct kzgamd::MsmContext {
     DevBuf<AffPt> table;  // rows x n (prepared) or n
     Workspace ws;
     hipStream_t stream = nullptr;
+    bool profile = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start, accum-begin, accum-end, end
+    bool ev_valid = false;
     ~MsmContext() {
         table.release();
         ws.release();
+        for (auto& e : ev)
+            if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -410,7 +431,7 @@ static void require_device() {
 }
 
 // uploads points (host or device pointer), builds the fixed-base rows when `prepare`
-MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare) {
+MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare, bool points_are_affpt) {
     require_device();
     auto* ctx = new MsmContext();
     try {
@@ -424,12 +445,19 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         ctx->table.ensure((size_t)ctx->rows * n);
         DevBuf<ff::Fp> staging;
         const ff::Fp* src = (const ff::Fp*)points;
-        if (!points_on_device) {
-            staging.ensure(2 * n);
-            HIP_TRY(hipMemcpyAsync(staging.p, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
-            src = staging.p;
+        if (points_are_affpt) {
+            if (!points_on_device) throw HipErr{hipErrorInvalidValue, "AffPt input must be device-resident"};
+            hipLaunchKernelGGL(k_copy_affpt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->table.p,
+                               (const AffPt*)points, n);
+        } else {
+            if (!points_on_device) {
+                staging.ensure(2 * n);
+                HIP_TRY(hipMemcpyAsync(staging.p, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
+                src = staging.p;
+            }
+            hipLaunchKernelGGL(k_points_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->table.p, src,
+                               n);
         }
-        hipLaunchKernelGGL(k_points_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->table.p, src, n);
         if (prepare && ctx->rows > 1)
             hipLaunchKernelGGL(k_table_rows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, ctx->table.p, n,
                                ctx->rows, ctx->c);
@@ -447,7 +475,7 @@ void msm_destroy(MsmContext* ctx) { delete ctx; }
 
 // enqueue nbatch MSMs over the first npoints bases; d_scalars / d_out device pointers
 void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npoints, size_t nbatch, int mont,
-                 hipStream_t stream) {
+                 hipStream_t stream, int out_mode) {
     if (npoints > ctx->n) throw HipErr{hipErrorInvalidValue, "npoints exceeds the prepared size"};
     if (nbatch == 0) return;
     const int c = ctx->c;
@@ -457,6 +485,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     const size_t set_cap = ctx->prepared ? npoints * (size_t)nwin : npoints;
     const size_t nseg = (nb + SEG - 1) / SEG;
     if (npoints == 0) {
+        if (out_mode == OUT_COMPRESSED) throw HipErr{hipErrorInvalidValue, "empty MSM in compressed mode"};
         HIP_TRY(hipMemsetAsync(d_out, 0, nbatch * 144, stream));
         return;
     }
@@ -469,6 +498,11 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     ws.segout.ensure(nsets * nseg);
     ws.setout.ensure(nsets);
     DigitParams P{npoints, nbatch, c, nwin, ctx->prepared ? 1 : 0, mont, nb, ctx->n};
+    if (ctx->profile) {
+        for (auto& e : ctx->ev)
+            if (!e) HIP_TRY(hipEventCreate(&e));
+        HIP_TRY(hipEventRecord(ctx->ev[0], stream));
+    }
     HIP_TRY(hipMemsetAsync(ws.counts.p, 0, nsets * nb * sizeof(u32), stream));
     const unsigned gdig = (unsigned)((npoints * nbatch + 255) / 256);
     hipLaunchKernelGGL(k_digits<0>, dim3(gdig), dim3(256), 0, stream, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
@@ -476,15 +510,35 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     hipLaunchKernelGGL(k_scan, dim3((unsigned)nsets), dim3(1024), 0, stream, ws.counts.p, ws.offsets.p, nb);
     hipLaunchKernelGGL(k_digits<1>, dim3(gdig), dim3(256), 0, stream, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
                        (const u32*)ws.offsets.p, ws.sorted.p, set_cap);
+    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[1], stream));
     hipLaunchKernelGGL(k_accum, dim3((unsigned)((nsets * nb + 255) / 256)), dim3(256), 0, stream, (const u32*)ws.offsets.p,
                        (const u32*)ws.sorted.p, (const AffPt*)ctx->table.p, ws.buckets.p, nb, nsets, set_cap);
+    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[2], stream));
     hipLaunchKernelGGL(k_reduce, dim3((unsigned)((nsets * nseg + 127) / 128)), dim3(128), 0, stream,
                        (const Xyzz*)ws.buckets.p, ws.segout.p, nb, nsets);
     hipLaunchKernelGGL(k_setsum, dim3((unsigned)nsets), dim3(256), 256 * sizeof(Xyzz), stream, (const Xyzz*)ws.segout.p,
                        ws.setout.p, nseg);
     hipLaunchKernelGGL(k_final, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)ws.setout.p,
-                       (ff::Fp*)d_out, nbatch, nwin, c, ctx->prepared ? 1 : 0);
+                       d_out, nbatch, nwin, c, ctx->prepared ? 1 : 0, out_mode);
+    if (ctx->profile) {
+        HIP_TRY(hipEventRecord(ctx->ev[3], stream));
+        ctx->ev_valid = true;
+    }
     HIP_TRY(hipGetLastError());
+}
+
+void msm_lock(MsmContext* ctx) { ctx->mu.lock(); }
+void msm_unlock(MsmContext* ctx) { ctx->mu.unlock(); }
+void msm_set_profile(MsmContext* ctx, bool on) {
+    ctx->profile = on;
+    ctx->ev_valid = false;
+}
+bool msm_get_profile(MsmContext* ctx, float* accum_ms, float* total_ms) {
+    if (!ctx->profile || !ctx->ev_valid) return false;
+    if (hipEventSynchronize(ctx->ev[3]) != hipSuccess) return false;
+    if (hipEventElapsedTime(accum_ms, ctx->ev[1], ctx->ev[2]) != hipSuccess) return false;
+    if (hipEventElapsedTime(total_ms, ctx->ev[0], ctx->ev[3]) != hipSuccess) return false;
+    return true;
 }
 
 // host buffers in, host buffers out
@@ -495,7 +549,7 @@ void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoint
     ctx->ws.out.ensure(nbatch * 3 + 3);
     if (npoints * nbatch)
         HIP_TRY(hipMemcpyAsync(ctx->ws.scalars.p, scalars, nbatch * npoints * 32, hipMemcpyHostToDevice, ctx->stream));
-    msm_enqueue(ctx, ctx->ws.out.p, ctx->ws.scalars.p, npoints, nbatch, 1, ctx->stream);
+    msm_enqueue(ctx, ctx->ws.out.p, ctx->ws.scalars.p, npoints, nbatch, 1, ctx->stream, OUT_JACOBIAN);
     HIP_TRY(hipMemcpyAsync(out, ctx->ws.out.p, nbatch * 144, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
 }
@@ -520,7 +574,7 @@ static RustError guarded(F&& f) {
 extern "C" void* prepare_msm(const blst_p1_affine points[], size_t npoints) {
     try {
         if (!points || npoints == 0) return nullptr;
-        return kzgamd::msm_create(points, npoints, false, true);
+        return kzgamd::msm_create(points, npoints, false, true, false);
     } catch (const HipErr& e) {
         fprintf(stderr, "kzg_mi355x: prepare_msm failed: %s: %s\n", e.what, hipGetErrorString(e.e));
         return nullptr;
@@ -551,7 +605,7 @@ extern "C" RustError mult_pippenger(blst_p1* out, const blst_p1_affine points[],
             memset(out, 0, sizeof *out);
             return;
         }
-        MsmContext* ctx = kzgamd::msm_create(points, npoints, false, false);
+        MsmContext* ctx = kzgamd::msm_create(points, npoints, false, false, false);
         try {
             kzgamd::msm_run_host(ctx, out, scalars, npoints, 1);
         } catch (...) {
@@ -568,7 +622,7 @@ extern "C" RustError kzgamd_msm_prepared_batch_device(void* msm, void* d_out, co
     return guarded([&] {
         MsmContext* ctx = (MsmContext*)msm;
         std::lock_guard<std::mutex> lk(ctx->mu);
-        kzgamd::msm_enqueue(ctx, d_out, d_scalars, npoints, nbatch, scalars_mont, (hipStream_t)stream);
+        kzgamd::msm_enqueue(ctx, d_out, d_scalars, npoints, nbatch, scalars_mont, (hipStream_t)stream, kzgamd::OUT_JACOBIAN);
     });
 }
 
@@ -580,6 +634,16 @@ extern "C" int kzgamd_msm_info(void* msm, int* window_bits, int* rows, size_t* n
     if (nbuckets) *nbuckets = ctx->nb;
     if (npoints) *npoints = ctx->n;
     return 0;
+}
+
+extern "C" int kzgamd_msm_set_profile(void* msm, int on) {
+    if (!msm) return 1;
+    kzgamd::msm_set_profile((MsmContext*)msm, on != 0);
+    return 0;
+}
+extern "C" int kzgamd_msm_get_profile(void* msm, float* accum_ms, float* total_ms) {
+    if (!msm || !accum_ms || !total_ms) return 1;
+    return kzgamd::msm_get_profile((MsmContext*)msm, accum_ms, total_ms) ? 0 : 1;
 }
 
 extern "C" int kzgamd_device_count(void) {

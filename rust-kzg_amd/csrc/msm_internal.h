@@ -5,11 +5,17 @@
 
 namespace kzgamd {
 struct MsmContext;
-// points: blst_p1_affine[n] (host or device); prepare = build fixed-base rows
-MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare);
+enum { OUT_JACOBIAN = 0, OUT_COMPRESSED = 1 };
+// points: blst_p1_affine[n] (host or device) or g1::AffPt[n] (device); prepare = build fixed-base rows
+MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare, bool points_are_affpt);
 void msm_destroy(MsmContext* ctx);
-// enqueue nbatch MSMs (device pointers, no sync); d_out = blst_p1[nbatch]
+// enqueue nbatch MSMs (device pointers, no sync); d_out = blst_p1[nbatch] or 48-byte compressed points
 void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npoints, size_t nbatch, int mont,
-                 hipStream_t stream);
+                 hipStream_t stream, int out_mode);
 void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoints, size_t nbatch);
+void msm_lock(MsmContext* ctx);
+void msm_unlock(MsmContext* ctx);
+// per-kernel timing of the last enqueue (events on the launch stream); ms < 0 when disabled
+void msm_set_profile(MsmContext* ctx, bool on);
+bool msm_get_profile(MsmContext* ctx, float* accum_ms, float* total_ms);
 }  // namespace kzgamd
