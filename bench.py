@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py — blob_to_kzg_commitment throughput on MI355X (BASELINE.json metric).
+
+One step = one pass of the hot path over one batch of synthetic blobs per GPU:
+  B blobs (4096 x 32-byte field elements each, already resident in HBM)
+    -> canonical scalars -> fixed-base Pippenger MSM over the mainnet trusted setup
+    -> 48-byte compressed commitments (in HBM).
+Workload = BASELINE.json configs[1] (n = 4096 G1 MSM over the trusted-setup points, random Fr
+scalars), batched B per GPU; N > 1 shards whole blobs across ranks (weak scaling, no data-path
+collective).  Prints ONE JSON line on rank 0.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import ctypes as C
+import importlib.util
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+SETUP = os.path.join(ROOT, "tests", "golden", "trusted_setup.txt")
+BLOB = 131072
+N = 4096
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ALG_BYTES_PER_COMMIT = 128 * N             # 96 B point + 32 B scalar per pair
+ALG_ADDS_PER_COMMIT = 20 * N + 8192        # BGMW count for the fixed-base 4096 case
+# lane-level v_mad_u64_u32 issue peak: 1024 SIMDs x 64 lanes x 2.4 GHz / 5.5 cycles (tools/ffbench.hip)
+MAD_PEAK_PER_S = 1024 * 64 * 2.4e9 / 5.5
+
+
+def load_pkg():
+    path = os.path.join(ROOT, "rust-kzg_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location("rust_kzg_amd", path, submodule_search_locations=[os.path.dirname(path)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["rust_kzg_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def make_blobs(torch, nblobs, seed, device):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    b = torch.randint(0, 256, (nblobs, N, 32), dtype=torch.uint8, generator=g)
+    b[:, :, 0] = 0  # generate_random_blob_bytes: every element < r (kzg-bench/src/tests/eip_4844.rs:28-37)
+    return b.reshape(nblobs, BLOB).to(device)
+
+
+def cpu_baseline(blobs_host, budget_s=12.0):
+    """Times the CPU oracle (portable C restatement of the reference's Pippenger path — NOT blst asm)
+    on this box's host cores: one thread per core, each committing to its own blobs."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as O
+
+    L = O.lib()
+    with open(SETUP, "rb") as f:
+        rc, s = O.load_settings(f.read())
+    assert rc == 0
+    out = C.create_string_buffer(48)
+    t0 = time.perf_counter()
+    assert L.oblob_to_kzg_commitment(out, blobs_host[0], C.byref(s)) == 0
+    t1 = time.perf_counter() - t0
+    cores = os.cpu_count() or 1
+    per_thread = max(1, min(64, int(budget_s / max(t1, 1e-3) / 1.5)))
+    done = [0] * cores
+
+    def work(t):
+        o = C.create_string_buffer(48)
+        for k in range(per_thread):
+            L.oblob_to_kzg_commitment(o, blobs_host[(t + k) % len(blobs_host)], C.byref(s))
+            done[t] += 1
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    return {"value": sum(done) / dt, "unit": "commitments/s", "cores": cores, "kind": "port",
+            "single_thread_ms": t1 * 1e3,
+            "sample": "%d commitments (%d threads x %d, seeded random blobs, mainnet setup) in %.1f s; "
+                      "portable-C oracle (oracle/msm.c tiling Pippenger), not blst asm" % (sum(done), cores, per_thread, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="blobs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large", action="store_true", help="skip the 2^20-point MSM latency line")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    kzg = load_pkg()
+    settings = kzg.KZGSettings.from_file(SETUP)
+    handle = settings.msm_handle()
+    info = kzg.PreparedMsm.info(type("H", (), {"handle": handle})())
+
+    B = args.batch
+    blobs = make_blobs(torch, B, 4844 + rank, dev)
+    out = torch.zeros(B * 48, dtype=torch.uint8, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    scratch = torch.empty(B * BLOB, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        kzg.blob_to_kzg_commitment_device(out.data_ptr(), status.data_ptr(), scratch.data_ptr(), blobs.data_ptr(), B,
+                                          settings, stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    kzg.msm_set_profile(handle, True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    sync_all()
+    wall = time.perf_counter() - t0
+    prof = kzg.msm_get_profile(handle)
+    kzg.msm_set_profile(handle, False)
+    assert int(status.sum().item()) == 0
+    tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall_max = float(tmax.item())
+
+    total_commits = B * args.steps * world
+    value = total_commits / wall_max
+    res = {
+        "metric": "blob_to_kzg_commitment_per_s",
+        "value": value,
+        "unit": "commitments/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall_max / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32 (14x28-bit limbs, v_mad_u64_u32)",
+        "data": "synthetic: seeded random blobs (byte 0 of each element zeroed), Ethereum mainnet trusted setup",
+        "config": {"workload": "G1 Pippenger MSM n=4096 (EIP-4844 blob) x trusted-setup Lagrange points, "
+                               "blob bytes -> 48-byte commitment, batched",
+                   "blobs_per_gpu_per_step": B, "msm_window_bits": info["window_bits"], "table_rows": info["rows"],
+                   "parallelism": "blobs sharded across %d GPU(s), table replicated, no collective" % world},
+        "g1_adds_per_s": value * ALG_ADDS_PER_COMMIT,
+        "gpu_event_ms_per_step": e0.elapsed_time(e1) / args.steps,
+    }
+    if prof is not None:
+        accum_ms, total_ms, cnt = prof
+        alg_bytes = ALG_BYTES_PER_COMMIT * B
+        ach = alg_bytes / (accum_ms * 1e-3) / 1e9
+        res["roofline"] = {"bound": "hbm", "kernel": "k_accum", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "kernel_ms": accum_ms, "pipeline_ms": total_ms, "launches_averaged": cnt,
+                           "algorithmic_bytes_per_launch": alg_bytes,
+                           "note": "MSM is integer-VALU bound, not HBM bound (SURVEY §8d); see `valu`"}
+        # executed work of k_accum: ~20*4096 mixed adds per blob, 8 mul + 2 sqr each = 8*392 + 2*301 mads
+        mads = B * 20 * N * (8 * 392 + 2 * 301)
+        res["valu"] = {"bound": "int-mad issue", "achieved": mads / (accum_ms * 1e-3), "peak": MAD_PEAK_PER_S,
+                       "unit": "lane v_mad_u64_u32/s", "frac": mads / (accum_ms * 1e-3) / MAD_PEAK_PER_S}
+
+    # second half of the metric: 2^20-point G1 MSM latency (variable-base engine, device-resident inputs)
+    if not args.no_large and rank == 0:
+        n = 1 << 20
+        pts = torch.empty(n * 96, dtype=torch.uint8, device=dev)
+        kzg.generate_points(pts.data_ptr(), n, 2, stream)
+        g = torch.Generator(device="cpu")
+        g.manual_seed(2)
+        sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g)
+        sc[:, 31] &= 0x3f  # little-endian canonical scalars < 2^254 < r
+        sc = sc.to(dev)
+        big = kzg.DeviceMsm(pts.data_ptr(), n, False)
+        o = torch.zeros(144, dtype=torch.uint8, device=dev)
+        kzg.msm_prepared_batch_device(big, o.data_ptr(), sc.data_ptr(), n, 1, False, stream)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            kzg.msm_prepared_batch_device(big, o.data_ptr(), sc.data_ptr(), n, 1, False, stream)
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        res["msm_2p20_ms"] = min(ts)
+        res["msm_2p20_pairs_per_s"] = n / (min(ts) * 1e-3)
+        big.close()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        host = blobs[: min(B, 64)].cpu().numpy()
+        res["cpu_baseline"] = cpu_baseline([host[i].tobytes() for i in range(host.shape[0])])
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res))
+    settings.close()
+
+
+if __name__ == "__main__":
+    main()

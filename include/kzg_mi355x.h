@@ -53,9 +53,15 @@ RustError kzgamd_msm_prepared_batch_device(void *msm, void *d_out, const void *d
 /* introspection for benches/tests: window bits, table rows, buckets of a handle */
 int kzgamd_msm_info(void *msm, int *window_bits, int *rows, size_t *nbuckets, size_t *npoints);
 /* HIP-event timing of the bucket-accumulation kernel (k_accum) and of the whole enqueue, recorded on
- * the launch stream of the most recent enqueue; get returns non-zero until a profiled enqueue has run */
+ * the launch stream; set(on) resets; get returns the number of enqueues averaged (-1 if none) */
 int kzgamd_msm_set_profile(void *msm, int on);
 int kzgamd_msm_get_profile(void *msm, float *accum_ms, float *total_ms);
+/* Handle over DEVICE-resident bases (blst_p1_affine[npoints] in HBM); prepare != 0 builds the fixed-base
+ * rows like prepare_msm, 0 gives the variable-base engine mult_pippenger uses. */
+void *kzgamd_msm_create_device(const void *d_points_affine, size_t npoints, int prepare);
+/* bench/test utility: npoints distinct G1 points h_i*G (h_i from splitmix64(seed,i), 248 bits) written
+ * as blst_p1_affine into device memory */
+RustError kzgamd_generate_points(void *d_out_affine, size_t npoints, uint64_t seed, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * B2 — NTT plug-in.  Replaces FFTFr::fft_fr / DASExtension::das_fft_extension for FsFFTSettings

@@ -51,7 +51,7 @@ _lib = None
 EXPORTS = [
     "prepare_msm", "mult_pippenger_prepared", "mult_pippenger", "free_msm", "mult_pippenger_prepared_batch",
     "kzgamd_msm_prepared_batch_device", "kzgamd_msm_info", "kzgamd_msm_set_profile", "kzgamd_msm_get_profile",
-    "kzgamd_device_count", "kzgamd_version",
+    "kzgamd_device_count", "kzgamd_version", "kzgamd_msm_create_device", "kzgamd_generate_points",
     "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
     "kzgamd_blob_to_kzg_commitment_batch", "kzgamd_blob_to_kzg_commitment_device", "kzgamd_settings_msm_handle",
 ]
@@ -99,6 +99,10 @@ def lib():
     L.kzgamd_msm_set_profile.argtypes = [vp, C.c_int]
     L.kzgamd_msm_get_profile.restype = C.c_int
     L.kzgamd_msm_get_profile.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.kzgamd_msm_create_device.restype = vp
+    L.kzgamd_msm_create_device.argtypes = [vp, sz, C.c_int]
+    L.kzgamd_generate_points.restype = RustError
+    L.kzgamd_generate_points.argtypes = [vp, sz, C.c_uint64, vp]
     sp = C.POINTER(CKZGSettings)
     L.load_trusted_setup.restype = C.c_int
     L.load_trusted_setup.argtypes = [sp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64,
@@ -288,7 +292,23 @@ def msm_set_profile(handle, on=True):
 
 
 def msm_get_profile(handle):
+    """(avg k_accum ms, avg whole-enqueue ms, enqueues averaged) or None"""
     a, t = C.c_float(), C.c_float()
-    if lib().kzgamd_msm_get_profile(C.c_void_p(handle), C.byref(a), C.byref(t)) != 0:
+    cnt = lib().kzgamd_msm_get_profile(C.c_void_p(handle), C.byref(a), C.byref(t))
+    if cnt <= 0:
         return None
-    return a.value, t.value
+    return a.value, t.value, cnt
+
+
+class DeviceMsm(PreparedMsm):
+    """Handle over device-resident bases (kzgamd_msm_create_device)."""
+
+    def __init__(self, d_points, npoints, prepare):
+        self.npoints = npoints
+        self.handle = lib().kzgamd_msm_create_device(C.c_void_p(d_points), npoints, 1 if prepare else 0)
+        if not self.handle:
+            raise KzgAmdError("kzgamd_msm_create_device failed")
+
+
+def generate_points(d_out, npoints, seed, stream=0):
+    _check(lib().kzgamd_generate_points(C.c_void_p(d_out), npoints, seed, C.c_void_p(stream)), "kzgamd_generate_points")

@@ -132,7 +132,7 @@ FF_HD Fe neg(const Fe& a) {
 // a*b*2^-392 mod p.  Product scanning with the Montgomery quotient digits
 // folded into the same column accumulators; two accumulators keep two mad
 // chains in flight.
-FF_HD Fe mul(const Fe& a, const Fe& b) {
+FF_HD Fe mul_inline(const Fe& a, const Fe& b) {
     u32 m[L];
     Fe r;
     u64 acc = 0;
@@ -164,7 +164,7 @@ FF_HD Fe mul(const Fe& a, const Fe& b) {
 }
 
 // a^2: the off-diagonal products are taken once against 2a.
-FF_HD Fe sqr(const Fe& a) {
+FF_HD Fe sqr_inline(const Fe& a) {
     u32 m[L], a2[L];
     Fe r;
 #pragma unroll
@@ -198,6 +198,33 @@ FF_HD Fe sqr(const Fe& a) {
     r.v[L - 1] = (u32)acc;
     return r;
 }
+
+// On the device mul/sqr are real (out-of-line) functions.  A point addition is ~10 of them; fully
+// inlined that is ~75 KB of straight-line code per loop iteration, which overflows the instruction
+// cache shared by neighbouring CUs and left the first k_accum 45x off its issue-bound time
+// (profiles/r01_bench_a.json).  Operands travel in VGPRs as 14-wide vectors (no scratch traffic).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef u32 fe_vec __attribute__((ext_vector_type(14)));
+__device__ __forceinline__ fe_vec to_vec(const Fe& a) {
+    fe_vec r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r[i] = a.v[i];
+    return r;
+}
+__device__ __forceinline__ Fe from_vec(fe_vec a) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.v[i] = a[i];
+    return r;
+}
+static __device__ __noinline__ fe_vec mul_call(fe_vec a, fe_vec b) { return to_vec(mul_inline(from_vec(a), from_vec(b))); }
+static __device__ __noinline__ fe_vec sqr_call(fe_vec a) { return to_vec(sqr_inline(from_vec(a))); }
+__device__ __forceinline__ Fe mul(const Fe& a, const Fe& b) { return from_vec(mul_call(to_vec(a), to_vec(b))); }
+__device__ __forceinline__ Fe sqr(const Fe& a) { return from_vec(sqr_call(to_vec(a))); }
+#else
+inline Fe mul(const Fe& a, const Fe& b) { return mul_inline(a, b); }
+inline Fe sqr(const Fe& a) { return sqr_inline(a); }
+#endif
 
 // exact test a == 0 (mod p) for normalized a with value < 64p.
 // If a = k*p then k = a_0 * p_0^-1 mod 2^28 must be < 64: a 3-instruction filter that

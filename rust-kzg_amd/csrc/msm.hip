@@ -11,7 +11,7 @@
 //   k_digits   : scalar -> signed c-bit digits, per-bucket histogram (global atomics)
 //   k_scan     : exclusive scan of the histogram per set
 //   k_scatter  : counting-sort of (point index | sign) by bucket
-//   k_accum    : one lane per bucket, chain of XYZZ mixed adds over its sorted run
+//   k_accum    : one lane per 16 sorted entries, chain of XYZZ mixed adds, pieces per (bucket, chunk)
 //   k_reduce   : one lane per 32-bucket segment: running-sum trick + small scalar multiple
 //   k_setsum   : one workgroup per set, LDS tree sum of the segment results
 //   k_final    : Horner over windows (unprepared), convert to blst Jacobian
@@ -36,7 +36,8 @@ using g1::Xyzz;
 
 namespace {
 
-constexpr int SEG = 32;  // buckets per k_reduce lane
+constexpr int SEG = 32;    // buckets per k_reduce lane
+constexpr u32 CHUNK = 16;  // sorted entries per k_accum lane
 
 // ---------------------------------------------------------------- helpers
 struct HipErr {
@@ -228,42 +229,84 @@ __global__ void __launch_bounds__(1024) k_scan(u32* __restrict__ counts, u32* __
     if (threadIdx.x == 0) off[nb] = base_s;
 }
 
-// one lane per bucket: sum of its sorted run
+// Bucket accumulation, load-balanced: one lane per CHUNK consecutive entries of the sorted list
+// (not per bucket), so skewed digit distributions (e.g. the < 2^248 elements of a "random blob",
+// or a blob of equal elements) cost the same as uniform ones.  A lane walks its chunk, keeps the
+// running sum of the current bucket and writes it out whenever the bucket changes and at the end
+// of the chunk.  The piece of bucket b inside chunk t goes to slot b + t: along the sorted list
+// both b and t are non-decreasing and consecutive pieces differ in at least one, so slots are
+// unique, and bucket b's value is the sum of slots b + t for the chunks t its run touches.
 __global__ void __launch_bounds__(256) k_accum(const u32* __restrict__ offsets, const u32* __restrict__ sorted,
-                                               const AffPt* __restrict__ pts, Xyzz* __restrict__ buckets, size_t nb,
-                                               size_t nsets, size_t set_cap) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nb * nsets) return;
-    size_t set = t / nb, bk = t % nb;
+                                               const AffPt* __restrict__ pts, Xyzz* __restrict__ partials, size_t nb,
+                                               size_t nsets, size_t set_cap, size_t nchunk) {
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= nchunk * nsets) return;
+    const size_t set = tid / nchunk, t = tid % nchunk;
     const u32* off = offsets + set * (nb + 1);
-    u32 beg = off[bk], end = off[bk + 1];
+    const u32 total = off[nb];
+    const u32 base = (u32)(t * CHUNK);
+    if (base >= total) return;
+    const u32 end = base + CHUNK < total ? base + CHUNK : total;
     const u32* run = sorted + set * set_cap;
+    Xyzz* out = partials + set * (nb + nchunk) + t;
+    // bucket containing position `base`: largest b with off[b] <= base
+    u32 lo = 0, hi = (u32)nb;
+    while (hi - lo > 1) {
+        u32 mid = (lo + hi) >> 1;
+        if (off[mid] <= base) lo = mid;
+        else hi = mid;
+    }
+    u32 b = lo, next_off = off[b + 1];
     Xyzz acc;
     g1::set_inf(acc);
-    for (u32 k = beg; k < end; ++k) {
+    for (u32 k = base; k < end; ++k) {
+        if (k >= next_off) {
+            out[b] = acc;  // non-empty: position k-1 belonged to bucket b and to this chunk
+            g1::set_inf(acc);
+            do {
+                ++b;
+                next_off = off[b + 1];
+            } while (k >= next_off);
+        }
         u32 e = run[k];
         const AffPt* p = pts + (e & 0x7fffffffu);
         fp28::Fe x = p->x, y = p->y;
         if (e >> 31) y = fp28::neg<2>(y);
         g1::madd(acc, x, y);
     }
-    buckets[t] = acc;
+    out[b] = acc;
+}
+
+// value of bucket bk of a set: sum of its pieces
+__device__ __forceinline__ void load_bucket(Xyzz& v, const Xyzz* __restrict__ partials, const u32* __restrict__ off,
+                                            size_t bk) {
+    const u32 beg = off[bk], end = off[bk + 1];
+    g1::set_inf(v);
+    if (end == beg) return;
+    const u32 t0 = beg / CHUNK, t1 = (end - 1) / CHUNK;
+    v = partials[bk + t0];
+    for (u32 t = t0 + 1; t <= t1; ++t) {
+        Xyzz pz = partials[bk + t];
+        g1::dadd(v, pz);
+    }
 }
 
 // one lane per SEG consecutive buckets: contribution sum_{k in seg} k * B_k
-__global__ void __launch_bounds__(128) k_reduce(const Xyzz* __restrict__ buckets, Xyzz* __restrict__ segout, size_t nb,
-                                                size_t nsets) {
+__global__ void __launch_bounds__(128) k_reduce(const Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
+                                                Xyzz* __restrict__ segout, size_t nb, size_t nsets, size_t nchunk) {
     const size_t nseg = (nb + SEG - 1) / SEG;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nseg * nsets) return;
     size_t set = t / nseg, sg = t % nseg;
-    const Xyzz* bk = buckets + set * nb;
+    const Xyzz* pz = partials + set * (nb + nchunk);
+    const u32* off = offsets + set * (nb + 1);
     size_t lo = sg * SEG, hi = lo + SEG < nb ? lo + SEG : nb;  // bucket k (0-based) has weight k+1
     Xyzz run, tot;
     g1::set_inf(run);
     g1::set_inf(tot);
     for (size_t k = hi; k-- > lo;) {
-        Xyzz b = bk[k];
+        Xyzz b;
+        load_bucket(b, pz, off, k);
         g1::dadd(run, b);
         g1::dadd(tot, run);
     }
@@ -346,6 +389,50 @@ __global__ void __launch_bounds__(256) k_copy_affpt(AffPt* __restrict__ dst, con
     if (i < n) dst[i] = src[i];
 }
 
+// P_i = h_i * G with h_i a 248-bit value from splitmix64(seed, i); output in blst affine layout
+__device__ __forceinline__ u64 splitmix64(u64& x) {
+    x += 0x9e3779b97f4a7c15ull;
+    u64 z = x;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(128) k_gen_points(ff::Fp* __restrict__ out, size_t n, u64 seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 st = seed ^ (0xd1b54a32d192ed03ull * (u64)(i + 1));
+    u64 h[4];
+    for (int k = 0; k < 4; ++k) h[k] = splitmix64(st);
+    h[3] &= 0x00ffffffffffffffull;  // < 2^248 < r
+    // generator in blst layout (blst/src/consts.rs:52-84)
+    ff::Fp gx, gy;
+    const u64 GX[6] = {0x5cb38790fd530c16ull, 0x7817fc679976fff5ull, 0x154f95c7143ba1c1ull,
+                       0xf0ae6acdf3d0e747ull, 0xedce6ecc21dbf440ull, 0x120177419e0bfb75ull};
+    const u64 GY[6] = {0xbaac93d50ce72271ull, 0x8c22631a7918fd8eull, 0xdd595f13570725ceull,
+                       0x51ac582950405194ull, 0x0e1c8c3fad0059c0ull, 0x0bbc3efc5008a26aull};
+    for (int k = 0; k < 6; ++k) {
+        gx.v[2 * k] = (u32)GX[k];
+        gx.v[2 * k + 1] = (u32)(GX[k] >> 32);
+        gy.v[2 * k] = (u32)GY[k];
+        gy.v[2 * k + 1] = (u32)(GY[k] >> 32);
+    }
+    fp28::Fe x = fp28::canon(fp28::from_blst(gx)), y = fp28::canon(fp28::from_blst(gy));
+    Xyzz acc;
+    g1::set_inf(acc);
+    for (int bit = 247; bit >= 0; --bit) {
+        if (!g1::is_inf(acc)) g1::dbl(acc);
+        if ((h[bit >> 6] >> (bit & 63)) & 1) g1::madd(acc, x, y);
+    }
+    if (g1::is_inf(acc)) {
+        out[2 * i] = ff::Fp::zero();
+        out[2 * i + 1] = ff::Fp::zero();
+        return;
+    }
+    fp28::Fe zi = g1io::inverse(fp28::mul(acc.zz, acc.zzz));
+    out[2 * i] = fp28::to_blst(fp28::mul(acc.x, fp28::mul(zi, acc.zzz)));
+    out[2 * i + 1] = fp28::to_blst(fp28::mul(acc.y, fp28::mul(zi, acc.zz)));
+}
+
 // ---------------------------------------------------------------- host side
 
 int choose_window(size_t n, bool prepared) {
@@ -411,8 +498,10 @@ struct kzgamd::MsmContext {
     Workspace ws;
     hipStream_t stream = nullptr;
     bool profile = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start, accum-begin, accum-end, end
-    bool ev_valid = false;
+    // per enqueue: start, accum-begin, accum-end, end (events on the launch stream)
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    static constexpr size_t EV_MAX = 4 * 512;
     ~MsmContext() {
         table.release();
         ws.release();
@@ -494,14 +583,20 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     ws.counts.ensure(nsets * nb);
     ws.offsets.ensure(nsets * (nb + 1));
     ws.sorted.ensure(nsets * set_cap);
-    ws.buckets.ensure(nsets * nb);
+    const size_t nchunk = (set_cap + CHUNK - 1) / CHUNK;
+    ws.buckets.ensure(nsets * (nb + nchunk));
     ws.segout.ensure(nsets * nseg);
     ws.setout.ensure(nsets);
     DigitParams P{npoints, nbatch, c, nwin, ctx->prepared ? 1 : 0, mont, nb, ctx->n};
-    if (ctx->profile) {
-        for (auto& e : ctx->ev)
-            if (!e) HIP_TRY(hipEventCreate(&e));
-        HIP_TRY(hipEventRecord(ctx->ev[0], stream));
+    hipEvent_t* pev = nullptr;
+    if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
+        while (ctx->ev.size() < ctx->ev_used + 4) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            ctx->ev.push_back(e);
+        }
+        pev = &ctx->ev[ctx->ev_used];
+        HIP_TRY(hipEventRecord(pev[0], stream));
     }
     HIP_TRY(hipMemsetAsync(ws.counts.p, 0, nsets * nb * sizeof(u32), stream));
     const unsigned gdig = (unsigned)((npoints * nbatch + 255) / 256);
@@ -510,19 +605,20 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     hipLaunchKernelGGL(k_scan, dim3((unsigned)nsets), dim3(1024), 0, stream, ws.counts.p, ws.offsets.p, nb);
     hipLaunchKernelGGL(k_digits<1>, dim3(gdig), dim3(256), 0, stream, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
                        (const u32*)ws.offsets.p, ws.sorted.p, set_cap);
-    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[1], stream));
-    hipLaunchKernelGGL(k_accum, dim3((unsigned)((nsets * nb + 255) / 256)), dim3(256), 0, stream, (const u32*)ws.offsets.p,
-                       (const u32*)ws.sorted.p, (const AffPt*)ctx->table.p, ws.buckets.p, nb, nsets, set_cap);
-    if (ctx->profile) HIP_TRY(hipEventRecord(ctx->ev[2], stream));
+    if (pev) HIP_TRY(hipEventRecord(pev[1], stream));
+    hipLaunchKernelGGL(k_accum, dim3((unsigned)((nsets * nchunk + 255) / 256)), dim3(256), 0, stream,
+                       (const u32*)ws.offsets.p, (const u32*)ws.sorted.p, (const AffPt*)ctx->table.p, ws.buckets.p, nb, nsets,
+                       set_cap, nchunk);
+    if (pev) HIP_TRY(hipEventRecord(pev[2], stream));
     hipLaunchKernelGGL(k_reduce, dim3((unsigned)((nsets * nseg + 127) / 128)), dim3(128), 0, stream,
-                       (const Xyzz*)ws.buckets.p, ws.segout.p, nb, nsets);
+                       (const Xyzz*)ws.buckets.p, (const u32*)ws.offsets.p, ws.segout.p, nb, nsets, nchunk);
     hipLaunchKernelGGL(k_setsum, dim3((unsigned)nsets), dim3(256), 256 * sizeof(Xyzz), stream, (const Xyzz*)ws.segout.p,
                        ws.setout.p, nseg);
     hipLaunchKernelGGL(k_final, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)ws.setout.p,
                        d_out, nbatch, nwin, c, ctx->prepared ? 1 : 0, out_mode);
-    if (ctx->profile) {
-        HIP_TRY(hipEventRecord(ctx->ev[3], stream));
-        ctx->ev_valid = true;
+    if (pev) {
+        HIP_TRY(hipEventRecord(pev[3], stream));
+        ctx->ev_used += 4;
     }
     HIP_TRY(hipGetLastError());
 }
@@ -531,14 +627,25 @@ void msm_lock(MsmContext* ctx) { ctx->mu.lock(); }
 void msm_unlock(MsmContext* ctx) { ctx->mu.unlock(); }
 void msm_set_profile(MsmContext* ctx, bool on) {
     ctx->profile = on;
-    ctx->ev_valid = false;
+    ctx->ev_used = 0;
 }
-bool msm_get_profile(MsmContext* ctx, float* accum_ms, float* total_ms) {
-    if (!ctx->profile || !ctx->ev_valid) return false;
-    if (hipEventSynchronize(ctx->ev[3]) != hipSuccess) return false;
-    if (hipEventElapsedTime(accum_ms, ctx->ev[1], ctx->ev[2]) != hipSuccess) return false;
-    if (hipEventElapsedTime(total_ms, ctx->ev[0], ctx->ev[3]) != hipSuccess) return false;
-    return true;
+// averages over every enqueue recorded since msm_set_profile(true)
+int msm_get_profile(MsmContext* ctx, float* accum_ms, float* total_ms) {
+    if (!ctx->profile || ctx->ev_used == 0) return 0;
+    double a = 0, t = 0;
+    int cnt = 0;
+    for (size_t k = 0; k + 4 <= ctx->ev_used; k += 4) {
+        float fa, ft;
+        if (hipEventSynchronize(ctx->ev[k + 3]) != hipSuccess) return 0;
+        if (hipEventElapsedTime(&fa, ctx->ev[k + 1], ctx->ev[k + 2]) != hipSuccess) return 0;
+        if (hipEventElapsedTime(&ft, ctx->ev[k], ctx->ev[k + 3]) != hipSuccess) return 0;
+        a += fa;
+        t += ft;
+        ++cnt;
+    }
+    *accum_ms = (float)(a / cnt);
+    *total_ms = (float)(t / cnt);
+    return cnt;
 }
 
 // host buffers in, host buffers out
@@ -643,7 +750,31 @@ extern "C" int kzgamd_msm_set_profile(void* msm, int on) {
 }
 extern "C" int kzgamd_msm_get_profile(void* msm, float* accum_ms, float* total_ms) {
     if (!msm || !accum_ms || !total_ms) return 1;
-    return kzgamd::msm_get_profile((MsmContext*)msm, accum_ms, total_ms) ? 0 : 1;
+    int cnt = kzgamd::msm_get_profile((MsmContext*)msm, accum_ms, total_ms);
+    return cnt > 0 ? cnt : -1;
+}
+
+// bench/test utility: n distinct G1 points P_i = h_i * G, blst affine layout, on the device
+extern "C" RustError kzgamd_generate_points(void* d_out_affine, size_t n, uint64_t seed, void* stream) {
+    if (!d_out_affine) return make_error(1, "null output");
+    return guarded([&] {
+        hipLaunchKernelGGL(k_gen_points, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream,
+                           (ff::Fp*)d_out_affine, n, seed);
+        HIP_TRY(hipGetLastError());
+    });
+}
+
+// device-resident bases: prepare != 0 builds the fixed-base rows (like prepare_msm)
+extern "C" void* kzgamd_msm_create_device(const void* d_points_affine, size_t npoints, int prepare) {
+    try {
+        if (!d_points_affine || npoints == 0) return nullptr;
+        return kzgamd::msm_create(d_points_affine, npoints, true, prepare != 0, false);
+    } catch (const HipErr& e) {
+        fprintf(stderr, "kzg_mi355x: kzgamd_msm_create_device failed: %s: %s\n", e.what, hipGetErrorString(e.e));
+        return nullptr;
+    } catch (...) {
+        return nullptr;
+    }
 }
 
 extern "C" int kzgamd_device_count(void) {

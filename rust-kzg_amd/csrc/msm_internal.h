@@ -17,5 +17,5 @@ void msm_lock(MsmContext* ctx);
 void msm_unlock(MsmContext* ctx);
 // per-kernel timing of the last enqueue (events on the launch stream); ms < 0 when disabled
 void msm_set_profile(MsmContext* ctx, bool on);
-bool msm_get_profile(MsmContext* ctx, float* accum_ms, float* total_ms);
+int msm_get_profile(MsmContext* ctx, float* accum_ms, float* total_ms);  // number of enqueues averaged
 }  // namespace kzgamd
