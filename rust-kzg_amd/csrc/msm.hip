@@ -12,8 +12,8 @@
 //   k_scan     : exclusive scan of the histogram per set
 //   k_scatter  : counting-sort of (point index | sign) by bucket
 //   k_accum    : one lane per 16 sorted entries, chain of XYZZ mixed adds, pieces per (bucket, chunk)
-//   k_reduce   : one lane per 32-bucket segment: running-sum trick + small scalar multiple
-//   k_setsum   : one workgroup per set, LDS tree sum of the segment results
+//   k_heavy    : one wave per over-full bucket: combine its pieces
+//   k_level    : bucket reduction sum (k+1)*B_k as an 8-ary tree of (plain sum, weighted sum) pairs
 //   k_final    : Horner over windows (unprepared), convert to blst Jacobian
 // All arithmetic is integer VALU (v_mad_u64_u32); there is no MFMA-shaped work here.
 #include <hip/hip_runtime.h>
@@ -36,7 +36,8 @@ using g1::Xyzz;
 
 namespace {
 
-constexpr int SEG = 32;    // buckets per k_reduce lane
+constexpr int GRP = 8;      // children folded per lane in the bucket-reduction tree
+constexpr u32 HEAVY = 512;  // entries above which a bucket's pieces are combined by a whole wave
 constexpr u32 CHUNK = 16;  // sorted entries per k_accum lane
 
 // ---------------------------------------------------------------- helpers
@@ -196,8 +197,12 @@ __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __rest
     }
 }
 
-// exclusive scan of counts[set][0..nb) -> offsets[set][0..nb]; zeroes counts for the scatter pass
-__global__ void __launch_bounds__(1024) k_scan(u32* __restrict__ counts, u32* __restrict__ offsets, size_t nb) {
+// exclusive scan of counts[set][0..nb) -> offsets[set][0..nb]; zeroes counts for the scatter pass.
+// Buckets with more than HEAVY entries (> HEAVY/CHUNK pieces after k_accum) are flagged and listed
+// so that k_heavy can combine their pieces with a whole wave instead of one lane.
+__global__ void __launch_bounds__(1024) k_scan(u32* __restrict__ counts, u32* __restrict__ offsets, size_t nb,
+                                               unsigned char* __restrict__ heavy, u32* __restrict__ heavy_list,
+                                               u32* __restrict__ nheavy, u32 heavy_cap) {
     __shared__ u32 wsum[16];
     __shared__ u32 base_s;
     size_t set = blockIdx.x;
@@ -209,7 +214,18 @@ __global__ void __launch_bounds__(1024) k_scan(u32* __restrict__ counts, u32* __
     for (size_t start = 0; start < nb; start += 1024) {
         size_t k = start + threadIdx.x;
         u32 v = k < nb ? cnt[k] : 0;
-        if (k < nb) cnt[k] = 0;
+        if (k < nb) {
+            cnt[k] = 0;
+            const bool hv = v > HEAVY;
+            heavy[set * nb + k] = hv ? 1 : 0;
+            if (hv) {
+                u32 slot = atomicAdd(nheavy, 1u);
+                if (slot < heavy_cap) {
+                    heavy_list[2 * slot] = (u32)set;
+                    heavy_list[2 * slot + 1] = (u32)k;
+                }
+            }
+        }
         u32 x = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -277,13 +293,48 @@ __global__ void __launch_bounds__(256) k_accum(const u32* __restrict__ offsets, 
     out[b] = acc;
 }
 
+// One wave per heavy bucket: lanes sum the bucket's pieces strided, then an LDS tree; the total
+// replaces the first piece (load_bucket reads only that one for flagged buckets).
+__global__ void __launch_bounds__(64) k_heavy(Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
+                                              const u32* __restrict__ heavy_list, const u32* __restrict__ nheavy,
+                                              u32 heavy_cap, size_t nb, size_t nchunk) {
+    __shared__ Xyzz sh[64];
+    u32 cnt = *nheavy;
+    if (cnt > heavy_cap) cnt = heavy_cap;
+    const int lane = threadIdx.x;
+    for (u32 idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
+        const size_t set = heavy_list[2 * idx], bk = heavy_list[2 * idx + 1];
+        const u32* off = offsets + set * (nb + 1);
+        Xyzz* pz = partials + set * (nb + nchunk) + bk;
+        const u32 t0 = off[bk] / CHUNK, t1 = (off[bk + 1] - 1) / CHUNK;
+        Xyzz acc;
+        g1::set_inf(acc);
+        for (u32 t = t0 + lane; t <= t1; t += 64) {
+            Xyzz q = pz[t];
+            g1::dadd(acc, q);
+        }
+        sh[lane] = acc;
+        __syncthreads();
+        for (int stride = 32; stride > 0; stride >>= 1) {
+            if (lane < stride) {
+                Xyzz q = sh[lane + stride];
+                g1::dadd(acc, q);
+                sh[lane] = acc;
+            }
+            __syncthreads();
+        }
+        if (lane == 0) pz[t0] = acc;
+        __syncthreads();
+    }
+}
+
 // value of bucket bk of a set: sum of its pieces
 __device__ __forceinline__ void load_bucket(Xyzz& v, const Xyzz* __restrict__ partials, const u32* __restrict__ off,
-                                            size_t bk) {
+                                            const unsigned char* __restrict__ heavy, size_t bk) {
     const u32 beg = off[bk], end = off[bk + 1];
     g1::set_inf(v);
     if (end == beg) return;
-    const u32 t0 = beg / CHUNK, t1 = (end - 1) / CHUNK;
+    const u32 t0 = beg / CHUNK, t1 = heavy[bk] ? t0 : (end - 1) / CHUNK;
     v = partials[bk + t0];
     for (u32 t = t0 + 1; t <= t1; ++t) {
         Xyzz pz = partials[bk + t];
@@ -291,66 +342,55 @@ __device__ __forceinline__ void load_bucket(Xyzz& v, const Xyzz* __restrict__ pa
     }
 }
 
-// one lane per SEG consecutive buckets: contribution sum_{k in seg} k * B_k
-__global__ void __launch_bounds__(128) k_reduce(const Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
-                                                Xyzz* __restrict__ segout, size_t nb, size_t nsets, size_t nchunk) {
-    const size_t nseg = (nb + SEG - 1) / SEG;
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nseg * nsets) return;
-    size_t set = t / nseg, sg = t % nseg;
-    const Xyzz* pz = partials + set * (nb + nchunk);
-    const u32* off = offsets + set * (nb + 1);
-    size_t lo = sg * SEG, hi = lo + SEG < nb ? lo + SEG : nb;  // bucket k (0-based) has weight k+1
-    Xyzz run, tot;
+// Bucket reduction  sum_k (k+1) * B_k  as a GRP-ary tree of (A, M) pairs:
+//   A = plain sum of the subtree's buckets,  M = sum (k - first_k) * B_k over the subtree.
+// A lane folds GRP children:  A = sum A_j,  M = sum M_j + S * sum_j j*A_j  with S = buckets per child
+// (a power of two -> doublings).  Level 0 reads the buckets themselves (M_j = 0, S = 1).
+// Every level is a short chain (<= ~3*GRP adds) over many lanes instead of one long running sum.
+template <bool FIRST>
+__global__ void __launch_bounds__(128) k_level(const Xyzz* __restrict__ inA, const Xyzz* __restrict__ inM,
+                                               Xyzz* __restrict__ outA, Xyzz* __restrict__ outM, size_t nin, size_t nsets,
+                                               int logS, const u32* __restrict__ offsets,
+                                               const unsigned char* __restrict__ heavy, size_t nb, size_t nchunk) {
+    const size_t nout = (nin + GRP - 1) / GRP;
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= nout * nsets) return;
+    const size_t set = tid / nout, g = tid % nout;
+    const size_t lo = g * GRP, hi = lo + GRP < nin ? lo + GRP : nin;
+    Xyzz run, wsum, msum;
     g1::set_inf(run);
-    g1::set_inf(tot);
+    g1::set_inf(wsum);
+    g1::set_inf(msum);
     for (size_t k = hi; k-- > lo;) {
-        Xyzz b;
-        load_bucket(b, pz, off, k);
-        g1::dadd(run, b);
-        g1::dadd(tot, run);
-    }
-    // tot = sum (k-lo+1) B_k ;  add lo * sum B_k
-    if (lo != 0) {
-        g1::mul_small(run, (u32)lo);
-        g1::dadd(tot, run);
-    }
-    segout[t] = tot;
-}
-
-// one workgroup per set: sum of its nseg segment results
-__global__ void __launch_bounds__(256) k_setsum(const Xyzz* __restrict__ segout, Xyzz* __restrict__ setout, size_t nseg) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Xyzz* sh = reinterpret_cast<Xyzz*>(smem);
-    size_t set = blockIdx.x;
-    const Xyzz* in = segout + set * nseg;
-    Xyzz acc;
-    g1::set_inf(acc);
-    for (size_t k = threadIdx.x; k < nseg; k += blockDim.x) {
-        Xyzz b = in[k];
-        g1::dadd(acc, b);
-    }
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (int stride = blockDim.x / 2; stride > 0; stride >>= 1) {
-        if ((int)threadIdx.x < stride) {
-            Xyzz b = sh[threadIdx.x + stride];
-            g1::dadd(acc, b);
-            sh[threadIdx.x] = acc;
+        Xyzz a;
+        if (FIRST) {
+            load_bucket(a, inA + set * (nb + nchunk), offsets + set * (nb + 1), heavy + set * nb, k);
+        } else {
+            a = inA[set * nin + k];
+            Xyzz m = inM[set * nin + k];
+            g1::dadd(msum, m);
         }
-        __syncthreads();
+        g1::dadd(run, a);
+        if (k > lo) g1::dadd(wsum, run);  // after the loop: wsum = sum_j j * A_j
     }
-    if (threadIdx.x == 0) setout[set] = acc;
+    if (!g1::is_inf(wsum))
+        for (int d = 0; d < logS; ++d) g1::dbl(wsum);
+    g1::dadd(msum, wsum);
+    outA[set * nout + g] = run;
+    outM[set * nout + g] = msum;
 }
 
 // one lane per MSM: Horner over windows (unprepared) and conversion to blst Jacobian
-__global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ setout, void* __restrict__ out_v, size_t nbatch,
-                                              int nwin, int c, int prepared, int out_mode) {
+__global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, const Xyzz* __restrict__ rootM,
+                                              void* __restrict__ out_v, size_t nbatch, int nwin, int c, int prepared,
+                                              int out_mode) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbatch) return;
     Xyzz acc;
     if (prepared) {
-        acc = setout[b];
+        acc = rootM[b];  // sum (k+1) B_k = M + A
+        Xyzz a = rootA[b];
+        g1::dadd(acc, a);
     } else {
         g1::set_inf(acc);
         for (int w = nwin - 1; w >= 0; --w) {
@@ -362,7 +402,9 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ setout, v
                     }
                     g1::dbl(acc);
                 }
-            Xyzz r = setout[b * nwin + w];
+            Xyzz r = rootM[b * nwin + w];
+            g1::dadd(acc, r);
+            r = rootA[b * nwin + w];
             g1::dadd(acc, r);
         }
     }
@@ -437,6 +479,10 @@ __global__ void __launch_bounds__(128) k_gen_points(ff::Fp* __restrict__ out, si
 
 int choose_window(size_t n, bool prepared) {
     // minimise adds: prepared  n*ceil(256/c) + 3*2^(c-1);  unprepared  ceil(256/c) * (n + 3*2^(c-1))
+    if (const char* e = getenv(prepared ? "KZGAMD_WINDOW_PREPARED" : "KZGAMD_WINDOW")) {
+        int c = atoi(e);
+        if (c >= 2 && c <= 22) return c;
+    }
     int best = 2;
     double best_cost = 1e300;
     for (int c = 2; c <= 22; ++c) {
@@ -471,7 +517,9 @@ struct DevBuf {
 
 struct Workspace {
     DevBuf<u32> counts, offsets, sorted, scalars;
-    DevBuf<Xyzz> buckets, segout, setout;
+    DevBuf<Xyzz> buckets, lvlA[2], lvlM[2];
+    DevBuf<unsigned char> heavy;
+    DevBuf<u32> heavy_list, nheavy;
     DevBuf<ff::Fp> out;
     void release() {
         counts.release();
@@ -479,8 +527,13 @@ struct Workspace {
         sorted.release();
         scalars.release();
         buckets.release();
-        segout.release();
-        setout.release();
+        for (int k = 0; k < 2; ++k) {
+            lvlA[k].release();
+            lvlM[k].release();
+        }
+        heavy.release();
+        heavy_list.release();
+        nheavy.release();
         out.release();
     }
 };
@@ -572,7 +625,6 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     const size_t nb = ctx->nb;
     const size_t nsets = ctx->prepared ? nbatch : nbatch * (size_t)nwin;
     const size_t set_cap = ctx->prepared ? npoints * (size_t)nwin : npoints;
-    const size_t nseg = (nb + SEG - 1) / SEG;
     if (npoints == 0) {
         if (out_mode == OUT_COMPRESSED) throw HipErr{hipErrorInvalidValue, "empty MSM in compressed mode"};
         HIP_TRY(hipMemsetAsync(d_out, 0, nbatch * 144, stream));
@@ -585,8 +637,15 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     ws.sorted.ensure(nsets * set_cap);
     const size_t nchunk = (set_cap + CHUNK - 1) / CHUNK;
     ws.buckets.ensure(nsets * (nb + nchunk));
-    ws.segout.ensure(nsets * nseg);
-    ws.setout.ensure(nsets);
+    const size_t n1 = (nb + GRP - 1) / GRP, n2 = (n1 + GRP - 1) / GRP;
+    ws.lvlA[0].ensure(nsets * n1);
+    ws.lvlM[0].ensure(nsets * n1);
+    ws.lvlA[1].ensure(nsets * n2);
+    ws.lvlM[1].ensure(nsets * n2);
+    ws.heavy.ensure(nsets * nb);
+    const size_t heavy_cap = nsets * set_cap / HEAVY + 1;  // a heavy bucket holds > HEAVY entries
+    ws.heavy_list.ensure(2 * heavy_cap);
+    ws.nheavy.ensure(1);
     DigitParams P{npoints, nbatch, c, nwin, ctx->prepared ? 1 : 0, mont, nb, ctx->n};
     hipEvent_t* pev = nullptr;
     if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
@@ -602,7 +661,9 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     const unsigned gdig = (unsigned)((npoints * nbatch + 255) / 256);
     hipLaunchKernelGGL(k_digits<0>, dim3(gdig), dim3(256), 0, stream, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
                        (const u32*)nullptr, (u32*)nullptr, set_cap);
-    hipLaunchKernelGGL(k_scan, dim3((unsigned)nsets), dim3(1024), 0, stream, ws.counts.p, ws.offsets.p, nb);
+    HIP_TRY(hipMemsetAsync(ws.nheavy.p, 0, sizeof(u32), stream));
+    hipLaunchKernelGGL(k_scan, dim3((unsigned)nsets), dim3(1024), 0, stream, ws.counts.p, ws.offsets.p, nb, ws.heavy.p,
+                       ws.heavy_list.p, ws.nheavy.p, (u32)heavy_cap);
     hipLaunchKernelGGL(k_digits<1>, dim3(gdig), dim3(256), 0, stream, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
                        (const u32*)ws.offsets.p, ws.sorted.p, set_cap);
     if (pev) HIP_TRY(hipEventRecord(pev[1], stream));
@@ -610,12 +671,33 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                        (const u32*)ws.offsets.p, (const u32*)ws.sorted.p, (const AffPt*)ctx->table.p, ws.buckets.p, nb, nsets,
                        set_cap, nchunk);
     if (pev) HIP_TRY(hipEventRecord(pev[2], stream));
-    hipLaunchKernelGGL(k_reduce, dim3((unsigned)((nsets * nseg + 127) / 128)), dim3(128), 0, stream,
-                       (const Xyzz*)ws.buckets.p, (const u32*)ws.offsets.p, ws.segout.p, nb, nsets, nchunk);
-    hipLaunchKernelGGL(k_setsum, dim3((unsigned)nsets), dim3(256), 256 * sizeof(Xyzz), stream, (const Xyzz*)ws.segout.p,
-                       ws.setout.p, nseg);
-    hipLaunchKernelGGL(k_final, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)ws.setout.p,
-                       d_out, nbatch, nwin, c, ctx->prepared ? 1 : 0, out_mode);
+    hipLaunchKernelGGL(k_heavy, dim3(1024), dim3(64), 0, stream, ws.buckets.p, (const u32*)ws.offsets.p,
+                       (const u32*)ws.heavy_list.p, (const u32*)ws.nheavy.p, (u32)heavy_cap, nb, nchunk);
+    // bucket-reduction tree: nb -> nb/GRP -> ... -> 1 per set
+    {
+        size_t nin = nb;
+        int logS = 0, lvl = 0;
+        const Xyzz *inA = ws.buckets.p, *inM = nullptr;
+        for (;;) {
+            const size_t nout = (nin + GRP - 1) / GRP;
+            Xyzz *oA = ws.lvlA[lvl & 1].p, *oM = ws.lvlM[lvl & 1].p;
+            const unsigned grid = (unsigned)((nsets * nout + 127) / 128);
+            if (lvl == 0)
+                hipLaunchKernelGGL(k_level<true>, dim3(grid), dim3(128), 0, stream, inA, inM, oA, oM, nin, nsets, logS,
+                                   (const u32*)ws.offsets.p, (const unsigned char*)ws.heavy.p, nb, nchunk);
+            else
+                hipLaunchKernelGGL(k_level<false>, dim3(grid), dim3(128), 0, stream, inA, inM, oA, oM, nin, nsets, logS,
+                                   (const u32*)nullptr, (const unsigned char*)nullptr, nb, nchunk);
+            inA = oA;
+            inM = oM;
+            nin = nout;
+            logS += 3;  // GRP = 8
+            ++lvl;
+            if (nin == 1) break;
+        }
+        hipLaunchKernelGGL(k_final, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, inA, inM,
+                           d_out, nbatch, nwin, c, ctx->prepared ? 1 : 0, out_mode);
+    }
     if (pev) {
         HIP_TRY(hipEventRecord(pev[3], stream));
         ctx->ev_used += 4;
