@@ -50,7 +50,7 @@ _lib = None
 # every symbol include/kzg_mi355x.h declares; tests check the library exports all of them
 EXPORTS = [
     "prepare_msm", "mult_pippenger_prepared", "mult_pippenger", "free_msm", "mult_pippenger_prepared_batch",
-    "kzgamd_msm_prepared_batch_device", "kzgamd_msm_info", "kzgamd_msm_set_profile", "kzgamd_msm_get_profile",
+    "kzgamd_msm_prepared_batch_device", "kzgamd_msm_info", "kzgamd_msm_uses_wide_table", "kzgamd_msm_set_profile", "kzgamd_msm_get_profile",
     "kzgamd_device_count", "kzgamd_version", "kzgamd_msm_create_device", "kzgamd_generate_points",
     "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
     "kzgamd_blob_to_kzg_commitment_batch", "kzgamd_blob_to_kzg_commitment_device", "kzgamd_settings_msm_handle",
@@ -93,6 +93,8 @@ def lib():
     L.kzgamd_msm_prepared_batch_device.argtypes = [vp, vp, vp, sz, sz, C.c_int, vp]
     L.kzgamd_msm_info.restype = C.c_int
     L.kzgamd_msm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(sz), C.POINTER(sz)]
+    L.kzgamd_msm_uses_wide_table.restype = C.c_int
+    L.kzgamd_msm_uses_wide_table.argtypes = [vp]
     L.kzgamd_device_count.restype = C.c_int
     L.kzgamd_version.restype = C.c_char_p
     L.kzgamd_msm_set_profile.restype = C.c_int
@@ -145,7 +147,8 @@ class PreparedMsm:
     def info(self):
         c, rows, nb, n = C.c_int(), C.c_int(), C.c_size_t(), C.c_size_t()
         lib().kzgamd_msm_info(self.handle, C.byref(c), C.byref(rows), C.byref(nb), C.byref(n))
-        return {"window_bits": c.value, "rows": rows.value, "nbuckets": nb.value, "npoints": n.value}
+        return {"window_bits": c.value, "rows": rows.value, "nbuckets": nb.value, "npoints": n.value,
+                "wide_table": bool(lib().kzgamd_msm_uses_wide_table(self.handle))}
 
     def close(self):
         if self.handle:

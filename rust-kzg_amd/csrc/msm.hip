@@ -388,9 +388,11 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, co
     if (b >= nbatch) return;
     Xyzz acc;
     if (prepared) {
-        acc = rootM[b];  // sum (k+1) B_k = M + A
-        Xyzz a = rootA[b];
-        g1::dadd(acc, a);
+        acc = rootM[b];  // sum (k+1) B_k = M + A   (wide-table path: rootM is the sum, rootA absent)
+        if (rootA) {
+            Xyzz a = rootA[b];
+            g1::dadd(acc, a);
+        }
     } else {
         g1::set_inf(acc);
         for (int w = nwin - 1; w >= 0; --w) {
@@ -423,6 +425,133 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, co
     out[3 * b] = j[0];
     out[3 * b + 1] = j[1];
     out[3 * b + 2] = j[2];
+}
+
+
+// ============================ wide fixed-base table ("FBW") ============================
+// With 288 GB of HBM per GPU the 4096-point setup can afford the full signed-window table
+//     W[w][i][m-1] = m * 2^(c*w) * P_i ,   m = 1 .. 2^(c-1)
+// (c = 13: 20 x 4096 x 4096 slots of 128 B = 43 GB).  A commitment is then a plain sum of
+// n * ceil(256/c) gathered affine points: no sort, no buckets, no bucket reduction, and every
+// lane does the same amount of work whatever the digit distribution.  This is the reference's
+// "wbits" fixed-base idea (kzg/src/msm/wbits.rs:357-373 table, :442-488 evaluation) resized
+// from CPU-cache-sized windows (w = 8) to HBM-sized ones.
+
+// chain kernel: lane (slot, seg) writes FBW_SEG consecutive multiples of base `slot` as XYZZ
+constexpr int FBW_SEG = 64;
+__global__ void __launch_bounds__(128) k_fbw_chain(Xyzz* __restrict__ tmp, const AffPt* __restrict__ rows, size_t slot0,
+                                                   size_t nslots, size_t mults) {
+    const size_t segs = mults / FBW_SEG;
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= nslots * segs) return;
+    const size_t sl = tid / segs, sg = tid % segs;
+    const AffPt base = rows[slot0 + sl];
+    Xyzz* out = tmp + (sl * mults + sg * FBW_SEG);
+    Xyzz acc;
+    g1::set_inf(acc);
+    if (base.flags & 1) {
+        for (int k = 0; k < FBW_SEG; ++k) out[k] = acc;
+        return;
+    }
+    if (sg != 0) {
+        g1::set_affine(acc, base.x, base.y);
+        g1::mul_small(acc, (u32)(sg * FBW_SEG));
+    }
+    for (int k = 0; k < FBW_SEG; ++k) {
+        g1::madd(acc, base.x, base.y);
+        out[k] = acc;
+    }
+}
+
+// XYZZ -> affine table slots, one Montgomery batch inversion per FBW_INV consecutive entries
+constexpr int FBW_INV = 32;
+__global__ void __launch_bounds__(128) k_fbw_affine(AffPt* __restrict__ wide, const Xyzz* __restrict__ tmp,
+                                                    fp28::Fe* __restrict__ pref, size_t count) {
+    size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t lo = tid * FBW_INV;
+    if (lo >= count) return;
+    size_t hi = lo + FBW_INV < count ? lo + FBW_INV : count;
+    fp28::Fe p = fp28::one();
+    for (size_t k = lo; k < hi; ++k) {
+        pref[k] = p;
+        const Xyzz* q = tmp + k;
+        if (!fp28::is_zero_limbs(q->zz)) p = fp28::mul(p, fp28::mul(q->zz, q->zzz));
+    }
+    fp28::Fe inv = g1io::inverse(p);
+    for (size_t k = hi; k-- > lo;) {
+        Xyzz q = tmp[k];
+        AffPt o;
+        o.pad[0] = o.pad[1] = o.pad[2] = 0;
+        if (g1::is_inf(q)) {
+            o.flags = 1;
+            o.x = fp28::zero();
+            o.y = fp28::zero();
+        } else {
+            o.flags = 0;
+            fp28::Fe zi = fp28::mul(inv, pref[k]);                  // 1 / (ZZ*ZZZ)
+            inv = fp28::mul(inv, fp28::mul(q.zz, q.zzz));
+            o.x = fp28::canon(fp28::mul(q.x, fp28::mul(zi, q.zzz)));  // X / ZZ
+            o.y = fp28::canon(fp28::mul(q.y, fp28::mul(zi, q.zz)));   // Y / ZZZ
+        }
+        wide[k] = o;
+    }
+}
+
+// one lane per (MSM, scalar): all windows of that scalar against the wide table
+__global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __restrict__ scalars,
+                                                   const AffPt* __restrict__ wide, Xyzz* __restrict__ partial) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.n * P.nbatch) return;
+    const size_t i = t % P.n;
+    u32 s[8];
+    load_scalar(s, scalars, t, P.mont);
+    Xyzz acc;
+    g1::set_inf(acc);
+    u32 carry = 0;
+    const u32 half = 1u << (P.c - 1);
+    const int sh = P.c - 1;
+    for (int w = 0; w < P.nwin; ++w) {
+        u32 d = window_bits(s, w * P.c, P.c) + carry;
+        u32 neg = 0;
+        carry = 0;
+        if (d > half) {
+            d = (1u << P.c) - d;
+            neg = 1;
+            carry = 1;
+        }
+        if (d == 0) continue;
+        const AffPt* p = wide + ((((size_t)w * P.row_stride + i) << sh) + (d - 1));
+        if (p->flags & 1) continue;
+        fp28::Fe x = p->x, y = p->y;
+        if (neg) y = fp28::neg<2>(y);
+        g1::madd(acc, x, y);
+    }
+    partial[t] = acc;
+}
+
+// one workgroup per MSM: plain sum of its n partial sums
+__global__ void __launch_bounds__(256) k_blocksum(const Xyzz* __restrict__ in_all, Xyzz* __restrict__ out, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Xyzz* sh = reinterpret_cast<Xyzz*>(smem);
+    const size_t set = blockIdx.x;
+    const Xyzz* in = in_all + set * n;
+    Xyzz acc;
+    g1::set_inf(acc);
+    for (size_t k = threadIdx.x; k < n; k += blockDim.x) {
+        Xyzz b = in[k];
+        g1::dadd(acc, b);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int stride = blockDim.x / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) {
+            Xyzz b = sh[threadIdx.x + stride];
+            g1::dadd(acc, b);
+            sh[threadIdx.x] = acc;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[set] = acc;
 }
 
 // device copy of already-converted table slots (row 0)
@@ -548,6 +677,8 @@ struct kzgamd::MsmContext {
     int c = 0, rows = 0;
     size_t nb = 0;
     DevBuf<AffPt> table;  // rows x n (prepared) or n
+    DevBuf<AffPt> wide;   // wide fixed-base table: (rows x n) x 2^(c-1), when it fits the budget
+    bool fbw = false;
     Workspace ws;
     hipStream_t stream = nullptr;
     bool profile = false;
@@ -557,6 +688,7 @@ struct kzgamd::MsmContext {
     static constexpr size_t EV_MAX = 4 * 512;
     ~MsmContext() {
         table.release();
+        wide.release();
         ws.release();
         for (auto& e : ev)
             if (e) (void)hipEventDestroy(e);
@@ -570,6 +702,42 @@ static void require_device() {
     int cnt = 0;
     hipError_t e = hipGetDeviceCount(&cnt);
     if (e != hipSuccess || cnt <= 0) throw HipErr{e == hipSuccess ? hipErrorNoDevice : e, "no gfx950 device visible"};
+}
+
+// Wide table: built tile by tile (chain of multiples as XYZZ -> batch-inverted affine slots).
+static void build_wide_table(MsmContext* ctx) {
+    double budget_gb = 64.0;
+    if (const char* e = getenv("KZGAMD_FBW_MAX_GB")) budget_gb = atof(e);
+    const size_t mults = ctx->nb;  // 2^(c-1)
+    const size_t nslots = (size_t)ctx->rows * ctx->n;
+    const double gb = (double)nslots * (double)mults * sizeof(AffPt) / 1e9;
+    if (budget_gb <= 0 || gb > budget_gb || mults < (size_t)FBW_SEG) return;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if ((double)free_b < gb * 1e9 * 1.15 + 8e9) return;
+    ctx->wide.ensure(nslots * mults);
+    // tile: up to 2^22 table entries at a time (XYZZ 224 B + prefix 56 B of scratch each)
+    size_t tile_slots = ((size_t)1 << 22) / mults;
+    if (tile_slots == 0) tile_slots = 1;
+    if (tile_slots > nslots) tile_slots = nslots;
+    DevBuf<Xyzz> tmp;
+    DevBuf<fp28::Fe> pref;
+    tmp.ensure(tile_slots * mults);
+    pref.ensure(tile_slots * mults);
+    for (size_t s0 = 0; s0 < nslots; s0 += tile_slots) {
+        const size_t ns = s0 + tile_slots <= nslots ? tile_slots : nslots - s0;
+        const size_t chain_threads = ns * (mults / FBW_SEG), cnt = ns * mults;
+        hipLaunchKernelGGL(k_fbw_chain, dim3((unsigned)((chain_threads + 127) / 128)), dim3(128), 0, ctx->stream, tmp.p,
+                           (const AffPt*)ctx->table.p, s0, ns, mults);
+        const size_t inv_threads = (cnt + FBW_INV - 1) / FBW_INV;
+        hipLaunchKernelGGL(k_fbw_affine, dim3((unsigned)((inv_threads + 127) / 128)), dim3(128), 0, ctx->stream,
+                           ctx->wide.p + s0 * mults, (const Xyzz*)tmp.p, pref.p, cnt);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    tmp.release();
+    pref.release();
+    ctx->fbw = true;
 }
 
 // uploads points (host or device pointer), builds the fixed-base rows when `prepare`
@@ -606,6 +774,7 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         staging.release();
+        if (prepare) build_wide_table(ctx);
     } catch (...) {
         delete ctx;
         throw;
@@ -632,6 +801,36 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     }
     if (set_cap >= ((size_t)1 << 31) || nsets * nb >= ((size_t)1 << 40)) throw HipErr{hipErrorInvalidValue, "MSM too large"};
     Workspace& ws = ctx->ws;
+    if (ctx->fbw) {
+        // wide-table path: gather + add, then one block-sum per MSM
+        ws.buckets.ensure(nbatch * npoints);
+        ws.lvlM[0].ensure(nbatch);
+        DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n};
+        hipEvent_t* pev = nullptr;
+        if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
+            while (ctx->ev.size() < ctx->ev_used + 4) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                ctx->ev.push_back(e);
+            }
+            pev = &ctx->ev[ctx->ev_used];
+            HIP_TRY(hipEventRecord(pev[0], stream));
+            HIP_TRY(hipEventRecord(pev[1], stream));
+        }
+        hipLaunchKernelGGL(k_fbw_accum, dim3((unsigned)((npoints * nbatch + 255) / 256)), dim3(256), 0, stream, P,
+                           (const u32*)d_scalars, (const AffPt*)ctx->wide.p, ws.buckets.p);
+        if (pev) HIP_TRY(hipEventRecord(pev[2], stream));
+        hipLaunchKernelGGL(k_blocksum, dim3((unsigned)nbatch), dim3(256), 256 * sizeof(Xyzz), stream,
+                           (const Xyzz*)ws.buckets.p, ws.lvlM[0].p, npoints);
+        hipLaunchKernelGGL(k_final, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)nullptr,
+                           (const Xyzz*)ws.lvlM[0].p, d_out, nbatch, nwin, c, 1, out_mode);
+        if (pev) {
+            HIP_TRY(hipEventRecord(pev[3], stream));
+            ctx->ev_used += 4;
+        }
+        HIP_TRY(hipGetLastError());
+        return;
+    }
     ws.counts.ensure(nsets * nb);
     ws.offsets.ensure(nsets * (nb + 1));
     ws.sorted.ensure(nsets * set_cap);
@@ -824,6 +1023,8 @@ extern "C" int kzgamd_msm_info(void* msm, int* window_bits, int* rows, size_t* n
     if (npoints) *npoints = ctx->n;
     return 0;
 }
+
+extern "C" int kzgamd_msm_uses_wide_table(void* msm) { return msm && ((MsmContext*)msm)->fbw ? 1 : 0; }
 
 extern "C" int kzgamd_msm_set_profile(void* msm, int on) {
     if (!msm) return 1;
