@@ -49,6 +49,18 @@ def make_blobs(torch, nblobs, seed, device):
     return b.reshape(nblobs, BLOB).to(device)
 
 
+def host_cores():
+    """usable host cores: affinity mask capped by the cgroup CPU quota (cpu.max)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(blobs_host, budget_s=12.0):
     """Times the CPU oracle (portable C restatement of the reference's Pippenger path — NOT blst asm)
     on this box's host cores: one thread per core, each committing to its own blobs."""
@@ -63,8 +75,8 @@ def cpu_baseline(blobs_host, budget_s=12.0):
     t0 = time.perf_counter()
     assert L.oblob_to_kzg_commitment(out, blobs_host[0], C.byref(s)) == 0
     t1 = time.perf_counter() - t0
-    cores = os.cpu_count() or 1
-    per_thread = max(1, min(64, int(budget_s / max(t1, 1e-3) / 1.5)))
+    cores = host_cores()
+    per_thread = max(1, min(256, int(budget_s / max(t1, 1e-3))))
     done = [0] * cores
 
     def work(t):
@@ -180,7 +192,7 @@ def main():
         accum_ms, total_ms, cnt = prof
         alg_bytes = ALG_BYTES_PER_COMMIT * B
         ach = alg_bytes / (accum_ms * 1e-3) / 1e9
-        res["roofline"] = {"bound": "hbm", "kernel": "k_accum", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        res["roofline"] = {"bound": "hbm", "kernel": "k_fbw_accum" if info.get("wide_table") else "k_accum", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": ach / HBM_PEAK_GBS, "traffic": None,
                            "kernel_ms": accum_ms, "pipeline_ms": total_ms, "launches_averaged": cnt,
                            "algorithmic_bytes_per_launch": alg_bytes,
