@@ -52,6 +52,7 @@ EXPORTS = [
     "prepare_msm", "mult_pippenger_prepared", "mult_pippenger", "free_msm", "mult_pippenger_prepared_batch",
     "kzgamd_msm_prepared_batch_device", "kzgamd_msm_info", "kzgamd_msm_uses_wide_table", "kzgamd_msm_set_profile", "kzgamd_msm_get_profile",
     "kzgamd_device_count", "kzgamd_version", "kzgamd_msm_create_device", "kzgamd_generate_points",
+    "kzgamd_ntt_new", "kzgamd_ntt_free", "ntt_fr", "das_fft_extension", "kzgamd_ntt_fr_device", "kzgamd_ntt_roots",
     "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
     "kzgamd_blob_to_kzg_commitment_batch", "kzgamd_blob_to_kzg_commitment_device", "kzgamd_settings_msm_handle",
 ]
@@ -105,6 +106,18 @@ def lib():
     L.kzgamd_msm_create_device.argtypes = [vp, sz, C.c_int]
     L.kzgamd_generate_points.restype = RustError
     L.kzgamd_generate_points.argtypes = [vp, sz, C.c_uint64, vp]
+    L.kzgamd_ntt_new.restype = vp
+    L.kzgamd_ntt_new.argtypes = [C.c_uint]
+    L.kzgamd_ntt_free.restype = None
+    L.kzgamd_ntt_free.argtypes = [vp]
+    L.ntt_fr.restype = C.c_int
+    L.ntt_fr.argtypes = [vp, vp, vp, sz, C.c_int]
+    L.das_fft_extension.restype = C.c_int
+    L.das_fft_extension.argtypes = [vp, vp, vp, sz]
+    L.kzgamd_ntt_fr_device.restype = C.c_int
+    L.kzgamd_ntt_fr_device.argtypes = [vp, vp, vp, sz, sz, C.c_int, vp]
+    L.kzgamd_ntt_roots.restype = C.c_int
+    L.kzgamd_ntt_roots.argtypes = [vp, vp, vp, vp]
     sp = C.POINTER(CKZGSettings)
     L.load_trusted_setup.restype = C.c_int
     L.load_trusted_setup.argtypes = [sp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64,
@@ -315,3 +328,67 @@ class DeviceMsm(PreparedMsm):
 
 def generate_points(d_out, npoints, seed, stream=0):
     _check(lib().kzgamd_generate_points(C.c_void_p(d_out), npoints, seed, C.c_void_p(stream)), "kzgamd_generate_points")
+
+
+# ---------------------------------------------------------------- NTT plug-in (B2)
+class FFTSettings:
+    """Mirror of FsFFTSettings (blst/src/types/fft_settings.rs:14-58) + FFTFr / DASExtension
+    (blst/src/fft_fr.rs:156-165, blst/src/data_availability_sampling.rs:78-100).
+    Errors are raised with the reference's messages."""
+
+    def __init__(self, scale):
+        if scale >= 32:
+            raise KzgAmdError("Scale is expected to be within root of unity matrix row size")
+        self.scale = scale
+        self.max_width = 1 << scale
+        self.handle = lib().kzgamd_ntt_new(scale)
+        if not self.handle:
+            raise KzgAmdError("kzgamd_ntt_new failed (no GPU?)")
+
+    def fft_fr(self, data, n, inverse=False):
+        """data: blst_fr[n] (ctypes array / buffer). Returns a new (BlstFr * n)."""
+        out = (BlstFr * max(n, 1))()
+        rc = lib().ntt_fr(self.handle, out, _addr(data), n, 1 if inverse else 0)
+        if rc == 1:
+            raise KzgAmdError("Supplied list is longer than the available max width")
+        if rc == 2:
+            raise KzgAmdError("A list with power-of-two length expected")
+        if rc != 0:
+            raise KzgAmdError("ntt_fr: device error %d" % rc)
+        return out
+
+    def das_fft_extension(self, evens, n):
+        out = (BlstFr * max(n, 1))()
+        rc = lib().das_fft_extension(self.handle, out, _addr(evens), n)
+        if rc == 1:
+            raise KzgAmdError("A non-zero list ab expected")
+        if rc == 2:
+            raise KzgAmdError("A list with power-of-two length expected")
+        if rc == 3:
+            raise KzgAmdError("Supplied list is longer than the available max width")
+        if rc != 0:
+            raise KzgAmdError("das_fft_extension: device error %d" % rc)
+        return out
+
+    def fft_fr_device(self, d_out, d_in, n, nbatch=1, inverse=False, stream=0):
+        rc = lib().kzgamd_ntt_fr_device(self.handle, C.c_void_p(d_out), C.c_void_p(d_in), n, nbatch, 1 if inverse else 0,
+                                        C.c_void_p(stream))
+        if rc != 0:
+            raise KzgAmdError("kzgamd_ntt_fr_device: %d" % rc)
+
+    def roots(self):
+        W = self.max_width
+        r, rr, br = (BlstFr * (W + 1))(), (BlstFr * (W + 1))(), (BlstFr * W)()
+        lib().kzgamd_ntt_roots(self.handle, r, rr, br)
+        return r, rr, br
+
+    def close(self):
+        if self.handle:
+            lib().kzgamd_ntt_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

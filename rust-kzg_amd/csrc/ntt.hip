@@ -1,0 +1,324 @@
+// MI355X-native radix-2 NTT over Fr (B2): replaces FsFFTSettings::fft_fr
+// (blst/src/fft_fr.rs:112-165) and das_fft_extension (blst/src/data_availability_sampling.rs:78-100).
+//
+// Contract identical to the reference: natural order in, natural order out, Montgomery blst_fr,
+// roots taken with stride max_width/n from roots_of_unity (forward) or reverse_roots_of_unity
+// (inverse), inverse scaled by n^-1.  The reference recurses (out-of-place DIT, even/odd split);
+// here the same butterfly network is run iteratively:
+//   n <= 4096 : one workgroup per transform, all log2(n) stages in LDS (4096 x 32 B = 128 KiB of the
+//               160 KiB CDNA4 LDS), bit-reversal folded into the load;
+//   n  > 4096 : pass 1 = the 12 low stages on contiguous 4096-blocks (same kernel), pass 2 = the
+//               remaining stages on column tiles (C columns x n/4096 rows = 4096 elements per workgroup)
+//               so every element crosses HBM twice (64*n algorithmic bytes per pass pair).
+// Field arithmetic: 8 x 32-bit Montgomery (ff.cuh); integer VALU only.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+
+#include "../../include/kzg_mi355x.h"
+#include "ckzg_internal.h"
+#include "ff.cuh"
+
+using ff::Fr;
+using ff::u32;
+using ff::u64;
+
+namespace {
+
+constexpr int LOG_TILE = 12;
+constexpr int TILE = 1 << LOG_TILE;  // elements per workgroup
+constexpr int NT = 1024;             // threads per workgroup
+
+struct NttErr {
+    hipError_t e;
+};
+#define NTT_TRY(x)                           \
+    do {                                     \
+        hipError_t _e = (x);                 \
+        if (_e != hipSuccess) throw NttErr{_e}; \
+    } while (0)
+
+__device__ __forceinline__ u32 brev(u32 v, int bits) { return __builtin_bitreverse32(v) >> (32 - bits); }
+
+// LDS holds elements limb-major: sh[limb * TILE + idx] -> unit-stride lanes hit distinct banks
+__device__ __forceinline__ Fr lds_get(const u32* sh, int cnt, int idx) {
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.v[k] = sh[k * cnt + idx];
+    return r;
+}
+__device__ __forceinline__ void lds_put(u32* sh, int cnt, int idx, const Fr& a) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[k * cnt + idx] = a.v[k];
+}
+
+// `stages` butterfly stages of a DIT network on the `cnt` elements in LDS.
+// Element e of the tile has global index  g = e_hi * gstride + goff  pattern handled by the caller
+// through twiddle_index(); here: stage s pairs e and e + 2^s (s = 0 .. stages-1).
+template <class TwFn>
+__device__ __forceinline__ void lds_stages(u32* sh, int cnt, int stages, TwFn tw) {
+    for (int s = 0; s < stages; ++s) {
+        const int half = 1 << s;
+        for (int b = threadIdx.x; b < cnt / 2; b += NT) {
+            const int j = b & (half - 1);
+            const int i0 = ((b >> s) << (s + 1)) | j, i1 = i0 + half;
+            Fr x = lds_get(sh, cnt, i0), y = lds_get(sh, cnt, i1);
+            Fr t = ff::mul(y, tw(s, j, i0));
+            lds_put(sh, cnt, i0, ff::add(x, t));
+            lds_put(sh, cnt, i1, ff::sub(x, t));
+        }
+        __syncthreads();
+    }
+}
+
+struct NttParams {
+    u32 n;          // transform length
+    int logn;
+    u32 W;          // roots table width (max_width)
+    int inverse;
+    Fr scale;       // n^-1 (Montgomery) when inverse, else unused
+};
+
+// Pass 1 (and the whole transform when n <= TILE): block `blk` of min(n,TILE) consecutive
+// positions of the bit-reversed sequence; stages 0 .. min(logn,12)-1.
+__global__ void __launch_bounds__(NT) k_ntt_low(Fr* __restrict__ out, const Fr* __restrict__ in,
+                                                const Fr* __restrict__ roots, NttParams P, u32 blocks_per_xform) {
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    const u32 xf = blockIdx.x / blocks_per_xform, blk = blockIdx.x % blocks_per_xform;
+    const int cnt = P.n < (u32)TILE ? (int)P.n : TILE;
+    const int stages = P.logn < LOG_TILE ? P.logn : LOG_TILE;
+    const Fr* src = in + (size_t)xf * P.n;
+    Fr* dst = out + (size_t)xf * P.n;
+    for (int e = threadIdx.x; e < cnt; e += NT) {
+        const u32 pos = blk * (u32)cnt + (u32)e;  // position in the bit-reversed sequence
+        lds_put(sh, cnt, e, src[brev(pos, P.logn)]);
+    }
+    __syncthreads();
+    // stage s: half = 2^s, twiddle w_n^(j * n / 2^(s+1)) = roots[j * (W / 2^(s+1))]
+    const bool last_pass = P.logn <= LOG_TILE;
+    lds_stages(sh, cnt, stages, [&](int s, int j, int) -> Fr {
+        const u32 idx = (u32)j * (P.W >> (s + 1));
+        return roots[P.inverse ? P.W - idx : idx];
+    });
+    for (int e = threadIdx.x; e < cnt; e += NT) {
+        Fr v = lds_get(sh, cnt, e);
+        if (last_pass && P.inverse) v = ff::mul(v, P.scale);
+        dst[blk * (u32)cnt + (u32)e] = v;
+    }
+}
+
+// Pass 2: stages 12 .. logn-1 on a tile of C consecutive columns x R = n/4096 rows (in place).
+__global__ void __launch_bounds__(NT) k_ntt_high(Fr* __restrict__ data, const Fr* __restrict__ roots, NttParams P,
+                                                 u32 tiles_per_xform) {
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    const u32 xf = blockIdx.x / tiles_per_xform, tile = blockIdx.x % tiles_per_xform;
+    const int logR = P.logn - LOG_TILE, R = 1 << logR, C = TILE >> logR, logC = LOG_TILE - logR;
+    Fr* base = data + (size_t)xf * P.n;
+    const u32 col0 = tile * (u32)C;
+    // LDS element e = c * R + r  (row index fastest, so a butterfly pairs e and e + 2^s)
+    for (int e = threadIdx.x; e < TILE; e += NT) {
+        const int c = e & (C - 1), r = e >> logC;  // consecutive lanes -> consecutive columns (coalesced)
+        lds_put(sh, TILE, c * R + r, base[(size_t)r * TILE + col0 + c]);
+    }
+    __syncthreads();
+    lds_stages(sh, TILE, logR, [&](int s, int j, int i0) -> Fr {
+        // global stage 12+s: half = 4096 * 2^s; j_global = (r mod 2^s) * 4096 + column
+        const u32 col = col0 + (u32)(i0 >> logR);
+        const u32 jg = ((u32)j << LOG_TILE) + col;
+        const u32 idx = jg * (P.W >> (LOG_TILE + s + 1));
+        return roots[P.inverse ? P.W - idx : idx];
+    });
+    for (int e = threadIdx.x; e < TILE; e += NT) {
+        const int c = e & (C - 1), r = e >> logC;
+        Fr v = lds_get(sh, TILE, c * R + r);
+        if (P.inverse) v = ff::mul(v, P.scale);
+        base[(size_t)r * TILE + col0 + c] = v;
+    }
+}
+
+// DAS helper: data[i] *= roots[i * stride]  (the shift by the 2n-th root between the two NTTs)
+__global__ void __launch_bounds__(256) k_twist(Fr* __restrict__ data, const Fr* __restrict__ roots, u32 n, u32 stride,
+                                               size_t total) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    u32 i = (u32)(t % n);
+    data[t] = ff::mul(data[t], roots[(size_t)i * stride]);
+}
+
+}  // namespace
+
+struct NttCtx {
+    int device = 0;
+    unsigned scale = 0;
+    size_t W = 0;
+    Fr* d_roots = nullptr;  // W + 1
+    std::vector<Fr> roots;  // host copy
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    Fr *d_a = nullptr, *d_b = nullptr;
+    size_t cap = 0;
+    ~NttCtx() {
+        if (d_roots) (void)hipFree(d_roots);
+        if (d_a) (void)hipFree(d_a);
+        if (d_b) (void)hipFree(d_b);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    void ensure(size_t n) {
+        if (n <= cap) return;
+        if (d_a) (void)hipFree(d_a);
+        if (d_b) (void)hipFree(d_b);
+        d_a = d_b = nullptr;
+        cap = 0;
+        NTT_TRY(hipMalloc(&d_a, n * sizeof(Fr)));
+        NTT_TRY(hipMalloc(&d_b, n * sizeof(Fr)));
+        cap = n;
+    }
+};
+
+namespace {
+
+int ilog2(size_t n) {
+    int l = 0;
+    while (((size_t)1 << l) < n) ++l;
+    return l;
+}
+
+// n^-1 in Montgomery form
+Fr inv_len(size_t n) {
+    Fr v = Fr::zero();
+    v.v[0] = (u32)n;
+    v.v[1] = (u32)((u64)n >> 32);
+    return ff::inverse(ff::to_mont(v));
+}
+
+// enqueue nbatch transforms of length n (device pointers; out may equal in only when n > TILE is false... so never alias)
+void ntt_enqueue(NttCtx* ctx, Fr* d_out, const Fr* d_in, size_t n, size_t nbatch, bool inverse, hipStream_t stream) {
+    NttParams P;
+    P.n = (u32)n;
+    P.logn = ilog2(n);
+    P.W = (u32)ctx->W;
+    P.inverse = inverse ? 1 : 0;
+    P.scale = inverse ? inv_len(n) : Fr::one();
+    const size_t lds = (n < (size_t)TILE ? n : (size_t)TILE) * sizeof(Fr);
+    const u32 blocks = n <= (size_t)TILE ? 1u : (u32)(n >> LOG_TILE);
+    hipLaunchKernelGGL(k_ntt_low, dim3((unsigned)(blocks * nbatch)), dim3(NT), lds, stream, d_out, d_in,
+                       (const Fr*)ctx->d_roots, P, blocks);
+    if (n > (size_t)TILE) {
+        const int logR = P.logn - LOG_TILE;
+        const u32 tiles = (u32)1 << logR;  // 4096 columns / C columns per tile, C = 4096 >> logR
+        hipLaunchKernelGGL(k_ntt_high, dim3((unsigned)(tiles * nbatch)), dim3(NT), (size_t)TILE * sizeof(Fr), stream, d_out,
+                           (const Fr*)ctx->d_roots, P, tiles);
+    }
+    NTT_TRY(hipGetLastError());
+}
+
+}  // namespace
+
+extern "C" void* kzgamd_ntt_new(unsigned scale) {
+    if (scale >= 32) return nullptr;  // "Scale is expected to be within root of unity matrix row size"
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "kzg_mi355x: kzgamd_ntt_new: no gfx950 device visible\n");
+        return nullptr;
+    }
+    auto* ctx = new NttCtx();
+    try {
+        NTT_TRY(hipGetDevice(&ctx->device));
+        NTT_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->scale = scale;
+        ctx->W = (size_t)1 << scale;
+        kzgamd::expand_roots(ctx->roots, scale);
+        NTT_TRY(hipMalloc(&ctx->d_roots, (ctx->W + 1) * sizeof(Fr)));
+        NTT_TRY(hipMemcpy(ctx->d_roots, ctx->roots.data(), (ctx->W + 1) * sizeof(Fr), hipMemcpyHostToDevice));
+    } catch (...) {
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+extern "C" void kzgamd_ntt_free(void* ctx) { delete (NttCtx*)ctx; }
+
+extern "C" int kzgamd_ntt_fr_device(void* vctx, void* d_out, const void* d_in, size_t n, size_t nbatch, int inverse,
+                                    void* stream) {
+    NttCtx* ctx = (NttCtx*)vctx;
+    if (!ctx || !d_out || !d_in) return -1;
+    if (n > ctx->W) return 1;
+    if (n == 0 || (n & (n - 1))) return 2;
+    if (n > ((size_t)1 << (2 * LOG_TILE))) return -2;  // two-pass limit (2^24)
+    if (d_out == d_in) return -3;
+    try {
+        ntt_enqueue(ctx, (Fr*)d_out, (const Fr*)d_in, n, nbatch, inverse != 0, (hipStream_t)stream);
+    } catch (const NttErr& e) {
+        return -(int)e.e - 100;
+    }
+    return 0;
+}
+
+extern "C" int ntt_fr(void* vctx, blst_fr* out, const blst_fr* in, size_t n, int inverse) {
+    NttCtx* ctx = (NttCtx*)vctx;
+    if (!ctx || !out || !in) return -1;
+    if (n > ctx->W) return 1;                 // "Supplied list is longer than the available max width"
+    if (n == 0 || (n & (n - 1))) return 2;    // "A list with power-of-two length expected"
+    if (n > ((size_t)1 << (2 * LOG_TILE))) return -2;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    try {
+        NTT_TRY(hipSetDevice(ctx->device));
+        ctx->ensure(n);
+        NTT_TRY(hipMemcpyAsync(ctx->d_a, in, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        ntt_enqueue(ctx, ctx->d_b, ctx->d_a, n, 1, inverse != 0, ctx->stream);
+        NTT_TRY(hipMemcpyAsync(out, ctx->d_b, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        NTT_TRY(hipStreamSynchronize(ctx->stream));
+    } catch (const NttErr& e) {
+        return -(int)e.e - 100;
+    }
+    return 0;
+}
+
+// odds = FFT_n( w^j * IFFT_n(evens)_j ), w the 2n-th root: the values of the degree < n interpolant of
+// `evens` at the odd positions of the size-2n domain — what das_fft_extension_stride computes with its
+// fused butterfly network (data_availability_sampling.rs:14-72), including the final n^-1 (:95-97,
+// absorbed here by the inverse transform).
+extern "C" int das_fft_extension(void* vctx, blst_fr* odds, const blst_fr* evens, size_t n) {
+    NttCtx* ctx = (NttCtx*)vctx;
+    if (!ctx || !odds || !evens) return -1;
+    if (n == 0) return 1;                  // "A non-zero list ab expected"
+    if (n & (n - 1)) return 2;             // "A list with power-of-two length expected"
+    if (n * 2 > ctx->W) return 3;          // "Supplied list is longer than the available max width"
+    if (n > ((size_t)1 << (2 * LOG_TILE))) return -2;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    try {
+        NTT_TRY(hipSetDevice(ctx->device));
+        ctx->ensure(n);
+        NTT_TRY(hipMemcpyAsync(ctx->d_a, evens, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+        ntt_enqueue(ctx, ctx->d_b, ctx->d_a, n, 1, true, ctx->stream);
+        hipLaunchKernelGGL(k_twist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_b,
+                           (const Fr*)ctx->d_roots, (u32)n, (u32)(ctx->W / (2 * n)), n);
+        ntt_enqueue(ctx, ctx->d_a, ctx->d_b, n, 1, false, ctx->stream);
+        NTT_TRY(hipMemcpyAsync(odds, ctx->d_a, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        NTT_TRY(hipStreamSynchronize(ctx->stream));
+    } catch (const NttErr& e) {
+        return -(int)e.e - 100;
+    }
+    return 0;
+}
+
+extern "C" int kzgamd_ntt_roots(void* vctx, blst_fr* roots, blst_fr* reverse_roots, blst_fr* brp_roots) {
+    NttCtx* ctx = (NttCtx*)vctx;
+    if (!ctx) return -1;
+    const size_t W = ctx->W;
+    if (roots) memcpy(roots, ctx->roots.data(), (W + 1) * sizeof(Fr));
+    if (reverse_roots)
+        for (size_t i = 0; i <= W; ++i) memcpy(&reverse_roots[i], &ctx->roots[W - i], sizeof(Fr));
+    if (brp_roots)
+        for (size_t i = 0; i < W; ++i) {
+            size_t r = 0;
+            for (unsigned b = 0; b < ctx->scale; ++b)
+                if (i & ((size_t)1 << b)) r |= (size_t)1 << (ctx->scale - 1 - b);
+            memcpy(&brp_roots[i], &ctx->roots[r], sizeof(Fr));
+        }
+    return 0;
+}

@@ -1,0 +1,113 @@
+"""NTT parity on the GPU (B2) vs the CPU oracle; mirrors kzg-bench/src/tests/fft_fr.rs and das.rs."""
+import ctypes as C
+import hashlib
+import random
+
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+
+def fr_bulk(vals):
+    arr = (O.Fr * len(vals))()
+    raw = b"".join(((v << 256) % O.R).to_bytes(32, "little") for v in vals)
+    C.memmove(arr, raw, len(raw))
+    return arr
+
+
+def limbs(fr):
+    return [int(x) for x in fr.l]
+
+
+def test_inverse_fft_kat_and_das_kat(kzg, oracle, kats):
+    L = oracle.lib()
+    fs = kzg.FFTSettings(4)
+    data = fr_bulk(list(range(16)))
+    out = fs.fft_fr(data, 16, inverse=True)
+    for i, row in enumerate(kats["inverse_fft"]["expected"]):
+        got = (C.c_uint64 * 4)()
+        f = O.Fr()
+        C.memmove(C.byref(f), C.byref(out[i]), 32)
+        L.ofr_to_u64_arr(got, C.byref(f))
+        assert list(got) == row, i
+    odds = fs.das_fft_extension(fr_bulk(list(range(8))), 8)
+    for i, row in enumerate(kats["das_extension_known"]["expected"]):
+        got = (C.c_uint64 * 4)()
+        f = O.Fr()
+        C.memmove(C.byref(f), C.byref(odds[i]), 32)
+        L.ofr_to_u64_arr(got, C.byref(f))
+        assert list(got) == row, i
+    fs.close()
+
+
+@pytest.mark.parametrize("logn", [0, 1, 2, 5, 9, 12, 13, 15])
+def test_fft_matches_oracle(kzg, oracle, logn):
+    L = oracle.lib()
+    scale = max(logn, 1) + 1
+    fs = kzg.FFTSettings(scale)
+    ofs = O.FFTSettings()
+    assert L.offt_settings_new(C.byref(ofs), scale) == 0
+    n = 1 << logn
+    rnd = random.Random(100 + logn)
+    data = fr_bulk([rnd.randrange(O.R) for _ in range(n)])
+    for inv in (False, True):
+        exp = (O.Fr * n)()
+        assert L.offt_fr(C.byref(ofs), exp, data, n, 1 if inv else 0) == 0
+        got = fs.fft_fr(data, n, inverse=inv)
+        assert bytes(got)[: 32 * n] == bytes(exp), (logn, inv)
+    if n >= 1:
+        exp = (O.Fr * n)()
+        rc = L.odas_fft_extension(C.byref(ofs), exp, data, n)
+        assert rc == 0
+        got = fs.das_fft_extension(data, n)
+        assert bytes(got)[: 32 * n] == bytes(exp)
+    L.offt_settings_free(C.byref(ofs))
+    fs.close()
+
+
+def test_roots_and_errors(kzg, oracle):
+    L = oracle.lib()
+    fs = kzg.FFTSettings(8)
+    ofs = O.FFTSettings()
+    assert L.offt_settings_new(C.byref(ofs), 8) == 0
+    r, rr, br = fs.roots()
+    assert bytes(r) == bytes((O.Fr * 257).from_address(C.addressof(ofs.roots_of_unity.contents)))
+    assert bytes(rr) == bytes((O.Fr * 257).from_address(C.addressof(ofs.reverse_roots_of_unity.contents)))
+    assert bytes(br) == bytes((O.Fr * 256).from_address(C.addressof(ofs.brp_roots_of_unity.contents)))
+    buf = (O.Fr * 512)()
+    with pytest.raises(kzg.KzgAmdError, match="longer than the available max width"):
+        fs.fft_fr(buf, 512)
+    with pytest.raises(kzg.KzgAmdError, match="power-of-two"):
+        fs.fft_fr(buf, 24)
+    with pytest.raises(kzg.KzgAmdError, match="non-zero list"):
+        fs.das_fft_extension(buf, 0)
+    with pytest.raises(kzg.KzgAmdError, match="power-of-two"):
+        fs.das_fft_extension(buf, 24)
+    with pytest.raises(kzg.KzgAmdError, match="longer than the available max width"):
+        fs.das_fft_extension(buf, 256)
+    with pytest.raises(kzg.KzgAmdError):
+        kzg.FFTSettings(32)
+    L.offt_settings_free(C.byref(ofs))
+    fs.close()
+
+
+def test_large_2p20_roundtrip_and_digest(kzg, oracle):
+    # BASELINE configs[3]: n = 2^20.  fft then ifft == identity (size-independent property) and the
+    # forward transform equals the oracle's (compared by digest; the oracle takes ~1 s at this size)
+    L = oracle.lib()
+    logn = 20
+    n = 1 << logn
+    fs = kzg.FFTSettings(logn)
+    ofs = O.FFTSettings()
+    assert L.offt_settings_new(C.byref(ofs), logn) == 0
+    data = fr_bulk(list(range(n)))  # data[i] = Fr(i), as in kzg-bench/src/tests/fft_fr.rs:35-37
+    fwd = fs.fft_fr(data, n)
+    back = fs.fft_fr(fwd, n, inverse=True)
+    assert bytes(back) == bytes(data)
+    exp = (O.Fr * n)()
+    assert L.offt_fr(C.byref(ofs), exp, data, n, 0) == 0
+    assert hashlib.sha256(bytes(fwd)).digest() == hashlib.sha256(bytes(exp)).digest()
+    L.offt_settings_free(C.byref(ofs))
+    fs.close()
