@@ -130,8 +130,10 @@ C_KZG_RET compute_kzg_proof(KZGProof *proof_out, Bytes32 *y_out, const Blob *blo
                             const CKZGSettings *s);                                            /* eip_4844.rs:476-496 */
 C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, const Bytes48 *commitment_bytes,
                                  const CKZGSettings *s);                                       /* eip_4844.rs:274-291 */
-/* helper exported by the reference for the test-suite (eip_4844.rs:501-514) */
-C_KZG_RET compute_challenge(Bytes32 *out, const Blob *blob, const Bytes48 *commitment_bytes);
+/* helpers the reference exports for the binding test-suites (eip_4844.rs:501-530) */
+void compute_challenge(blst_fr *eval_challenge_out, const Blob *blob, const blst_p1 *commitment);
+C_KZG_RET bytes_to_kzg_commitment(blst_p1 *out, const Bytes48 *b);
+void bytes_from_bls_field(Bytes32 *out, const blst_fr *in);
 
 /* Batched forms (new API; BASELINE.json configs[4] names a compute_blob_kzg_proof_batch the reference
  * does not have — its closest behaviour is a host loop, kzg-bench/src/benches/eip_4844.rs:56-60).

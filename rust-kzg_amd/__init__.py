@@ -54,6 +54,8 @@ EXPORTS = [
     "kzgamd_device_count", "kzgamd_version", "kzgamd_msm_create_device", "kzgamd_generate_points",
     "kzgamd_ntt_new", "kzgamd_ntt_free", "ntt_fr", "das_fft_extension", "kzgamd_ntt_fr_device", "kzgamd_ntt_roots",
     "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
+    "compute_kzg_proof", "compute_blob_kzg_proof", "kzgamd_compute_blob_kzg_proof_batch", "compute_challenge",
+    "bytes_to_kzg_commitment", "bytes_from_bls_field",
     "kzgamd_blob_to_kzg_commitment_batch", "kzgamd_blob_to_kzg_commitment_device", "kzgamd_settings_msm_handle",
 ]
 
@@ -132,6 +134,18 @@ def lib():
     L.kzgamd_blob_to_kzg_commitment_batch.argtypes = [vp, vp, sz, sp]
     L.kzgamd_blob_to_kzg_commitment_device.restype = C.c_int
     L.kzgamd_blob_to_kzg_commitment_device.argtypes = [vp, vp, vp, vp, sz, sp, vp]
+    L.compute_kzg_proof.restype = C.c_int
+    L.compute_kzg_proof.argtypes = [vp, vp, vp, vp, sp]
+    L.compute_blob_kzg_proof.restype = C.c_int
+    L.compute_blob_kzg_proof.argtypes = [vp, vp, vp, sp]
+    L.kzgamd_compute_blob_kzg_proof_batch.restype = C.c_int
+    L.kzgamd_compute_blob_kzg_proof_batch.argtypes = [vp, vp, vp, sz, sp]
+    L.compute_challenge.restype = None
+    L.compute_challenge.argtypes = [vp, vp, vp]
+    L.bytes_to_kzg_commitment.restype = C.c_int
+    L.bytes_to_kzg_commitment.argtypes = [vp, vp]
+    L.bytes_from_bls_field.restype = None
+    L.bytes_from_bls_field.argtypes = [vp, vp]
     L.kzgamd_settings_msm_handle.restype = vp
     L.kzgamd_settings_msm_handle.argtypes = [sp]
     _lib = L
@@ -392,3 +406,54 @@ class FFTSettings:
             self.close()
         except Exception:
             pass
+
+
+def compute_kzg_proof(blob: bytes, z: bytes, settings: KZGSettings):
+    """blst/src/eip_4844.rs:476-496 -> (proof48, y32)"""
+    if len(blob) != BYTES_PER_BLOB or len(z) != 32:
+        raise KzgAmdError("compute_kzg_proof: C_KZG_RET %d" % C_KZG_BADARGS)
+    proof, y = C.create_string_buffer(48), C.create_string_buffer(32)
+    rc = lib().compute_kzg_proof(proof, y, blob, z, C.byref(settings.c))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("compute_kzg_proof: C_KZG_RET %d" % rc)
+    return proof.raw, y.raw
+
+
+def compute_blob_kzg_proof(blob: bytes, commitment: bytes, settings: KZGSettings) -> bytes:
+    """blst/src/eip_4844.rs:274-291"""
+    if len(blob) != BYTES_PER_BLOB or len(commitment) != 48:
+        raise KzgAmdError("compute_blob_kzg_proof: C_KZG_RET %d" % C_KZG_BADARGS)
+    proof = C.create_string_buffer(48)
+    rc = lib().compute_blob_kzg_proof(proof, blob, commitment, C.byref(settings.c))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("compute_blob_kzg_proof: C_KZG_RET %d" % rc)
+    return proof.raw
+
+
+def compute_blob_kzg_proof_batch(blobs: bytes, commitments: bytes, n: int, settings: KZGSettings):
+    """New batched API (BASELINE.json configs[4]); equals n compute_blob_kzg_proof calls."""
+    out = C.create_string_buffer(48 * n)
+    rc = lib().kzgamd_compute_blob_kzg_proof_batch(out, blobs, commitments, n, C.byref(settings.c))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("kzgamd_compute_blob_kzg_proof_batch: C_KZG_RET %d" % rc)
+    return [out.raw[48 * i:48 * i + 48] for i in range(n)]
+
+
+def compute_challenge(blob: bytes, commitment_p1) -> BlstFr:
+    """blst/src/eip_4844.rs:501-514 (commitment: BlstP1)"""
+    out = BlstFr()
+    lib().compute_challenge(C.byref(out), blob, C.byref(commitment_p1))
+    return out
+
+
+def bytes_to_kzg_commitment(b: bytes) -> BlstP1:
+    out = BlstP1()
+    if len(b) != 48 or lib().bytes_to_kzg_commitment(C.byref(out), b) != C_KZG_OK:
+        raise KzgAmdError("bytes_to_kzg_commitment: C_KZG_RET %d" % C_KZG_BADARGS)
+    return out
+
+
+def bytes_from_bls_field(fr) -> bytes:
+    out = C.create_string_buffer(32)
+    lib().bytes_from_bls_field(out, C.byref(fr))
+    return out.raw

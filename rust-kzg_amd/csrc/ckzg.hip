@@ -19,8 +19,10 @@
 #include "ckzg_internal.h"
 #include "fr_host.h"
 #include "g1_io.cuh"
+#include "host_g1.h"
 #include "msm_internal.h"
 #include "sha256.h"
+#include <thread>
 
 using ff::u32;
 using ff::u64;
@@ -95,6 +97,207 @@ __global__ void __launch_bounds__(256) k_blob_to_scalars(u32* __restrict__ out, 
     for (int k = 0; k < 8; ++k) out[t * 8 + k] = w[k];
 }
 
+
+
+
+// ---- Fr helpers for the proving kernel (Montgomery, 8 x u32) ----
+__device__ __forceinline__ ff::Fr fr_load_be(const u32* __restrict__ w8, bool* ok) {
+    // 32 big-endian bytes -> canonical limbs; *ok = value < r
+    ff::Fr a;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a.v[k] = __builtin_bswap32(w8[7 - k]);
+    u64 borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        u64 d = (u64)a.v[k] - ff::FrParams::p(k) - borrow;
+        borrow = (d >> 32) & 1;
+    }
+    *ok = borrow != 0;
+    return a;
+}
+__device__ ff::Fr fr_inverse(const ff::Fr& a) {  // a^(r-2); 0 -> 0 like blst_fr_eucl_inverse
+    ff::Fr r = ff::Fr::one();
+    bool started = false;
+    for (int i = 7; i >= 0; --i) {
+        u32 e = ff::FrParams::p(i);
+        if (i == 0) e = 0xffffffffu;             // r - 2: the low limb 1 - 2 borrows ...
+        if (i == 1) e = ff::FrParams::p(1) - 1;  // ... from limb 1
+        for (int b = 31; b >= 0; --b) {
+            if (started) r = ff::sqr(r);
+            if ((e >> b) & 1) {
+                r = started ? ff::mul(r, a) : a;
+                started = true;
+            }
+        }
+    }
+    return r;
+}
+
+constexpr int QT = 512;            // threads per blob
+constexpr int QE = (int)(N / QT);  // elements per thread (8), element index i = k*QT + t
+
+// compute_kzg_proof_rust up to the MSM (kzg/src/eip_4844.rs:437-510): y = p(z) by the barycentric
+// formula (evaluate_polynomial_in_evaluation_form :954-1003) and the quotient polynomial in
+// evaluation form, including the z-inside-the-domain column (:484-510).  One workgroup per blob;
+// the 4096 inversions are one Fermat inversion per blob via a block-wide product scan
+// (the reference's fr_batch_inv :882-914 is the same trick, serial).
+// Outputs: q as canonical little-endian scalars (ready for the MSM), y canonical.
+__global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* __restrict__ y_out, int* __restrict__ status,
+                                                 const u32* __restrict__ blobs, const u32* __restrict__ z_be,
+                                                 const ff::Fr* __restrict__ roots_brp) {
+    __shared__ ff::Fr sh_a[QT];
+    __shared__ ff::Fr sh_b[QT];
+    __shared__ ff::Fr sh_misc[4];  // 0: total^-1, 1: y, 2: z^-1 (domain case)
+    __shared__ int sh_m, sh_bad;
+    const int t = threadIdx.x;
+    const size_t blob = blockIdx.x;
+    const u32* bw = blobs + blob * (N * 8);
+    if (t == 0) {
+        sh_m = -1;
+        sh_bad = 0;
+    }
+    __syncthreads();
+    bool zok;
+    ff::Fr z = ff::to_mont(fr_load_be(z_be + blob * 8, &zok));
+    if (!zok && t == 0) sh_bad = 1;
+
+    // d_k = z - w_i, prefix products within the thread
+    ff::Fr pre[QE];
+    ff::Fr prod = ff::Fr::one();
+#pragma unroll
+    for (int k = 0; k < QE; ++k) {
+        const int i = k * QT + t;
+        ff::Fr d = ff::sub(z, roots_brp[i]);
+        if (d.is_zero()) {
+            sh_m = i;
+            d = ff::Fr::one();
+        }
+        pre[k] = prod;
+        prod = ff::mul(prod, d);
+    }
+    // block-wide inclusive prefix (sh_a) and suffix (sh_b) products of the per-thread products
+    sh_a[t] = prod;
+    sh_b[t] = prod;
+    __syncthreads();
+    for (int off = 1; off < QT; off <<= 1) {
+        ff::Fr pa = sh_a[t], pb = sh_b[t];
+        if (t >= off) pa = ff::mul(sh_a[t - off], pa);
+        if (t + off < QT) pb = ff::mul(pb, sh_b[t + off]);
+        __syncthreads();
+        sh_a[t] = pa;
+        sh_b[t] = pb;
+        __syncthreads();
+    }
+    if (t == 0) sh_misc[0] = fr_inverse(sh_a[QT - 1]);
+    __syncthreads();
+    ff::Fr inv = sh_misc[0];
+    if (t > 0) inv = ff::mul(inv, sh_a[t - 1]);
+    if (t + 1 < QT) inv = ff::mul(inv, sh_b[t + 1]);  // inv = 1 / P_t
+    const int m = sh_m;
+    __syncthreads();
+
+    // back-substitution: inv_k = 1/d_k; barycentric sum  sum p_i w_i / (z - w_i)
+    ff::Fr invs[QE];
+    ff::Fr acc = ff::Fr::zero();
+    bool bad = false;
+#pragma unroll
+    for (int k = QE - 1; k >= 0; --k) {
+        const int i = k * QT + t;
+        const ff::Fr w = roots_brp[i];
+        ff::Fr d = ff::sub(z, w);
+        if (i == m) d = ff::Fr::one();
+        invs[k] = ff::mul(inv, pre[k]);
+        inv = ff::mul(inv, d);
+        bool ok;
+        ff::Fr p = ff::to_mont(fr_load_be(bw + (size_t)i * 8, &ok));
+        bad |= !ok;
+        acc = ff::add(acc, ff::mul(ff::mul(invs[k], w), p));
+    }
+    if (bad) sh_bad = 1;
+    sh_a[t] = acc;
+    __syncthreads();
+    for (int off = QT / 2; off > 0; off >>= 1) {
+        if (t < off) sh_a[t] = ff::add(sh_a[t], sh_a[t + off]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        ff::Fr y;
+        if (m >= 0) {
+            bool ok;
+            y = ff::to_mont(fr_load_be(bw + (size_t)m * 8, &ok));
+            sh_misc[2] = fr_inverse(z);
+        } else {
+            // out = sum / N * (z^N - 1)
+            ff::Fr zn = z;
+            for (int k = 0; k < 12; ++k) zn = ff::sqr(zn);
+            ff::Fr nfr = ff::Fr::zero();
+            nfr.v[0] = (u32)N;
+            ff::Fr ninv = fr_inverse(ff::to_mont(nfr));
+            y = ff::mul(ff::mul(sh_a[0], ninv), ff::sub(zn, ff::Fr::one()));
+        }
+        sh_misc[1] = y;
+        ff::Fr yc = ff::from_mont(y);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y_out[blob * 8 + k] = yc.v[k];
+        if (sh_bad) status[blob] = 1;
+    }
+    __syncthreads();
+    const ff::Fr y = sh_misc[1];
+    // q_i = (p_i - y) / (w_i - z) = (y - p_i) * inv_i ;  domain case: column m gets
+    // sum_{i != m} (p_i - y) * w_i / (z * (z - w_i))
+    ff::Fr col = ff::Fr::zero();
+#pragma unroll
+    for (int k = 0; k < QE; ++k) {
+        const int i = k * QT + t;
+        if (i == m) continue;
+        bool ok;
+        ff::Fr p = ff::to_mont(fr_load_be(bw + (size_t)i * 8, &ok));
+        ff::Fr ymp = ff::sub(y, p);
+        ff::Fr q = ff::mul(ymp, invs[k]);
+        if (m >= 0) col = ff::add(col, ff::mul(ff::mul(ff::neg(ymp), roots_brp[i]), invs[k]));
+        ff::Fr qc = ff::from_mont(q);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) q_out[(blob * N + i) * 8 + l] = qc.v[l];
+    }
+    if (m >= 0) {
+        sh_a[t] = col;
+        __syncthreads();
+        for (int off = QT / 2; off > 0; off >>= 1) {
+            if (t < off) sh_a[t] = ff::add(sh_a[t], sh_a[t + off]);
+            __syncthreads();
+        }
+        if (t == 0) {
+            ff::Fr qc = ff::from_mont(ff::mul(sh_a[0], sh_misc[2]));
+#pragma unroll
+            for (int l = 0; l < 8; ++l) q_out[(blob * N + m) * 8 + l] = qc.v[l];
+        }
+    }
+}
+
+// commitment bytes -> status: 0 ok (valid encoding, and infinity or in the r-torsion subgroup), 1 bad
+// (FsG1::from_bytes + `!is_inf && !is_valid`, kzg/src/eip_4844.rs:556-558,577)
+__global__ void __launch_bounds__(64) k_check_commitments(int* __restrict__ status, const unsigned char* __restrict__ in,
+                                                          size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned char buf[48];
+    for (int k = 0; k < 48; ++k) buf[k] = in[48 * i + k];
+    AffPt p;
+    if (!g1io::uncompress(p, buf)) {
+        status[i] = 1;
+        return;
+    }
+    if (p.flags & 1) return;
+    // [r]P == infinity
+    g1::Xyzz acc;
+    g1::set_inf(acc);
+    for (int bit = 254; bit >= 0; --bit) {
+        if (!g1::is_inf(acc)) g1::dbl(acc);
+        if ((ff::FrParams::p(bit >> 5) >> (bit & 31)) & 1) g1::madd(acc, p.x, p.y);
+    }
+    if (!g1::is_inf(acc)) status[i] = 1;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- settings object
@@ -108,9 +311,17 @@ struct KzgAmdSettings {
     u32* d_scalars = nullptr;
     int* d_status = nullptr;
     unsigned char* d_out = nullptr;
+    u32* d_z = nullptr;              // n x 32 B big-endian evaluation points
+    u32* d_y = nullptr;              // n x 8 u32 canonical y
+    unsigned char* d_commit = nullptr;  // n x 48 B
     size_t cap_blobs = 0;
     std::vector<ff::Fr> brp_roots;  // brp_roots_of_unity[0..8192) (host copy, Montgomery)
+    ff::Fr* d_brp_roots = nullptr;  // first 4096 = the blob evaluation domain
     ~KzgAmdSettings() {
+        if (d_z) (void)hipFree(d_z);
+        if (d_y) (void)hipFree(d_y);
+        if (d_commit) (void)hipFree(d_commit);
+        if (d_brp_roots) (void)hipFree(d_brp_roots);
         if (msm) kzgamd::msm_destroy(msm);
         if (d_blobs) (void)hipFree(d_blobs);
         if (d_scalars) (void)hipFree(d_scalars);
@@ -124,15 +335,24 @@ struct KzgAmdSettings {
         if (d_scalars) (void)hipFree(d_scalars);
         if (d_status) (void)hipFree(d_status);
         if (d_out) (void)hipFree(d_out);
+        if (d_z) (void)hipFree(d_z);
+        if (d_y) (void)hipFree(d_y);
+        if (d_commit) (void)hipFree(d_commit);
         d_blobs = nullptr;
         d_scalars = nullptr;
         d_status = nullptr;
         d_out = nullptr;
+        d_z = nullptr;
+        d_y = nullptr;
+        d_commit = nullptr;
         cap_blobs = 0;
         CK_HIP(hipMalloc(&d_blobs, nblobs * BYTES_PER_BLOB));
         CK_HIP(hipMalloc(&d_scalars, nblobs * BYTES_PER_BLOB));
         CK_HIP(hipMalloc(&d_status, nblobs * sizeof(int)));
         CK_HIP(hipMalloc(&d_out, nblobs * 48));
+        CK_HIP(hipMalloc(&d_z, nblobs * 32));
+        CK_HIP(hipMalloc(&d_y, nblobs * 32));
+        CK_HIP(hipMalloc(&d_commit, nblobs * 48));
         cap_blobs = nblobs;
     }
 };
@@ -295,6 +515,8 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
             dev->brp_roots[i] = roots[reverse_bits(i, 13)];
             memcpy(&out->brp_roots_of_unity[i], &dev->brp_roots[i], 32);
         }
+        CK_HIP(hipMalloc(&dev->d_brp_roots, N * sizeof(ff::Fr)));
+        CK_HIP(hipMemcpy(dev->d_brp_roots, dev->brp_roots.data(), N * sizeof(ff::Fr), hipMemcpyHostToDevice));
         // g2_values_monomial / x_ext_fft_columns / tables stay NULL: pairing and FK20 state are not
         // part of this path (blst/src/eip_4844.rs:140-142 leaves tables/wbits/scratch_size empty too)
         (void)hipFree(d_bytes);
@@ -328,6 +550,125 @@ void commit_enqueue(KzgAmdSettings* dev, void* d_out, int* d_status, const void*
         throw;
     }
     kzgamd::msm_unlock(dev->msm);
+}
+
+
+// blobs + evaluation points (device) -> proofs (48 B) + y (canonical limbs), all on `stream`
+void prove_enqueue(KzgAmdSettings* dev, size_t n, hipStream_t stream) {
+    CK_HIP(hipMemsetAsync(dev->d_status, 0, n * sizeof(int), stream));
+    hipLaunchKernelGGL(k_quotient, dim3((unsigned)n), dim3(QT), 0, stream, dev->d_scalars, dev->d_y, dev->d_status,
+                       (const u32*)dev->d_blobs, (const u32*)dev->d_z, (const ff::Fr*)dev->d_brp_roots);
+    kzgamd::msm_lock(dev->msm);
+    try {
+        kzgamd::msm_enqueue(dev->msm, dev->d_out, dev->d_scalars, N, n, 0, stream, kzgamd::OUT_COMPRESSED);
+    } catch (...) {
+        kzgamd::msm_unlock(dev->msm);
+        throw;
+    }
+    kzgamd::msm_unlock(dev->msm);
+}
+
+// compute_challenge_rust (kzg/src/eip_4844.rs:920-945) on already-validated inputs: the canonical
+// re-serialisation of valid blob elements / a valid commitment equals the input bytes
+void challenge_bytes(uint8_t out[32], const uint8_t* blob, const uint8_t commitment[48]) {
+    kzgamd::Sha256 h;
+    uint8_t head[32] = {0};
+    memcpy(head, "FSBLOBVERIFY_V1_", 16);
+    const uint64_t nfe = N;
+    for (int i = 0; i < 8; ++i) head[24 + 7 - i] = (uint8_t)(nfe >> (8 * i));
+    h.update(head, 32);
+    h.update(blob, BYTES_PER_BLOB);
+    h.update(commitment, 48);
+    uint8_t digest[32];
+    h.finish(digest);
+    // hash_to_bls_field: from_bytes_unchecked = value mod r, re-serialised big-endian
+    ff::Fr v;
+    for (int i = 0; i < 8; ++i) {
+        const uint8_t* q = digest + (7 - i) * 4;
+        v.v[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+    }
+    ff::Fr red = ff::from_mont(ff::mul(v, ff::Fr::r2()));  // v * R^2 / R / R = v mod r
+    for (int i = 0; i < 8; ++i) {
+        uint8_t* q = out + (7 - i) * 4;
+        q[0] = (uint8_t)(red.v[i] >> 24);
+        q[1] = (uint8_t)(red.v[i] >> 16);
+        q[2] = (uint8_t)(red.v[i] >> 8);
+        q[3] = (uint8_t)red.v[i];
+    }
+}
+
+void fr_limbs_to_be32(uint8_t out[32], const u32 limbs[8]) {
+    for (int i = 0; i < 8; ++i) {
+        uint8_t* q = out + (7 - i) * 4;
+        q[0] = (uint8_t)(limbs[i] >> 24);
+        q[1] = (uint8_t)(limbs[i] >> 16);
+        q[2] = (uint8_t)(limbs[i] >> 8);
+        q[3] = (uint8_t)limbs[i];
+    }
+}
+
+bool host_blob_valid(const uint8_t* blob) {
+    for (size_t i = 0; i < N; ++i) {
+        const uint8_t* e = blob + 32 * i;
+        // big-endian compare with r
+        static const uint8_t R_BE[32] = {0x73, 0xed, 0xa7, 0x53, 0x29, 0x9d, 0x7d, 0x48, 0x33, 0x39, 0xd8,
+                                         0x08, 0x09, 0xa1, 0xd8, 0x05, 0x53, 0xbd, 0xa4, 0x02, 0xff, 0xfe,
+                                         0x5b, 0xfe, 0xff, 0xff, 0xff, 0xff, 0x00, 0x00, 0x00, 0x01};
+        if (memcmp(e, R_BE, 32) >= 0) return false;
+    }
+    return true;
+}
+
+// proofs for n (blob, z) pairs; z_src = explicit evaluation points or nullptr to derive them
+// from the commitments (compute_blob_kzg_proof)
+void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32* zs, const Bytes48* commitments, size_t n,
+                 KzgAmdSettings* dev) {
+    std::lock_guard<std::mutex> lk(dev->mu);
+    CK_HIP(hipSetDevice(dev->device));
+    dev->ensure(n);
+    CK_HIP(hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream));
+    std::vector<Bytes32> zbuf;
+    if (!zs) {
+        // commitment validity (decode + subgroup) on the device, Fiat-Shamir hashes on host threads meanwhile
+        CK_HIP(hipMemcpyAsync(dev->d_commit, commitments, n * 48, hipMemcpyHostToDevice, dev->stream));
+        CK_HIP(hipMemsetAsync(dev->d_status, 0, n * sizeof(int), dev->stream));
+        hipLaunchKernelGGL(k_check_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, dev->stream, dev->d_status,
+                           (const unsigned char*)dev->d_commit, n);
+        std::vector<int> cstat(n);
+        CK_HIP(hipMemcpyAsync(cstat.data(), dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
+        zbuf.resize(n);
+        std::vector<char> blob_ok(n, 1);
+        unsigned nth = std::thread::hardware_concurrency();
+        if (nth == 0) nth = 1;
+        if (nth > 32) nth = 32;
+        if (nth > n) nth = (unsigned)n;
+        std::vector<std::thread> th;
+        for (unsigned w = 0; w < nth; ++w)
+            th.emplace_back([&, w] {
+                for (size_t i = w; i < n; i += nth) {
+                    blob_ok[i] = host_blob_valid(blobs[i].bytes) ? 1 : 0;
+                    if (blob_ok[i]) challenge_bytes(zbuf[i].bytes, blobs[i].bytes, commitments[i].bytes);
+                }
+            });
+        for (auto& t : th) t.join();
+        CK_HIP(hipStreamSynchronize(dev->stream));
+        for (size_t i = 0; i < n; ++i) {
+            CK_REQUIRE(blob_ok[i], "Invalid scalar");
+            CK_REQUIRE(cstat[i] == 0, "Invalid commitment");
+        }
+        zs = zbuf.data();
+    }
+    CK_HIP(hipMemcpyAsync(dev->d_z, zs, n * 32, hipMemcpyHostToDevice, dev->stream));
+    prove_enqueue(dev, n, dev->stream);
+    std::vector<int> status(n);
+    std::vector<u32> ylimbs(n * 8);
+    CK_HIP(hipMemcpyAsync(status.data(), dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
+    CK_HIP(hipMemcpyAsync(ylimbs.data(), dev->d_y, n * 32, hipMemcpyDeviceToHost, dev->stream));
+    CK_HIP(hipMemcpyAsync(proofs, dev->d_out, n * 48, hipMemcpyDeviceToHost, dev->stream));
+    CK_HIP(hipStreamSynchronize(dev->stream));
+    for (size_t i = 0; i < n; ++i) CK_REQUIRE(status[i] == 0, "Invalid scalar");
+    if (ys)
+        for (size_t i = 0; i < n; ++i) fr_limbs_to_be32(ys[i].bytes, &ylimbs[8 * i]);
 }
 
 template <class F>
@@ -424,6 +765,56 @@ extern "C" C_KZG_RET kzgamd_blob_to_kzg_commitment_device(void* d_out, void* d_s
     if (!dev || !d_out || !d_status || !d_scratch || !d_blobs) return C_KZG_BADARGS;
     if (n == 0) return C_KZG_OK;
     return guarded([&] { commit_enqueue(dev, d_out, (int*)d_status, d_blobs, (u32*)d_scratch, n, (hipStream_t)stream); });
+}
+
+
+extern "C" C_KZG_RET compute_kzg_proof(KZGProof* proof_out, Bytes32* y_out, const Blob* blob, const Bytes32* z_bytes,
+                                       const CKZGSettings* s) {
+    if (!proof_out || !y_out || !blob || !z_bytes) return C_KZG_BADARGS;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    return guarded([&] { prove_batch(proof_out, y_out, blob, z_bytes, nullptr, 1, dev); });
+}
+
+extern "C" C_KZG_RET kzgamd_compute_blob_kzg_proof_batch(KZGProof* out, const Blob* blobs, const Bytes48* commitments,
+                                                         size_t n, const CKZGSettings* s) {
+    if (!out || !blobs || !commitments) return C_KZG_BADARGS;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    if (n == 0) return C_KZG_OK;
+    return guarded([&] { prove_batch(out, nullptr, blobs, nullptr, commitments, n, dev); });
+}
+
+extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof* out, const Blob* blob, const Bytes48* commitment_bytes,
+                                            const CKZGSettings* s) {
+    return kzgamd_compute_blob_kzg_proof_batch(out, blob, commitment_bytes, 1, s);
+}
+
+// The reference exports this helper with raw blst types (blst/src/eip_4844.rs:501-514): the commitment
+// is a blst_p1, the result a Montgomery blst_fr; inputs are trusted (the reference unwraps).
+extern "C" void compute_challenge(blst_fr* eval_challenge_out, const Blob* blob, const blst_p1* commitment) {
+    uint8_t cbytes[48], zbe[32];
+    kzgamd::host_p1_compress(cbytes, commitment);
+    challenge_bytes(zbe, blob->bytes, cbytes);
+    ff::Fr v;
+    for (int i = 0; i < 8; ++i) {
+        const uint8_t* q = zbe + (7 - i) * 4;
+        v.v[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+    }
+    v = ff::to_mont(v);
+    memcpy(eval_challenge_out, &v, 32);
+}
+
+extern "C" C_KZG_RET bytes_to_kzg_commitment(blst_p1* out, const Bytes48* b) {   /* blst/src/eip_4844.rs:519-523 */
+    if (!out || !b) return C_KZG_BADARGS;
+    return kzgamd::host_p1_uncompress(out, b->bytes) ? C_KZG_OK : C_KZG_BADARGS;
+}
+
+extern "C" void bytes_from_bls_field(Bytes32* out, const blst_fr* in) {          /* blst/src/eip_4844.rs:528-530 */
+    ff::Fr v;
+    memcpy(&v, in, 32);
+    v = ff::from_mont(v);
+    fr_limbs_to_be32(out->bytes, v.v);
 }
 
 extern "C" void* kzgamd_settings_msm_handle(const CKZGSettings* s) {

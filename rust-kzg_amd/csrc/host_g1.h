@@ -1,0 +1,95 @@
+// Host-side G1 (de)serialisation on blst-layout values, for the few single-point conversions the
+// c-kzg helpers need (compute_challenge takes a blst_p1; bytes_to_kzg_commitment returns one).
+// Bulk work goes through the device kernels in g1_io.cuh instead.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/kzg_mi355x.h"
+#include "ff.cuh"
+
+namespace kzgamd {
+
+inline ff::Fp host_fp_from_be48(const uint8_t* in, bool* lt_p) {
+    ff::Fp r;
+    for (int i = 0; i < 12; ++i) {
+        const uint8_t* q = in + (11 - i) * 4;
+        r.v[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+    }
+    uint64_t borrow = 0;
+    for (int i = 0; i < 12; ++i) {
+        uint64_t d = (uint64_t)r.v[i] - ff::FpParams::p(i) - borrow;
+        borrow = (d >> 32) & 1;
+    }
+    *lt_p = borrow != 0;
+    return r;
+}
+
+inline void host_fp_to_be48(uint8_t* out, const ff::Fp& plain) {
+    for (int i = 0; i < 12; ++i) {
+        uint8_t* q = out + (11 - i) * 4;
+        q[0] = (uint8_t)(plain.v[i] >> 24);
+        q[1] = (uint8_t)(plain.v[i] >> 16);
+        q[2] = (uint8_t)(plain.v[i] >> 8);
+        q[3] = (uint8_t)plain.v[i];
+    }
+}
+
+inline bool host_fp_lex_largest(const ff::Fp& plain) {  // plain > (p-1)/2
+    static const uint32_t half[12] = {0xffffd555u, 0xdcff7fffu, 0x58a9ffffu, 0x0f55ffffu, 0x7b587b12u, 0xb3986950u,
+                                      0x79c2895fu, 0xb23ba5c2u, 0x21a5d66bu, 0x258dd3dbu, 0x1cbff34du, 0x0d0088f5u};
+    uint64_t borrow = 0;
+    for (int i = 0; i < 12; ++i) {
+        uint64_t d = (uint64_t)half[i] - plain.v[i] - borrow;
+        borrow = (d >> 32) & 1;
+    }
+    return borrow != 0;
+}
+
+// blst_p1_compress
+inline void host_p1_compress(uint8_t out[48], const blst_p1* p) {
+    const ff::Fp* P = reinterpret_cast<const ff::Fp*>(p);
+    if (P[2].is_zero()) {
+        memset(out, 0, 48);
+        out[0] = 0xc0;
+        return;
+    }
+    ff::Fp zi = ff::inverse(P[2]), zi2 = ff::sqr(zi);
+    ff::Fp x = ff::from_mont(ff::mul(P[0], zi2)), y = ff::from_mont(ff::mul(P[1], ff::mul(zi2, zi)));
+    host_fp_to_be48(out, x);
+    out[0] |= 0x80;
+    if (host_fp_lex_largest(y)) out[0] |= 0x20;
+}
+
+// blst_p1_uncompress + blst_p1_from_affine (FsG1::from_bytes, blst/src/types/g1.rs:65-87)
+inline bool host_p1_uncompress(blst_p1* out, const uint8_t in[48]) {
+    ff::Fp* O = reinterpret_cast<ff::Fp*>(out);
+    const bool compressed = (in[0] >> 7) & 1, infinity = (in[0] >> 6) & 1, sort = (in[0] >> 5) & 1;
+    if (!compressed) return false;
+    uint8_t tmp[48];
+    memcpy(tmp, in, 48);
+    tmp[0] &= 0x1f;
+    bool lt = false;
+    ff::Fp xs = host_fp_from_be48(tmp, &lt);
+    if (infinity) {
+        if (sort || !xs.is_zero()) return false;
+        memset(out, 0, sizeof *out);
+        return true;
+    }
+    if (!lt) return false;
+    ff::Fp x = ff::to_mont(xs);
+    ff::Fp four = ff::Fp::zero();
+    four.v[0] = 4;
+    ff::Fp y2 = ff::add(ff::mul(ff::sqr(x), x), ff::to_mont(four));
+    static const uint32_t e[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
+                                   0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};
+    ff::Fp y = ff::pow_u32(y2, e, 12);
+    if (ff::sqr(y) != y2) return false;
+    if (host_fp_lex_largest(ff::from_mont(y)) != sort) y = ff::neg(y);
+    O[0] = x;
+    O[1] = y;
+    O[2] = ff::Fp::one();
+    return true;
+}
+
+}  // namespace kzgamd

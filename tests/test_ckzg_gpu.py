@@ -112,3 +112,130 @@ def test_load_rejects_bad_setups(kzg, trusted_setup_text):
     kzg.lib().free_trusted_setup(C.byref(s.c))
     kzg.lib().free_trusted_setup(None)
     s.loaded = False
+
+
+def test_vectors_compute_kzg_proof(kzg, settings, golden, blob_loader):
+    nvalid = 0
+    for case in golden["compute_kzg_proof"]:
+        blob = blob_loader(case["blob"])
+        z = bytes.fromhex(case["z"][2:])
+        if case["output"] is None:
+            with pytest.raises(kzg.KzgAmdError):
+                kzg.compute_kzg_proof(blob, z, settings)
+        else:
+            proof, y = kzg.compute_kzg_proof(blob, z, settings)
+            assert [hx(proof), hx(y)] == case["output"], case["name"]
+            nvalid += 1
+    assert nvalid == 42
+
+
+def test_vectors_compute_blob_kzg_proof(kzg, settings, golden, blob_loader):
+    nvalid = 0
+    for case in golden["compute_blob_kzg_proof"]:
+        blob = blob_loader(case["blob"])
+        cm = bytes.fromhex(case["commitment"][2:])
+        if case["output"] is None:
+            with pytest.raises(kzg.KzgAmdError):
+                kzg.compute_blob_kzg_proof(blob, cm, settings)
+        else:
+            assert hx(kzg.compute_blob_kzg_proof(blob, cm, settings)) == case["output"], case["name"]
+            nvalid += 1
+    assert nvalid == 7
+
+
+def test_vectors_compute_challenge(kzg, golden, blob_loader):
+    n = 0
+    for case in golden["compute_challenge"]:
+        blob = blob_loader(case["blob"])
+        p1 = kzg.bytes_to_kzg_commitment(bytes.fromhex(case["commitment"][2:]))
+        z = kzg.compute_challenge(blob, p1)
+        assert hx(kzg.bytes_from_bls_field(z)) == case["output"], case["name"]
+        n += 1
+    assert n == 9
+
+
+def test_kat_proof_and_domain_points(kzg, settings, kats, oracle, oracle_settings):
+    k = kats["compute_kzg_proof_test"]
+    blob = bytes.fromhex(k["field_element"][2:]) + bytes(BLOB - 32)
+    proof, y = kzg.compute_kzg_proof(blob, bytes.fromhex(k["z"][2:]), settings)
+    assert hx(proof) == k["proof"]
+    # z inside the evaluation domain (compute_and_verify_kzg_proof_within_domain_test,
+    # kzg-bench/src/tests/eip_4844.rs:236-288), checked against the oracle
+    L = oracle.lib()
+    rnd = random.Random(9)
+    blob = bytearray(rnd.randbytes(BLOB))
+    for i in range(0, BLOB, 32):
+        blob[i] = 0
+    blob = bytes(blob)
+    brp = (O.Fr * 8192).from_address(settings.c.brp_roots_of_unity)
+    for idx in (0, 1, 5, 4095):
+        zb = C.create_string_buffer(32)
+        f = O.Fr()
+        C.memmove(C.byref(f), C.byref(brp[idx]), 32)
+        L.ofr_to_be32(zb, C.byref(f))
+        ep, ey = C.create_string_buffer(48), C.create_string_buffer(32)
+        assert L.ocompute_kzg_proof(ep, ey, blob, zb.raw, C.byref(oracle_settings)) == 0
+        proof, y = kzg.compute_kzg_proof(blob, zb.raw, settings)
+        assert (proof, y) == (ep.raw, ey.raw), idx
+        assert y == blob[32 * idx:32 * idx + 32]
+
+
+def test_blob_proof_batch_equals_singles_and_oracle(kzg, settings, oracle, oracle_settings):
+    L = oracle.lib()
+    rnd = random.Random(77)
+    n = 4
+    blobs = bytearray(rnd.randbytes(n * BLOB))
+    for i in range(0, n * BLOB, 32):
+        blobs[i] = 0
+    blobs = bytes(blobs)
+    cms = kzg.blob_to_kzg_commitment_batch(blobs, n, settings)
+    got = kzg.compute_blob_kzg_proof_batch(blobs, b"".join(cms), n, settings)
+    for b in range(n):
+        bl = blobs[b * BLOB:(b + 1) * BLOB]
+        assert got[b] == kzg.compute_blob_kzg_proof(bl, cms[b], settings)
+        ep = C.create_string_buffer(48)
+        assert L.ocompute_blob_kzg_proof(ep, bl, cms[b], C.byref(oracle_settings)) == 0
+        assert got[b] == ep.raw
+    # commitment = infinity is accepted (kzg-bench/src/tests/c_bindings.rs:584-616)
+    inf = b"\xc0" + bytes(47)
+    ep = C.create_string_buffer(48)
+    assert L.ocompute_blob_kzg_proof(ep, blobs[:BLOB], inf, C.byref(oracle_settings)) == 0
+    assert kzg.compute_blob_kzg_proof(blobs[:BLOB], inf, settings) == ep.raw
+
+
+def test_compute_cells_vectors_pin_gpu_ntt(kzg, golden, blob_loader, oracle):
+    # polynomial half of compute_cells (kzg/src/das.rs:258-279) through the GPU NTT:
+    # ifft(brp(blob)) -> zero-extend -> fft 8192 -> brp, against the c-kzg vectors
+    import hashlib
+
+    fs = kzg.FFTSettings(13)
+
+    def brp(vals):
+        n = len(vals)
+        bits = n.bit_length() - 1
+        return [vals[int(format(i, "0%db" % bits)[::-1], 2)] for i in range(n)]
+
+    nvalid = 0
+    for case in golden["compute_cells"]:
+        if case["output"] is None:
+            continue
+        blob = blob_loader(case["blob"])
+        elems = [int.from_bytes(blob[32 * i:32 * i + 32], "big") for i in range(4096)]
+        raw = b"".join(((v << 256) % O.R).to_bytes(32, "little") for v in brp(elems))
+        poly = (kzg.BlstFr * 4096)()
+        C.memmove(poly, raw, len(raw))
+        mono = fs.fft_fr(poly, 4096, inverse=True)
+        ext = (kzg.BlstFr * 8192)()
+        C.memmove(ext, mono, 4096 * 32)
+        ev = fs.fft_fr(ext, 8192)
+        ints = []
+        for i in range(8192):
+            f = O.Fr()
+            C.memmove(C.byref(f), C.byref(ev[i]), 32)
+            ints.append(O.fr_to_int(f))
+        cells = b"".join(v.to_bytes(32, "big") for v in brp(ints))
+        assert hx(cells[:2048]) == case["output"]["cell0"], case["name"]
+        assert hashlib.sha256(cells).hexdigest() == case["output"]["sha256"], case["name"]
+        nvalid += 1
+    assert nvalid == 7
+    fs.close()
