@@ -1,0 +1,37 @@
+"""Whole-blob sharding across the GPUs of one node.
+
+Blobs are independent units: rank r takes a contiguous slab of the batch, runs the single-GPU
+pipeline on it with its own replica of the fixed-base table, and the 48-byte results are gathered.
+There is no data-path collective (nothing is exchanged while computing); the only communication
+is one all_gather of the results at the end of a batch, and only if every rank needs all of them.
+"""
+from typing import Callable, List, Sequence, Tuple
+
+
+def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous slab [lo, hi) of rank `rank`; slab sizes differ by at most one; empty slabs allowed."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def commit_sharded(blobs: Sequence[bytes], commit_batch: Callable[[List[bytes]], List[bytes]], dist=None) -> List[bytes]:
+    """Commit to `blobs` with the work split over the ranks of `dist` (a torch.distributed-like module
+    that is already initialised; None = single process).  `commit_batch` is the per-rank engine
+    (the GPU pipeline in production, any equivalent in tests).  Returns all results on every rank."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return commit_batch(list(blobs))
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(len(blobs), world, rank)
+    mine = commit_batch(list(blobs[lo:hi])) if hi > lo else []
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    out: List[bytes] = []
+    for part in gathered:
+        out.extend(part)
+    if len(out) != len(blobs):
+        raise RuntimeError("sharded commit lost results")
+    return out
