@@ -28,6 +28,7 @@ N = 4096
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 ALG_BYTES_PER_COMMIT = 128 * N             # 96 B point + 32 B scalar per pair
 ALG_ADDS_PER_COMMIT = 20 * N + 8192        # BGMW count for the fixed-base 4096 case
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
 # lane-level v_mad_u64_u32 issue peak: 1024 SIMDs x 64 lanes x 2.4 GHz / 5.5 cycles (tools/ffbench.hip)
 MAD_PEAK_PER_S = 1024 * 64 * 2.4e9 / 5.5
 
@@ -103,7 +104,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="blobs per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="blobs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the 2^20-point MSM latency line")
     args = ap.parse_args()
@@ -192,13 +193,20 @@ def main():
         accum_ms, total_ms, cnt = prof
         alg_bytes = ALG_BYTES_PER_COMMIT * B
         ach = alg_bytes / (accum_ms * 1e-3) / 1e9
-        res["roofline"] = {"bound": "hbm", "kernel": "k_fbw_accum" if info.get("wide_table") else "k_accum", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same window), scaled to B
+            pm = json.load(open(PMC_SUMMARY))
+            if info.get("wide_table") and pm.get("window_bits") == info["window_bits"]:
+                traffic = pm["k_fbw_accum"]["hbm_bytes_per_launch"] / pm["batch"] * B
+        except Exception:
+            pass
+        res["roofline"] = {"bound": "hbm", "kernel": "k_fbw_accum" if info.get("wide_table") else "k_accum", "achieved": ach,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "kernel_ms": accum_ms, "pipeline_ms": total_ms, "launches_averaged": cnt,
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "note": "MSM is integer-VALU bound, not HBM bound (SURVEY §8d); see `valu`"}
         # executed work of k_accum: ~20*4096 mixed adds per blob, 8 mul + 2 sqr each = 8*392 + 2*301 mads
-        mads = B * 20 * N * (8 * 392 + 2 * 301)
+        mads = B * info["rows"] * N * (8 * 392 + 2 * 301)
         res["valu"] = {"bound": "int-mad issue", "achieved": mads / (accum_ms * 1e-3), "peak": MAD_PEAK_PER_S,
                        "unit": "lane v_mad_u64_u32/s", "frac": mads / (accum_ms * 1e-3) / MAD_PEAK_PER_S}
 
@@ -227,6 +235,16 @@ def main():
         res["msm_2p20_ms"] = min(ts)
         res["msm_2p20_pairs_per_s"] = n / (min(ts) * 1e-3)
         big.close()
+
+    if rank == 0 and not args.no_large:
+        # host buffers in / host buffers out through the c-kzg batch entry point (PCIe both ways) — never `value`
+        nb = min(B, 256)
+        hb = blobs[:nb].cpu().numpy().tobytes()
+        kzg.blob_to_kzg_commitment_batch(hb, nb, settings)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            kzg.blob_to_kzg_commitment_batch(hb, nb, settings)
+        res["pcie_inclusive_commitments_per_s"] = 3 * nb / (time.perf_counter() - t0)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         host = blobs[: min(B, 64)].cpu().numpy()

@@ -612,6 +612,15 @@ int choose_window(size_t n, bool prepared) {
         int c = atoi(e);
         if (c >= 2 && c <= 22) return c;
     }
+    if (prepared) {
+        // wide-table path: fewest table rows (= fewest adds per scalar) that fit the HBM budget
+        double budget_gb = 100.0;
+        if (const char* e = getenv("KZGAMD_FBW_MAX_GB")) budget_gb = atof(e);
+        for (int c = 16; c >= 10 && budget_gb > 0; --c) {
+            double gb = (double)(255 / c + 1) * (double)n * (double)((size_t)1 << (c - 1)) * 128.0 / 1e9;
+            if (gb <= budget_gb) return c;
+        }
+    }
     int best = 2;
     double best_cost = 1e300;
     for (int c = 2; c <= 22; ++c) {
@@ -706,7 +715,7 @@ static void require_device() {
 
 // Wide table: built tile by tile (chain of multiples as XYZZ -> batch-inverted affine slots).
 static void build_wide_table(MsmContext* ctx) {
-    double budget_gb = 64.0;
+    double budget_gb = 100.0;
     if (const char* e = getenv("KZGAMD_FBW_MAX_GB")) budget_gb = atof(e);
     const size_t mults = ctx->nb;  // 2^(c-1)
     const size_t nslots = (size_t)ctx->rows * ctx->n;
