@@ -288,14 +288,36 @@ __global__ void __launch_bounds__(64) k_check_commitments(int* __restrict__ stat
         return;
     }
     if (p.flags & 1) return;
-    // [r]P == infinity
-    g1::Xyzz acc;
-    g1::set_inf(acc);
-    for (int bit = 254; bit >= 0; --bit) {
-        if (!g1::is_inf(acc)) g1::dbl(acc);
-        if ((ff::FrParams::p(bit >> 5) >> (bit & 31)) & 1) g1::madd(acc, p.x, p.y);
+    // Subgroup membership by the endomorphism test phi(P) == -[x^2]P, phi(x,y) = (beta*x, y), x the BLS
+    // parameter (the in-tree statement of the same test: zkcrypto/bls12_381/src/g1.rs:401-435).  Two
+    // 64-bit scalar multiplications instead of one by the 255-bit group order.
+    const unsigned long long BLS_X = 0xd201000000010000ull;  // |x|; the sign cancels in x^2
+    g1::Xyzz q1, q2;
+    g1::set_inf(q1);
+    for (int bit = 63; bit >= 0; --bit) {
+        if (!g1::is_inf(q1)) g1::dbl(q1);
+        if ((BLS_X >> bit) & 1) g1::madd(q1, p.x, p.y);
     }
-    if (!g1::is_inf(acc)) status[i] = 1;
+    g1::set_inf(q2);
+    for (int bit = 63; bit >= 0; --bit) {
+        if (!g1::is_inf(q2)) g1::dbl(q2);
+        if ((BLS_X >> bit) & 1) g1::dadd(q2, q1);
+    }
+    if (g1::is_inf(q2)) {
+        status[i] = 1;
+        return;
+    }
+    fp28::Fe beta;
+    {
+        constexpr u32 t[14] = {0xa75929au, 0x681b798u, 0x22a3e9du, 0xabc02bfu, 0x4e5bb45u, 0x55e6e7eu, 0x4814117u,
+                               0x6d04f1bu, 0xae3387du, 0x54acb0cu, 0xa4c74bu, 0x56138b5u, 0xb64e066u, 0x76f2u};
+#pragma unroll
+        for (int k = 0; k < 14; ++k) beta.v[k] = t[k];  // cube root of unity, Montgomery 2^392
+    }
+    // phi(P) == -Q2  <=>  beta*x*ZZ == X  and  y*ZZZ == -Y
+    fp28::Fe dx = fp28::sub<16>(fp28::mul(fp28::mul(beta, p.x), q2.zz), q2.x);
+    fp28::Fe dy = fp28::addn(fp28::mul(p.y, q2.zzz), q2.y);
+    if (!fp28::is_zero_mod_p(dx) || !fp28::is_zero_mod_p(dy)) status[i] = 1;
 }
 
 }  // namespace

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Secondary measurements for BASELINE.json configs[2..4] (not the headline bench line):
+  - G1 MSM scaling sweep n = 2^16 .. 2^22 (variable-base engine, device-resident inputs)
+  - Fr NTT n = 4096 (batched) and n = 2^20, forward
+  - compute_blob_kzg_proof_batch over 256 blobs (host buffers in/out, Fiat-Shamir hash on host)
+Prints one JSON object; run on an MI355X:  python tools/extra_bench.py > profiles/r01_extra.json
+"""
+import ctypes as C
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SETUP = os.path.join(ROOT, "tests", "golden", "trusted_setup.txt")
+
+
+def load_pkg():
+    path = os.path.join(ROOT, "rust-kzg_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location("rust_kzg_amd", path, submodule_search_locations=[os.path.dirname(path)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["rust_kzg_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def window_for(n):  # reference pippenger_window_size (kzg/src/msm/pippenger_utils.rs:300-317)
+    b = n.bit_length()
+    return b - 4 if b > 13 else (b - 3 if b > 5 else 2)
+
+
+def main():
+    import torch
+
+    kzg = load_pkg()
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    res = {}
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return min(ts)
+
+    # ---- MSM sweep ----
+    sweep = []
+    nmax = 1 << 22
+    pts = torch.empty(nmax * 96, dtype=torch.uint8, device=dev)
+    kzg.generate_points(pts.data_ptr(), nmax, 2, stream)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(2)
+    sc = torch.randint(0, 256, (nmax, 32), dtype=torch.uint8, generator=g)
+    sc[:, 31] &= 0x3F
+    sc = sc.to(dev)
+    out = torch.zeros(144, dtype=torch.uint8, device=dev)
+    for logn in (12, 14, 16, 18, 20, 21, 22):
+        n = 1 << logn
+        h = kzg.DeviceMsm(pts.data_ptr(), n, False)
+        info = h.info()
+        ms = timed(lambda: kzg.msm_prepared_batch_device(h, out.data_ptr(), sc.data_ptr(), n, 1, False, stream))
+        c = window_for(n)
+        w = -(-255 // c)
+        adds = n * w + (1 << c) * w  # algorithmic adds with the reference's window
+        sweep.append({"n": n, "ms": ms, "pairs_per_s": n / (ms * 1e-3), "g1_adds_per_s": adds / (ms * 1e-3),
+                      "algorithmic_GBps": 128 * n / (ms * 1e-3) / 1e9, "kernel_window_bits": info["window_bits"]})
+        h.close()
+    res["msm_sweep_variable_base"] = sweep
+    del pts, sc
+
+    # ---- NTT ----
+    ntt = {}
+    fs = kzg.FFTSettings(20)
+    for n, nb in ((4096, 256), (1 << 20, 1)):
+        a = torch.randint(0, 2**31, (nb * n * 8,), dtype=torch.int32, device=dev)
+        a[7::8] &= 0x3FFFFFFF  # any 256-bit pattern below r is a valid Montgomery residue
+        b = torch.empty_like(a)
+        ms = timed(lambda: fs.fft_fr_device(b.data_ptr(), a.data_ptr(), n, nb, False, stream), reps=5)
+        import math
+
+        ntt["n=%d x %d" % (n, nb)] = {"ms": ms, "transforms_per_s": nb / (ms * 1e-3),
+                                       "algorithmic_GBps": 64 * n * nb / (ms * 1e-3) / 1e9,
+                                       "fr_mul_per_s": nb * (n / 2) * math.log2(n) / (ms * 1e-3)}
+    fs.close()
+    res["ntt_forward"] = ntt
+
+    # ---- blob proofs, batch of 256 through the host-buffer entry point ----
+    s = kzg.KZGSettings.from_file(SETUP)
+    import random
+
+    rnd = random.Random(5)
+    nb = 256
+    blobs = bytearray(rnd.randbytes(nb * 131072))
+    for i in range(0, len(blobs), 32):
+        blobs[i] = 0
+    blobs = bytes(blobs)
+    cms = b"".join(kzg.blob_to_kzg_commitment_batch(blobs, nb, s))
+    kzg.compute_blob_kzg_proof_batch(blobs, cms, nb, s)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        kzg.compute_blob_kzg_proof_batch(blobs, cms, nb, s)
+    dt = (time.perf_counter() - t0) / 3
+    res["compute_blob_kzg_proof_batch_256"] = {"ms": dt * 1e3, "proofs_per_s": nb / dt,
+                                               "note": "host buffers in/out, SHA-256 challenges on host threads"}
+    t0 = time.perf_counter()
+    for _ in range(3):
+        kzg.blob_to_kzg_commitment_batch(blobs, nb, s)
+    dt = (time.perf_counter() - t0) / 3
+    res["blob_to_kzg_commitment_batch_256_host_buffers"] = {"ms": dt * 1e3, "commitments_per_s": nb / dt}
+    one = blobs[:131072]
+    t0 = time.perf_counter()
+    for _ in range(20):
+        kzg.blob_to_kzg_commitment(one, s)
+    res["blob_to_kzg_commitment_single_call_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    t0 = time.perf_counter()
+    for _ in range(20):
+        kzg.compute_blob_kzg_proof(one, cms[:48], s)
+    res["compute_blob_kzg_proof_single_call_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    s.close()
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
