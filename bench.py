@@ -205,8 +205,9 @@ def main():
                            "kernel_ms": accum_ms, "pipeline_ms": total_ms, "launches_averaged": cnt,
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "note": "MSM is integer-VALU bound, not HBM bound (SURVEY §8d); see `valu`"}
-        # executed work of k_accum: ~20*4096 mixed adds per blob, 8 mul + 2 sqr each = 8*392 + 2*301 mads
-        mads = B * info["rows"] * N * (8 * 392 + 2 * 301)
+        # executed work of the accumulation kernel: rows*4096 mixed adds per blob, each 6 mul + 2 sqr + one
+        # fused two-product multiply = 6*392 + 2*301 + 588 v_mad_u64_u32
+        mads = B * info["rows"] * N * (6 * 392 + 2 * 301 + 588)
         res["valu"] = {"bound": "int-mad issue", "achieved": mads / (accum_ms * 1e-3), "peak": MAD_PEAK_PER_S,
                        "unit": "lane v_mad_u64_u32/s", "frac": mads / (accum_ms * 1e-3) / MAD_PEAK_PER_S}
 

@@ -119,6 +119,15 @@ FF_HD Fe sub(const Fe& a, const Fe& b) {
     return r;
 }
 
+// a + K*p - b without the carry pass: limbs < 2^28 + 2^29 (still a valid mul/sqr operand)
+template <int K>
+FF_HD Fe sub_lazy(const Fe& a, const Fe& b) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.v[i] = a.v[i] + pad_l<K>(i) - b.v[i];
+    return r;
+}
+
 // K*p - a  (a normalized, value < (K-1)p)
 template <int K>
 FF_HD Fe neg(const Fe& a) {
@@ -229,9 +238,12 @@ inline Fe sqr(const Fe& a) { return sqr_inline(a); }
 // exact test a == 0 (mod p) for normalized a with value < 64p.
 // If a = k*p then k = a_0 * p_0^-1 mod 2^28 must be < 64: a 3-instruction filter that
 // rejects all but 64/2^28 of the non-zero values; the exact compare runs only then.
-FF_HD bool is_zero_mod_p(const Fe& a) {
-    const u32 k = (a.v[0] * P0INV_POS) & MASK;
+FF_HD bool is_zero_mod_p(const Fe& a_in) {
+    // the low 28 bits of limb 0 are the value mod 2^28 whether or not the limbs are normalized
+    const u32 k = (a_in.v[0] * P0INV_POS) & MASK;
     if (k >= 64) return false;
+    Fe a = a_in;
+    norm(a);
     u64 c = 0;
     u32 diff = 0;
 #pragma unroll
@@ -243,6 +255,43 @@ FF_HD bool is_zero_mod_p(const Fe& a) {
     c += (u64)k * pl(L - 1);
     diff |= (u32)c ^ a.v[L - 1];
     return diff == 0;
+}
+
+// (a*b + c*d) * 2^-392 mod p with ONE reduction: both products share the column accumulators.
+// Limb bounds: a*b and c*d columns together must stay below 2^63 (e.g. one lazy operand per product).
+FF_HD Fe mul2_inline(const Fe& a, const Fe& b, const Fe& c, const Fe& d) {
+    u32 m[L];
+    Fe r;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        u64 acc2 = 0, acc3 = 0;
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (u64)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc3 += (u64)c.v[i] * d.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc2 += (u64)m[i] * pl(k - i);
+        acc += acc2 + acc3;
+        m[k] = ((u32)acc * P0INV) & MASK;
+        acc += (u64)m[k] * pl(0);
+        acc >>= 28;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; ++k) {
+        u64 acc2 = 0, acc3 = 0;
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) acc += (u64)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) acc3 += (u64)c.v[i] * d.v[k - i];
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) acc2 += (u64)m[i] * pl(k - i);
+        acc += acc2 + acc3;
+        r.v[k - L] = (u32)acc & MASK;
+        acc >>= 28;
+    }
+    r.v[L - 1] = (u32)acc;
+    return r;
 }
 
 // ---- boundary conversions (blst layout: 12 x u32 saturated, Montgomery 2^384) ----

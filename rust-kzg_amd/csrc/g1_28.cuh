@@ -82,8 +82,9 @@ FF_HD void madd(Xyzz& acc, const Fe& x2, const Fe& y2) {
         set_affine(acc, x2, y2);
         return;
     }
-    Fe p = sub<16>(mul(x2, acc.zz), acc.x);
-    Fe r = sub<16>(mul(y2, acc.zzz), acc.y);
+    // P and R only ever feed multiplications, so they skip the carry pass (limbs < 2^28 + 2^29)
+    Fe p = sub_lazy<16>(mul(x2, acc.zz), acc.x);
+    Fe r = sub_lazy<16>(mul(y2, acc.zzz), acc.y);
     if (is_zero_mod_p(p)) {
         if (is_zero_mod_p(r)) dbl_affine(acc, x2, y2);
         else set_inf(acc);
@@ -93,7 +94,8 @@ FF_HD void madd(Xyzz& acc, const Fe& x2, const Fe& y2) {
     Fe ppp = mul(p, pp);
     Fe q = mul(acc.x, pp);
     Fe x3 = sub<8>(sqr(r), addn(add(q, q), ppp));
-    Fe y3 = sub<4>(mul(r, sub<16>(q, x3)), mul(acc.y, ppp));
+    // Y3 = R*(Q - X3) - Y1*PPP as one two-product Montgomery reduction: R*V + (8p - Y1)*PPP
+    Fe y3 = mul2_inline(r, sub<16>(q, x3), sub_lazy<8>(zero(), acc.y), ppp);
     acc.x = x3;
     acc.y = y3;
     acc.zz = mul(acc.zz, pp);
