@@ -208,11 +208,12 @@ FF_HD Fe sqr_inline(const Fe& a) {
     return r;
 }
 
-// On the device mul/sqr are real (out-of-line) functions.  A point addition is ~10 of them; fully
-// inlined that is ~75 KB of straight-line code per loop iteration, which overflows the instruction
-// cache shared by neighbouring CUs and left the first k_accum 45x off its issue-bound time
-// (profiles/r01_bench_a.json).  Operands travel in VGPRs as 14-wide vectors (no scratch traffic).
-#if defined(__HIP_DEVICE_COMPILE__)
+// mul/sqr are inlined by default.  -DFP28_OUTLINE_MUL makes them real device functions (operands in
+// VGPRs as 14-wide vectors, no scratch traffic): ~8x smaller kernels, but the argument marshalling
+// (~60 v_mov per call) costs 5 % in the accumulation kernel and 9 % end to end (A/B on MI355X:
+// 83.3k vs 76.0k commitments/s), and the fully inlined ~75 KB loop body showed no instruction-cache
+// penalty.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FP28_OUTLINE_MUL)
 typedef u32 fe_vec __attribute__((ext_vector_type(14)));
 __device__ __forceinline__ fe_vec to_vec(const Fe& a) {
     fe_vec r;
@@ -231,8 +232,8 @@ static __device__ __noinline__ fe_vec sqr_call(fe_vec a) { return to_vec(sqr_inl
 __device__ __forceinline__ Fe mul(const Fe& a, const Fe& b) { return from_vec(mul_call(to_vec(a), to_vec(b))); }
 __device__ __forceinline__ Fe sqr(const Fe& a) { return from_vec(sqr_call(to_vec(a))); }
 #else
-inline Fe mul(const Fe& a, const Fe& b) { return mul_inline(a, b); }
-inline Fe sqr(const Fe& a) { return sqr_inline(a); }
+FF_HD Fe mul(const Fe& a, const Fe& b) { return mul_inline(a, b); }
+FF_HD Fe sqr(const Fe& a) { return sqr_inline(a); }
 #endif
 
 // exact test a == 0 (mod p) for normalized a with value < 64p.
