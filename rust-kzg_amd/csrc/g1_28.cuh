@@ -130,6 +130,39 @@ FF_HD void dadd(Xyzz& acc, const Xyzz& b) {
     acc.zzz = mul(mul(acc.zzz, b.zzz), ppp);
 }
 
+// acc = 2^k * acc through Jacobian doublings (dbl-2009-l with S = 4*X*YY taken as one product:
+// 3M + 4S against 6M + 3S for the XYZZ doubling) — the Horner steps of the windowed MSM are a serial
+// chain of ~255 of these.  XYZZ -> Jacobian is (X*ZZ, Y*ZZZ, ZZ) (pippenger_utils.rs:84-88);
+// Jacobian -> XYZZ is (X, Y, Z^2, Z^3).
+// Bounds: a mul/sqr whose input bounds multiply to <= 64 p^2 returns < 1.04p.  Loop invariant:
+// X < 18p, Y < 17.1p, Z < 2.1p, all normalized.
+FF_HD void dbl_k(Xyzz& acc, int k) {
+    using namespace fp28;
+    if (is_inf(acc) || k <= 0) return;
+    Fe X = mul(acc.x, acc.zz), Y = mul(acc.y, acc.zzz), Z = acc.zz;
+    for (int i = 0; i < k; ++i) {
+        Fe A = sqr(X), B = sqr(Y), C = sqr(B);         // XX, YY, YYYY  (< 1.04p each... A,B < 1.2p)
+        Fe S = mul(X, B);                              // X*YY
+        S = addn(S, S);
+        S = addn(S, S);                                // 4*X*YY < 4.2p
+        Fe E = addn(add(A, A), A);                     // 3*XX < 3.6p
+        Fe X3 = sub<16>(sqr(E), addn(S, S));           // M^2 - 2S  < 18p
+        Fe C8 = addn(C, C);
+        C8 = addn(C8, C8);
+        C8 = addn(C8, C8);                             // 8*YYYY < 8.4p
+        Fe Y3 = sub<16>(mul(E, sub<32>(S, X3)), C8);   // M*(S - X3) - 8*YYYY  < 17.1p
+        Fe Z3 = mul(Y, Z);
+        Z = addn(Z3, Z3);                              // 2*Y*Z < 2.1p
+        X = X3;
+        Y = Y3;
+    }
+    const Fe o = one();
+    acc.x = mul(X, o);  // back under the XYZZ bounds (value unchanged: multiplication by 1)
+    acc.y = mul(Y, o);
+    acc.zz = sqr(Z);
+    acc.zzz = mul(acc.zz, Z);
+}
+
 // acc = k * acc for a small public integer k (double-and-add, MSB first)
 FF_HD void mul_small(Xyzz& acc, ff::u32 k) {
     if (k == 0 || is_inf(acc)) {

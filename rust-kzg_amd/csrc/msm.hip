@@ -396,14 +396,7 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, co
     } else {
         g1::set_inf(acc);
         for (int w = nwin - 1; w >= 0; --w) {
-            if (!g1::is_inf(acc))
-                for (int k = 0; k < c; ++k) {
-                    if (fp28::is_zero_mod_p(acc.y)) {
-                        g1::set_inf(acc);
-                        break;
-                    }
-                    g1::dbl(acc);
-                }
+            g1::dbl_k(acc, c);  // the curve has odd order: doubling never reaches infinity
             Xyzz r = rootM[b * nwin + w];
             g1::dadd(acc, r);
             r = rootA[b * nwin + w];
