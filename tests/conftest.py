@@ -69,6 +69,15 @@ def load_package():
 
     if "rust_kzg_amd" in sys.modules:
         return sys.modules["rust_kzg_amd"]
+    # tests that also use torch for device buffers need torch's HIP runtime initialised before the
+    # library pulls in libamdhip64 (both resolve the same SONAME; first loaded wins)
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     path = os.path.join(ROOT, "rust-kzg_amd", "__init__.py")
     spec = importlib.util.spec_from_file_location("rust_kzg_amd", path, submodule_search_locations=[os.path.dirname(path)])
     mod = importlib.util.module_from_spec(spec)

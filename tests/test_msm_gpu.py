@@ -173,3 +173,71 @@ def test_linearity_property_large(oracle, kzg):
     e = O.G1()
     L.omsm_affine(C.byref(e), base, folded, 16)
     assert compressed(L, e) == compressed(L, a)
+
+
+def _splitmix_scalar(seed, i):
+    """h_i of kzgamd_generate_points: four splitmix64 outputs, top byte cleared (little-endian limbs)"""
+    M = (1 << 64) - 1
+    st = seed ^ ((0xD1B54A32D192ED03 * (i + 1)) & M)
+    out = []
+    for _ in range(4):
+        st = (st + 0x9E3779B97F4A7C15) & M
+        z = st
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        out.append(z ^ (z >> 31))
+    out[3] &= 0x00FFFFFFFFFFFFFF
+    return sum(v << (64 * k) for k, v in enumerate(out))
+
+
+def test_empty_msm_and_generated_points(oracle, kzg):
+    import torch
+
+    L = oracle.lib()
+    # npoints == 0: identity, output overwritten
+    out = kzg.multi_scalar_mult((O.G1Affine * 1)(), (O.Fr * 1)(), 0)
+    assert bytes(out) == bytes(144)
+    # device point generator == h_i * G (oracle) on a subsample
+    n = 4096
+    d = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    kzg.generate_points(d.data_ptr(), n, 2, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    host = d.cpu().numpy().tobytes()
+    g = O.G1()
+    L.og1_generator(C.byref(g))
+    for i in (0, 1, 77, 4095):
+        t, a = O.G1(), O.G1Affine()
+        kf = O.fr_from_int(_splitmix_scalar(2, i))
+        L.og1_mul(C.byref(t), C.byref(g), C.byref(kf))
+        L.og1_to_affine(C.byref(a), C.byref(t))
+        assert bytes(a) == host[96 * i:96 * i + 96], i
+
+
+def test_msm_2p20_matches_oracle(oracle, kzg):
+    # BASELINE configs[2] size: n = 2^20 device-generated points, random scalars, GPU (variable-base engine,
+    # device-resident inputs) vs the CPU oracle's Booth Pippenger on the same data
+    import numpy as np
+    import torch
+
+    L = oracle.lib()
+    n = 1 << 20
+    stream = torch.cuda.current_stream().cuda_stream
+    d_pts = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    kzg.generate_points(d_pts.data_ptr(), n, 7, stream)
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(11)
+    sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=gen)
+    sc[:, 31] &= 0x3F  # canonical little-endian scalars < 2^254
+    sc[::10] = 0       # 10 % zero scalars
+    d_sc = sc.cuda()
+    d_out = torch.zeros(144, dtype=torch.uint8, device="cuda")
+    h = kzg.DeviceMsm(d_pts.data_ptr(), n, False)
+    kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr(), n, 1, False, stream)
+    torch.cuda.synchronize()
+    got = O.G1()
+    C.memmove(C.byref(got), d_out.cpu().numpy().tobytes(), 144)
+    pts = (O.G1Affine * n).from_buffer_copy(d_pts.cpu().numpy().tobytes())
+    exp = O.G1()
+    L.omsm_tiling_pippenger(C.byref(exp), pts, sc.numpy().tobytes(), n)
+    assert compressed(L, got) == compressed(L, exp)
+    h.close()
