@@ -1,0 +1,125 @@
+// Fr for the NTT butterflies: 9 limbs of 29 bits, Montgomery radix R' = 2^261 — the same idea as
+// fp28.cuh (carry-free columns of v_mad_u64_u32: 18 partial products < 2^58 per 64-bit column).
+//
+// Data elements keep blst's Montgomery form d*2^256 (only re-sliced 32 -> 29 bits); twiddles are
+// stored as w*2^261, so  mul(D, W) = d*w*2^256  stays in blst form without any domain conversion.
+// Butterfly outputs are lazy (value < 64r, limbs renormalised each stage); a pass ends with one
+// multiplication by 2^261 mod r (or by the inverse-transform scale) that brings the value below 2r.
+#pragma once
+#include "ff.cuh"
+
+namespace fr29 {
+using ff::u32;
+using ff::u64;
+
+constexpr int L = 9;
+constexpr u32 MASK = (1u << 29) - 1;
+constexpr u32 R0INV = 0x1fffffffu;  // -r^-1 mod 2^29
+
+struct Fe {
+    u32 v[L];
+};
+
+FF_HD constexpr u32 rl(int i) {
+    constexpr u32 t[L] = {0x1u, 0x1ffffff8u, 0x1f96ffbfu, 0x1b4805ffu, 0x1d80553bu, 0xc0404d0u, 0x1520cce7u, 0xa6533afu, 0x73eda7u};
+    return t[i];
+}
+FF_HD constexpr u32 one_l(int i) {  // 2^261 mod r
+    constexpr u32 t[L] = {0x1fffffbau, 0x22fu, 0x1cb61180u, 0xa4e5c00u, 0xee8b1a2u, 0x16e6aedfu, 0x1907f8bbu, 0x853ddf7u, 0x4d043fu};
+    return t[i];
+}
+FF_HD constexpr u32 pad4_l(int i) {  // 4r with limbs 0..7 >= 2^29 - 1
+    constexpr u32 t[L] = {0x20000004u, 0x3fffffdfu, 0x3e5bfefeu, 0x2d2017feu, 0x360154eeu, 0x30101342u, 0x3483339cu, 0x2994cebdu, 0x1cfb69cu};
+    return t[i];
+}
+
+FF_HD Fe one() {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) r.v[i] = one_l(i);
+    return r;
+}
+
+FF_HD void norm(Fe& a) {
+#pragma unroll
+    for (int i = 0; i < L - 1; ++i) {
+        a.v[i + 1] += a.v[i] >> 29;
+        a.v[i] &= MASK;
+    }
+}
+
+// x + t and x + 4r - t  (t normalized, value < 3r), both renormalised
+FF_HD void butterfly(Fe& x, Fe& y_out, const Fe& t) {
+    Fe s, d;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        s.v[i] = x.v[i] + t.v[i];
+        d.v[i] = x.v[i] + pad4_l(i) - t.v[i];
+    }
+    norm(s);
+    norm(d);
+    x = s;
+    y_out = d;
+}
+
+// a*b*2^-261 mod r; limbs of a < 2^31, of b < 2^29; a*b < 2^261 * r; output normalized, < 2r
+FF_HD Fe mul(const Fe& a, const Fe& b) {
+    u32 m[L];
+    Fe r;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        u64 acc2 = 0;
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (u64)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc2 += (u64)m[i] * rl(k - i);
+        acc += acc2;
+        m[k] = ((u32)acc * R0INV) & MASK;
+        acc += (u64)m[k] * rl(0);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; ++k) {
+        u64 acc2 = 0;
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) acc += (u64)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) acc2 += (u64)m[i] * rl(k - i);
+        acc += acc2;
+        r.v[k - L] = (u32)acc & MASK;
+        acc >>= 29;
+    }
+    r.v[L - 1] = (u32)acc;
+    return r;
+}
+
+// bit re-slicing 8 x 32 <-> 9 x 29
+FF_HD Fe unpack(const ff::Fr& a) {
+    Fe r;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const int bit = 29 * i, w = bit >> 5, s = bit & 31;
+        u64 two = (u64)a.v[w] | ((w + 1 < 8) ? ((u64)a.v[w + 1] << 32) : 0);
+        r.v[i] = (u32)(two >> s) & MASK;
+    }
+    return r;
+}
+FF_HD ff::Fr pack(const Fe& a) {  // normalized, value < 2^256
+    ff::Fr r;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const int lo = (32 * w) / 29, s = 32 * w - 29 * lo;
+        u64 two = (u64)a.v[lo] | ((lo + 1 < L) ? ((u64)a.v[lo + 1] << 29) : 0);
+        r.v[w] = (u32)(two >> s);
+    }
+    return r;
+}
+// lazy value (< 64r) times a normalized canonical multiplier (W = w*2^261), fully reduced to [0, r)
+FF_HD ff::Fr finish(const Fe& a, const Fe& mult) {
+    ff::Fr r = pack(mul(a, mult));
+    ff::reduce_once(r);
+    return r;
+}
+
+}  // namespace fr29

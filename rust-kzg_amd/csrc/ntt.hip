@@ -10,7 +10,7 @@
 //   n  > 4096 : pass 1 = the 12 low stages on contiguous 4096-blocks (same kernel), pass 2 = the
 //               remaining stages on column tiles (C columns x n/4096 rows = 4096 elements per workgroup)
 //               so every element crosses HBM twice (64*n algorithmic bytes per pass pair).
-// Field arithmetic: 8 x 32-bit Montgomery (ff.cuh); integer VALU only.
+// Field arithmetic: 9 x 29-bit Montgomery with lazy butterflies (fr29.cuh); integer VALU only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -21,8 +21,10 @@
 #include "../../include/kzg_mi355x.h"
 #include "ckzg_internal.h"
 #include "ff.cuh"
+#include "fr29.cuh"
 
 using ff::Fr;
+using fr29::Fe;
 using ff::u32;
 using ff::u64;
 
@@ -43,16 +45,17 @@ struct NttErr {
 
 __device__ __forceinline__ u32 brev(u32 v, int bits) { return __builtin_bitreverse32(v) >> (32 - bits); }
 
-// LDS holds elements limb-major: sh[limb * TILE + idx] -> unit-stride lanes hit distinct banks
-__device__ __forceinline__ Fr lds_get(const u32* sh, int cnt, int idx) {
-    Fr r;
+// LDS holds elements in the 9 x 29-bit form, limb-major: sh[limb * cnt + idx] -> unit-stride lanes hit
+// distinct banks (4096 x 36 B = 144 KiB of the 160 KiB LDS)
+__device__ __forceinline__ Fe lds_get(const u32* sh, int cnt, int idx) {
+    Fe r;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) r.v[k] = sh[k * cnt + idx];
+    for (int k = 0; k < fr29::L; ++k) r.v[k] = sh[k * cnt + idx];
     return r;
 }
-__device__ __forceinline__ void lds_put(u32* sh, int cnt, int idx, const Fr& a) {
+__device__ __forceinline__ void lds_put(u32* sh, int cnt, int idx, const Fe& a) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sh[k * cnt + idx] = a.v[k];
+    for (int k = 0; k < fr29::L; ++k) sh[k * cnt + idx] = a.v[k];
 }
 
 // `stages` butterfly stages of a DIT network on the `cnt` elements in LDS.
@@ -65,10 +68,11 @@ __device__ __forceinline__ void lds_stages(u32* sh, int cnt, int stages, TwFn tw
         for (int b = threadIdx.x; b < cnt / 2; b += NT) {
             const int j = b & (half - 1);
             const int i0 = ((b >> s) << (s + 1)) | j, i1 = i0 + half;
-            Fr x = lds_get(sh, cnt, i0), y = lds_get(sh, cnt, i1);
-            Fr t = ff::mul(y, tw(s, j, i0));
-            lds_put(sh, cnt, i0, ff::add(x, t));
-            lds_put(sh, cnt, i1, ff::sub(x, t));
+            Fe x = lds_get(sh, cnt, i0), y = lds_get(sh, cnt, i1);
+            Fe t = fr29::mul(y, fr29::unpack(tw(s, j, i0)));
+            fr29::butterfly(x, y, t);
+            lds_put(sh, cnt, i0, x);
+            lds_put(sh, cnt, i1, y);
         }
         __syncthreads();
     }
@@ -79,7 +83,7 @@ struct NttParams {
     int logn;
     u32 W;          // roots table width (max_width)
     int inverse;
-    Fr scale;       // n^-1 (Montgomery) when inverse, else unused
+    Fr scale;       // final multiplier in the 2^261 domain: 2^261 mod r, times n^-1 on the last pass of an inverse
 };
 
 // Pass 1 (and the whole transform when n <= TILE): block `blk` of min(n,TILE) consecutive
@@ -94,7 +98,7 @@ __global__ void __launch_bounds__(NT) k_ntt_low(Fr* __restrict__ out, const Fr* 
     Fr* dst = out + (size_t)xf * P.n;
     for (int e = threadIdx.x; e < cnt; e += NT) {
         const u32 pos = blk * (u32)cnt + (u32)e;  // position in the bit-reversed sequence
-        lds_put(sh, cnt, e, src[brev(pos, P.logn)]);
+        lds_put(sh, cnt, e, fr29::unpack(src[brev(pos, P.logn)]));
     }
     __syncthreads();
     // stage s: half = 2^s, twiddle w_n^(j * n / 2^(s+1)) = roots[j * (W / 2^(s+1))]
@@ -103,11 +107,8 @@ __global__ void __launch_bounds__(NT) k_ntt_low(Fr* __restrict__ out, const Fr* 
         const u32 idx = (u32)j * (P.W >> (s + 1));
         return roots[P.inverse ? P.W - idx : idx];
     });
-    for (int e = threadIdx.x; e < cnt; e += NT) {
-        Fr v = lds_get(sh, cnt, e);
-        if (last_pass && P.inverse) v = ff::mul(v, P.scale);
-        dst[blk * (u32)cnt + (u32)e] = v;
-    }
+    const Fe fin = last_pass ? fr29::unpack(P.scale) : fr29::one();
+    for (int e = threadIdx.x; e < cnt; e += NT) dst[blk * (u32)cnt + (u32)e] = fr29::finish(lds_get(sh, cnt, e), fin);
 }
 
 // Pass 2: stages 12 .. logn-1 on a tile of C consecutive columns x R = n/4096 rows (in place).
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(NT) k_ntt_high(Fr* __restrict__ data, const Fr
     // LDS element e = c * R + r  (row index fastest, so a butterfly pairs e and e + 2^s)
     for (int e = threadIdx.x; e < TILE; e += NT) {
         const int c = e & (C - 1), r = e >> logC;  // consecutive lanes -> consecutive columns (coalesced)
-        lds_put(sh, TILE, c * R + r, base[(size_t)r * TILE + col0 + c]);
+        lds_put(sh, TILE, c * R + r, fr29::unpack(base[(size_t)r * TILE + col0 + c]));
     }
     __syncthreads();
     lds_stages(sh, TILE, logR, [&](int s, int j, int i0) -> Fr {
@@ -133,9 +134,7 @@ __global__ void __launch_bounds__(NT) k_ntt_high(Fr* __restrict__ data, const Fr
     });
     for (int e = threadIdx.x; e < TILE; e += NT) {
         const int c = e & (C - 1), r = e >> logC;
-        Fr v = lds_get(sh, TILE, c * R + r);
-        if (P.inverse) v = ff::mul(v, P.scale);
-        base[(size_t)r * TILE + col0 + c] = v;
+        base[(size_t)r * TILE + col0 + c] = fr29::finish(lds_get(sh, TILE, c * R + r), fr29::unpack(P.scale));
     }
 }
 
@@ -145,7 +144,7 @@ __global__ void __launch_bounds__(256) k_twist(Fr* __restrict__ data, const Fr* 
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     u32 i = (u32)(t % n);
-    data[t] = ff::mul(data[t], roots[(size_t)i * stride]);
+    data[t] = fr29::finish(fr29::unpack(data[t]), fr29::unpack(roots[(size_t)i * stride]));
 }
 
 }  // namespace
@@ -186,6 +185,14 @@ int ilog2(size_t n) {
     return l;
 }
 
+Fr times32(Fr a) {  // a * 2^5 mod r
+    for (int k = 0; k < 5; ++k) a = ff::add(a, a);
+    return a;
+}
+Fr one261() {  // 2^261 mod r = (2^256 mod r) * 2^5
+    return times32(Fr::one());
+}
+
 // n^-1 in Montgomery form
 Fr inv_len(size_t n) {
     Fr v = Fr::zero();
@@ -201,15 +208,17 @@ void ntt_enqueue(NttCtx* ctx, Fr* d_out, const Fr* d_in, size_t n, size_t nbatch
     P.logn = ilog2(n);
     P.W = (u32)ctx->W;
     P.inverse = inverse ? 1 : 0;
-    P.scale = inverse ? inv_len(n) : Fr::one();
-    const size_t lds = (n < (size_t)TILE ? n : (size_t)TILE) * sizeof(Fr);
+    // 2^261 mod r as a plain residue (= "one" of the 2^261 domain); an inverse transform folds n^-1 in:
+    // data is d*2^256, so the multiplier n^-1*2^261 is (n^-1 in blst Montgomery form) * 2^5
+    P.scale = inverse ? times32(inv_len(n)) : one261();
+    const size_t lds = (n < (size_t)TILE ? n : (size_t)TILE) * sizeof(u32) * fr29::L;
     const u32 blocks = n <= (size_t)TILE ? 1u : (u32)(n >> LOG_TILE);
     hipLaunchKernelGGL(k_ntt_low, dim3((unsigned)(blocks * nbatch)), dim3(NT), lds, stream, d_out, d_in,
                        (const Fr*)ctx->d_roots, P, blocks);
     if (n > (size_t)TILE) {
         const int logR = P.logn - LOG_TILE;
         const u32 tiles = (u32)1 << logR;  // 4096 columns / C columns per tile, C = 4096 >> logR
-        hipLaunchKernelGGL(k_ntt_high, dim3((unsigned)(tiles * nbatch)), dim3(NT), (size_t)TILE * sizeof(Fr), stream, d_out,
+        hipLaunchKernelGGL(k_ntt_high, dim3((unsigned)(tiles * nbatch)), dim3(NT), (size_t)TILE * sizeof(u32) * fr29::L, stream, d_out,
                            (const Fr*)ctx->d_roots, P, tiles);
     }
     NTT_TRY(hipGetLastError());
@@ -231,8 +240,11 @@ extern "C" void* kzgamd_ntt_new(unsigned scale) {
         ctx->scale = scale;
         ctx->W = (size_t)1 << scale;
         kzgamd::expand_roots(ctx->roots, scale);
+        // device twiddles in the 2^261 domain: w*2^261 = (w*2^256) * 2^5
+        std::vector<Fr> tw(ctx->W + 1);
+        for (size_t i = 0; i <= ctx->W; ++i) tw[i] = times32(ctx->roots[i]);
         NTT_TRY(hipMalloc(&ctx->d_roots, (ctx->W + 1) * sizeof(Fr)));
-        NTT_TRY(hipMemcpy(ctx->d_roots, ctx->roots.data(), (ctx->W + 1) * sizeof(Fr), hipMemcpyHostToDevice));
+        NTT_TRY(hipMemcpy(ctx->d_roots, tw.data(), (ctx->W + 1) * sizeof(Fr), hipMemcpyHostToDevice));
     } catch (...) {
         delete ctx;
         return nullptr;
