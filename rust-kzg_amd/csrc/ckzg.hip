@@ -115,23 +115,8 @@ __device__ __forceinline__ ff::Fr fr_load_be(const u32* __restrict__ w8, bool* o
     *ok = borrow != 0;
     return a;
 }
-__device__ ff::Fr fr_inverse(const ff::Fr& a) {  // a^(r-2); 0 -> 0 like blst_fr_eucl_inverse
-    ff::Fr r = ff::Fr::one();
-    bool started = false;
-    for (int i = 7; i >= 0; --i) {
-        u32 e = ff::FrParams::p(i);
-        if (i == 0) e = 0xffffffffu;             // r - 2: the low limb 1 - 2 borrows ...
-        if (i == 1) e = ff::FrParams::p(1) - 1;  // ... from limb 1
-        for (int b = 31; b >= 0; --b) {
-            if (started) r = ff::sqr(r);
-            if ((e >> b) & 1) {
-                r = started ? ff::mul(r, a) : a;
-                started = true;
-            }
-        }
-    }
-    return r;
-}
+// Montgomery inverse by binary Euclid (ff.cuh); 0 -> 0 like blst_fr_eucl_inverse
+__device__ ff::Fr fr_inverse(const ff::Fr& a) { return ff::inverse_bgcd(a); }
 
 constexpr int QT = 512;            // threads per blob
 constexpr int QE = (int)(N / QT);  // elements per thread (8), element index i = k*QT + t

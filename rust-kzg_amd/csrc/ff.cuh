@@ -313,6 +313,81 @@ FF_HD Field<P> inverse(const Field<P>& a) {
     return pow_u32(a, e, N);
 }
 
+// Modular inverse of a PLAIN residue by the binary extended Euclid algorithm (right-shift variant):
+// ~2*bits rounds of 32-bit-limb shifts / adds instead of the ~1.5*bits Montgomery multiplications of
+// Fermat's a^(p-2) — about 10x fewer instructions, which matters where one lane inverts alone
+// (affine conversion before compressing a commitment).  Not constant time; inputs are public.
+// Returns 0 for a == 0.
+template <class P>
+FF_HD Field<P> inverse_plain_bgcd(const Field<P>& a) {
+    constexpr int N = P::N;
+    typedef Field<P> F;
+    if (a.is_zero()) return F::zero();
+    F u = a, v = F::modulus(), x1 = F::zero(), x2 = F::zero();
+    x1.v[0] = 1;
+    auto is_one = [](const F& x) {
+        u32 acc = x.v[0] ^ 1u;
+#pragma unroll
+        for (int i = 1; i < N; ++i) acc |= x.v[i];
+        return acc == 0;
+    };
+    auto shr1 = [](F& x) {
+#pragma unroll
+        for (int i = 0; i < N - 1; ++i) x.v[i] = (x.v[i] >> 1) | (x.v[i + 1] << 31);
+        x.v[N - 1] >>= 1;
+    };
+    auto add_p = [](F& x) {  // x += p (no overflow: x < p < 2^(32N-1))
+        u64 c = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            c += (u64)x.v[i] + P::p(i);
+            x.v[i] = (u32)c;
+            c >>= 32;
+        }
+    };
+    auto sub_raw = [](F& x, const F& y) -> u32 {  // x -= y, returns borrow
+        u64 b = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            u64 d = (u64)x.v[i] - y.v[i] - b;
+            x.v[i] = (u32)d;
+            b = (d >> 32) & 1;
+        }
+        return (u32)b;
+    };
+    auto halve_mod = [&](F& x) {  // x = x/2 mod p
+        if (x.v[0] & 1) add_p(x);
+        shr1(x);
+    };
+    while (!is_one(u) && !is_one(v)) {
+        while (!(u.v[0] & 1)) {
+            shr1(u);
+            halve_mod(x1);
+        }
+        while (!(v.v[0] & 1)) {
+            shr1(v);
+            halve_mod(x2);
+        }
+        F t = u;
+        if (!sub_raw(t, v)) {  // u >= v
+            u = t;
+            if (sub_raw(x1, x2)) add_p(x1);
+        } else {
+            sub_raw(v, u);
+            if (sub_raw(x2, x1)) add_p(x2);
+        }
+    }
+    return is_one(u) ? x1 : x2;
+}
+
+// inverse in Montgomery form: (a*R)^-1 as a residue is a^-1 * R^-1; two multiplications by R^2 give a^-1 * R
+template <class P>
+FF_HD Field<P> inverse_bgcd(const Field<P>& a_mont) {
+    Field<P> r = inverse_plain_bgcd(a_mont);
+    const Field<P> r2 = Field<P>::r2();
+    return mul(mul(r, r2), r2);
+}
+
 typedef Field<FpParams> Fp;
 typedef Field<FrParams> Fr;
 

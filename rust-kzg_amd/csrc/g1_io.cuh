@@ -82,8 +82,20 @@ FF_HD Fe pow_sat(const Fe& a, ExpFn e) {
     }
     return r;
 }
-FF_HD Fe inverse(const Fe& a) {
+FF_HD Fe inverse_fermat(const Fe& a) {
     return pow_sat(a, [](int i) -> u32 { return i == 0 ? ff::FpParams::p(0) - 2 : ff::FpParams::p(i); });
+}
+// a^-1 in the 2^392 Montgomery domain via the binary-Euclid inverse of the plain residue:
+// (x*R')^-1 = x^-1 * R'^-1, then two multiplications by R'^2 give x^-1 * R'
+FF_HD Fe inverse(const Fe& a) {
+    ff::Fp s = fp28::pack(a);  // normalized, value < 2^384 (callers pass mul outputs, < 2p)
+    ff::reduce_once(s);
+    ff::reduce_once(s);
+    const ff::Fp inv = ff::inverse_plain_bgcd(s);
+    Fe c;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) c.v[i] = r2_392_l(i);
+    return fp28::mul(fp28::mul(fp28::unpack(inv), c), c);
 }
 
 // 48 big-endian bytes -> saturated plain integer
@@ -142,19 +154,23 @@ FF_HD bool uncompress(g1::AffPt& out, const unsigned char in[48]) {
     return true;
 }
 
-// blst_p1_compress of an XYZZ point
-FF_HD void compress(unsigned char out[48], const g1::Xyzz& p) {
+// blst_p1_compress of an XYZZ point, given zi = 1 / (ZZ * ZZZ)
+FF_HD void compress_with_inverse(unsigned char out[48], const g1::Xyzz& p, const Fe& zi) {
     if (g1::is_inf(p)) {
         for (int i = 0; i < 48; ++i) out[i] = 0;
         out[0] = 0xc0;
         return;
     }
-    Fe zi = inverse(fp28::mul(p.zz, p.zzz));
     Fe x = fp28::mul(p.x, fp28::mul(zi, p.zzz));
     Fe y = fp28::mul(p.y, fp28::mul(zi, p.zz));
     sat_to_be48(out, to_plain(x));
     out[0] |= 0x80;
     if (is_lex_largest(to_plain(y))) out[0] |= 0x20;
+}
+FF_HD void compress(unsigned char out[48], const g1::Xyzz& p) {
+    Fe zi = fp28::one();
+    if (!g1::is_inf(p)) zi = inverse(fp28::mul(p.zz, p.zzz));
+    compress_with_inverse(out, p, zi);
 }
 
 }  // namespace g1io

@@ -54,7 +54,7 @@ inline void host_p1_compress(uint8_t out[48], const blst_p1* p) {
         out[0] = 0xc0;
         return;
     }
-    ff::Fp zi = ff::inverse(P[2]), zi2 = ff::sqr(zi);
+    ff::Fp zi = ff::inverse_bgcd(P[2]), zi2 = ff::sqr(zi);
     ff::Fp x = ff::from_mont(ff::mul(P[0], zi2)), y = ff::from_mont(ff::mul(P[1], ff::mul(zi2, zi)));
     host_fp_to_be48(out, x);
     out[0] |= 0x80;

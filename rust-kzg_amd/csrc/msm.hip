@@ -74,24 +74,6 @@ __global__ void __launch_bounds__(256) k_points_in(AffPt* __restrict__ dst, cons
     dst[i] = o;
 }
 
-// a^(p-2) in fp28 (Fermat); only used while building tables
-__device__ fp28::Fe fe_inverse(const fp28::Fe& a) {
-    fp28::Fe r = fp28::one();
-    bool started = false;
-    for (int i = 11; i >= 0; --i) {
-        u32 e = ff::FpParams::p(i);
-        if (i == 0) e -= 2;
-        for (int b = 31; b >= 0; --b) {
-            if (started) r = fp28::sqr(r);
-            if ((e >> b) & 1) {
-                r = started ? fp28::mul(r, a) : a;
-                started = true;
-            }
-        }
-    }
-    return r;
-}
-
 // table rows j = 1..rows-1:  T[j][i] = 2^c * T[j-1][i], kept affine (one inversion per entry)
 __global__ void __launch_bounds__(128) k_table_rows(AffPt* __restrict__ table, size_t n, int rows, int c) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,7 +102,7 @@ __global__ void __launch_bounds__(128) k_table_rows(AffPt* __restrict__ table, s
                 nxt.x = fp28::zero();
                 nxt.y = fp28::zero();
             } else {
-                fp28::Fe zi = fe_inverse(fp28::mul(acc.zz, acc.zzz));  // 1/(ZZ*ZZZ)
+                fp28::Fe zi = g1io::inverse(fp28::mul(acc.zz, acc.zzz));  // 1/(ZZ*ZZZ)
                 fp28::Fe izz = fp28::mul(zi, acc.zzz), izzz = fp28::mul(zi, acc.zz);
                 nxt.x = fp28::canon(fp28::mul(acc.x, izz));
                 nxt.y = fp28::canon(fp28::mul(acc.y, izzz));
@@ -385,7 +367,8 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, co
                                               void* __restrict__ out_v, size_t nbatch, int nwin, int c, int prepared,
                                               int out_mode) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbatch) return;
+    const bool live = b < nbatch;
+    if (!live) b = nbatch - 1;  // idle lanes shadow the last MSM so that the whole block reaches the barriers
     Xyzz acc;
     if (prepared) {
         acc = rootM[b];  // sum (k+1) B_k = M + A   (wide-table path: rootM is the sum, rootA absent)
@@ -404,14 +387,39 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, co
         }
     }
     if (out_mode == kzgamd::OUT_COMPRESSED) {
+        // affine conversion needs 1/(ZZ*ZZZ) per point: one inversion per 64-lane block (Montgomery's trick
+        // over an LDS product scan) instead of one per lane
+        __shared__ fp28::Fe sh_pre[64], sh_suf[64];
+        __shared__ fp28::Fe sh_inv;
+        const int t = threadIdx.x;
+        fp28::Fe z = (!live || g1::is_inf(acc)) ? fp28::one() : fp28::mul(acc.zz, acc.zzz);
+        sh_pre[t] = z;
+        sh_suf[t] = z;
+        __syncthreads();
+        for (int off = 1; off < 64; off <<= 1) {
+            fp28::Fe a = sh_pre[t], c2 = sh_suf[t];
+            if (t >= off) a = fp28::mul(sh_pre[t - off], a);
+            if (t + off < 64) c2 = fp28::mul(c2, sh_suf[t + off]);
+            __syncthreads();
+            sh_pre[t] = a;
+            sh_suf[t] = c2;
+            __syncthreads();
+        }
+        if (t == 0) sh_inv = g1io::inverse(sh_pre[63]);
+        __syncthreads();
+        fp28::Fe zi = sh_inv;
+        if (t > 0) zi = fp28::mul(zi, sh_pre[t - 1]);
+        if (t < 63) zi = fp28::mul(zi, sh_suf[t + 1]);
+        if (!live) return;
         unsigned char buf[48];
-        g1io::compress(buf, acc);
+        g1io::compress_with_inverse(buf, acc, zi);
         u32* o = (u32*)out_v + 12 * b;
 #pragma unroll
         for (int k = 0; k < 12; ++k)
             o[k] = (u32)buf[4 * k] | ((u32)buf[4 * k + 1] << 8) | ((u32)buf[4 * k + 2] << 16) | ((u32)buf[4 * k + 3] << 24);
         return;
     }
+    if (!live) return;
     ff::Fp* out = (ff::Fp*)out_v;
     ff::Fp j[3];
     g1::to_blst_jacobian(j, acc);
@@ -490,34 +498,42 @@ __global__ void __launch_bounds__(128) k_fbw_affine(AffPt* __restrict__ wide, co
     }
 }
 
-// one lane per (MSM, scalar): all windows of that scalar against the wide table
+// one lane per (MSM, `spl` consecutive scalars): all windows of those scalars against the wide table.
+// spl > 1 (large batches) leaves fewer partial sums for k_blocksum to fold.
+template <int SPL>
 __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __restrict__ scalars,
-                                                   const AffPt* __restrict__ wide, Xyzz* __restrict__ partial) {
+                                                   const AffPt* __restrict__ wide, Xyzz* __restrict__ partial,
+                                                   size_t lanes_per_msm) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= P.n * P.nbatch) return;
-    const size_t i = t % P.n;
-    u32 s[8];
-    load_scalar(s, scalars, t, P.mont);
+    if (t >= lanes_per_msm * P.nbatch) return;
+    const size_t b = t / lanes_per_msm, l = t % lanes_per_msm;
     Xyzz acc;
     g1::set_inf(acc);
-    u32 carry = 0;
     const u32 half = 1u << (P.c - 1);
     const int sh = P.c - 1;
-    for (int w = 0; w < P.nwin; ++w) {
-        u32 d = window_bits(s, w * P.c, P.c) + carry;
-        u32 neg = 0;
-        carry = 0;
-        if (d > half) {
-            d = (1u << P.c) - d;
-            neg = 1;
-            carry = 1;
+#pragma unroll
+    for (int k = 0; k < SPL; ++k) {
+        const size_t i = l * (size_t)SPL + k;
+        if (SPL > 1 && i >= P.n) break;
+        u32 s[8];
+        load_scalar(s, scalars, b * P.n + i, P.mont);
+        u32 carry = 0;
+        for (int w = 0; w < P.nwin; ++w) {
+            u32 d = window_bits(s, w * P.c, P.c) + carry;
+            u32 neg = 0;
+            carry = 0;
+            if (d > half) {
+                d = (1u << P.c) - d;
+                neg = 1;
+                carry = 1;
+            }
+            if (d == 0) continue;
+            const AffPt* p = wide + ((((size_t)w * P.row_stride + i) << sh) + (d - 1));
+            if (p->flags & 1) continue;
+            fp28::Fe x = p->x, y = p->y;
+            if (neg) y = fp28::neg<2>(y);
+            g1::madd(acc, x, y);
         }
-        if (d == 0) continue;
-        const AffPt* p = wide + ((((size_t)w * P.row_stride + i) << sh) + (d - 1));
-        if (p->flags & 1) continue;
-        fp28::Fe x = p->x, y = p->y;
-        if (neg) y = fp28::neg<2>(y);
-        g1::madd(acc, x, y);
     }
     partial[t] = acc;
 }
@@ -805,7 +821,13 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     Workspace& ws = ctx->ws;
     if (ctx->fbw) {
         // wide-table path: gather + add, then one block-sum per MSM
-        ws.buckets.ensure(nbatch * npoints);
+        // scalars per lane: 1 measured best on MI355X (2 and 4 fold fewer partial sums but slow the gather loop
+        // by more than that: 12.20 / 12.22 / 12.39 ms per 1024 blobs); kept selectable for experiments
+        int spl = 1;
+        if (const char* e = getenv("KZGAMD_SPL")) spl = atoi(e) > 0 ? atoi(e) : spl;
+        if (spl == 3 || spl > 4) spl = 4;
+        const size_t lanes = (npoints + spl - 1) / spl;
+        ws.buckets.ensure(nbatch * lanes);
         ws.lvlM[0].ensure(nbatch);
         DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n};
         hipEvent_t* pev = nullptr;
@@ -819,11 +841,19 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             HIP_TRY(hipEventRecord(pev[0], stream));
             HIP_TRY(hipEventRecord(pev[1], stream));
         }
-        hipLaunchKernelGGL(k_fbw_accum, dim3((unsigned)((npoints * nbatch + 255) / 256)), dim3(256), 0, stream, P,
-                           (const u32*)d_scalars, (const AffPt*)ctx->wide.p, ws.buckets.p);
+        const dim3 grid((unsigned)((lanes * nbatch + 255) / 256));
+        if (spl == 1)
+            hipLaunchKernelGGL(k_fbw_accum<1>, grid, dim3(256), 0, stream, P, (const u32*)d_scalars,
+                               (const AffPt*)ctx->wide.p, ws.buckets.p, lanes);
+        else if (spl == 2)
+            hipLaunchKernelGGL(k_fbw_accum<2>, grid, dim3(256), 0, stream, P, (const u32*)d_scalars,
+                               (const AffPt*)ctx->wide.p, ws.buckets.p, lanes);
+        else
+            hipLaunchKernelGGL(k_fbw_accum<4>, grid, dim3(256), 0, stream, P, (const u32*)d_scalars,
+                               (const AffPt*)ctx->wide.p, ws.buckets.p, lanes);
         if (pev) HIP_TRY(hipEventRecord(pev[2], stream));
         hipLaunchKernelGGL(k_blocksum, dim3((unsigned)nbatch), dim3(256), 256 * sizeof(Xyzz), stream,
-                           (const Xyzz*)ws.buckets.p, ws.lvlM[0].p, npoints);
+                           (const Xyzz*)ws.buckets.p, ws.lvlM[0].p, lanes);
         hipLaunchKernelGGL(k_final, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)nullptr,
                            (const Xyzz*)ws.lvlM[0].p, d_out, nbatch, nwin, c, 1, out_mode);
         if (pev) {

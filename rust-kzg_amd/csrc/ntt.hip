@@ -198,7 +198,7 @@ Fr inv_len(size_t n) {
     Fr v = Fr::zero();
     v.v[0] = (u32)n;
     v.v[1] = (u32)((u64)n >> 32);
-    return ff::inverse(ff::to_mont(v));
+    return ff::inverse_bgcd(ff::to_mont(v));
 }
 
 // enqueue nbatch transforms of length n (device pointers; out may equal in only when n > TILE is false... so never alias)
