@@ -92,4 +92,74 @@ inline bool host_p1_uncompress(blst_p1* out, const uint8_t in[48]) {
     return true;
 }
 
+// ---- host-side Jacobian arithmetic on blst-layout values (a handful of points per call at most) ----
+struct HostJac {
+    ff::Fp x, y, z;  // Montgomery; infinity <=> z == 0
+};
+inline HostJac host_jac_dbl(const HostJac& p) {  // dbl-2009-l (a = 0)
+    if (p.z.is_zero()) return p;
+    using namespace ff;
+    Fp A = sqr(p.x), B = sqr(p.y), C = sqr(B);
+    Fp t = sub(sub(sqr(add(p.x, B)), A), C);
+    Fp D = add(t, t), E = add(add(A, A), A), F = sqr(E);
+    HostJac r;
+    r.x = sub(sub(F, D), D);
+    Fp C8 = dbl(dbl(dbl(C)));
+    r.y = sub(mul(E, sub(D, r.x)), C8);
+    r.z = dbl(mul(p.y, p.z));
+    return r;
+}
+inline HostJac host_jac_add(const HostJac& a, const HostJac& b) {  // add-2007-bl with the exceptional cases
+    if (a.z.is_zero()) return b;
+    if (b.z.is_zero()) return a;
+    using namespace ff;
+    Fp z1z1 = sqr(a.z), z2z2 = sqr(b.z);
+    Fp u1 = mul(a.x, z2z2), u2 = mul(b.x, z1z1);
+    Fp s1 = mul(mul(a.y, b.z), z2z2), s2 = mul(mul(b.y, a.z), z1z1);
+    Fp h = sub(u2, u1), rr = sub(s2, s1);
+    if (h.is_zero()) {
+        if (rr.is_zero()) return host_jac_dbl(a);
+        HostJac inf;
+        inf.x = inf.y = inf.z = Fp::zero();
+        return inf;
+    }
+    rr = dbl(rr);
+    Fp i = sqr(dbl(h)), j = mul(h, i), v = mul(u1, i);
+    HostJac r;
+    r.x = sub(sub(sub(sqr(rr), j), v), v);
+    r.y = sub(mul(rr, sub(v, r.x)), dbl(mul(s1, j)));
+    r.z = mul(sub(sub(sqr(add(a.z, b.z)), z1z1), z2z2), h);
+    return r;
+}
+inline HostJac host_jac_mul_u64(const HostJac& p, uint64_t k) {
+    HostJac acc;
+    acc.x = acc.y = acc.z = ff::Fp::zero();
+    for (int bit = 63; bit >= 0; --bit) {
+        acc = host_jac_dbl(acc);
+        if ((k >> bit) & 1) acc = host_jac_add(acc, p);
+    }
+    return acc;
+}
+// blst_p1_in_g1 by the endomorphism test phi(P) == -[x^2]P (see k_check_commitments in ckzg.hip)
+inline bool host_p1_in_g1(const blst_p1* pt) {
+    const ff::Fp* P = reinterpret_cast<const ff::Fp*>(pt);
+    if (P[2].is_zero()) return true;
+    HostJac p{P[0], P[1], P[2]};
+    const uint64_t BLS_X = 0xd201000000010000ull;
+    HostJac q = host_jac_mul_u64(host_jac_mul_u64(p, BLS_X), BLS_X);
+    if (q.z.is_zero()) return false;
+    // beta (cube root of unity), plain: 0x5f19672f...fffefffe
+    static const uint32_t beta_plain[12] = {0xfffefffeu, 0x2e01ffffu, 0x620a0002u, 0xde17d813u, 0xe6f89688u, 0xddb3a93bu,
+                                            0x6a0f77eau, 0xba69c607u, 0xdf76ce51u, 0x5f19672fu, 0x00000000u, 0x00000000u};
+    ff::Fp beta;
+    for (int i = 0; i < 12; ++i) beta.v[i] = beta_plain[i];
+    beta = ff::to_mont(beta);
+    HostJac e{ff::mul(p.x, beta), p.y, p.z};  // phi(P) in Jacobian form (x scales by beta, Z unchanged)
+    q.y = ff::neg(q.y);
+    // projective equality
+    ff::Fp z1z1 = ff::sqr(e.z), z2z2 = ff::sqr(q.z);
+    if (ff::mul(e.x, z2z2) != ff::mul(q.x, z1z1)) return false;
+    return ff::mul(e.y, ff::mul(z2z2, q.z)) == ff::mul(q.y, ff::mul(z1z1, e.z));
+}
+
 }  // namespace kzgamd

@@ -239,3 +239,27 @@ def test_compute_cells_vectors_pin_gpu_ntt(kzg, golden, blob_loader, oracle):
         nvalid += 1
     assert nvalid == 7
     fs.close()
+
+
+def test_batch_rejects_invalid_commitments_device_path(kzg, settings, golden, blob_loader):
+    # n > 4 takes the device-side commitment check (k_check_commitments); every invalid-commitment vector of
+    # compute_blob_kzg_proof (bad flags, x >= p, not on curve, not in the subgroup) must fail the batch
+    rnd = random.Random(31)
+    n = 6
+    blobs = bytearray(rnd.randbytes(n * BLOB))
+    for i in range(0, n * BLOB, 32):
+        blobs[i] = 0
+    blobs = bytes(blobs)
+    cms = kzg.blob_to_kzg_commitment_batch(blobs, n, settings)
+    assert len(kzg.compute_blob_kzg_proof_batch(blobs, b"".join(cms), n, settings)) == n
+    bad = [c for c in golden["compute_blob_kzg_proof"] if "invalid_commitment" in c["name"]]
+    assert len(bad) == 4
+    for c in bad:
+        cm = bytes.fromhex(c["commitment"][2:])
+        if len(cm) != 48:
+            continue
+        for pos in (0, 5):
+            mixed = list(cms)
+            mixed[pos] = cm
+            with pytest.raises(kzg.KzgAmdError):
+                kzg.compute_blob_kzg_proof_batch(blobs, b"".join(mixed), n, settings)
