@@ -149,6 +149,13 @@ C_KZG_RET kzgamd_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, 
  * d_scratch = n x 131072 B of workspace. */
 C_KZG_RET kzgamd_blob_to_kzg_commitment_device(void *d_out, void *d_status, void *d_scratch, const void *d_blobs,
                                                size_t n, const CKZGSettings *s, void *stream);
+/* EIP-7594: cells (128 x 2048 B) and cell proofs (128 x 48 B) of a blob, same name
+ * and signature as the reference (kzg/src/eth/c_bindings.rs:356-372); either output may be NULL, not
+ * both.  The first call that asks for proofs builds a second wide table over g1_values_monomial. */
+typedef struct { uint8_t bytes[2048]; } Cell;
+C_KZG_RET compute_cells_and_kzg_proofs(Cell *cells, KZGProof *proofs, const Blob *blob, const CKZGSettings *s);
+C_KZG_RET kzgamd_compute_cells_and_kzg_proofs_batch(Cell *cells, KZGProof *proofs, const Blob *blobs, size_t n,
+                                                    const CKZGSettings *s);
 /* the prepared-MSM handle behind a settings object (for kzgamd_msm_* calls) */
 void *kzgamd_settings_msm_handle(const CKZGSettings *s);
 

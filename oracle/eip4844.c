@@ -288,3 +288,41 @@ int ocompute_cells(uint8_t *cells_out, const uint8_t *blob, const osettings_t *s
     free(ext);
     return rc;
 }
+
+/* KZG multiproof of cell k by its definition (the value the reference's FK20 path,
+ * kzg/src/das.rs:660-696, arrives at): proof_k = [q_k(tau)] with
+ * q_k(X) = p(X) div (X^64 - a_k), a_k = h_k^64, h_k = w_8192^brp7(k) the coset shift of cell k.
+ * Coefficients by the division recurrence q_j = p_{j+64} + a_k q_{j+64}; commitment by MSM over the
+ * monomial setup.  One 4096-point MSM per proof, so tests ask for a few k only. */
+static size_t brp_bits(size_t v, unsigned bits) {
+    size_t r = 0;
+    for (unsigned b = 0; b < bits; ++b)
+        if (v & ((size_t)1 << b)) r |= (size_t)1 << (bits - 1 - b);
+    return r;
+}
+
+int ocompute_cell_proof(uint8_t proof[48], const uint8_t *blob, size_t k, const osettings_t *s) {
+    if (k >= 128) return 1;
+    ofr_t *poly = malloc(N * sizeof(ofr_t)), *mono = malloc(N * sizeof(ofr_t)), *q = calloc(N, sizeof(ofr_t));
+    int rc = oblob_to_fr(poly, blob);
+    if (!rc) {
+        oreverse_bit_order(poly, sizeof(ofr_t), N);
+        rc = offt_fr(&s->fs, mono, poly, N, 1);
+    }
+    if (!rc) {
+        const ofr_t *a = &s->fs.roots_of_unity[64 * brp_bits(k, 7)];
+        for (size_t j = N - 64; j-- > 0;) {
+            ofr_t t;
+            if (j + 64 < N - 64) ofr_mul(&t, a, &q[j + 64]);
+            else ofr_zero(&t);
+            ofr_add(&q[j], &mono[j + 64], &t);
+        }
+        og1_t pr;
+        omsm_affine(&pr, s->g1_monomial, q, N);
+        og1_compress(proof, &pr);
+    }
+    free(poly);
+    free(mono);
+    free(q);
+    return rc;
+}

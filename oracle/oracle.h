@@ -144,6 +144,8 @@ int  ocompute_kzg_proof(uint8_t proof[48], uint8_t y[32], const uint8_t *blob, c
 int  ocompute_blob_kzg_proof(uint8_t proof[48], const uint8_t *blob, const uint8_t commitment[48], const osettings_t *s);
 /* polynomial part of compute_cells (kzg/src/das.rs:244-292): ifft(brp(blob)) -> pad -> fft 8192 -> brp; out = 8192 x 32 B BE */
 int  ocompute_cells(uint8_t *cells_out, const uint8_t *blob, const osettings_t *s);
+/* KZG multiproof of cell k (0..127), by definition: quotient by X^64 - h_k^64, MSM over the monomial setup */
+int  ocompute_cell_proof(uint8_t proof[48], const uint8_t *blob, size_t k, const osettings_t *s);
 
 #ifdef __cplusplus
 }

@@ -55,7 +55,8 @@ EXPORTS = [
     "kzgamd_ntt_new", "kzgamd_ntt_free", "ntt_fr", "das_fft_extension", "kzgamd_ntt_fr_device", "kzgamd_ntt_roots",
     "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
     "compute_kzg_proof", "compute_blob_kzg_proof", "kzgamd_compute_blob_kzg_proof_batch", "compute_challenge",
-    "bytes_to_kzg_commitment", "bytes_from_bls_field",
+    "bytes_to_kzg_commitment", "bytes_from_bls_field", "compute_cells_and_kzg_proofs",
+    "kzgamd_compute_cells_and_kzg_proofs_batch",
     "kzgamd_blob_to_kzg_commitment_batch", "kzgamd_blob_to_kzg_commitment_device", "kzgamd_settings_msm_handle",
 ]
 
@@ -146,6 +147,10 @@ def lib():
     L.bytes_to_kzg_commitment.argtypes = [vp, vp]
     L.bytes_from_bls_field.restype = None
     L.bytes_from_bls_field.argtypes = [vp, vp]
+    L.compute_cells_and_kzg_proofs.restype = C.c_int
+    L.compute_cells_and_kzg_proofs.argtypes = [vp, vp, vp, sp]
+    L.kzgamd_compute_cells_and_kzg_proofs_batch.restype = C.c_int
+    L.kzgamd_compute_cells_and_kzg_proofs_batch.argtypes = [vp, vp, vp, sz, sp]
     L.kzgamd_settings_msm_handle.restype = vp
     L.kzgamd_settings_msm_handle.argtypes = [sp]
     _lib = L
@@ -457,3 +462,24 @@ def bytes_from_bls_field(fr) -> bytes:
     out = C.create_string_buffer(32)
     lib().bytes_from_bls_field(out, C.byref(fr))
     return out.raw
+
+
+def compute_cells_and_kzg_proofs(blob: bytes, settings: KZGSettings, want_cells=True, want_proofs=True):
+    """kzg/src/eth/c_bindings.rs:356-372 -> (cells bytes 128*2048 | None, proofs bytes 128*48 | None)"""
+    if len(blob) != BYTES_PER_BLOB:
+        raise KzgAmdError("compute_cells_and_kzg_proofs: C_KZG_RET %d" % C_KZG_BADARGS)
+    cells = C.create_string_buffer(128 * 2048) if want_cells else None
+    proofs = C.create_string_buffer(128 * 48) if want_proofs else None
+    rc = lib().compute_cells_and_kzg_proofs(cells, proofs, blob, C.byref(settings.c))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("compute_cells_and_kzg_proofs: C_KZG_RET %d" % rc)
+    return (cells.raw if cells else None), (proofs.raw if proofs else None)
+
+
+def compute_cells_and_kzg_proofs_batch(blobs: bytes, n: int, settings: KZGSettings):
+    cells = C.create_string_buffer(n * 128 * 2048)
+    proofs = C.create_string_buffer(n * 128 * 48)
+    rc = lib().kzgamd_compute_cells_and_kzg_proofs_batch(cells, proofs, blobs, n, C.byref(settings.c))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("kzgamd_compute_cells_and_kzg_proofs_batch: C_KZG_RET %d" % rc)
+    return cells.raw, proofs.raw

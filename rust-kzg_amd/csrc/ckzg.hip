@@ -305,6 +305,71 @@ __global__ void __launch_bounds__(64) k_check_commitments(int* __restrict__ stat
     if (!fp28::is_zero_mod_p(dx) || !fp28::is_zero_mod_p(dy)) status[i] = 1;
 }
 
+
+// ---------------- EIP-7594 cells + cell proofs ----------------
+__device__ __forceinline__ u32 brev32(u32 v, int bits) { return __builtin_bitreverse32(v) >> (32 - bits); }
+
+// blob bytes -> Montgomery Fr in bit-reversed order (blob_to_polynomial + reverse_bit_order of
+// poly_lagrange_to_monomial, kzg/src/das.rs:618-629); status = 1 when an element is >= r
+__global__ void __launch_bounds__(256) k_blob_to_fr_brp(ff::Fr* __restrict__ out, int* __restrict__ status,
+                                                        const u32* __restrict__ blobs, size_t nblobs) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblobs * N) return;
+    const size_t b = t / N, i = t % N;
+    bool ok;
+    ff::Fr v = fr_load_be(blobs + (b * N + brev32((u32)i, 12)) * 8, &ok);
+    if (!ok) status[b] = 1;
+    out[t] = ff::to_mont(v);
+}
+
+// monomial coefficients (4096) -> zero-extended 8192 (das.rs:260-261)
+__global__ void __launch_bounds__(256) k_zero_extend(ff::Fr* __restrict__ ext, const ff::Fr* __restrict__ mono, size_t nblobs) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblobs * 2 * N) return;
+    const size_t b = t / (2 * N), i = t % (2 * N);
+    ext[t] = i < N ? mono[b * N + i] : ff::Fr::zero();
+}
+
+// evaluations on the 8192 domain -> cells: bit-reversed order, 32-byte big-endian (das.rs:267-275)
+__global__ void __launch_bounds__(256) k_cells_out(u32* __restrict__ cells, const ff::Fr* __restrict__ ev, size_t nblobs) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblobs * 2 * N) return;
+    const size_t b = t / (2 * N), f = t % (2 * N);
+    ff::Fr v = ff::from_mont(ev[b * 2 * N + brev32((u32)f, 13)]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) cells[t * 8 + k] = __builtin_bswap32(v.v[7 - k]);
+}
+
+// Quotient coefficients of the 128 cell proofs: q_k = p div (X^64 - a_k), a_k = w_128^brp7(k).
+// The reference reaches the same commitments through FK20 (Toeplitz FFTs + fft_g1, kzg/src/das.rs:660-696);
+// with the 4096-point wide table a proof is simply one more fixed-base MSM, so the division recurrence
+//   q_j = p_{j+64} + a_k * q_{j+64}
+// is run per (cell, residue class mod 64) and the 128 scalar vectors go to the MSM engine.
+__global__ void __launch_bounds__(64) k_cell_quotients(u32* __restrict__ q_out, const ff::Fr* __restrict__ mono,
+                                                       const ff::Fr* __restrict__ roots8192, size_t nblobs) {
+    const size_t b = blockIdx.x / 128, k = blockIdx.x % 128;
+    const int r = threadIdx.x;  // residue class
+    const ff::Fr a = roots8192[64 * brev32((u32)k, 7)];
+    const ff::Fr* p = mono + b * N;
+    u32* q = q_out + (b * 128 + k) * N * 8;
+    ff::Fr acc = ff::Fr::zero();
+    // j = r + 64*t ; top quotient index is N - 65
+#pragma unroll 1
+    for (int t = 63; t >= 0; --t) {
+        const int j = r + 64 * t;
+        ff::Fr v;
+        if (t == 63) {
+            v = ff::Fr::zero();  // q_j = 0 for j >= N - 64
+        } else {
+            acc = ff::add(p[j + 64], ff::mul(a, acc));
+            v = acc;
+        }
+        ff::Fr c = ff::from_mont(v);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) q[(size_t)j * 8 + l] = c.v[l];
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- settings object
@@ -313,6 +378,16 @@ struct KzgAmdSettings {
     kzgamd::MsmContext* msm = nullptr;  // prepared over g1_lagrange_brp
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // commitment validation runs beside the proving pipeline
+    // EIP-7594 state, built on first use
+    AffPt* d_monomial = nullptr;              // g1_values_monomial as table slots
+    kzgamd::MsmContext* msm_monomial = nullptr;
+    void* ntt = nullptr;                      // kzgamd_ntt_new(13)
+    ff::Fr* d_roots8192 = nullptr;            // roots_of_unity[0..=8192], Montgomery
+    ff::Fr *d_fr_a = nullptr, *d_fr_b = nullptr, *d_fr_ext = nullptr;  // 4096, 4096, 8192 per blob
+    u32* d_cells = nullptr;
+    u32* d_q = nullptr;                       // 128 x 4096 x 8 per blob
+    unsigned char* d_proofs = nullptr;
+    size_t cap_cells = 0;
     int* d_cstatus = nullptr;
     std::mutex mu;
     // staging for the host-buffer entry points
@@ -331,6 +406,11 @@ struct KzgAmdSettings {
         if (d_y) (void)hipFree(d_y);
         if (d_commit) (void)hipFree(d_commit);
         if (d_brp_roots) (void)hipFree(d_brp_roots);
+        if (d_monomial) (void)hipFree(d_monomial);
+        if (msm_monomial) kzgamd::msm_destroy(msm_monomial);
+        if (ntt) kzgamd_ntt_free(ntt);
+        if (d_roots8192) (void)hipFree(d_roots8192);
+        release_cells();
         if (d_cstatus) (void)hipFree(d_cstatus);
         if (stream2) (void)hipStreamDestroy(stream2);
         if (msm) kzgamd::msm_destroy(msm);
@@ -339,6 +419,29 @@ struct KzgAmdSettings {
         if (d_status) (void)hipFree(d_status);
         if (d_out) (void)hipFree(d_out);
         if (stream) (void)hipStreamDestroy(stream);
+    }
+    void release_cells() {
+        if (d_fr_a) (void)hipFree(d_fr_a);
+        if (d_fr_b) (void)hipFree(d_fr_b);
+        if (d_fr_ext) (void)hipFree(d_fr_ext);
+        if (d_cells) (void)hipFree(d_cells);
+        if (d_q) (void)hipFree(d_q);
+        if (d_proofs) (void)hipFree(d_proofs);
+        d_fr_a = d_fr_b = d_fr_ext = nullptr;
+        d_cells = d_q = nullptr;
+        d_proofs = nullptr;
+        cap_cells = 0;
+    }
+    void ensure_cells(size_t nblobs) {
+        if (nblobs <= cap_cells) return;
+        release_cells();
+        CK_HIP(hipMalloc(&d_fr_a, nblobs * N * 32));
+        CK_HIP(hipMalloc(&d_fr_b, nblobs * N * 32));
+        CK_HIP(hipMalloc(&d_fr_ext, nblobs * 2 * N * 32));
+        CK_HIP(hipMalloc(&d_cells, nblobs * 2 * N * 32));
+        CK_HIP(hipMalloc(&d_q, nblobs * 128 * N * 32));
+        CK_HIP(hipMalloc(&d_proofs, nblobs * 128 * 48));
+        cap_cells = nblobs;
     }
     void ensure(size_t nblobs) {
         if (nblobs <= cap_blobs) return;
@@ -502,6 +605,8 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
         // fixed-base MSM table over the bit-reversed Lagrange points (FsKZGSettings::new ->
         // prepare_msm, blst/src/types/kzg_settings.rs:109-123)
         dev->msm = kzgamd::msm_create(d_pts + N, N, true, true, true);
+        CK_HIP(hipMalloc(&dev->d_monomial, N * sizeof(AffPt)));
+        CK_HIP(hipMemcpy(dev->d_monomial, d_pts, N * sizeof(AffPt), hipMemcpyDeviceToDevice));
 
         // Lagrange-form sanity check.  The reference compares two pairings
         // (is_trusted_setup_in_lagrange_form, eip_4844.rs:1005-1020); the pairing is outside this
@@ -707,6 +812,58 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
         for (size_t i = 0; i < n; ++i) fr_limbs_to_be32(ys[i].bytes, &ylimbs[8 * i]);
 }
 
+
+// compute_cells_and_kzg_proofs (kzg/src/das.rs:244-292) for n blobs; cells / proofs may be null (not both)
+void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_t n, const CKZGSettings* cs,
+                      KzgAmdSettings* dev) {
+    std::lock_guard<std::mutex> lk(dev->mu);
+    CK_HIP(hipSetDevice(dev->device));
+    if (!dev->ntt) {
+        dev->ntt = kzgamd_ntt_new(13);
+        if (!dev->ntt) throw CkErr{C_KZG_ERROR, "kzgamd_ntt_new failed"};
+        CK_HIP(hipMalloc(&dev->d_roots8192, (2 * N + 1) * sizeof(ff::Fr)));
+        CK_HIP(hipMemcpy(dev->d_roots8192, cs->roots_of_unity, (2 * N + 1) * sizeof(ff::Fr), hipMemcpyHostToDevice));
+    }
+    if (proofs && !dev->msm_monomial) dev->msm_monomial = kzgamd::msm_create(dev->d_monomial, N, true, true, true);
+    dev->ensure(n);
+    dev->ensure_cells(n);
+    hipStream_t st = dev->stream;
+    CK_HIP(hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, st));
+    CK_HIP(hipMemsetAsync(dev->d_status, 0, n * sizeof(int), st));
+    hipLaunchKernelGGL(k_blob_to_fr_brp, dim3((unsigned)((n * N + 255) / 256)), dim3(256), 0, st, dev->d_fr_a, dev->d_status,
+                       (const u32*)dev->d_blobs, n);
+    // poly_lagrange_to_monomial: inverse NTT of the bit-reversed evaluations
+    if (kzgamd_ntt_fr_device(dev->ntt, dev->d_fr_b, dev->d_fr_a, N, n, 1, st) != 0) throw CkErr{C_KZG_ERROR, "ntt"};
+    if (cells) {
+        hipLaunchKernelGGL(k_zero_extend, dim3((unsigned)((n * 2 * N + 255) / 256)), dim3(256), 0, st, dev->d_fr_ext,
+                           (const ff::Fr*)dev->d_fr_b, n);
+        // d_fr_a is free again only for n*N elements; the 8192-point result needs its own buffer: reuse d_cells
+        // as scratch for the transform output, then convert in place through d_fr_ext
+        ff::Fr* ev = reinterpret_cast<ff::Fr*>(dev->d_cells);
+        if (kzgamd_ntt_fr_device(dev->ntt, ev, dev->d_fr_ext, 2 * N, n, 0, st) != 0) throw CkErr{C_KZG_ERROR, "ntt"};
+        hipLaunchKernelGGL(k_cells_out, dim3((unsigned)((n * 2 * N + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<u32*>(dev->d_fr_ext), (const ff::Fr*)ev, n);
+        CK_HIP(hipMemcpyAsync(cells, dev->d_fr_ext, n * 2 * N * 32, hipMemcpyDeviceToHost, st));
+    }
+    if (proofs) {
+        hipLaunchKernelGGL(k_cell_quotients, dim3((unsigned)(n * 128)), dim3(64), 0, st, dev->d_q, (const ff::Fr*)dev->d_fr_b,
+                           (const ff::Fr*)dev->d_roots8192, n);
+        kzgamd::msm_lock(dev->msm_monomial);
+        try {
+            kzgamd::msm_enqueue(dev->msm_monomial, dev->d_proofs, dev->d_q, N, n * 128, 0, st, kzgamd::OUT_COMPRESSED);
+        } catch (...) {
+            kzgamd::msm_unlock(dev->msm_monomial);
+            throw;
+        }
+        kzgamd::msm_unlock(dev->msm_monomial);
+        CK_HIP(hipMemcpyAsync(proofs, dev->d_proofs, n * 128 * 48, hipMemcpyDeviceToHost, st));
+    }
+    std::vector<int> status(n);
+    CK_HIP(hipMemcpyAsync(status.data(), dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, st));
+    CK_HIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < n; ++i) CK_REQUIRE(status[i] == 0, "Invalid scalar");
+}
+
 template <class F>
 C_KZG_RET guarded(F&& f) {
     try {
@@ -851,6 +1008,23 @@ extern "C" void bytes_from_bls_field(Bytes32* out, const blst_fr* in) {         
     memcpy(&v, in, 32);
     v = ff::from_mont(v);
     fr_limbs_to_be32(out->bytes, v.v);
+}
+
+// kzg/src/eth/c_bindings.rs:356-372 (EIP-7594).  cells or proofs may be NULL, not both (das.rs:250-252).
+extern "C" C_KZG_RET compute_cells_and_kzg_proofs(Cell* cells, KZGProof* proofs, const Blob* blob, const CKZGSettings* s) {
+    if (!blob || (!cells && !proofs)) return C_KZG_BADARGS;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    return guarded([&] { cells_and_proofs(cells ? cells->bytes : nullptr, proofs, blob, 1, s, dev); });
+}
+
+extern "C" C_KZG_RET kzgamd_compute_cells_and_kzg_proofs_batch(Cell* cells, KZGProof* proofs, const Blob* blobs, size_t n,
+                                                               const CKZGSettings* s) {
+    if (!blobs || (!cells && !proofs)) return C_KZG_BADARGS;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    if (n == 0) return C_KZG_OK;
+    return guarded([&] { cells_and_proofs(cells ? cells->bytes : nullptr, proofs, blobs, n, s, dev); });
 }
 
 extern "C" void* kzgamd_settings_msm_handle(const CKZGSettings* s) {

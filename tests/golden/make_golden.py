@@ -92,6 +92,22 @@ def main():
                   "output": {"sha256": hashlib.sha256(cells).hexdigest(), "cell0": o[0], "cell127": o[127]}})
     out["compute_cells"] = v
 
+    # compute_cells_and_kzg_proofs: 128 cells + 128 proofs per blob; digests + end points
+    v = []
+    for name, y in cases("compute_cells_and_kzg_proofs"):
+        o = y["output"]
+        if o is None:
+            v.append({"name": name, "blob": blob_ref(unhex(y["input"]["blob"])), "output": None})
+            continue
+        cells = b"".join(unhex(c) for c in o[0])
+        proofs = b"".join(unhex(c) for c in o[1])
+        assert len(cells) == 128 * 2048 and len(proofs) == 128 * 48
+        v.append({"name": name, "blob": blob_ref(unhex(y["input"]["blob"])),
+                  "output": {"cells_sha256": hashlib.sha256(cells).hexdigest(),
+                             "proofs_sha256": hashlib.sha256(proofs).hexdigest(),
+                             "proof0": o[1][0], "proof1": o[1][1], "proof127": o[1][127]}})
+    out["compute_cells_and_kzg_proofs"] = v
+
     for h, b in blobs.items():
         with gzip.GzipFile(os.path.join(OUT, "blobs", h + ".bin.gz"), "wb", mtime=0) as f:
             f.write(b)

@@ -98,6 +98,7 @@ def lib():
         "ocompute_kzg_proof": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Settings)]),
         "ocompute_blob_kzg_proof": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Settings)]),
         "ocompute_cells": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(Settings)]),
+        "ocompute_cell_proof": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(Settings)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)

@@ -263,3 +263,33 @@ def test_batch_rejects_invalid_commitments_device_path(kzg, settings, golden, bl
             mixed[pos] = cm
             with pytest.raises(kzg.KzgAmdError):
                 kzg.compute_blob_kzg_proof_batch(blobs, b"".join(mixed), n, settings)
+
+
+def test_vectors_compute_cells_and_kzg_proofs(kzg, settings, golden, blob_loader):
+    # SURVEY §8(f) item 1; c-kzg vectors: 7 valid (128 cells + 128 proofs each), 4 invalid blobs
+    import hashlib
+
+    nvalid = 0
+    for case in golden["compute_cells_and_kzg_proofs"]:
+        blob = blob_loader(case["blob"])
+        if case["output"] is None:
+            with pytest.raises(kzg.KzgAmdError):
+                kzg.compute_cells_and_kzg_proofs(blob, settings)
+            continue
+        cells, proofs = kzg.compute_cells_and_kzg_proofs(blob, settings)
+        exp = case["output"]
+        assert hx(proofs[:48]) == exp["proof0"] and hx(proofs[-48:]) == exp["proof127"], case["name"]
+        assert hashlib.sha256(cells).hexdigest() == exp["cells_sha256"], case["name"]
+        assert hashlib.sha256(proofs).hexdigest() == exp["proofs_sha256"], case["name"]
+        nvalid += 1
+    assert nvalid == 7
+    # cells-only and proofs-only calls, and the batch form
+    blob = blob_loader(golden["compute_cells_and_kzg_proofs"][-1]["blob"])
+    c_only, none = kzg.compute_cells_and_kzg_proofs(blob, settings, want_proofs=False)
+    assert none is None and c_only == cells
+    none, p_only = kzg.compute_cells_and_kzg_proofs(blob, settings, want_cells=False)
+    assert none is None and p_only == proofs
+    blob2 = blob_loader(golden["compute_cells_and_kzg_proofs"][-2]["blob"])
+    bc, bp = kzg.compute_cells_and_kzg_proofs_batch(blob2 + blob, 2, settings)
+    assert bc[128 * 2048:] == cells and bp[128 * 48:] == proofs
+    assert hashlib.sha256(bp[:128 * 48]).hexdigest() == golden["compute_cells_and_kzg_proofs"][-2]["output"]["proofs_sha256"]

@@ -314,3 +314,20 @@ def test_vectors_compute_cells_pin_ntt(oracle, oracle_settings, golden, blob_loa
             assert hashlib.sha256(out.raw).hexdigest() == case["output"]["sha256"], case["name"]
             nvalid += 1
     assert nvalid == 7
+
+
+def test_vectors_cell_proofs_pin_definition(oracle, oracle_settings, golden, blob_loader):
+    # the cell proofs of compute_cells_and_kzg_proofs (FK20 in the reference) equal the
+    # per-cell quotient commitments; three cells of two vectors (one 4096-point CPU MSM each)
+    L = oracle.lib()
+    done = 0
+    for case in golden["compute_cells_and_kzg_proofs"]:
+        if case["output"] is None or done >= 2:
+            continue
+        blob = blob_loader(case["blob"])
+        for k, key in ((0, "proof0"), (1, "proof1"), (127, "proof127")):
+            out = C.create_string_buffer(48)
+            assert L.ocompute_cell_proof(out, blob, k, C.byref(oracle_settings)) == 0
+            assert hx(out.raw) == case["output"][key], (case["name"], k)
+        done += 1
+    assert done == 2

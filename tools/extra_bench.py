@@ -124,6 +124,18 @@ def main():
     for _ in range(20):
         kzg.compute_blob_kzg_proof(one, cms[:48], s)
     res["compute_blob_kzg_proof_single_call_ms"] = (time.perf_counter() - t0) / 20 * 1e3
+    # EIP-7594: cells + 128 cell proofs per blob (128 fixed-base MSMs over the monomial setup)
+    nb2 = 8
+    kzg.compute_cells_and_kzg_proofs_batch(blobs[:nb2 * 131072], nb2, s)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        kzg.compute_cells_and_kzg_proofs_batch(blobs[:nb2 * 131072], nb2, s)
+    dt = (time.perf_counter() - t0) / 3
+    res["compute_cells_and_kzg_proofs_batch_8"] = {"ms": dt * 1e3, "blobs_per_s": nb2 / dt, "cell_proofs_per_s": 128 * nb2 / dt}
+    t0 = time.perf_counter()
+    for _ in range(5):
+        kzg.compute_cells_and_kzg_proofs(one, s)
+    res["compute_cells_and_kzg_proofs_single_call_ms"] = (time.perf_counter() - t0) / 5 * 1e3
     s.close()
     print(json.dumps(res, indent=1))
 
