@@ -27,6 +27,7 @@
 
 #include "../../include/kzg_mi355x.h"
 #include "g1_io.cuh"
+#include "host_g1.h"
 #include "msm_internal.h"
 
 using ff::u32;
@@ -367,6 +368,20 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, co
                                               void* __restrict__ out_v, size_t nbatch, int nwin, int c, int prepared,
                                               int out_mode) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (out_mode == kzgamd::OUT_WINDOWS) {
+        // b indexes (MSM, window): window sum = M + A, handed to the host as a Jacobian point
+        if (b >= nbatch * (size_t)nwin) return;
+        Xyzz acc = rootM[b];
+        Xyzz a = rootA[b];
+        g1::dadd(acc, a);
+        ff::Fp* out = (ff::Fp*)out_v;
+        ff::Fp j[3];
+        g1::to_blst_jacobian(j, acc);
+        out[3 * b] = j[0];
+        out[3 * b + 1] = j[1];
+        out[3 * b + 2] = j[2];
+        return;
+    }
     const bool live = b < nbatch;
     if (!live) b = nbatch - 1;  // idle lanes shadow the last MSM so that the whole block reaches the barriers
     Xyzz acc;
@@ -926,7 +941,8 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             ++lvl;
             if (nin == 1) break;
         }
-        hipLaunchKernelGGL(k_final, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, inA, inM,
+        const size_t nfinal = out_mode == OUT_WINDOWS ? nbatch * (size_t)nwin : nbatch;
+        hipLaunchKernelGGL(k_final, dim3((unsigned)((nfinal + 63) / 64)), dim3(64), 0, stream, inA, inM,
                            d_out, nbatch, nwin, c, ctx->prepared ? 1 : 0, out_mode);
     }
     if (pev) {
@@ -969,6 +985,30 @@ void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoint
     ctx->ws.out.ensure(nbatch * 3 + 3);
     if (npoints * nbatch)
         HIP_TRY(hipMemcpyAsync(ctx->ws.scalars.p, scalars, nbatch * npoints * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (!ctx->prepared && npoints > 0) {
+        // variable-base engine: the ~255 Horner doublings are one serial chain; a CPU core runs that chain
+        // several times faster than a single GPU lane, and the result goes to the host anyway
+        const int nwin = 255 / ctx->c + 1;
+        ctx->ws.out.ensure(nbatch * (size_t)nwin * 3);
+        msm_enqueue(ctx, ctx->ws.out.p, ctx->ws.scalars.p, npoints, nbatch, 1, ctx->stream, OUT_WINDOWS);
+        std::vector<blst_p1> win(nbatch * (size_t)nwin);
+        HIP_TRY(hipMemcpyAsync(win.data(), ctx->ws.out.p, win.size() * 144, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (size_t b = 0; b < nbatch; ++b) {
+            HostJac acc;
+            acc.x = acc.y = acc.z = ff::Fp::zero();
+            for (int w = nwin - 1; w >= 0; --w) {
+                for (int k = 0; k < ctx->c; ++k) acc = host_jac_dbl(acc);
+                const ff::Fp* P = reinterpret_cast<const ff::Fp*>(&win[b * nwin + w]);
+                acc = host_jac_add(acc, HostJac{P[0], P[1], P[2]});
+            }
+            ff::Fp* O = reinterpret_cast<ff::Fp*>((blst_p1*)out + b);
+            O[0] = acc.x;
+            O[1] = acc.y;
+            O[2] = acc.z;
+        }
+        return;
+    }
     msm_enqueue(ctx, ctx->ws.out.p, ctx->ws.scalars.p, npoints, nbatch, 1, ctx->stream, OUT_JACOBIAN);
     HIP_TRY(hipMemcpyAsync(out, ctx->ws.out.p, nbatch * 144, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -5,7 +5,8 @@
 
 namespace kzgamd {
 struct MsmContext;
-enum { OUT_JACOBIAN = 0, OUT_COMPRESSED = 1 };
+// OUT_WINDOWS (unprepared handles): one Jacobian point per (MSM, window); the caller does the Horner steps
+enum { OUT_JACOBIAN = 0, OUT_COMPRESSED = 1, OUT_WINDOWS = 2 };
 // points: blst_p1_affine[n] (host or device) or g1::AffPt[n] (device); prepare = build fixed-base rows
 MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare, bool points_are_affpt);
 void msm_destroy(MsmContext* ctx);

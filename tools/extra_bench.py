@@ -74,6 +74,28 @@ def main():
                       "algorithmic_GBps": 128 * n / (ms * 1e-3) / 1e9, "kernel_window_bits": info["window_bits"]})
         h.close()
     res["msm_sweep_variable_base"] = sweep
+    # prepared handle at n = 2^20 (fixed-base rows, one bucket set, no Horner) and the host-buffer B1 calls
+    n = 1 << 20
+    t0 = time.perf_counter()
+    h = kzg.DeviceMsm(pts.data_ptr(), n, True)
+    torch.cuda.synchronize()
+    prep_s = time.perf_counter() - t0
+    info = h.info()
+    ms = timed(lambda: kzg.msm_prepared_batch_device(h, out.data_ptr(), sc.data_ptr(), n, 1, False, stream))
+    res["msm_2p20_prepared"] = {"ms": ms, "prepare_s": prep_s, "window_bits": info["window_bits"], "rows": info["rows"],
+                                "wide_table": info["wide_table"]}
+    h.close()
+    hp = pts[: 4096 * 96].cpu().numpy().tobytes()
+    hs = bytes(4096 * 32)
+    import ctypes as C2
+    sc_host = sc[:4096].cpu().numpy().copy()
+    sc_host[:, 31] = 0
+    hs = sc_host.tobytes()  # any value < r is a valid Montgomery residue
+    kzg.multi_scalar_mult(hp, hs, 4096)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        kzg.multi_scalar_mult(hp, hs, 4096)
+    res["mult_pippenger_n4096_host_call_ms"] = (time.perf_counter() - t0) / 10 * 1e3
     del pts, sc
 
     # ---- NTT ----
