@@ -1,0 +1,162 @@
+//! FFI to libkzg_mi355x.so (include/kzg_mi355x.h) and the thin safe layer `rust-kzg-blst` would call.
+//!
+//! NOT COMPILED in the build image (no rustc/cargo there); every behaviour that matters is implemented
+//! and tested on the C side of this boundary.  Mapping to the reference:
+//!   * `GpuMsm` / `msm_prepared` / `msm`  <->  blst-sppark/src/lib.rs:8-62 (same three C symbols)
+//!   * `GpuNtt::fft_fr` / `das_fft_extension`  <->  blst/src/fft_fr.rs:156-165,
+//!     blst/src/data_availability_sampling.rs:78-100
+use blst::{blst_fr, blst_p1, blst_p1_affine};
+use core::ffi::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct RustError {
+    pub code: c_int,
+    pub message: *mut c_char,
+}
+
+extern "C" {
+    fn prepare_msm(points: *const blst_p1_affine, npoints: usize) -> *mut c_void;
+    fn free_msm(msm: *mut c_void);
+    fn mult_pippenger_prepared(msm: *mut c_void, out: *mut blst_p1, npoints: usize, scalars: *const blst_fr) -> RustError;
+    fn mult_pippenger_prepared_batch(msm: *mut c_void, out: *mut blst_p1, npoints: usize, nbatch: usize,
+                                     scalars: *const blst_fr) -> RustError;
+    fn mult_pippenger(out: *mut blst_p1, points: *const blst_p1_affine, npoints: usize, scalars: *const blst_fr) -> RustError;
+
+    fn kzgamd_ntt_new(scale: u32) -> *mut c_void;
+    fn kzgamd_ntt_free(ctx: *mut c_void);
+    fn ntt_fr(ctx: *mut c_void, out: *mut blst_fr, input: *const blst_fr, n: usize, inverse: c_int) -> c_int;
+    fn das_fft_extension(ctx: *mut c_void, odds: *mut blst_fr, evens: *const blst_fr, half_n: usize) -> c_int;
+}
+
+fn check(err: RustError, what: &str) -> Result<(), String> {
+    if err.code == 0 {
+        return Ok(());
+    }
+    let msg = if err.message.is_null() {
+        format!("{what}: error {}", err.code)
+    } else {
+        // the library malloc()s the message; take a copy and release it
+        let s = unsafe { std::ffi::CStr::from_ptr(err.message) }.to_string_lossy().into_owned();
+        unsafe { libc_free(err.message as *mut c_void) };
+        format!("{what}: {s}")
+    };
+    Err(msg)
+}
+
+extern "C" {
+    #[link_name = "free"]
+    fn libc_free(p: *mut c_void);
+}
+
+/// Owning handle over the device-resident fixed-base table (what `SpparkPrecomputation.table` points at,
+/// kzg/src/msm/sppark.rs:5-22).  Unlike the reference it is released on drop.
+pub struct GpuMsm {
+    handle: *mut c_void,
+    npoints: usize,
+}
+unsafe impl Send for GpuMsm {}
+unsafe impl Sync for GpuMsm {} // calls on one handle serialise inside the library
+
+impl GpuMsm {
+    pub fn new(points: &[blst_p1_affine]) -> Result<Self, String> {
+        if points.is_empty() {
+            return Err("empty point set".into());
+        }
+        let handle = unsafe { prepare_msm(points.as_ptr(), points.len()) };
+        if handle.is_null() {
+            return Err("prepare_msm failed (no gfx950 device?)".into());
+        }
+        Ok(Self { handle, npoints: points.len() })
+    }
+
+    /// Sum of scalars[i] * points[i] over the first scalars.len() points; scalars in Montgomery form.
+    pub fn msm_prepared(&self, scalars: &[blst_fr]) -> Result<blst_p1, String> {
+        if scalars.len() > self.npoints {
+            return Err("more scalars than prepared points".into());
+        }
+        let mut out = blst_p1::default();
+        check(unsafe { mult_pippenger_prepared(self.handle, &mut out, scalars.len(), scalars.as_ptr()) },
+              "mult_pippenger_prepared")?;
+        Ok(out)
+    }
+
+    /// `nbatch` MSMs at once; `scalars` is nbatch x npoints, row-major.
+    pub fn msm_prepared_batch(&self, scalars: &[blst_fr], npoints: usize) -> Result<Vec<blst_p1>, String> {
+        if npoints == 0 || scalars.len() % npoints != 0 || npoints > self.npoints {
+            return Err("bad batch shape".into());
+        }
+        let nbatch = scalars.len() / npoints;
+        let mut out = vec![blst_p1::default(); nbatch];
+        check(unsafe { mult_pippenger_prepared_batch(self.handle, out.as_mut_ptr(), npoints, nbatch, scalars.as_ptr()) },
+              "mult_pippenger_prepared_batch")?;
+        Ok(out)
+    }
+}
+
+impl Drop for GpuMsm {
+    fn drop(&mut self) {
+        unsafe { free_msm(self.handle) }
+    }
+}
+
+/// Variable-base MSM (the `None` precomputation arm of blst/src/kzg_proofs.rs:53-57).
+pub fn msm(points: &[blst_p1_affine], scalars: &[blst_fr]) -> Result<blst_p1, String> {
+    if points.len() != scalars.len() {
+        return Err("length mismatch".into());
+    }
+    let mut out = blst_p1::default();
+    if points.is_empty() {
+        return Ok(out);
+    }
+    check(unsafe { mult_pippenger(&mut out, points.as_ptr(), points.len(), scalars.as_ptr()) }, "mult_pippenger")?;
+    Ok(out)
+}
+
+/// Device NTT context; one per `FsFFTSettings` (created in `FFTSettings::new(scale)`).
+pub struct GpuNtt {
+    ctx: *mut c_void,
+}
+unsafe impl Send for GpuNtt {}
+unsafe impl Sync for GpuNtt {}
+
+impl GpuNtt {
+    pub fn new(scale: usize) -> Result<Self, String> {
+        if scale >= 32 {
+            return Err(String::from("Scale is expected to be within root of unity matrix row size"));
+        }
+        let ctx = unsafe { kzgamd_ntt_new(scale as u32) };
+        if ctx.is_null() {
+            return Err("kzgamd_ntt_new failed (no gfx950 device?)".into());
+        }
+        Ok(Self { ctx })
+    }
+
+    /// `FFTFr::fft_fr`: natural order in and out, inverse scaled by 1/n; error strings as in the reference.
+    pub fn fft_fr(&self, data: &[blst_fr], inverse: bool) -> Result<Vec<blst_fr>, String> {
+        let mut out = vec![blst_fr::default(); data.len()];
+        match unsafe { ntt_fr(self.ctx, out.as_mut_ptr(), data.as_ptr(), data.len(), inverse as c_int) } {
+            0 => Ok(out),
+            1 => Err(String::from("Supplied list is longer than the available max width")),
+            2 => Err(String::from("A list with power-of-two length expected")),
+            e => Err(format!("GPU NTT failed: {e}")),
+        }
+    }
+
+    /// `DASExtension::das_fft_extension`.
+    pub fn das_fft_extension(&self, evens: &[blst_fr]) -> Result<Vec<blst_fr>, String> {
+        let mut out = vec![blst_fr::default(); evens.len()];
+        match unsafe { das_fft_extension(self.ctx, out.as_mut_ptr(), evens.as_ptr(), evens.len()) } {
+            0 => Ok(out),
+            1 => Err(String::from("A non-zero list ab expected")),
+            2 => Err(String::from("A list with power-of-two length expected")),
+            3 => Err(String::from("Supplied list is longer than the available max width")),
+            e => Err(format!("GPU DAS extension failed: {e}")),
+        }
+    }
+}
+
+impl Drop for GpuNtt {
+    fn drop(&mut self) {
+        unsafe { kzgamd_ntt_free(self.ctx) }
+    }
+}
