@@ -1,4 +1,4 @@
-# full GPU pass: parity tests, smoke, bench, rocprofv3 kernel stats, PMC passes (one counter group per run)
+# full GPU pass (run on the MI355X box through gpurun): parity tests, smoke, bench, rocprofv3 kernel stats, PMC passes
 mkdir -p gpurun_out
 R=$GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
