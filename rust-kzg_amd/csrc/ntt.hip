@@ -7,9 +7,10 @@
 // here the same butterfly network is run iteratively:
 //   n <= 4096 : one workgroup per transform, all log2(n) stages in LDS (4096 x 32 B = 128 KiB of the
 //               160 KiB CDNA4 LDS), bit-reversal folded into the load;
-//   n  > 4096 : pass 1 = the 12 low stages on contiguous 4096-blocks (same kernel), pass 2 = the
-//               remaining stages on column tiles (C columns x n/4096 rows = 4096 elements per workgroup)
-//               so every element crosses HBM twice (64*n algorithmic bytes per pass pair).
+//   n  > 4096 : pass 1 = the 12 low stages on contiguous 4096-blocks (same kernel), then up to 12 further
+//               stages per pass on strided tiles (C positions x R rows = 4096 elements per workgroup): two
+//               passes up to 2^24, three up to the 2^31 the roots table allows; every element crosses HBM
+//               once per pass (64*n algorithmic bytes each).
 // Field arithmetic: 9 x 29-bit Montgomery with lazy butterflies (fr29.cuh); integer VALU only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -111,30 +112,36 @@ __global__ void __launch_bounds__(NT) k_ntt_low(Fr* __restrict__ out, const Fr* 
     for (int e = threadIdx.x; e < cnt; e += NT) dst[blk * (u32)cnt + (u32)e] = fr29::finish(lds_get(sh, cnt, e), fin);
 }
 
-// Pass 2: stages 12 .. logn-1 on a tile of C consecutive columns x R = n/4096 rows (in place).
+// Passes 2, 3: `logR` stages starting at global stage `stage0` (a multiple of 12), in place.
+// View the bit-reversed-order array as [hi][r][lo] with lo < 2^stage0, r < R = 2^logR: stage stage0+s pairs
+// rows r and r + 2^s.  A workgroup takes C = 4096 / R consecutive lo positions of one hi block
+// (C * 32 B contiguous per row: coalesced while R <= 256), runs the logR stages in LDS, writes back.
 __global__ void __launch_bounds__(NT) k_ntt_high(Fr* __restrict__ data, const Fr* __restrict__ roots, NttParams P,
-                                                 u32 tiles_per_xform) {
+                                                 u32 tiles_per_xform, int stage0, int logR, int last) {
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     const u32 xf = blockIdx.x / tiles_per_xform, tile = blockIdx.x % tiles_per_xform;
-    const int logR = P.logn - LOG_TILE, R = 1 << logR, C = TILE >> logR, logC = LOG_TILE - logR;
+    const int R = 1 << logR, C = TILE >> logR, logC = LOG_TILE - logR;
     Fr* base = data + (size_t)xf * P.n;
-    const u32 col0 = tile * (u32)C;
+    const u32 lo_tiles = (1u << stage0) >> logC;  // tiles per hi block
+    const u32 hi = tile / lo_tiles, lo0 = (tile % lo_tiles) << logC;
+    const size_t origin = ((size_t)hi << (stage0 + logR)) + lo0;
     // LDS element e = c * R + r  (row index fastest, so a butterfly pairs e and e + 2^s)
     for (int e = threadIdx.x; e < TILE; e += NT) {
-        const int c = e & (C - 1), r = e >> logC;  // consecutive lanes -> consecutive columns (coalesced)
-        lds_put(sh, TILE, c * R + r, fr29::unpack(base[(size_t)r * TILE + col0 + c]));
+        const int c = e & (C - 1), r = e >> logC;  // consecutive lanes -> consecutive positions
+        lds_put(sh, TILE, c * R + r, fr29::unpack(base[origin + ((size_t)r << stage0) + c]));
     }
     __syncthreads();
     lds_stages(sh, TILE, logR, [&](int s, int j, int i0) -> Fr {
-        // global stage 12+s: half = 4096 * 2^s; j_global = (r mod 2^s) * 4096 + column
-        const u32 col = col0 + (u32)(i0 >> logR);
-        const u32 jg = ((u32)j << LOG_TILE) + col;
-        const u32 idx = jg * (P.W >> (LOG_TILE + s + 1));
+        // global stage stage0+s: half = 2^(stage0+s); position mod half = (r mod 2^s) * 2^stage0 + lo
+        const u32 lo = lo0 + (u32)(i0 >> logR);
+        const u32 jg = ((u32)j << stage0) + lo;
+        const u32 idx = jg * (P.W >> (stage0 + s + 1));
         return roots[P.inverse ? P.W - idx : idx];
     });
+    const Fe fin = last ? fr29::unpack(P.scale) : fr29::one();
     for (int e = threadIdx.x; e < TILE; e += NT) {
         const int c = e & (C - 1), r = e >> logC;
-        base[(size_t)r * TILE + col0 + c] = fr29::finish(lds_get(sh, TILE, c * R + r), fr29::unpack(P.scale));
+        base[origin + ((size_t)r << stage0) + c] = fr29::finish(lds_get(sh, TILE, c * R + r), fin);
     }
 }
 
@@ -215,11 +222,13 @@ void ntt_enqueue(NttCtx* ctx, Fr* d_out, const Fr* d_in, size_t n, size_t nbatch
     const u32 blocks = n <= (size_t)TILE ? 1u : (u32)(n >> LOG_TILE);
     hipLaunchKernelGGL(k_ntt_low, dim3((unsigned)(blocks * nbatch)), dim3(NT), lds, stream, d_out, d_in,
                        (const Fr*)ctx->d_roots, P, blocks);
-    if (n > (size_t)TILE) {
-        const int logR = P.logn - LOG_TILE;
-        const u32 tiles = (u32)1 << logR;  // 4096 columns / C columns per tile, C = 4096 >> logR
-        hipLaunchKernelGGL(k_ntt_high, dim3((unsigned)(tiles * nbatch)), dim3(NT), (size_t)TILE * sizeof(u32) * fr29::L, stream, d_out,
-                           (const Fr*)ctx->d_roots, P, tiles);
+    // remaining stages, up to 12 per pass: 12..23, then 24..30
+    for (int stage0 = LOG_TILE; stage0 < P.logn; stage0 += LOG_TILE) {
+        const int logR = P.logn - stage0 < LOG_TILE ? P.logn - stage0 : LOG_TILE;
+        const int last = stage0 + logR == P.logn;
+        const u32 tiles = (u32)(n >> LOG_TILE);
+        hipLaunchKernelGGL(k_ntt_high, dim3((unsigned)(tiles * nbatch)), dim3(NT), (size_t)TILE * sizeof(u32) * fr29::L, stream,
+                           d_out, (const Fr*)ctx->d_roots, P, tiles, stage0, logR, last);
     }
     NTT_TRY(hipGetLastError());
 }
@@ -260,7 +269,6 @@ extern "C" int kzgamd_ntt_fr_device(void* vctx, void* d_out, const void* d_in, s
     if (!ctx || !d_out || !d_in) return -1;
     if (n > ctx->W) return 1;
     if (n == 0 || (n & (n - 1))) return 2;
-    if (n > ((size_t)1 << (2 * LOG_TILE))) return -2;  // two-pass limit (2^24)
     if (d_out == d_in) return -3;
     try {
         ntt_enqueue(ctx, (Fr*)d_out, (const Fr*)d_in, n, nbatch, inverse != 0, (hipStream_t)stream);
@@ -275,7 +283,6 @@ extern "C" int ntt_fr(void* vctx, blst_fr* out, const blst_fr* in, size_t n, int
     if (!ctx || !out || !in) return -1;
     if (n > ctx->W) return 1;                 // "Supplied list is longer than the available max width"
     if (n == 0 || (n & (n - 1))) return 2;    // "A list with power-of-two length expected"
-    if (n > ((size_t)1 << (2 * LOG_TILE))) return -2;
     std::lock_guard<std::mutex> lk(ctx->mu);
     try {
         NTT_TRY(hipSetDevice(ctx->device));
@@ -300,7 +307,6 @@ extern "C" int das_fft_extension(void* vctx, blst_fr* odds, const blst_fr* evens
     if (n == 0) return 1;                  // "A non-zero list ab expected"
     if (n & (n - 1)) return 2;             // "A list with power-of-two length expected"
     if (n * 2 > ctx->W) return 3;          // "Supplied list is longer than the available max width"
-    if (n > ((size_t)1 << (2 * LOG_TILE))) return -2;
     std::lock_guard<std::mutex> lk(ctx->mu);
     try {
         NTT_TRY(hipSetDevice(ctx->device));

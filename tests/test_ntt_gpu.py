@@ -111,3 +111,27 @@ def test_large_2p20_roundtrip_and_digest(kzg, oracle):
     assert hashlib.sha256(bytes(fwd)).digest() == hashlib.sha256(bytes(exp)).digest()
     L.offt_settings_free(C.byref(ofs))
     fs.close()
+
+
+def test_three_pass_2p25_matches_oracle(kzg, oracle):
+    # n = 2^25 needs the third pass (stages 24..); raw random residues (< 2^254) as input
+    import numpy as np
+
+    L = oracle.lib()
+    logn = 25
+    n = 1 << logn
+    fs = kzg.FFTSettings(logn)
+    ofs = O.FFTSettings()
+    assert L.offt_settings_new(C.byref(ofs), logn) == 0
+    rng = np.random.default_rng(25)
+    raw = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    raw[:, 31] &= 0x3F
+    data = (O.Fr * n).from_buffer(raw)
+    fwd = fs.fft_fr(data, n)
+    exp = (O.Fr * n)()
+    assert L.offt_fr(C.byref(ofs), exp, data, n, 0) == 0
+    assert hashlib.sha256(bytes(fwd)).digest() == hashlib.sha256(bytes(exp)).digest()
+    back = fs.fft_fr(fwd, n, inverse=True)
+    assert bytes(back) == raw.tobytes()
+    L.offt_settings_free(C.byref(ofs))
+    fs.close()
