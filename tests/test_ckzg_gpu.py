@@ -293,3 +293,36 @@ def test_vectors_compute_cells_and_kzg_proofs(kzg, settings, golden, blob_loader
     bc, bp = kzg.compute_cells_and_kzg_proofs_batch(blob2 + blob, 2, settings)
     assert bc[128 * 2048:] == cells and bp[128 * 48:] == proofs
     assert hashlib.sha256(bp[:128 * 48]).hexdigest() == golden["compute_cells_and_kzg_proofs"][-2]["output"]["proofs_sha256"]
+
+
+def test_batch_256_blobs_commit_and_prove(kzg, settings, oracle, oracle_settings):
+    # BASELINE configs[4] size: 256 blobs in one batched call; sampled blobs checked against the oracle,
+    # all of them against the single-blob path through a digest of digests
+    import hashlib
+
+    L = oracle.lib()
+    rnd = random.Random(256)
+    n = 256
+    blobs = bytearray(rnd.randbytes(n * BLOB))
+    for i in range(0, n * BLOB, 32):
+        blobs[i] = 0
+    blobs[7 * BLOB:8 * BLOB] = bytes(BLOB)                       # an all-zero blob -> infinity commitment
+    blobs[9 * BLOB:10 * BLOB] = (b"\x00" * 31 + b"\x05") * 4096  # all elements equal
+    blobs = bytes(blobs)
+    cms = kzg.blob_to_kzg_commitment_batch(blobs, n, settings)
+    proofs = kzg.compute_blob_kzg_proof_batch(blobs, b"".join(cms), n, settings)
+    assert cms[7] == b"\xc0" + bytes(47)
+    for b in (0, 7, 9, 100, 255):
+        bl = blobs[b * BLOB:(b + 1) * BLOB]
+        ec, ep = C.create_string_buffer(48), C.create_string_buffer(48)
+        assert L.oblob_to_kzg_commitment(ec, bl, C.byref(oracle_settings)) == 0
+        assert L.ocompute_blob_kzg_proof(ep, bl, ec.raw, C.byref(oracle_settings)) == 0
+        assert (cms[b], proofs[b]) == (ec.raw, ep.raw), b
+    singles = hashlib.sha256()
+    for b in range(0, n, 16):
+        bl = blobs[b * BLOB:(b + 1) * BLOB]
+        singles.update(kzg.blob_to_kzg_commitment(bl, settings) + kzg.compute_blob_kzg_proof(bl, cms[b], settings))
+    batch = hashlib.sha256()
+    for b in range(0, n, 16):
+        batch.update(cms[b] + proofs[b])
+    assert singles.digest() == batch.digest()

@@ -241,3 +241,37 @@ def test_msm_2p20_matches_oracle(oracle, kzg):
     L.omsm_tiling_pippenger(C.byref(exp), pts, sc.numpy().tobytes(), n)
     assert compressed(L, got) == compressed(L, exp)
     h.close()
+
+
+def test_msm_2p22_split_property(oracle, kzg):
+    # BASELINE configs[2] upper size (n = 2^22): a size-independent property instead of a CPU recomputation:
+    # MSM over all points == MSM(first half) + MSM(second half), plus one oracle-checked small prefix
+    import torch
+
+    L = oracle.lib()
+    n = 1 << 22
+    stream = torch.cuda.current_stream().cuda_stream
+    d_pts = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    kzg.generate_points(d_pts.data_ptr(), n, 22, stream)
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(22)
+    sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=gen)
+    sc[:, 31] &= 0x3F
+    d_sc = sc.cuda()
+    outs = []
+    for lo, cnt in ((0, n), (0, n // 2), (n // 2, n // 2), (0, 512)):
+        h = kzg.DeviceMsm(d_pts.data_ptr() + lo * 96, cnt, False)
+        d_out = torch.zeros(144, dtype=torch.uint8, device="cuda")
+        kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr() + lo * 32, cnt, 1, False, stream)
+        torch.cuda.synchronize()
+        g = O.G1()
+        C.memmove(C.byref(g), d_out.cpu().numpy().tobytes(), 144)
+        outs.append(g)
+        h.close()
+    s = O.G1()
+    L.og1_add_or_dbl(C.byref(s), C.byref(outs[1]), C.byref(outs[2]))
+    assert compressed(L, s) == compressed(L, outs[0])
+    pts = (O.G1Affine * 512).from_buffer_copy(d_pts[: 512 * 96].cpu().numpy().tobytes())
+    exp = O.G1()
+    L.omsm_tiling_pippenger(C.byref(exp), pts, sc[:512].numpy().tobytes(), 512)
+    assert compressed(L, exp) == compressed(L, outs[3])
