@@ -33,12 +33,14 @@
 using ff::u32;
 using ff::u64;
 using g1::AffPt;
+using g1::WidePt;
 using g1::Xyzz;
 
 namespace {
 
 constexpr int GRP = 8;      // children folded per lane in the bucket-reduction tree
 constexpr u32 HEAVY = 512;  // entries above which a bucket's pieces are combined by a whole wave
+constexpr double FBW_DEFAULT_GB = 160.0;  // default HBM budget of one wide fixed-base table
 constexpr u32 CHUNK = 16;  // sorted entries per k_accum lane
 
 // ---------------------------------------------------------------- helpers
@@ -447,7 +449,7 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, co
 // ============================ wide fixed-base table ("FBW") ============================
 // With 288 GB of HBM per GPU the 4096-point setup can afford the full signed-window table
 //     W[w][i][m-1] = m * 2^(c*w) * P_i ,   m = 1 .. 2^(c-1)
-// (c = 13: 20 x 4096 x 4096 slots of 128 B = 43 GB).  A commitment is then a plain sum of
+// (c = 15: 18 x 4096 x 16384 slots of 128 B = 154 GB; c = 14: 19 x 4096 x 8192 slots = 82 GB).  A commitment is then a plain sum of
 // n * ceil(256/c) gathered affine points: no sort, no buckets, no bucket reduction, and every
 // lane does the same amount of work whatever the digit distribution.  This is the reference's
 // "wbits" fixed-base idea (kzg/src/msm/wbits.rs:357-373 table, :442-488 evaluation) resized
@@ -481,7 +483,7 @@ __global__ void __launch_bounds__(128) k_fbw_chain(Xyzz* __restrict__ tmp, const
 
 // XYZZ -> affine table slots, one Montgomery batch inversion per FBW_INV consecutive entries
 constexpr int FBW_INV = 32;
-__global__ void __launch_bounds__(128) k_fbw_affine(AffPt* __restrict__ wide, const Xyzz* __restrict__ tmp,
+__global__ void __launch_bounds__(128) k_fbw_affine(WidePt* __restrict__ wide, const Xyzz* __restrict__ tmp,
                                                     fp28::Fe* __restrict__ pref, size_t count) {
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t lo = tid * FBW_INV;
@@ -496,14 +498,12 @@ __global__ void __launch_bounds__(128) k_fbw_affine(AffPt* __restrict__ wide, co
     fp28::Fe inv = g1io::inverse(p);
     for (size_t k = hi; k-- > lo;) {
         Xyzz q = tmp[k];
-        AffPt o;
-        o.pad[0] = o.pad[1] = o.pad[2] = 0;
+        WidePt o;
+        o.pad[0] = o.pad[1] = o.pad[2] = o.pad[3] = 0;
         if (g1::is_inf(q)) {
-            o.flags = 1;
             o.x = fp28::zero();
             o.y = fp28::zero();
         } else {
-            o.flags = 0;
             fp28::Fe zi = fp28::mul(inv, pref[k]);                  // 1 / (ZZ*ZZZ)
             inv = fp28::mul(inv, fp28::mul(q.zz, q.zzz));
             o.x = fp28::canon(fp28::mul(q.x, fp28::mul(zi, q.zzz)));  // X / ZZ
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(128) k_fbw_affine(AffPt* __restrict__ wide, co
 // spl > 1 (large batches) leaves fewer partial sums for k_blocksum to fold.
 template <int SPL>
 __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __restrict__ scalars,
-                                                   const AffPt* __restrict__ wide, Xyzz* __restrict__ partial,
+                                                   const WidePt* __restrict__ wide, Xyzz* __restrict__ partial,
                                                    size_t lanes_per_msm) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= lanes_per_msm * P.nbatch) return;
@@ -543,9 +543,9 @@ __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __r
                 carry = 1;
             }
             if (d == 0) continue;
-            const AffPt* p = wide + ((((size_t)w * P.row_stride + i) << sh) + (d - 1));
-            if (p->flags & 1) continue;
-            fp28::Fe x = p->x, y = p->y;
+            const WidePt pk = wide[(((size_t)w * P.row_stride + i) << sh) + (d - 1)];
+            if (fp28::is_zero_limbs(pk.x) && fp28::is_zero_limbs(pk.y)) continue;  // multiple of a base at infinity
+            fp28::Fe x = pk.x, y = pk.y;
             if (neg) y = fp28::neg<2>(y);
             g1::madd(acc, x, y);
         }
@@ -630,6 +630,19 @@ __global__ void __launch_bounds__(128) k_gen_points(ff::Fp* __restrict__ out, si
 
 // ---------------------------------------------------------------- host side
 
+// HBM the wide table may take: KZGAMD_FBW_MAX_GB (default below), capped by what is free right now
+// (leaving room for the build scratch and the per-call workspaces)
+double fbw_budget_gb() {
+    double budget_gb = FBW_DEFAULT_GB;
+    if (const char* e = getenv("KZGAMD_FBW_MAX_GB")) budget_gb = atof(e);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const double room = ((double)free_b - 12e9) / 1.05 / 1e9;
+        if (room < budget_gb) budget_gb = room;
+    }
+    return budget_gb;
+}
+
 int choose_window(size_t n, bool prepared) {
     // minimise adds: prepared  n*ceil(256/c) + 3*2^(c-1);  unprepared  ceil(256/c) * (n + 3*2^(c-1))
     if (const char* e = getenv(prepared ? "KZGAMD_WINDOW_PREPARED" : "KZGAMD_WINDOW")) {
@@ -638,8 +651,7 @@ int choose_window(size_t n, bool prepared) {
     }
     if (prepared) {
         // wide-table path: fewest table rows (= fewest adds per scalar) that fit the HBM budget
-        double budget_gb = 100.0;
-        if (const char* e = getenv("KZGAMD_FBW_MAX_GB")) budget_gb = atof(e);
+        const double budget_gb = fbw_budget_gb();
         for (int c = 16; c >= 10 && budget_gb > 0; --c) {
             double gb = (double)(255 / c + 1) * (double)n * (double)((size_t)1 << (c - 1)) * 128.0 / 1e9;
             if (gb <= budget_gb) return c;
@@ -710,7 +722,7 @@ struct kzgamd::MsmContext {
     int c = 0, rows = 0;
     size_t nb = 0;
     DevBuf<AffPt> table;  // rows x n (prepared) or n
-    DevBuf<AffPt> wide;   // wide fixed-base table: (rows x n) x 2^(c-1), when it fits the budget
+    DevBuf<WidePt> wide;  // wide fixed-base table: (rows x n) x 2^(c-1) 128-byte slots, when it fits the budget
     bool fbw = false;
     Workspace ws;
     hipStream_t stream = nullptr;
@@ -739,15 +751,11 @@ static void require_device() {
 
 // Wide table: built tile by tile (chain of multiples as XYZZ -> batch-inverted affine slots).
 static void build_wide_table(MsmContext* ctx) {
-    double budget_gb = 100.0;
-    if (const char* e = getenv("KZGAMD_FBW_MAX_GB")) budget_gb = atof(e);
+    const double budget_gb = fbw_budget_gb();
     const size_t mults = ctx->nb;  // 2^(c-1)
     const size_t nslots = (size_t)ctx->rows * ctx->n;
-    const double gb = (double)nslots * (double)mults * sizeof(AffPt) / 1e9;
+    const double gb = (double)nslots * (double)mults * sizeof(WidePt) / 1e9;
     if (budget_gb <= 0 || gb > budget_gb || mults < (size_t)FBW_SEG) return;
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    if ((double)free_b < gb * 1e9 * 1.15 + 8e9) return;
     ctx->wide.ensure(nslots * mults);
     // tile: up to 2^22 table entries at a time (XYZZ 224 B + prefix 56 B of scratch each)
     size_t tile_slots = ((size_t)1 << 22) / mults;
@@ -859,13 +867,13 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         const dim3 grid((unsigned)((lanes * nbatch + 255) / 256));
         if (spl == 1)
             hipLaunchKernelGGL(k_fbw_accum<1>, grid, dim3(256), 0, stream, P, (const u32*)d_scalars,
-                               (const AffPt*)ctx->wide.p, ws.buckets.p, lanes);
+                               (const WidePt*)ctx->wide.p, ws.buckets.p, lanes);
         else if (spl == 2)
             hipLaunchKernelGGL(k_fbw_accum<2>, grid, dim3(256), 0, stream, P, (const u32*)d_scalars,
-                               (const AffPt*)ctx->wide.p, ws.buckets.p, lanes);
+                               (const WidePt*)ctx->wide.p, ws.buckets.p, lanes);
         else
             hipLaunchKernelGGL(k_fbw_accum<4>, grid, dim3(256), 0, stream, P, (const u32*)d_scalars,
-                               (const AffPt*)ctx->wide.p, ws.buckets.p, lanes);
+                               (const WidePt*)ctx->wide.p, ws.buckets.p, lanes);
         if (pev) HIP_TRY(hipEventRecord(pev[2], stream));
         hipLaunchKernelGGL(k_blocksum, dim3((unsigned)nbatch), dim3(256), 256 * sizeof(Xyzz), stream,
                            (const Xyzz*)ws.buckets.p, ws.lvlM[0].p, lanes);
