@@ -76,12 +76,20 @@ RustError kzgamd_generate_points(void *d_out_affine, size_t npoints, uint64_t se
  * Return codes mirror the reference's error conditions:
  *   ntt_fr:            0 ok, 1 "longer than the available max width", 2 "power-of-two length expected"
  *   das_fft_extension: 0 ok, 1 empty, 2 not a power of two, 3 longer than max width / 2
+ *   fft_g1:            as ntt_fr
  *   negative: device error
  * ------------------------------------------------------------------------------------------ */
 void *kzgamd_ntt_new(unsigned scale);           /* FsFFTSettings::new(scale), blst/src/types/fft_settings.rs:30-58 */
 void kzgamd_ntt_free(void *ctx);
 int ntt_fr(void *ctx, blst_fr *out, const blst_fr *in, size_t n, int inverse);
 int das_fft_extension(void *ctx, blst_fr *odds, const blst_fr *evens, size_t half_n);
+/* G1-valued transform: FFTG1::fft_g1 for FsFFTSettings (kzg/src/lib.rs:433-435; blst/src/fft_g1.rs:54-83).
+ * Jacobian blst_p1 in and out (any valid representation in; infinity = Z == 0), natural order, inverse
+ * scales by n^-1.  Outputs equal the reference's as group elements (the Jacobian representative differs).
+ * kzgamd_fft_g1_batch runs nbatch independent transforms of length n (contiguous) in the same launches —
+ * the shape of the 64 x size-128 transforms of the FK20 setup (blst/src/types/kzg_settings.rs:84-101). */
+int fft_g1(void *ctx, blst_p1 *out, const blst_p1 *in, size_t n, int inverse);
+int kzgamd_fft_g1_batch(void *ctx, blst_p1 *out, const blst_p1 *in, size_t n, size_t nbatch, int inverse);
 /* device-resident, batched (nbatch independent transforms of length n, contiguous), on `stream` */
 int kzgamd_ntt_fr_device(void *ctx, void *d_out, const void *d_in, size_t n, size_t nbatch, int inverse, void *stream);
 /* host copies of the settings arrays (FFTSettings getters, kzg/src/lib.rs:465-481); counts in elements */

@@ -166,3 +166,50 @@ int odas_fft_extension(const offt_settings_t *fs, ofr_t *odds, const ofr_t *even
     for (size_t i = 0; i < n; ++i) ofr_mul(&odds[i], &odds[i], &inv_len);
     return 0;
 }
+
+/* fft_g1_fast, blst/src/fft_g1.rs:13-52: the same recursive DIT network over G1 points; the butterfly
+ * multiplies by the root with a full scalar multiplication (FsG1::mul) */
+static void fft_g1_fast(og1_t *ret, size_t n, const og1_t *data, size_t stride, const ofr_t *roots, size_t roots_stride) {
+    size_t half = n / 2;
+    if (half > 0) {
+        fft_g1_fast(ret, half, data, stride * 2, roots, roots_stride * 2);
+        fft_g1_fast(ret + half, half, data + stride, stride * 2, roots, roots_stride * 2);
+        for (size_t i = 0; i < half; ++i) {
+            og1_t y_times_root, neg;
+            og1_mul(&y_times_root, &ret[i + half], &roots[i * roots_stride]);
+            og1_neg(&neg, &y_times_root);
+            og1_add_or_dbl(&ret[i + half], &ret[i], &neg);
+            og1_add_or_dbl(&ret[i], &ret[i], &y_times_root);
+        }
+    } else {
+        ret[0] = data[0];
+    }
+}
+
+/* FFTG1::fft_g1 for FsFFTSettings, blst/src/fft_g1.rs:54-83.  0 ok; 1 too long; 2 not a power of two */
+int offt_g1(const offt_settings_t *fs, og1_t *out, const og1_t *in, size_t n, int inverse) {
+    if (n > fs->max_width) return 1;
+    if (n == 0 || (n & (n - 1))) return 2;
+    size_t stride = fs->max_width / n;
+    fft_g1_fast(out, n, in, 1, inverse ? fs->reverse_roots_of_unity : fs->roots_of_unity, stride);
+    if (inverse) {
+        ofr_t inv_len;
+        ofr_from_u64(&inv_len, (uint64_t)n);
+        ofr_inv(&inv_len, &inv_len);
+        for (size_t i = 0; i < n; ++i) og1_mul(&out[i], &out[i], &inv_len);
+    }
+    return 0;
+}
+
+/* fft_g1_slow, blst/src/fft_g1.rs:86-104 (forward, stride 1) */
+void offt_g1_slow(const offt_settings_t *fs, og1_t *out, const og1_t *in, size_t n) {
+    size_t roots_stride = fs->max_width / n;
+    for (size_t i = 0; i < n; ++i) {
+        og1_mul(&out[i], &in[0], &fs->roots_of_unity[0]);
+        for (size_t j = 1; j < n; ++j) {
+            og1_t v;
+            og1_mul(&v, &in[j], &fs->roots_of_unity[((i * j) % n) * roots_stride]);
+            og1_add_or_dbl(&out[i], &out[i], &v);
+        }
+    }
+}

@@ -120,6 +120,9 @@ void offt_fr_slow(const offt_settings_t *fs, ofr_t *out, const ofr_t *in, size_t
 /* 0 ok; 1 empty; 2 not a power of two; 3 too long */
 int  odas_fft_extension(const offt_settings_t *fs, ofr_t *odds, const ofr_t *evens, size_t n);
 void oreverse_bit_order(void *data, size_t elem_size, size_t n);
+/* G1-valued NTT (blst/src/fft_g1.rs): 0 ok; 1 too long; 2 not a power of two */
+int  offt_g1(const offt_settings_t *fs, og1_t *out, const og1_t *in, size_t n, int inverse);
+void offt_g1_slow(const offt_settings_t *fs, og1_t *out, const og1_t *in, size_t n);
 
 /* ---- SHA-256 (sha256.c) ---- */
 void osha256(uint8_t out[32], const uint8_t *in, size_t len);

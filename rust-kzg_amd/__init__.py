@@ -6,9 +6,9 @@ reference's plug-in interface for the path:
 
   prepare_multi_scalar_mult / multi_scalar_mult_prepared / multi_scalar_mult
       = blst-sppark/src/lib.rs:8-62 (the three FFI wrappers `rust-kzg-blst` calls)
-  FFTSettings.fft_fr / das_fft_extension
-      = kzg::FFTFr / kzg::DASExtension for FsFFTSettings (blst/src/fft_fr.rs:156-165,
-        blst/src/data_availability_sampling.rs:78-100)
+  FFTSettings.fft_fr / das_fft_extension / fft_g1
+      = kzg::FFTFr / kzg::DASExtension / kzg::FFTG1 for FsFFTSettings (blst/src/fft_fr.rs:156-165,
+        blst/src/data_availability_sampling.rs:78-100, blst/src/fft_g1.rs:54-83)
 
 There is no CPU fallback: if the library is missing or no GPU is visible the calls raise.
 The directory name contains a hyphen; import it with `load()` from __graft_entry__ /
@@ -53,6 +53,7 @@ EXPORTS = [
     "kzgamd_msm_prepared_batch_device", "kzgamd_msm_info", "kzgamd_msm_uses_wide_table", "kzgamd_msm_set_profile", "kzgamd_msm_get_profile",
     "kzgamd_device_count", "kzgamd_version", "kzgamd_msm_create_device", "kzgamd_generate_points",
     "kzgamd_ntt_new", "kzgamd_ntt_free", "ntt_fr", "das_fft_extension", "kzgamd_ntt_fr_device", "kzgamd_ntt_roots",
+    "fft_g1", "kzgamd_fft_g1_batch",
     "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
     "compute_kzg_proof", "compute_blob_kzg_proof", "kzgamd_compute_blob_kzg_proof_batch", "compute_challenge",
     "bytes_to_kzg_commitment", "bytes_from_bls_field", "compute_cells_and_kzg_proofs",
@@ -119,6 +120,10 @@ def lib():
     L.das_fft_extension.argtypes = [vp, vp, vp, sz]
     L.kzgamd_ntt_fr_device.restype = C.c_int
     L.kzgamd_ntt_fr_device.argtypes = [vp, vp, vp, sz, sz, C.c_int, vp]
+    L.fft_g1.restype = C.c_int
+    L.fft_g1.argtypes = [vp, vp, vp, sz, C.c_int]
+    L.kzgamd_fft_g1_batch.restype = C.c_int
+    L.kzgamd_fft_g1_batch.argtypes = [vp, vp, vp, sz, sz, C.c_int]
     L.kzgamd_ntt_roots.restype = C.c_int
     L.kzgamd_ntt_roots.argtypes = [vp, vp, vp, vp]
     sp = C.POINTER(CKZGSettings)
@@ -374,6 +379,21 @@ class FFTSettings:
             raise KzgAmdError("A list with power-of-two length expected")
         if rc != 0:
             raise KzgAmdError("ntt_fr: device error %d" % rc)
+        return out
+
+    def fft_g1(self, data, n, inverse=False, nbatch=1):
+        """FFTG1::fft_g1 (blst/src/fft_g1.rs:54-83). data: blst_p1[n * nbatch]. Returns a new (BlstP1 * (n * nbatch))."""
+        out = (BlstP1 * max(n * nbatch, 1))()
+        if nbatch == 1:
+            rc = lib().fft_g1(self.handle, out, _addr(data), n, 1 if inverse else 0)
+        else:
+            rc = lib().kzgamd_fft_g1_batch(self.handle, out, _addr(data), n, nbatch, 1 if inverse else 0)
+        if rc == 1:
+            raise KzgAmdError("Supplied list is longer than the available max width")
+        if rc == 2:
+            raise KzgAmdError("A list with power-of-two length expected")
+        if rc != 0:
+            raise KzgAmdError("fft_g1: device error %d" % rc)
         return out
 
     def das_fft_extension(self, evens, n):

@@ -23,6 +23,7 @@
 #include "ckzg_internal.h"
 #include "ff.cuh"
 #include "fr29.cuh"
+#include "ntt_internal.h"
 
 using ff::Fr;
 using fr29::Fe;
@@ -34,15 +35,6 @@ namespace {
 constexpr int LOG_TILE = 12;
 constexpr int TILE = 1 << LOG_TILE;  // elements per workgroup
 constexpr int NT = 1024;             // threads per workgroup
-
-struct NttErr {
-    hipError_t e;
-};
-#define NTT_TRY(x)                           \
-    do {                                     \
-        hipError_t _e = (x);                 \
-        if (_e != hipSuccess) throw NttErr{_e}; \
-    } while (0)
 
 __device__ __forceinline__ u32 brev(u32 v, int bits) { return __builtin_bitreverse32(v) >> (32 - bits); }
 
@@ -155,34 +147,6 @@ __global__ void __launch_bounds__(256) k_twist(Fr* __restrict__ data, const Fr* 
 }
 
 }  // namespace
-
-struct NttCtx {
-    int device = 0;
-    unsigned scale = 0;
-    size_t W = 0;
-    Fr* d_roots = nullptr;  // W + 1
-    std::vector<Fr> roots;  // host copy
-    hipStream_t stream = nullptr;
-    std::mutex mu;
-    Fr *d_a = nullptr, *d_b = nullptr;
-    size_t cap = 0;
-    ~NttCtx() {
-        if (d_roots) (void)hipFree(d_roots);
-        if (d_a) (void)hipFree(d_a);
-        if (d_b) (void)hipFree(d_b);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
-    void ensure(size_t n) {
-        if (n <= cap) return;
-        if (d_a) (void)hipFree(d_a);
-        if (d_b) (void)hipFree(d_b);
-        d_a = d_b = nullptr;
-        cap = 0;
-        NTT_TRY(hipMalloc(&d_a, n * sizeof(Fr)));
-        NTT_TRY(hipMalloc(&d_b, n * sizeof(Fr)));
-        cap = n;
-    }
-};
 
 namespace {
 

@@ -1,0 +1,54 @@
+// Shared between ntt.hip (Fr transforms) and fftg1.hip (G1-valued transforms): the context object
+// behind the opaque handle of kzgamd_ntt_new().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <vector>
+
+#include "ff.cuh"
+
+struct NttErr {
+    hipError_t e;
+};
+#define NTT_TRY(x)                              \
+    do {                                        \
+        hipError_t _e = (x);                    \
+        if (_e != hipSuccess) throw NttErr{_e}; \
+    } while (0)
+
+struct NttCtx {
+    using Fr = ff::Fr;
+    int device = 0;
+    unsigned scale = 0;
+    size_t W = 0;
+    Fr* d_roots = nullptr;  // W + 1 twiddles in the 2^261 domain (Fr transforms)
+    std::vector<Fr> roots;  // host copy, blst Montgomery form
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    Fr *d_a = nullptr, *d_b = nullptr;
+    size_t cap = 0;
+    // G1-valued transforms (fftg1.hip): canonical (non-Montgomery) roots as scalars, staging and work buffers
+    ff::u32* d_kroots = nullptr;  // (W + 1) x 8 words
+    void *d_p1 = nullptr, *d_pts = nullptr, *d_tab = nullptr;
+    size_t cap_g1 = 0, cap_tab = 0;
+    ~NttCtx() {
+        if (d_roots) (void)hipFree(d_roots);
+        if (d_a) (void)hipFree(d_a);
+        if (d_b) (void)hipFree(d_b);
+        if (d_kroots) (void)hipFree(d_kroots);
+        if (d_p1) (void)hipFree(d_p1);
+        if (d_pts) (void)hipFree(d_pts);
+        if (d_tab) (void)hipFree(d_tab);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    void ensure(size_t n) {
+        if (n <= cap) return;
+        if (d_a) (void)hipFree(d_a);
+        if (d_b) (void)hipFree(d_b);
+        d_a = d_b = nullptr;
+        cap = 0;
+        NTT_TRY(hipMalloc(&d_a, n * sizeof(Fr)));
+        NTT_TRY(hipMalloc(&d_b, n * sizeof(Fr)));
+        cap = n;
+    }
+};

@@ -89,6 +89,8 @@ def lib():
         "offt_fr": (C.c_int, [C.POINTER(FFTSettings), frp, frp, C.c_size_t, C.c_int]),
         "offt_fr_slow": (None, [C.POINTER(FFTSettings), frp, frp, C.c_size_t]),
         "odas_fft_extension": (C.c_int, [C.POINTER(FFTSettings), frp, frp, C.c_size_t]),
+        "offt_g1": (C.c_int, [C.POINTER(FFTSettings), g1p, g1p, C.c_size_t, C.c_int]),
+        "offt_g1_slow": (None, [C.POINTER(FFTSettings), g1p, g1p, C.c_size_t]),
         "osha256": (None, [C.c_char_p, C.c_char_p, C.c_size_t]),
         "oload_trusted_setup_text": (C.c_int, [C.POINTER(Settings), C.c_char_p, C.c_size_t]),
         "ofree_trusted_setup": (None, [C.POINTER(Settings)]),

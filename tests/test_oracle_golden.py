@@ -331,3 +331,35 @@ def test_vectors_cell_proofs_pin_definition(oracle, oracle_settings, golden, blo
             assert hx(out.raw) == case["output"][key], (case["name"], k)
         done += 1
     assert done == 2
+
+
+def test_fft_g1_properties(oracle):
+    # compare_ft_fft / roundtrip_fft / stride_fft of kzg-bench/src/tests/fft_g1.rs, at CPU-friendly sizes
+    L = oracle.lib()
+    fs, fs2 = O.FFTSettings(), O.FFTSettings()
+    assert L.offt_settings_new(C.byref(fs), 4) == 0
+    assert L.offt_settings_new(C.byref(fs2), 6) == 0
+    n = 16
+    g = O.G1()
+    L.og1_generator(C.byref(g))
+    data = (O.G1 * n)()
+    acc = O.G1()
+    L.og1_generator(C.byref(acc))
+    for i in range(n):  # make_data: ascending multiples of the generator
+        data[i] = acc
+        L.og1_add_or_dbl(C.byref(acc), C.byref(acc), C.byref(g))
+    data[5] = O.G1()  # a point at infinity
+    fast, slow, other, back = (O.G1 * n)(), (O.G1 * n)(), (O.G1 * n)(), (O.G1 * n)()
+    assert L.offt_g1(C.byref(fs), fast, data, n, 0) == 0
+    L.offt_g1_slow(C.byref(fs), slow, data, n)
+    assert L.offt_g1(C.byref(fs2), other, data, n, 0) == 0
+    assert L.offt_g1(C.byref(fs), back, fast, n, 1) == 0
+    for i in range(n):
+        assert L.og1_equal(C.byref(fast[i]), C.byref(slow[i])) == 1
+        assert L.og1_equal(C.byref(fast[i]), C.byref(other[i])) == 1
+        assert L.og1_equal(C.byref(back[i]), C.byref(data[i])) == 1
+    big = (O.G1 * 32)()
+    assert L.offt_g1(C.byref(fs), big, big, 32, 0) == 1
+    assert L.offt_g1(C.byref(fs), big, big, 12, 0) == 2
+    L.offt_settings_free(C.byref(fs))
+    L.offt_settings_free(C.byref(fs2))

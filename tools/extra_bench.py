@@ -111,8 +111,29 @@ def main():
         ntt["n=%d x %d" % (n, nb)] = {"ms": ms, "transforms_per_s": nb / (ms * 1e-3),
                                        "algorithmic_GBps": 64 * n * nb / (ms * 1e-3) / 1e9,
                                        "fr_mul_per_s": nb * (n / 2) * math.log2(n) / (ms * 1e-3)}
-    fs.close()
     res["ntt_forward"] = ntt
+    # fft_g1 (host buffers in/out): the reference's bench_fft_g1 shape is scale 15 (kzg-bench/src/benches/fft.rs:13-21)
+    import numpy as np
+    g1 = {}
+    for logn, nb in ((7, 64), (12, 1), (15, 1)):
+        n = 1 << logn
+        tot = n * nb
+        aff = torch.empty(tot * 96, dtype=torch.uint8, device=dev)
+        kzg.generate_points(aff.data_ptr(), tot, 9, stream)
+        torch.cuda.synchronize()
+        a = aff.cpu().numpy().reshape(tot, 96)
+        one = np.array([0x760900000002fffd, 0xebf4000bc40c0002, 0x5f48985753c758ba, 0x77ce585370525745,
+                        0x5c071a97a256ec6d, 0x15f65ec3fa80e493], dtype="<u8").tobytes()  # 2^384 mod p (Z = 1)
+        jac = np.concatenate([a, np.tile(np.frombuffer(one, dtype=np.uint8), (tot, 1))], axis=1).copy()
+        buf = (kzg.BlstP1 * tot).from_buffer(jac)
+        fs.fft_g1(buf, n, nbatch=nb)
+        t0 = time.perf_counter()
+        fs.fft_g1(buf, n, nbatch=nb)
+        dt = time.perf_counter() - t0
+        g1["n=%d x %d" % (n, nb)] = {"ms": dt * 1e3, "scalar_muls_per_s": nb * (n / 2) * logn / dt}
+        del aff
+    res["fft_g1_forward_host_buffers"] = g1
+    fs.close()
 
     # ---- blob proofs, batch of 256 through the host-buffer entry point ----
     s = kzg.KZGSettings.from_file(SETUP)
