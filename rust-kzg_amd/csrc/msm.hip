@@ -63,8 +63,31 @@ RustError make_error(int code, const std::string& msg) {
 
 // ---------------------------------------------------------------- kernels
 
-// blst affine (2 x 12 u32, Montgomery 2^384) -> table slot (fp28, Montgomery 2^392)
-__global__ void __launch_bounds__(256) k_points_in(AffPt* __restrict__ dst, const ff::Fp* __restrict__ src, size_t n) {
+// cube root of unity beta (Montgomery 2^392): phi(x, y) = (beta*x, y) = -[x^2](x, y) on G1, x the BLS parameter
+// (the relation the subgroup check in ckzg.hip tests)
+__device__ __forceinline__ fp28::Fe beta28() {
+    constexpr u32 t[14] = {0xa75929au, 0x681b798u, 0x22a3e9du, 0xabc02bfu, 0x4e5bb45u, 0x55e6e7eu, 0x4814117u,
+                           0x6d04f1bu, 0xae3387du, 0x54acb0cu, 0xa4c74bu, 0x56138b5u, 0xb64e066u, 0x76f2u};
+    fp28::Fe b;
+#pragma unroll
+    for (int k = 0; k < 14; ++k) b.v[k] = t[k];
+    return b;
+}
+
+// [x^2]P = (beta*x, -y): the second base of the GLV split k = k1 + k2*x^2 (k_digits)
+__device__ __forceinline__ AffPt x2_image(const AffPt& a) {
+    AffPt o = a;
+    if (!(a.flags & 1)) {
+        o.x = fp28::canon(fp28::mul(a.x, beta28()));
+        o.y = fp28::canon(fp28::neg<2>(a.y));
+    }
+    return o;
+}
+
+// blst affine (2 x 12 u32, Montgomery 2^384) -> table slot (fp28, Montgomery 2^392);
+// glv: slot n + i receives [x^2]P_i
+__global__ void __launch_bounds__(256) k_points_in(AffPt* __restrict__ dst, const ff::Fp* __restrict__ src, size_t n,
+                                                   int glv) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     ff::Fp x = src[2 * i], y = src[2 * i + 1];
@@ -75,6 +98,7 @@ __global__ void __launch_bounds__(256) k_points_in(AffPt* __restrict__ dst, cons
     o.x = fp28::canon(fp28::from_blst(x));
     o.y = fp28::canon(fp28::from_blst(y));
     dst[i] = o;
+    if (glv) dst[n + i] = x2_image(o);
 }
 
 // table rows j = 1..rows-1:  T[j][i] = 2^c * T[j-1][i], kept affine (one inversion per entry)
@@ -124,7 +148,8 @@ struct DigitParams {
     int prepared;    // 1: all windows share one bucket set
     int mont;        // scalars are Montgomery blst_fr
     size_t nb;       // buckets per set = 2^(c-1)
-    size_t row_stride;  // prepared: points per table row
+    size_t row_stride;  // prepared: points per table row; glv: offset of the [x^2]P half of the table
+    int glv;         // 1: scalars are split k = k1 + k2*x^2 (two 128-bit halves, nwin windows each)
 };
 
 // canonical 256-bit scalar (8 x u32) -> signed digit of window w, carrying from below
@@ -146,6 +171,142 @@ __device__ __forceinline__ u32 window_bits(const u32 s[8], int bit, int c) {
     return (u32)(two >> sh) & ((1u << c) - 1);
 }
 
+// GLV split for the variable-base engine: k = +-k1 +- k2 * X2 with X2 = x^2 (x the BLS parameter, X2 ~ 2^127.4), so
+// k*P = +-k1*P +- k2*[x^2]P with [x^2]P = (beta*x, -y) one field multiplication away.  Half as many windows, and
+// the Horner chain over the window sums is ~112 doublings instead of 255.
+//   1. k > (r-1)/2 -> use r - k and flip both signs            (k <= (r-1)/2)
+//   2. q = floor(k / X2), rem = k - q*X2: division by the constant through its reciprocal
+//      M = floor(2^256 / X2), at most two corrections
+//   3. rem > X2/2 -> rem = X2 - rem (negative), q += 1
+// Both halves end below 2^126.5, so ceil(128/c) signed windows never carry out of the top one.
+__device__ __forceinline__ void glv_split(const u32 kin[8], u32 k1[8], u32 k2[8], u32& neg1, u32& neg2) {
+    constexpr u32 X2[4] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u};
+    constexpr u32 X2H[4] = {0x80000000u, 0x00000000u, 0x8000d201u, 0x5622d200u};  // X2 / 2
+    constexpr u32 M[5] = {0xf6cfee2eu, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x1u};
+    constexpr u32 RH[8] = {0x80000000u, 0x7fffffffu, 0x7fff2dffu, 0xa9ded201u,
+                           0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u};  // (r - 1) / 2
+    u32 k[8];
+    bool flip = false;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        if (kin[i] != RH[i]) {
+            flip = kin[i] > RH[i];
+            break;
+        }
+    }
+    {
+        u32 bw = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            u64 v = (u64)ff::FrParams::p(i) - kin[i] - bw;
+            k[i] = flip ? (u32)v : kin[i];
+            bw = (u32)(v >> 63);
+        }
+    }
+    u32 t[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32 carry = 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            u64 v = (u64)k[i] * M[j] + t[i + j] + carry;
+            t[i + j] = (u32)v;
+            carry = (u32)(v >> 32);
+        }
+        t[i + 5] = carry;
+    }
+    u32 q[4] = {t[8], t[9], t[10], t[11]};
+    // rem = k - q*X2 (160 bits are enough: rem < 3*X2)
+    u32 pr[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32 carry = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i + j < 5) {
+                u64 v = (u64)q[i] * X2[j] + pr[i + j] + carry;
+                pr[i + j] = (u32)v;
+                carry = (u32)(v >> 32);
+            }
+        }
+        if (i + 4 < 5) pr[i + 4] = carry;
+    }
+    u32 rem[5];
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        u64 v = (u64)k[i] - pr[i] - borrow;
+        rem[i] = (u32)v;
+        borrow = (u32)(v >> 63);
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        bool ge = rem[4] != 0;
+        if (!ge) {
+            ge = true;
+#pragma unroll
+            for (int i = 3; i >= 0; --i) {
+                if (rem[i] != X2[i]) {
+                    ge = rem[i] > X2[i];
+                    break;
+                }
+            }
+        }
+        if (ge) {
+            u32 bw = 0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                u64 v = (u64)rem[i] - (i < 4 ? X2[i] : 0u) - bw;
+                rem[i] = (u32)v;
+                bw = (u32)(v >> 63);
+            }
+            u32 cy = 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u64 v = (u64)q[i] + cy;
+                q[i] = (u32)v;
+                cy = (u32)(v >> 32);
+            }
+        }
+    }
+    // balance the remainder: rem > X2/2  ->  X2 - rem, negative
+    bool big = false;
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        if (rem[i] != X2H[i]) {
+            big = rem[i] > X2H[i];
+            break;
+        }
+    }
+    if (big) {
+        u32 bw = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u64 v = (u64)X2[i] - rem[i] - bw;
+            rem[i] = (u32)v;
+            bw = (u32)(v >> 63);
+        }
+        u32 cy = 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u64 v = (u64)q[i] + cy;
+            q[i] = (u32)v;
+            cy = (u32)(v >> 32);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        k1[i] = rem[i];
+        k2[i] = q[i];
+        k1[i + 4] = 0;
+        k2[i + 4] = 0;
+    }
+    neg1 = (big ? 1u : 0u) ^ (flip ? 1u : 0u);
+    neg2 = flip ? 1u : 0u;
+}
+
 // pass 0: histogram; pass 1: scatter (recomputes the digits instead of storing them)
 template <int PASS>
 __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __restrict__ scalars,
@@ -156,28 +317,65 @@ __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __rest
     if (t >= P.n * P.nbatch) return;
     size_t b = t / P.n, i = t % P.n;
     if (pts[i].flags & 1) return;  // infinity base contributes nothing (rows share the flag)
-    u32 s[8];
+    u32 s[8], s2[8];
     load_scalar(s, scalars, t, P.mont);
-    u32 carry = 0;
+    u32 pneg[2] = {0, 0};
+    if (P.glv) {
+        u32 k[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) k[q] = s[q];
+        glv_split(k, s, s2, pneg[0], pneg[1]);
+    }
     const u32 half = 1u << (P.c - 1);
-    for (int w = 0; w < P.nwin; ++w) {
-        u32 d = window_bits(s, w * P.c, P.c) + carry;
-        u32 neg = 0;
-        carry = 0;
-        if (d > half) {
-            d = (1u << P.c) - d;
-            neg = 1;
-            carry = 1;
-        }
-        if (d == 0) continue;
-        size_t set = P.prepared ? b : b * P.nwin + w;
-        size_t slot = set * P.nb + (d - 1);
-        if (PASS == 0) {
-            atomicAdd(&counts[slot], 1u);
-        } else {
-            u32 pos = offsets[set * (P.nb + 1) + (d - 1)] + atomicAdd(&counts[slot], 1u);
-            u32 pidx = P.prepared ? (u32)((size_t)w * P.row_stride + i) : (u32)i;
-            sorted[set * set_cap + pos] = pidx | (neg << 31);
+    const int lane = threadIdx.x & 63;
+    const u64 lt_mask = ((u64)1 << lane) - 1;
+    for (int part = 0; part <= P.glv; ++part) {
+        const u32* sv = part ? s2 : s;
+        u32 carry = 0;
+        for (int w = 0; w < P.nwin; ++w) {
+            u32 d = window_bits(sv, w * P.c, P.c) + carry;
+            u32 neg = 0;
+            carry = 0;
+            if (d > half) {
+                d = (1u << P.c) - d;
+                neg = 1;
+                carry = 1;
+            }
+            bool todo = d != 0;
+            const size_t set = P.prepared ? b : b * P.nwin + w;
+            const size_t slot = set * P.nb + (todo ? d - 1 : 0);
+            u32 rank = 0;  // position inside the bucket (scatter pass)
+            // Lanes of a wave that hit the same bucket share one atomic: a short top window, the carry-only
+            // window and blobs of equal elements put thousands of entries on one counter, and same-address
+            // atomics serialise.  Groups of fewer than 4 lanes are left to the plain per-lane atomic below, and
+            // the search stops after two such groups, so uniformly spread digits pay two ballots and no extra
+            // atomic round trip.
+            u64 pending = __ballot(todo);
+            for (int round = 0, misses = 0; round < 8 && pending && misses < 2; ++round) {
+                const int leader = __ffsll((unsigned long long)pending) - 1;
+                const u32 lo = __shfl((u32)slot, leader, 64), hi = __shfl((u32)(slot >> 32), leader, 64);
+                const bool same = todo && (u32)slot == lo && (u32)(slot >> 32) == hi;
+                const u64 m = __ballot(same);
+                pending &= ~m;
+                if (__popcll(m) < 4) {
+                    ++misses;
+                    continue;
+                }
+                u32 base = 0;
+                if (lane == leader) base = atomicAdd(&counts[slot], (u32)__popcll(m));
+                base = __shfl(base, leader, 64);
+                if (same) {
+                    rank = base + (u32)__popcll(m & lt_mask);
+                    todo = false;
+                }
+            }
+            const bool mine = d != 0;
+            if (todo) rank = atomicAdd(&counts[slot], 1u);
+            if (PASS == 1 && mine) {
+                const u32 pos = offsets[set * (P.nb + 1) + (d - 1)] + rank;
+                const u32 pidx = P.prepared ? (u32)((size_t)w * P.row_stride + i) : (u32)(part ? P.row_stride + i : i);
+                sorted[set * set_cap + pos] = pidx | ((neg ^ pneg[part]) << 31);
+            }
         }
     }
 }
@@ -278,11 +476,15 @@ __global__ void __launch_bounds__(256) k_accum(const u32* __restrict__ offsets, 
     out[b] = acc;
 }
 
-// One wave per heavy bucket: lanes sum the bucket's pieces strided, then an LDS tree; the total
-// replaces the first piece (load_bucket reads only that one for flagged buckets).
+// Heavy buckets: their pieces are combined by whole waves instead of one lane.  Two passes so that a bucket
+// holding a large share of all entries (short top window, equal scalars) is spread over many waves:
+//   pass 1 (step 1, span HSEG): wave (bucket, segment) sums HSEG consecutive pieces into the segment's first slot
+//   pass 2 (step HSEG, span all): one wave per bucket sums the segment sums into the bucket's first piece,
+// which is the only one load_bucket reads for flagged buckets.
+constexpr u32 HSEG = 1024;
 __global__ void __launch_bounds__(64) k_heavy(Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
                                               const u32* __restrict__ heavy_list, const u32* __restrict__ nheavy,
-                                              u32 heavy_cap, size_t nb, size_t nchunk) {
+                                              u32 heavy_cap, size_t nb, size_t nchunk, u32 step, u32 span) {
     __shared__ Xyzz sh[64];
     u32 cnt = *nheavy;
     if (cnt > heavy_cap) cnt = heavy_cap;
@@ -292,24 +494,30 @@ __global__ void __launch_bounds__(64) k_heavy(Xyzz* __restrict__ partials, const
         const u32* off = offsets + set * (nb + 1);
         Xyzz* pz = partials + set * (nb + nchunk) + bk;
         const u32 t0 = off[bk] / CHUNK, t1 = (off[bk + 1] - 1) / CHUNK;
-        Xyzz acc;
-        g1::set_inf(acc);
-        for (u32 t = t0 + lane; t <= t1; t += 64) {
-            Xyzz q = pz[t];
-            g1::dadd(acc, q);
-        }
-        sh[lane] = acc;
-        __syncthreads();
-        for (int stride = 32; stride > 0; stride >>= 1) {
-            if (lane < stride) {
-                Xyzz q = sh[lane + stride];
+        const u32 nelem = (t1 - t0) / step + 1;  // elements t0 + k*step, k < nelem
+        const u32 nseg = span ? (nelem + span - 1) / span : 1;
+        for (u32 seg = blockIdx.y; seg < nseg; seg += gridDim.y) {
+            const u32 k0 = span ? seg * span : 0;
+            const u32 k1 = span && k0 + span < nelem ? k0 + span : nelem;
+            Xyzz acc;
+            g1::set_inf(acc);
+            for (u32 k = k0 + lane; k < k1; k += 64) {
+                Xyzz q = pz[t0 + k * step];
                 g1::dadd(acc, q);
-                sh[lane] = acc;
             }
+            sh[lane] = acc;
+            __syncthreads();
+            for (int stride = 32; stride > 0; stride >>= 1) {
+                if (lane < stride) {
+                    Xyzz q = sh[lane + stride];
+                    g1::dadd(acc, q);
+                    sh[lane] = acc;
+                }
+                __syncthreads();
+            }
+            if (lane == 0) pz[t0 + k0 * step] = acc;
             __syncthreads();
         }
-        if (lane == 0) pz[t0] = acc;
-        __syncthreads();
     }
 }
 
@@ -327,21 +535,23 @@ __device__ __forceinline__ void load_bucket(Xyzz& v, const Xyzz* __restrict__ pa
     }
 }
 
-// Bucket reduction  sum_k (k+1) * B_k  as a GRP-ary tree of (A, M) pairs:
+// Bucket reduction  sum_k (k+1) * B_k  as a tree of (A, M) pairs:
 //   A = plain sum of the subtree's buckets,  M = sum (k - first_k) * B_k over the subtree.
-// A lane folds GRP children:  A = sum A_j,  M = sum M_j + S * sum_j j*A_j  with S = buckets per child
+// A lane folds grp children (a power of two, GRP by default; level 0 takes fewer when the buckets alone would not
+// fill the chip, since it also sums each bucket's pieces):  A = sum A_j,  M = sum M_j + S * sum_j j*A_j  with S = buckets per child
 // (a power of two -> doublings).  Level 0 reads the buckets themselves (M_j = 0, S = 1).
 // Every level is a short chain (<= ~3*GRP adds) over many lanes instead of one long running sum.
 template <bool FIRST>
 __global__ void __launch_bounds__(128) k_level(const Xyzz* __restrict__ inA, const Xyzz* __restrict__ inM,
                                                Xyzz* __restrict__ outA, Xyzz* __restrict__ outM, size_t nin, size_t nsets,
                                                int logS, const u32* __restrict__ offsets,
-                                               const unsigned char* __restrict__ heavy, size_t nb, size_t nchunk) {
-    const size_t nout = (nin + GRP - 1) / GRP;
+                                               const unsigned char* __restrict__ heavy, size_t nb, size_t nchunk,
+                                               int grp) {
+    const size_t nout = (nin + grp - 1) / grp;
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= nout * nsets) return;
     const size_t set = tid / nout, g = tid % nout;
-    const size_t lo = g * GRP, hi = lo + GRP < nin ? lo + GRP : nin;
+    const size_t lo = g * grp, hi = lo + grp < nin ? lo + grp : nin;
     Xyzz run, wsum, msum;
     g1::set_inf(run);
     g1::set_inf(wsum);
@@ -365,6 +575,63 @@ __global__ void __launch_bounds__(128) k_level(const Xyzz* __restrict__ inA, con
     outM[set * nout + g] = msum;
 }
 
+// Top of the reduction tree.  Once a set is down to nin <= TOP_MAX nodes (A_j, M_j) of S buckets each, further
+// GRP-ary levels are pure latency (a handful of waves, ~24 dependent additions plus log2(S) doublings per level).
+// Instead:   sum_k (k+1) B_k = sum_j A_j + sum_j M_j + S * sum_q 2^q R_q ,   R_q = sum over { j : bit q of j } of A_j
+// — B + 2 plain sums per set (B = ceil(log2 nin)), each a strided accumulate plus an LDS tree in its own workgroup,
+// all concurrent; k_winsum then runs the short Horner over q.
+constexpr int TOPT = 256;
+constexpr size_t TOP_MAX = 2048;
+__global__ void __launch_bounds__(TOPT) k_top(const Xyzz* __restrict__ inA, const Xyzz* __restrict__ inM,
+                                              Xyzz* __restrict__ top, size_t nin, int B) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_top[];
+    Xyzz* sh = (Xyzz*)smem_top;
+    const size_t set = blockIdx.x / (B + 2);
+    const int q = (int)(blockIdx.x % (B + 2));
+    const Xyzz* src = (q == B + 1 ? inM : inA) + set * nin;
+    const int lane = threadIdx.x;
+    Xyzz acc;
+    g1::set_inf(acc);
+    for (size_t j = lane; j < nin; j += TOPT) {
+        if (q >= B || ((j >> q) & 1)) {
+            Xyzz v = src[j];
+            g1::dadd(acc, v);
+        }
+    }
+    sh[lane] = acc;
+    __syncthreads();
+    for (int stride = TOPT / 2; stride > 0; stride >>= 1) {
+        if (lane < stride) {
+            Xyzz v = sh[lane + stride];
+            g1::dadd(acc, v);
+            sh[lane] = acc;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) top[blockIdx.x] = acc;
+}
+
+// one lane per set: window sum = A + M + 2^logS * sum_q 2^q R_q
+__global__ void __launch_bounds__(64) k_winsum(const Xyzz* __restrict__ top, Xyzz* __restrict__ win, size_t nsets, int B,
+                                               int logS) {
+    size_t set = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (set >= nsets) return;
+    const Xyzz* t = top + set * (B + 2);
+    Xyzz acc;
+    g1::set_inf(acc);
+    for (int q = B - 1; q >= 0; --q) {
+        if (!g1::is_inf(acc)) g1::dbl(acc);
+        Xyzz r = t[q];
+        g1::dadd(acc, r);
+    }
+    g1::dbl_k(acc, logS);
+    Xyzz r = t[B + 1];
+    g1::dadd(acc, r);
+    r = t[B];
+    g1::dadd(acc, r);
+    win[set] = acc;
+}
+
 // one lane per MSM: Horner over windows (unprepared) and conversion to blst Jacobian
 __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, const Xyzz* __restrict__ rootM,
                                               void* __restrict__ out_v, size_t nbatch, int nwin, int c, int prepared,
@@ -374,8 +641,10 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, co
         // b indexes (MSM, window): window sum = M + A, handed to the host as a Jacobian point
         if (b >= nbatch * (size_t)nwin) return;
         Xyzz acc = rootM[b];
-        Xyzz a = rootA[b];
-        g1::dadd(acc, a);
+        if (rootA) {
+            Xyzz a = rootA[b];
+            g1::dadd(acc, a);
+        }
         ff::Fp* out = (ff::Fp*)out_v;
         ff::Fp j[3];
         g1::to_blst_jacobian(j, acc);
@@ -399,8 +668,10 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, co
             g1::dbl_k(acc, c);  // the curve has odd order: doubling never reaches infinity
             Xyzz r = rootM[b * nwin + w];
             g1::dadd(acc, r);
-            r = rootA[b * nwin + w];
-            g1::dadd(acc, r);
+            if (rootA) {
+                r = rootA[b * nwin + w];
+                g1::dadd(acc, r);
+            }
         }
     }
     if (out_mode == kzgamd::OUT_COMPRESSED) {
@@ -579,9 +850,13 @@ __global__ void __launch_bounds__(256) k_blocksum(const Xyzz* __restrict__ in_al
 }
 
 // device copy of already-converted table slots (row 0)
-__global__ void __launch_bounds__(256) k_copy_affpt(AffPt* __restrict__ dst, const AffPt* __restrict__ src, size_t n) {
+__global__ void __launch_bounds__(256) k_copy_affpt(AffPt* __restrict__ dst, const AffPt* __restrict__ src, size_t n,
+                                                    int glv) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[i];
+    if (i >= n) return;
+    AffPt a = src[i];
+    dst[i] = a;
+    if (glv) dst[n + i] = x2_image(a);
 }
 
 // P_i = h_i * G with h_i a 248-bit value from splitmix64(seed, i); output in blst affine layout
@@ -643,8 +918,9 @@ double fbw_budget_gb() {
     return budget_gb;
 }
 
-int choose_window(size_t n, bool prepared) {
-    // minimise adds: prepared  n*ceil(256/c) + 3*2^(c-1);  unprepared  ceil(256/c) * (n + 3*2^(c-1))
+int choose_window(size_t n, bool prepared, bool glv) {
+    // minimise adds: prepared  n*ceil(256/c) + 3*2^(c-1);  unprepared  ceil(256/c) * (n + 3*2^(c-1));
+    // unprepared with the GLV split: (128/c + 1) bucket sets fed by 2n half-scalars
     if (const char* e = getenv(prepared ? "KZGAMD_WINDOW_PREPARED" : "KZGAMD_WINDOW")) {
         int c = atoi(e);
         if (c >= 2 && c <= 22) return c;
@@ -657,11 +933,19 @@ int choose_window(size_t n, bool prepared) {
             if (gb <= budget_gb) return c;
         }
     }
+    if (glv) {
+        // measured on MI355X (tools/sweep_window.py, device-resident inputs): c = 16 wins from n = 2^15 up to at
+        // least 2^22 — eight windows with a full top window after the balanced split; smaller n are latency-bound
+        // and prefer fewer buckets
+        if (n >= ((size_t)1 << 15)) return 16;
+        if (n >= ((size_t)1 << 13)) return 13;
+        if (n >= ((size_t)1 << 10)) return 10;
+    }
     int best = 2;
     double best_cost = 1e300;
     for (int c = 2; c <= 22; ++c) {
-        double w = 255 / c + 1, nb = (double)((size_t)1 << (c - 1));
-        double cost = prepared ? w * (double)n + 3.0 * nb : w * ((double)n + 3.0 * nb);
+        double w = glv ? (127 + c) / c : 255 / c + 1, nb = (double)((size_t)1 << (c - 1));
+        double cost = prepared ? w * (double)n + 3.0 * nb : w * ((glv ? 2.0 : 1.0) * (double)n + 3.0 * nb);
         if (cost < best_cost) {
             best_cost = cost;
             best = c;
@@ -691,7 +975,7 @@ struct DevBuf {
 
 struct Workspace {
     DevBuf<u32> counts, offsets, sorted, scalars;
-    DevBuf<Xyzz> buckets, lvlA[2], lvlM[2];
+    DevBuf<Xyzz> buckets, lvlA[2], lvlM[2], top, win;
     DevBuf<unsigned char> heavy;
     DevBuf<u32> heavy_list, nheavy;
     DevBuf<ff::Fp> out;
@@ -705,6 +989,8 @@ struct Workspace {
             lvlA[k].release();
             lvlM[k].release();
         }
+        top.release();
+        win.release();
         heavy.release();
         heavy_list.release();
         nheavy.release();
@@ -719,7 +1005,8 @@ struct kzgamd::MsmContext {
     int device = 0;
     size_t n = 0;
     bool prepared = false;
-    int c = 0, rows = 0;
+    bool glv = false;  // variable-base engine: scalars split k = k1 + k2*x^2, table = P_i followed by [x^2]P_i
+    int c = 0, rows = 0, nwin = 0;
     size_t nb = 0;
     DevBuf<AffPt> table;  // rows x n (prepared) or n
     DevBuf<WidePt> wide;  // wide fixed-base table: (rows x n) x 2^(c-1) 128-byte slots, when it fits the budget
@@ -790,16 +1077,19 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->n = n;
         ctx->prepared = prepare;
-        ctx->c = choose_window(n, prepare);
+        ctx->glv = !prepare;
+        if (const char* e = getenv("KZGAMD_GLV")) ctx->glv = ctx->glv && atoi(e) != 0;
+        ctx->c = choose_window(n, prepare, ctx->glv);
         ctx->rows = prepare ? (255 / ctx->c + 1) : 1;
+        ctx->nwin = ctx->glv ? (127 + ctx->c) / ctx->c : 255 / ctx->c + 1;
         ctx->nb = (size_t)1 << (ctx->c - 1);
-        ctx->table.ensure((size_t)ctx->rows * n);
+        ctx->table.ensure(ctx->glv ? 2 * n : (size_t)ctx->rows * n);
         DevBuf<ff::Fp> staging;
         const ff::Fp* src = (const ff::Fp*)points;
         if (points_are_affpt) {
             if (!points_on_device) throw HipErr{hipErrorInvalidValue, "AffPt input must be device-resident"};
             hipLaunchKernelGGL(k_copy_affpt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->table.p,
-                               (const AffPt*)points, n);
+                               (const AffPt*)points, n, ctx->glv ? 1 : 0);
         } else {
             if (!points_on_device) {
                 staging.ensure(2 * n);
@@ -807,7 +1097,7 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
                 src = staging.p;
             }
             hipLaunchKernelGGL(k_points_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->table.p, src,
-                               n);
+                               n, ctx->glv ? 1 : 0);
         }
         if (prepare && ctx->rows > 1)
             hipLaunchKernelGGL(k_table_rows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, ctx->table.p, n,
@@ -831,10 +1121,10 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     if (npoints > ctx->n) throw HipErr{hipErrorInvalidValue, "npoints exceeds the prepared size"};
     if (nbatch == 0) return;
     const int c = ctx->c;
-    const int nwin = 255 / c + 1;
+    const int nwin = ctx->nwin;
     const size_t nb = ctx->nb;
     const size_t nsets = ctx->prepared ? nbatch : nbatch * (size_t)nwin;
-    const size_t set_cap = ctx->prepared ? npoints * (size_t)nwin : npoints;
+    const size_t set_cap = ctx->prepared ? npoints * (size_t)nwin : (ctx->glv ? 2 * npoints : npoints);
     if (npoints == 0) {
         if (out_mode == OUT_COMPRESSED) throw HipErr{hipErrorInvalidValue, "empty MSM in compressed mode"};
         HIP_TRY(hipMemsetAsync(d_out, 0, nbatch * 144, stream));
@@ -852,7 +1142,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         const size_t lanes = (npoints + spl - 1) / spl;
         ws.buckets.ensure(nbatch * lanes);
         ws.lvlM[0].ensure(nbatch);
-        DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n};
+        DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n, 0};
         hipEvent_t* pev = nullptr;
         if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
             while (ctx->ev.size() < ctx->ev_used + 4) {
@@ -891,7 +1181,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     ws.sorted.ensure(nsets * set_cap);
     const size_t nchunk = (set_cap + CHUNK - 1) / CHUNK;
     ws.buckets.ensure(nsets * (nb + nchunk));
-    const size_t n1 = (nb + GRP - 1) / GRP, n2 = (n1 + GRP - 1) / GRP;
+    const size_t n1 = (nb + 1) / 2, n2 = (n1 + GRP - 1) / GRP;  // level 0 folds at least 2, later levels GRP
     ws.lvlA[0].ensure(nsets * n1);
     ws.lvlM[0].ensure(nsets * n1);
     ws.lvlA[1].ensure(nsets * n2);
@@ -900,7 +1190,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     const size_t heavy_cap = nsets * set_cap / HEAVY + 1;  // a heavy bucket holds > HEAVY entries
     ws.heavy_list.ensure(2 * heavy_cap);
     ws.nheavy.ensure(1);
-    DigitParams P{npoints, nbatch, c, nwin, ctx->prepared ? 1 : 0, mont, nb, ctx->n};
+    DigitParams P{npoints, nbatch, c, nwin, ctx->prepared ? 1 : 0, mont, nb, ctx->n, ctx->glv ? 1 : 0};
     hipEvent_t* pev = nullptr;
     if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
         while (ctx->ev.size() < ctx->ev_used + 4) {
@@ -925,33 +1215,56 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                        (const u32*)ws.offsets.p, (const u32*)ws.sorted.p, (const AffPt*)ctx->table.p, ws.buckets.p, nb, nsets,
                        set_cap, nchunk);
     if (pev) HIP_TRY(hipEventRecord(pev[2], stream));
-    hipLaunchKernelGGL(k_heavy, dim3(1024), dim3(64), 0, stream, ws.buckets.p, (const u32*)ws.offsets.p,
-                       (const u32*)ws.heavy_list.p, (const u32*)ws.nheavy.p, (u32)heavy_cap, nb, nchunk);
-    // bucket-reduction tree: nb -> nb/GRP -> ... -> 1 per set
+    hipLaunchKernelGGL(k_heavy, dim3(256, 16), dim3(64), 0, stream, ws.buckets.p, (const u32*)ws.offsets.p,
+                       (const u32*)ws.heavy_list.p, (const u32*)ws.nheavy.p, (u32)heavy_cap, nb, nchunk, 1u, HSEG);
+    hipLaunchKernelGGL(k_heavy, dim3(1024, 1), dim3(64), 0, stream, ws.buckets.p, (const u32*)ws.offsets.p,
+                       (const u32*)ws.heavy_list.p, (const u32*)ws.nheavy.p, (u32)heavy_cap, nb, nchunk, HSEG, 0u);
+    // bucket-reduction tree: GRP-ary levels while they are throughput work (nb -> nb/GRP -> ...), then the
+    // B + 2 concurrent plain sums of k_top and the short per-window Horner of k_winsum
     {
+        // many independent sets (batched MSMs) keep the levels busy on their own: plain tree down to one node
+        const bool use_top = nsets <= 64;
         size_t nin = nb;
         int logS = 0, lvl = 0;
         const Xyzz *inA = ws.buckets.p, *inM = nullptr;
-        for (;;) {
-            const size_t nout = (nin + GRP - 1) / GRP;
+        do {
+            // level 0 also folds each bucket's pieces (entries/CHUNK + 1 of them): keep >= ~128k lanes in flight
+            int grp = GRP, lg = 3;
+            if (lvl == 0)
+                while (grp > 2 && nsets * ((nin + grp - 1) / grp) < ((size_t)1 << 17)) {
+                    grp >>= 1;
+                    --lg;
+                }
+            const size_t nout = (nin + grp - 1) / grp;
             Xyzz *oA = ws.lvlA[lvl & 1].p, *oM = ws.lvlM[lvl & 1].p;
             const unsigned grid = (unsigned)((nsets * nout + 127) / 128);
             if (lvl == 0)
                 hipLaunchKernelGGL(k_level<true>, dim3(grid), dim3(128), 0, stream, inA, inM, oA, oM, nin, nsets, logS,
-                                   (const u32*)ws.offsets.p, (const unsigned char*)ws.heavy.p, nb, nchunk);
+                                   (const u32*)ws.offsets.p, (const unsigned char*)ws.heavy.p, nb, nchunk, grp);
             else
                 hipLaunchKernelGGL(k_level<false>, dim3(grid), dim3(128), 0, stream, inA, inM, oA, oM, nin, nsets, logS,
-                                   (const u32*)nullptr, (const unsigned char*)nullptr, nb, nchunk);
+                                   (const u32*)nullptr, (const unsigned char*)nullptr, nb, nchunk, grp);
             inA = oA;
             inM = oM;
             nin = nout;
-            logS += 3;  // GRP = 8
+            logS += lg;
             ++lvl;
-            if (nin == 1) break;
+        } while (nin > (use_top ? TOP_MAX : (size_t)1));
+        if (use_top) {
+            int B = 0;
+            while (((size_t)1 << B) < nin) ++B;
+            ws.top.ensure(nsets * (size_t)(B + 2));
+            ws.win.ensure(nsets);
+            hipLaunchKernelGGL(k_top, dim3((unsigned)(nsets * (size_t)(B + 2))), dim3(TOPT), TOPT * sizeof(Xyzz), stream, inA,
+                               inM, ws.top.p, nin, B);
+            hipLaunchKernelGGL(k_winsum, dim3((unsigned)((nsets + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)ws.top.p,
+                               ws.win.p, nsets, B, logS);
+            inA = nullptr;
+            inM = ws.win.p;
         }
         const size_t nfinal = out_mode == OUT_WINDOWS ? nbatch * (size_t)nwin : nbatch;
-        hipLaunchKernelGGL(k_final, dim3((unsigned)((nfinal + 63) / 64)), dim3(64), 0, stream, inA, inM,
-                           d_out, nbatch, nwin, c, ctx->prepared ? 1 : 0, out_mode);
+        hipLaunchKernelGGL(k_final, dim3((unsigned)((nfinal + 63) / 64)), dim3(64), 0, stream, inA, inM, d_out, nbatch, nwin,
+                           c, ctx->prepared ? 1 : 0, out_mode);
     }
     if (pev) {
         HIP_TRY(hipEventRecord(pev[3], stream));
@@ -996,7 +1309,7 @@ void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoint
     if (!ctx->prepared && npoints > 0) {
         // variable-base engine: the ~255 Horner doublings are one serial chain; a CPU core runs that chain
         // several times faster than a single GPU lane, and the result goes to the host anyway
-        const int nwin = 255 / ctx->c + 1;
+        const int nwin = ctx->nwin;
         ctx->ws.out.ensure(nbatch * (size_t)nwin * 3);
         msm_enqueue(ctx, ctx->ws.out.p, ctx->ws.scalars.p, npoints, nbatch, 1, ctx->stream, OUT_WINDOWS);
         std::vector<blst_p1> win(nbatch * (size_t)nwin);

@@ -94,6 +94,32 @@ def test_edge_scalars_and_points(oracle, kzg):
     hs.close()
 
 
+def test_glv_split_boundaries(oracle, kzg):
+    """The variable-base engine splits k = k1 + k2*x^2 (x the BLS parameter): scalars on the quotient /
+    remainder boundaries, including the largest quotient below r, through the host and the device entry points."""
+    L = oracle.lib()
+    rnd = random.Random(13)
+    X2 = 0xd201000000010000 ** 2
+    qmax = (O.R - 1) // X2
+    vals = []
+    for q in (0, 1, 2, (1 << 127) - 1, 1 << 127, qmax - 1, qmax):
+        for d in (0, 1, 2, X2 - 2, X2 - 1, X2 // 2 - 1, X2 // 2, X2 // 2 + 1, (1 << 127) - 1, 1 << 127, 1 << 64, (1 << 64) - 1):
+            k = q * X2 + d
+            if k < O.R:
+                vals.append(k)
+    vals += [X2 << s for s in range(0, 127, 9) if (X2 << s) < O.R]
+    vals += [O.R - 1 - X2, O.R - X2, (O.R - 1) // 2, (O.R + 1) // 2, (O.R - 1) // 2 - 1, (O.R + 1) // 2 + 1]
+    vals += [O.R - v for v in vals[:20] if v]
+    n = len(vals)
+    pts = gen_points(L, n, rnd)
+    sc = O.fr_array(vals)
+    check(L, kzg, pts, sc, n)
+    # one scalar at a time on a single point: isolates each split
+    for i in range(0, n, 5):
+        one = (O.G1Affine * 1)(pts[i])
+        check(L, kzg, one, O.fr_array([vals[i]]), 1)
+
+
 def test_sum_of_multiples_of_generator(oracle, kzg):
     # sum (i+1)*G with scalars (i+1), n = 255 (bls12_381.rs:184-219)
     L = oracle.lib()
