@@ -1,0 +1,144 @@
+// Fp spread over the lanes of a 16-lane DPP row: limb i of the 14 x 28-bit form (fp28.cuh) lives in lane i,
+// lanes 14 and 15 hold zero.  One element per wave (lanes 0..15 active, the rest idle).
+//
+// Why: the tails of the MSM (Horner over the window sums, the short per-window chains) are single dependency
+// chains of point doublings.  A lane that owns a whole field element issues ~490 VALU instructions per
+// multiplication and a wave cannot issue faster than one instruction per ~5 cycles however few lanes are live,
+// so the chain runs at ~8 us per doubling.  With the limbs across lanes the same multiplication is 14 steps of
+//     acc += a_i * b_j (b_j by v_readlane -> SGPR) ; m = acc_0 * p' (scalar ALU) ; acc += p_i * m ;
+//     acc_i <- low28(acc_{i+1}) + (acc_i >> 28)            (one DPP row shift folded into the add)
+// ~150 VALU instructions, three times shorter.  Only worth it where there is no other parallelism left.
+//
+// Representation: limbs <= 2^28 after wnorm (top limb, lane 13, unbounded); wmul/wsqr accept limbs < 2^29
+// (one lazy add of normalized values) and return normalized limbs, value < 2p under the same product bound as
+// fp28::mul.  Subtractions add a multiple of p whose low limbs are >= 2^29 - 2, so they never go negative.
+#pragma once
+#include "fp28.cuh"
+
+namespace fpw {
+using ff::u32;
+using ff::u64;
+constexpr u32 MASK = fp28::MASK;
+
+// lane i <- lane i-1 (lane 0 <- 0) / lane i <- lane i+1 (lane 15 <- 0), within the 16-lane row
+__device__ __forceinline__ u32 from_prev(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true); }
+__device__ __forceinline__ u32 from_next(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xF, 0xF, true); }
+
+// K*p with two units borrowed from each limb above: limbs 0..12 >= 2^29 - 2, same value as fp28::pad_l<K>
+template <int K>
+__device__ __forceinline__ constexpr u32 wpad_l(int i) {
+    return i >= 14 ? 0u : fp28::pad_l<K>(i) + (i <= 12 ? (1u << 28) : 0u) - (i >= 1 ? 1u : 0u);
+}
+
+// per-lane constants
+struct Lane {
+    u32 p;       // limb of p
+    u32 nmask;   // 2^28 - 1 for limbs 0..12, all ones above (the top limb keeps its excess)
+    u32 pad16, pad32;
+};
+
+__device__ __forceinline__ Lane lane_consts(int lane) {
+    constexpr u32 P[16] = {fp28::pl(0), fp28::pl(1), fp28::pl(2),  fp28::pl(3),  fp28::pl(4),  fp28::pl(5),  fp28::pl(6), fp28::pl(7),
+                           fp28::pl(8), fp28::pl(9), fp28::pl(10), fp28::pl(11), fp28::pl(12), fp28::pl(13), 0u,          0u};
+    constexpr u32 D16[16] = {wpad_l<16>(0), wpad_l<16>(1), wpad_l<16>(2),  wpad_l<16>(3),  wpad_l<16>(4),  wpad_l<16>(5),
+                             wpad_l<16>(6), wpad_l<16>(7), wpad_l<16>(8),  wpad_l<16>(9),  wpad_l<16>(10), wpad_l<16>(11),
+                             wpad_l<16>(12), wpad_l<16>(13), 0u, 0u};
+    constexpr u32 D32[16] = {wpad_l<32>(0), wpad_l<32>(1), wpad_l<32>(2),  wpad_l<32>(3),  wpad_l<32>(4),  wpad_l<32>(5),
+                             wpad_l<32>(6), wpad_l<32>(7), wpad_l<32>(8),  wpad_l<32>(9),  wpad_l<32>(10), wpad_l<32>(11),
+                             wpad_l<32>(12), wpad_l<32>(13), 0u, 0u};
+    Lane c;
+    c.p = P[lane & 15];
+    c.nmask = (lane & 15) < 13 ? MASK : 0xffffffffu;
+    c.pad16 = D16[lane & 15];
+    c.pad32 = D32[lane & 15];
+    return c;
+}
+
+// two carry rounds: limbs < 2^31 in, limbs <= 2^28 out (top limb absorbs)
+__device__ __forceinline__ u32 wnorm(u32 x, const Lane& c) {
+    x = (x & c.nmask) + from_prev((x & ~c.nmask) >> 28);
+    x = (x & c.nmask) + from_prev((x & ~c.nmask) >> 28);
+    return x;
+}
+
+// exact normalization (limbs 0..12 < 2^28): a carry travels at most 13 lanes
+__device__ __forceinline__ u32 wnorm_full(u32 x, const Lane& c) {
+#pragma unroll
+    for (int r = 0; r < fp28::L; ++r) x = (x & c.nmask) + from_prev((x & ~c.nmask) >> 28);
+    return x;
+}
+
+__device__ __forceinline__ u32 wadd(u32 a, u32 b) { return a + b; }  // lazy
+__device__ __forceinline__ u32 waddn(u32 a, u32 b, const Lane& c) { return wnorm(a + b, c); }
+// a + 16p - b, a + 32p - b (b normalized, value below 15p / 31p)
+__device__ __forceinline__ u32 wsub16(u32 a, u32 b, const Lane& c) { return wnorm(a + c.pad16 - b, c); }
+__device__ __forceinline__ u32 wsub32(u32 a, u32 b, const Lane& c) { return wnorm(a + c.pad32 - b, c); }
+
+// a * b * 2^-392 mod p
+__device__ __forceinline__ u32 wmul(u32 a, u32 b, const Lane& c) {
+    u32 acc = 0;
+#pragma unroll
+    for (int j = 0; j < fp28::L; ++j) {
+        const u32 bj = (u32)__builtin_amdgcn_readlane((int)b, j);
+        u64 t = (u64)a * bj + acc;
+        const u32 t0 = (u32)__builtin_amdgcn_readlane((int)(u32)t, 0);
+        const u32 m = (t0 * fp28::P0INV) & MASK;
+        t += (u64)c.p * m;
+        // lane 0 now holds a multiple of 2^28: drop it, everything moves one limb down
+        acc = from_next((u32)t & MASK) + (u32)(t >> 28);
+    }
+    return wnorm(acc, c);
+}
+__device__ __forceinline__ u32 wsqr(u32 a, const Lane& c) { return wmul(a, a, c); }
+
+// Jacobian doubling (dbl-2009-l with S = 4*X*YY as one product), the wide twin of the loop body of g1::dbl_k.
+// Bounds as there: X < 18p, Y < 17.1p, Z < 2.1p, all normalized.
+__device__ __forceinline__ void wdbl(u32& X, u32& Y, u32& Z, const Lane& c) {
+    const u32 A = wsqr(X, c), B = wsqr(Y, c), C = wsqr(B, c);
+    u32 S = wmul(X, B, c);
+    S = waddn(S, S, c);
+    S = waddn(S, S, c);                       // 4*X*YY
+    const u32 E = wnorm(A + A + A, c);        // 3*XX
+    const u32 X3 = wsub16(wsqr(E, c), waddn(S, S, c), c);
+    u32 C8 = waddn(C, C, c);
+    C8 = waddn(C8, C8, c);
+    C8 = waddn(C8, C8, c);                    // 8*YYYY
+    const u32 Y3 = wsub16(wmul(E, wsub32(S, X3, c), c), C8, c);
+    const u32 Z3 = wmul(Y, Z, c);
+    Z = waddn(Z3, Z3, c);
+    X = X3;
+    Y = Y3;
+}
+
+// The single-lane code that runs next to the wide code works on values that are the same in every lane.  The
+// compiler sees that and moves it to the scalar ALU, where a 64-bit multiply-add is four instructions instead
+// of one: keep such values in VGPRs.
+__device__ __forceinline__ void keep_in_vgprs(fp28::Fe& a) {
+#pragma unroll
+    for (int k = 0; k < fp28::L; ++k) asm volatile("" : "+v"(a.v[k]));
+}
+
+// single-lane element (the same value in every lane) <-> wide, through 16 words of LDS
+__device__ __forceinline__ u32 to_wide(const fp28::Fe& a, u32* sh, int lane) {
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < fp28::L; ++k) sh[k] = a.v[k];
+        sh[14] = 0;
+        sh[15] = 0;
+    }
+    __syncthreads();
+    return sh[lane & 15];
+}
+__device__ __forceinline__ fp28::Fe from_wide(u32 w, u32* sh, int lane) {
+    __syncthreads();
+    sh[lane & 15] = w;
+    __syncthreads();
+    fp28::Fe r;
+#pragma unroll
+    for (int k = 0; k < fp28::L; ++k) r.v[k] = sh[k];
+    keep_in_vgprs(r);
+    return r;
+}
+
+}  // namespace fpw

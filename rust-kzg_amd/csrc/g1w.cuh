@@ -1,0 +1,120 @@
+// G1 points with every coordinate spread over the lanes of a 16-lane row (fpw.cuh): XYZZ coordinates as in
+// g1_28.cuh, one point operation per wave, for the serial tails of the MSM where no other parallelism is left.
+// Coordinate bounds between calls: X, Y < 18p, ZZ, ZZZ < 2p, limbs <= 2^28.
+#pragma once
+#include "fpw.cuh"
+#include "g1_28.cuh"
+
+namespace g1w {
+using ff::u32;
+using ff::u64;
+using fpw::Lane;
+
+struct WPt {
+    u32 x, y, zzz, zz;  // this lane's limb of each coordinate
+};
+
+// infinity = ZZ all-zero, as in g1::Xyzz
+__device__ __forceinline__ bool is_inf(const WPt& p) { return __ballot(p.zz != 0) == 0; }
+__device__ __forceinline__ void set_inf(WPt& p) { p.x = p.y = p.zzz = p.zz = 0; }
+
+// lane i (< 14) of the row loads / stores limb i of each coordinate of a g1::Xyzz in memory
+__device__ __forceinline__ WPt load(const g1::Xyzz* src, int lane) {
+    WPt p;
+    const u32* w = (const u32*)src;
+    const int i = lane & 15;
+    const bool live = i < fp28::L;
+    p.x = live ? w[i] : 0u;
+    p.y = live ? w[fp28::L + i] : 0u;
+    p.zzz = live ? w[2 * fp28::L + i] : 0u;
+    p.zz = live ? w[3 * fp28::L + i] : 0u;
+    return p;
+}
+// stores exactly normalized limbs (what the single-lane code expects)
+__device__ __forceinline__ void store(g1::Xyzz* dst, const WPt& p, const Lane& c, int lane) {
+    u32* w = (u32*)dst;
+    const int i = lane & 15;
+    const u32 x = fpw::wnorm_full(p.x, c), y = fpw::wnorm_full(p.y, c), zzz = fpw::wnorm_full(p.zzz, c),
+              zz = fpw::wnorm_full(p.zz, c);
+    if (i < fp28::L) {
+        w[i] = x;
+        w[fp28::L + i] = y;
+        w[2 * fp28::L + i] = zzz;
+        w[3 * fp28::L + i] = zz;
+    }
+}
+
+// exact test a == 0 (mod p) for a normalized value < 64p (the wide twin of fp28::is_zero_mod_p): a multiple
+// k*p has k = a_0 * p_0^-1 mod 2^28 < 64, which almost no other value passes; the exact comparison runs on
+// the single-lane code behind that filter
+__device__ __forceinline__ bool is_zero_mod_p(u32 a, u32* sh, int lane) {
+    const u32 a0 = (u32)__builtin_amdgcn_readlane((int)a, 0);
+    const u32 k = (a0 * fp28::P0INV_POS) & fp28::MASK;
+    if (k >= 64) return false;
+    fp28::Fe f = fpw::from_wide(a, sh, lane);
+    fp28::norm(f);
+    return fp28::is_zero_mod_p(f);
+}
+
+// acc = 2 * acc (dbl-2008-s-1); acc != infinity
+__device__ __forceinline__ void dbl(WPt& acc, const Lane& c) {
+    using namespace fpw;
+    const u32 U = waddn(acc.y, acc.y, c);
+    const u32 V = wsqr(U, c), W = wmul(U, V, c), S = wmul(acc.x, V, c);
+    const u32 M = wsqr(acc.x, c);
+    const u32 M3 = wnorm(M + M + M, c);
+    const u32 X3 = wsub16(wsqr(M3, c), waddn(S, S, c), c);
+    const u32 Y3 = wsub16(wmul(M3, wsub32(S, X3, c), c), wmul(W, acc.y, c), c);
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = wmul(acc.zz, V, c);
+    acc.zzz = wmul(acc.zzz, W, c);
+}
+
+// acc += b (add-2008-s) with the exceptional cases of g1::dadd; sh = 16 words of LDS scratch
+__device__ __forceinline__ void dadd(WPt& acc, const WPt& b, const Lane& c, u32* sh, int lane) {
+    using namespace fpw;
+    if (is_inf(b)) return;
+    if (is_inf(acc)) {
+        acc = b;
+        return;
+    }
+    const u32 U = wmul(acc.x, b.zz, c), S = wmul(acc.y, b.zzz, c);
+    const u32 P = wsub32(wmul(b.x, acc.zz, c), U, c), R = wsub32(wmul(b.y, acc.zzz, c), S, c);
+    if (is_zero_mod_p(P, sh, lane)) {
+        if (is_zero_mod_p(R, sh, lane)) dbl(acc, c);
+        else set_inf(acc);
+        return;
+    }
+    const u32 PP = wsqr(P, c), PPP = wmul(P, PP, c), Q = wmul(U, PP, c);
+    const u32 X3 = wsub16(wsqr(R, c), wnorm(Q + Q + PPP, c), c);
+    const u32 Y3 = wsub16(wmul(R, wsub32(Q, X3, c), c), wmul(S, PPP, c), c);
+    acc.x = X3;
+    acc.y = Y3;
+    acc.zz = wmul(wmul(acc.zz, b.zz, c), PP, c);
+    acc.zzz = wmul(wmul(acc.zzz, b.zzz, c), PPP, c);
+}
+
+// acc = 2^k * acc through Jacobian doublings (7 multiplications each against 9 for the XYZZ form)
+__device__ __forceinline__ void dbl_k(WPt& acc, int k, const Lane& c) {
+    using namespace fpw;
+    if (k <= 0 || is_inf(acc)) return;
+    u32 X = wmul(acc.x, acc.zz, c), Y = wmul(acc.y, acc.zzz, c), Z = acc.zz;
+    for (int i = 0; i < k; ++i) wdbl(X, Y, Z, c);
+    acc.x = X;
+    acc.y = Y;
+    acc.zz = wsqr(Z, c);
+    acc.zzz = wmul(acc.zz, Z, c);
+}
+
+// wide -> single-lane (the same value in every lane), exactly normalized
+__device__ __forceinline__ g1::Xyzz to_single(const WPt& p, const Lane& c, u32* sh, int lane) {
+    g1::Xyzz r;
+    r.x = fpw::from_wide(fpw::wnorm_full(p.x, c), sh, lane);
+    r.y = fpw::from_wide(fpw::wnorm_full(p.y, c), sh, lane);
+    r.zzz = fpw::from_wide(fpw::wnorm_full(p.zzz, c), sh, lane);
+    r.zz = fpw::from_wide(fpw::wnorm_full(p.zz, c), sh, lane);
+    return r;
+}
+
+}  // namespace g1w

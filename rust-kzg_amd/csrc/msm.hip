@@ -27,6 +27,7 @@
 
 #include "../../include/kzg_mi355x.h"
 #include "g1_io.cuh"
+#include "g1w.cuh"
 #include "host_g1.h"
 #include "msm_internal.h"
 
@@ -150,6 +151,7 @@ struct DigitParams {
     size_t nb;       // buckets per set = 2^(c-1)
     size_t row_stride;  // prepared: points per table row; glv: offset of the [x^2]P half of the table
     int glv;         // 1: scalars are split k = k1 + k2*x^2 (two 128-bit halves, nwin windows each)
+    int w0, w1;      // windows [w0, w1) are emitted by this launch (the others only feed the digit carry)
 };
 
 // canonical 256-bit scalar (8 x u32) -> signed digit of window w, carrying from below
@@ -332,7 +334,7 @@ __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __rest
     for (int part = 0; part <= P.glv; ++part) {
         const u32* sv = part ? s2 : s;
         u32 carry = 0;
-        for (int w = 0; w < P.nwin; ++w) {
+        for (int w = 0; w < P.w1; ++w) {
             u32 d = window_bits(sv, w * P.c, P.c) + carry;
             u32 neg = 0;
             carry = 0;
@@ -341,6 +343,7 @@ __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __rest
                 neg = 1;
                 carry = 1;
             }
+            if (w < P.w0) continue;
             bool todo = d != 0;
             const size_t set = P.prepared ? b : b * P.nwin + w;
             const size_t slot = set * P.nb + (todo ? d - 1 : 0);
@@ -716,6 +719,63 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, co
     out[3 * b + 2] = j[2];
 }
 
+// The serial tails with limb-parallel arithmetic (fpw.cuh / g1w.cuh): one point operation per wave, ~3x shorter
+// instruction streams than the single-lane code.  Used when there are only a few chains (one large MSM).
+//
+// k_winsum_wide: one wave per set,  window sum = A + M + 2^logS * sum_q 2^q R_q
+__global__ void __launch_bounds__(64) k_winsum_wide(const Xyzz* __restrict__ top, Xyzz* __restrict__ win, int B, int logS) {
+    __shared__ u32 sh[16];
+    const int lane = threadIdx.x;
+    if (lane >= 16) return;
+    const fpw::Lane lc = fpw::lane_consts(lane);
+    const Xyzz* t = top + (size_t)blockIdx.x * (B + 2);
+    g1w::WPt acc;
+    g1w::set_inf(acc);
+    for (int q = B - 1; q >= 0; --q) {
+        if (!g1w::is_inf(acc)) g1w::dbl(acc, lc);
+        g1w::dadd(acc, g1w::load(t + q, lane), lc, sh, lane);
+    }
+    g1w::dbl_k(acc, logS, lc);
+    g1w::dadd(acc, g1w::load(t + B + 1, lane), lc, sh, lane);
+    g1w::dadd(acc, g1w::load(t + B, lane), lc, sh, lane);
+    g1w::store(win + blockIdx.x, acc, lc, lane);
+}
+
+// k_final_wide: Horner over the window sums of one variable-base MSM per wave
+__global__ void __launch_bounds__(64) k_final_wide(const Xyzz* __restrict__ win, void* __restrict__ out_v, int nwin, int c,
+                                                   int out_mode) {
+    __shared__ u32 sh[16];
+    const int lane = threadIdx.x;
+    if (lane >= 16) return;
+    const size_t b = blockIdx.x;
+    const fpw::Lane lc = fpw::lane_consts(lane);
+    g1w::WPt wacc = g1w::load(win + b * nwin + (nwin - 1), lane);
+    for (int w = nwin - 2; w >= 0; --w) {
+        g1w::dbl_k(wacc, c, lc);  // the curve has odd order: doubling never reaches infinity
+        g1w::dadd(wacc, g1w::load(win + b * nwin + w, lane), lc, sh, lane);
+    }
+    Xyzz acc = g1w::to_single(wacc, lc, sh, lane);
+    if (out_mode == kzgamd::OUT_COMPRESSED) {
+        unsigned char buf[48];
+        g1io::compress(buf, acc);
+        if (lane == 0) {
+            u32* o = (u32*)out_v + 12 * b;
+#pragma unroll
+            for (int k = 0; k < 12; ++k)
+                o[k] = (u32)buf[4 * k] | ((u32)buf[4 * k + 1] << 8) | ((u32)buf[4 * k + 2] << 16) | ((u32)buf[4 * k + 3] << 24);
+        }
+        return;
+    }
+    ff::Fp j[3];
+    g1::to_blst_jacobian(j, acc);
+    if (lane == 0) {
+        ff::Fp* out = (ff::Fp*)out_v;
+        out[3 * b] = j[0];
+        out[3 * b + 1] = j[1];
+        out[3 * b + 2] = j[2];
+    }
+}
+
 
 // ============================ wide fixed-base table ("FBW") ============================
 // With 288 GB of HBM per GPU the 4096-point setup can afford the full signed-window table
@@ -1013,6 +1073,11 @@ struct kzgamd::MsmContext {
     bool fbw = false;
     Workspace ws;
     hipStream_t stream = nullptr;
+    // window-group pipeline of the variable-base engine: one auxiliary stream per group, events to fork from /
+    // join into the caller's stream and to order the digit and accumulation kernels across groups
+    static constexpr int MAXG = 4;
+    hipStream_t aux[MAXG] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_dig[MAXG] = {}, ev_acc[MAXG] = {}, ev_done[MAXG] = {};
     bool profile = false;
     // per enqueue: start, accum-begin, accum-end, end (events on the launch stream)
     std::vector<hipEvent_t> ev;
@@ -1024,6 +1089,13 @@ struct kzgamd::MsmContext {
         ws.release();
         for (auto& e : ev)
             if (e) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (int g = 0; g < MAXG; ++g) {
+            if (ev_dig[g]) (void)hipEventDestroy(ev_dig[g]);
+            if (ev_acc[g]) (void)hipEventDestroy(ev_acc[g]);
+            if (ev_done[g]) (void)hipEventDestroy(ev_done[g]);
+            if (aux[g]) (void)hipStreamDestroy(aux[g]);
+        }
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -1142,7 +1214,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         const size_t lanes = (npoints + spl - 1) / spl;
         ws.buckets.ensure(nbatch * lanes);
         ws.lvlM[0].ensure(nbatch);
-        DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n, 0};
+        DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n, 0, 0, nwin};
         hipEvent_t* pev = nullptr;
         if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
             while (ctx->ev.size() < ctx->ev_used + 4) {
@@ -1187,10 +1259,27 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     ws.lvlA[1].ensure(nsets * n2);
     ws.lvlM[1].ensure(nsets * n2);
     ws.heavy.ensure(nsets * nb);
-    const size_t heavy_cap = nsets * set_cap / HEAVY + 1;  // a heavy bucket holds > HEAVY entries
-    ws.heavy_list.ensure(2 * heavy_cap);
-    ws.nheavy.ensure(1);
-    DigitParams P{npoints, nbatch, c, nwin, ctx->prepared ? 1 : 0, mont, nb, ctx->n, ctx->glv ? 1 : 0};
+    // Window groups.  The digit/sort kernels are bound by L2 atomics, the accumulation by the integer VALUs and the
+    // reduction tail by latency, so a single large MSM is cut into groups of windows that run as a pipeline on
+    // their own streams: digits of group g+1 overlap the accumulation of group g, whose tail overlaps the
+    // accumulation of g+1.  Only the Horner over the window sums (k_final) joins them.
+    int G = 1;
+    if (!ctx->prepared && nbatch == 1 && !ctx->profile && npoints >= ((size_t)1 << 19) && nwin >= 4) {
+        // measured at n = 2^20: 1 group 5.83 ms, 2 groups 5.47 ms, 4 groups slower (every group pays the scalar
+        // load + split again, and the tail of the last group is not hidden by anything)
+        G = 2;
+        if (const char* e = getenv("KZGAMD_GROUPS")) {
+            int v = atoi(e);
+            if (v >= 1 && v <= MsmContext::MAXG && v <= nwin) G = v;
+        }
+    }
+    const size_t sets_per_group = (nsets + G - 1) / G;
+    const size_t heavy_cap = sets_per_group * set_cap / HEAVY + 1;  // a heavy bucket holds > HEAVY entries
+    ws.heavy_list.ensure(2 * heavy_cap * G);
+    ws.nheavy.ensure(G);
+    const bool use_top = nsets <= 64;  // many independent sets (batched MSMs) keep plain tree levels busy on their own
+    // few chains: run the serial tails limb-parallel, one point operation per wave
+    const bool wide_tail = use_top && !getenv("KZGAMD_NO_WIDE_TAIL");
     hipEvent_t* pev = nullptr;
     if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
         while (ctx->ev.size() < ctx->ev_used + 4) {
@@ -1201,48 +1290,100 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         pev = &ctx->ev[ctx->ev_used];
         HIP_TRY(hipEventRecord(pev[0], stream));
     }
-    HIP_TRY(hipMemsetAsync(ws.counts.p, 0, nsets * nb * sizeof(u32), stream));
-    const unsigned gdig = (unsigned)((npoints * nbatch + 255) / 256);
-    hipLaunchKernelGGL(k_digits<0>, dim3(gdig), dim3(256), 0, stream, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
-                       (const u32*)nullptr, (u32*)nullptr, set_cap);
-    HIP_TRY(hipMemsetAsync(ws.nheavy.p, 0, sizeof(u32), stream));
-    hipLaunchKernelGGL(k_scan, dim3((unsigned)nsets), dim3(1024), 0, stream, ws.counts.p, ws.offsets.p, nb, ws.heavy.p,
-                       ws.heavy_list.p, ws.nheavy.p, (u32)heavy_cap);
-    hipLaunchKernelGGL(k_digits<1>, dim3(gdig), dim3(256), 0, stream, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
-                       (const u32*)ws.offsets.p, ws.sorted.p, set_cap);
-    if (pev) HIP_TRY(hipEventRecord(pev[1], stream));
-    hipLaunchKernelGGL(k_accum, dim3((unsigned)((nsets * nchunk + 255) / 256)), dim3(256), 0, stream,
-                       (const u32*)ws.offsets.p, (const u32*)ws.sorted.p, (const AffPt*)ctx->table.p, ws.buckets.p, nb, nsets,
-                       set_cap, nchunk);
-    if (pev) HIP_TRY(hipEventRecord(pev[2], stream));
-    hipLaunchKernelGGL(k_heavy, dim3(256, 16), dim3(64), 0, stream, ws.buckets.p, (const u32*)ws.offsets.p,
-                       (const u32*)ws.heavy_list.p, (const u32*)ws.nheavy.p, (u32)heavy_cap, nb, nchunk, 1u, HSEG);
-    hipLaunchKernelGGL(k_heavy, dim3(1024, 1), dim3(64), 0, stream, ws.buckets.p, (const u32*)ws.offsets.p,
-                       (const u32*)ws.heavy_list.p, (const u32*)ws.nheavy.p, (u32)heavy_cap, nb, nchunk, HSEG, 0u);
-    // bucket-reduction tree: GRP-ary levels while they are throughput work (nb -> nb/GRP -> ...), then the
-    // B + 2 concurrent plain sums of k_top and the short per-window Horner of k_winsum
+    if (G > 1) {
+        if (!ctx->ev_fork) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        for (int g = 0; g < G; ++g) {
+            if (!ctx->aux[g]) HIP_TRY(hipStreamCreateWithFlags(&ctx->aux[g], hipStreamNonBlocking));
+            if (!ctx->ev_dig[g]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_dig[g], hipEventDisableTiming));
+            if (!ctx->ev_acc[g]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_acc[g], hipEventDisableTiming));
+            if (!ctx->ev_done[g]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done[g], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(ctx->ev_fork, stream));
+    }
+    // shape of the tree (the same for every group: level 0 folds by the group size): k_top stride B + 2
+    size_t top_stride = 0;
     {
-        // many independent sets (batched MSMs) keep the levels busy on their own: plain tree down to one node
-        const bool use_top = nsets <= 64;
+        size_t nin = nb;
+        int lvl = 0;
+        do {
+            int grp = GRP;
+            if (lvl == 0)
+                while (grp > 2 && sets_per_group * ((nin + grp - 1) / grp) < ((size_t)1 << 17)) grp >>= 1;
+            nin = (nin + grp - 1) / grp;
+            ++lvl;
+        } while (nin > (use_top ? TOP_MAX : (size_t)1));
+        int B = 0;
+        while (((size_t)1 << B) < nin) ++B;
+        top_stride = (size_t)B + 2;
+        if (use_top) {
+            ws.top.ensure(nsets * top_stride);
+            ws.win.ensure(nsets);
+        }
+    }
+    const Xyzz *finA = nullptr, *finM = nullptr;
+    for (int g = 0; g < G; ++g) {
+        const size_t set0 = (size_t)g * sets_per_group;
+        if (set0 >= nsets) break;
+        const size_t ns = set0 + sets_per_group <= nsets ? sets_per_group : nsets - set0;
+        hipStream_t st = G > 1 ? ctx->aux[g] : stream;
+        if (G > 1) {
+            HIP_TRY(hipStreamWaitEvent(st, ctx->ev_fork, 0));
+            if (g > 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_dig[g - 1], 0));
+        }
+        // with groups, sets are windows (nbatch == 1): group g emits windows [set0, set0 + ns)
+        DigitParams P{npoints, nbatch, c, nwin, ctx->prepared ? 1 : 0, mont, nb, ctx->n, ctx->glv ? 1 : 0,
+                      G > 1 ? (int)set0 : 0, G > 1 ? (int)(set0 + ns) : nwin};
+        u32* counts = ws.counts.p + set0 * nb;
+        u32* offsets = ws.offsets.p + set0 * (nb + 1);
+        unsigned char* heavy = ws.heavy.p + set0 * nb;
+        u32* heavy_list = ws.heavy_list.p + 2 * heavy_cap * g;
+        u32* nheavy = ws.nheavy.p + g;
+        Xyzz* buckets = ws.buckets.p + set0 * (nb + nchunk);
+        HIP_TRY(hipMemsetAsync(counts, 0, ns * nb * sizeof(u32), st));
+        const unsigned gdig = (unsigned)((npoints * nbatch + 255) / 256);
+        // k_digits indexes sets globally (b * nwin + w): it gets the unshifted arrays
+        hipLaunchKernelGGL(k_digits<0>, dim3(gdig), dim3(256), 0, st, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
+                           (const u32*)nullptr, (u32*)nullptr, set_cap);
+        HIP_TRY(hipMemsetAsync(nheavy, 0, sizeof(u32), st));
+        hipLaunchKernelGGL(k_scan, dim3((unsigned)ns), dim3(1024), 0, st, counts, offsets, nb, heavy, heavy_list, nheavy,
+                           (u32)heavy_cap);
+        hipLaunchKernelGGL(k_digits<1>, dim3(gdig), dim3(256), 0, st, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
+                           (const u32*)ws.offsets.p, ws.sorted.p, set_cap);
+        if (G > 1) {
+            HIP_TRY(hipEventRecord(ctx->ev_dig[g], st));
+            if (g > 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_acc[g - 1], 0));
+        }
+        if (pev) HIP_TRY(hipEventRecord(pev[1], st));
+        hipLaunchKernelGGL(k_accum, dim3((unsigned)((ns * nchunk + 255) / 256)), dim3(256), 0, st, (const u32*)offsets,
+                           (const u32*)(ws.sorted.p + set0 * set_cap), (const AffPt*)ctx->table.p, buckets, nb, ns, set_cap,
+                           nchunk);
+        if (pev) HIP_TRY(hipEventRecord(pev[2], st));
+        if (G > 1) HIP_TRY(hipEventRecord(ctx->ev_acc[g], st));
+        hipLaunchKernelGGL(k_heavy, dim3(256, 16), dim3(64), 0, st, buckets, (const u32*)offsets, (const u32*)heavy_list,
+                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, 1u, HSEG);
+        hipLaunchKernelGGL(k_heavy, dim3(1024, 1), dim3(64), 0, st, buckets, (const u32*)offsets, (const u32*)heavy_list,
+                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, HSEG, 0u);
+        // bucket-reduction tree: GRP-ary levels while they are throughput work (nb -> nb/GRP -> ...), then the
+        // B + 2 concurrent plain sums of k_top and the short per-window Horner of k_winsum
         size_t nin = nb;
         int logS = 0, lvl = 0;
-        const Xyzz *inA = ws.buckets.p, *inM = nullptr;
+        const Xyzz *inA = buckets, *inM = nullptr;
         do {
             // level 0 also folds each bucket's pieces (entries/CHUNK + 1 of them): keep >= ~128k lanes in flight
             int grp = GRP, lg = 3;
             if (lvl == 0)
-                while (grp > 2 && nsets * ((nin + grp - 1) / grp) < ((size_t)1 << 17)) {
+                while (grp > 2 && sets_per_group * ((nin + grp - 1) / grp) < ((size_t)1 << 17)) {
                     grp >>= 1;
                     --lg;
                 }
             const size_t nout = (nin + grp - 1) / grp;
-            Xyzz *oA = ws.lvlA[lvl & 1].p, *oM = ws.lvlM[lvl & 1].p;
-            const unsigned grid = (unsigned)((nsets * nout + 127) / 128);
+            Xyzz *oA = ws.lvlA[lvl & 1].p + set0 * nout, *oM = ws.lvlM[lvl & 1].p + set0 * nout;
+            const unsigned grid = (unsigned)((ns * nout + 127) / 128);
             if (lvl == 0)
-                hipLaunchKernelGGL(k_level<true>, dim3(grid), dim3(128), 0, stream, inA, inM, oA, oM, nin, nsets, logS,
-                                   (const u32*)ws.offsets.p, (const unsigned char*)ws.heavy.p, nb, nchunk, grp);
+                hipLaunchKernelGGL(k_level<true>, dim3(grid), dim3(128), 0, st, inA, inM, oA, oM, nin, ns, logS,
+                                   (const u32*)offsets, (const unsigned char*)heavy, nb, nchunk, grp);
             else
-                hipLaunchKernelGGL(k_level<false>, dim3(grid), dim3(128), 0, stream, inA, inM, oA, oM, nin, nsets, logS,
+                hipLaunchKernelGGL(k_level<false>, dim3(grid), dim3(128), 0, st, inA, inM, oA, oM, nin, ns, logS,
                                    (const u32*)nullptr, (const unsigned char*)nullptr, nb, nchunk, grp);
             inA = oA;
             inM = oM;
@@ -1253,17 +1394,33 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         if (use_top) {
             int B = 0;
             while (((size_t)1 << B) < nin) ++B;
-            ws.top.ensure(nsets * (size_t)(B + 2));
-            ws.win.ensure(nsets);
-            hipLaunchKernelGGL(k_top, dim3((unsigned)(nsets * (size_t)(B + 2))), dim3(TOPT), TOPT * sizeof(Xyzz), stream, inA,
-                               inM, ws.top.p, nin, B);
-            hipLaunchKernelGGL(k_winsum, dim3((unsigned)((nsets + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)ws.top.p,
-                               ws.win.p, nsets, B, logS);
-            inA = nullptr;
-            inM = ws.win.p;
+            Xyzz* top = ws.top.p + set0 * top_stride;
+            hipLaunchKernelGGL(k_top, dim3((unsigned)(ns * (size_t)(B + 2))), dim3(TOPT), TOPT * sizeof(Xyzz), st, inA, inM,
+                               top, nin, B);
+            if (wide_tail)
+                hipLaunchKernelGGL(k_winsum_wide, dim3((unsigned)ns), dim3(64), 0, st, (const Xyzz*)top, ws.win.p + set0, B,
+                                   logS);
+            else
+                hipLaunchKernelGGL(k_winsum, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, st, (const Xyzz*)top,
+                                   ws.win.p + set0, ns, B, logS);
+            finA = nullptr;
+            finM = ws.win.p;
+        } else {
+            // plain tree: one (A, M) node per set, in the level buffers written last
+            finA = ws.lvlA[(lvl - 1) & 1].p;
+            finM = ws.lvlM[(lvl - 1) & 1].p;
         }
+        if (G > 1) {
+            HIP_TRY(hipEventRecord(ctx->ev_done[g], st));
+            HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done[g], 0));
+        }
+    }
+    if (wide_tail && !ctx->prepared && out_mode != OUT_WINDOWS && nwin > 1) {
+        // few independent Horner chains: one wave each, limb-parallel doublings
+        hipLaunchKernelGGL(k_final_wide, dim3((unsigned)nbatch), dim3(64), 0, stream, finM, d_out, nwin, c, out_mode);
+    } else {
         const size_t nfinal = out_mode == OUT_WINDOWS ? nbatch * (size_t)nwin : nbatch;
-        hipLaunchKernelGGL(k_final, dim3((unsigned)((nfinal + 63) / 64)), dim3(64), 0, stream, inA, inM, d_out, nbatch, nwin,
+        hipLaunchKernelGGL(k_final, dim3((unsigned)((nfinal + 63) / 64)), dim3(64), 0, stream, finA, finM, d_out, nbatch, nwin,
                            c, ctx->prepared ? 1 : 0, out_mode);
     }
     if (pev) {
