@@ -42,7 +42,9 @@ namespace {
 constexpr int GRP = 8;      // children folded per lane in the bucket-reduction tree
 constexpr u32 HEAVY = 512;  // entries above which a bucket's pieces are combined by a whole wave
 constexpr double FBW_DEFAULT_GB = 160.0;  // default HBM budget of one wide fixed-base table
-constexpr u32 CHUNK = 16;  // sorted entries per k_accum lane
+// sorted entries per k_accum lane ("chunk", a power of two passed as its log2): 32 for large MSMs (fewer pieces
+// per bucket for the reduction tree: n = 2^20 5.47 -> 5.38 ms, 2^22 19.2 -> 17.7 ms), 16 below 2^18, where the
+// accumulation is a latency chain of `chunk` mixed additions
 
 // ---------------------------------------------------------------- helpers
 struct HipErr {
@@ -384,7 +386,7 @@ __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __rest
 }
 
 // exclusive scan of counts[set][0..nb) -> offsets[set][0..nb]; zeroes counts for the scatter pass.
-// Buckets with more than HEAVY entries (> HEAVY/CHUNK pieces after k_accum) are flagged and listed
+// Buckets with more than HEAVY entries (> HEAVY/chunk pieces after k_accum) are flagged and listed
 // so that k_heavy can combine their pieces with a whole wave instead of one lane.
 __global__ void __launch_bounds__(1024) k_scan(u32* __restrict__ counts, u32* __restrict__ offsets, size_t nb,
                                                unsigned char* __restrict__ heavy, u32* __restrict__ heavy_list,
@@ -431,7 +433,7 @@ __global__ void __launch_bounds__(1024) k_scan(u32* __restrict__ counts, u32* __
     if (threadIdx.x == 0) off[nb] = base_s;
 }
 
-// Bucket accumulation, load-balanced: one lane per CHUNK consecutive entries of the sorted list
+// Bucket accumulation, load-balanced: one lane per `chunk` consecutive entries of the sorted list
 // (not per bucket), so skewed digit distributions (e.g. the < 2^248 elements of a "random blob",
 // or a blob of equal elements) cost the same as uniform ones.  A lane walks its chunk, keeps the
 // running sum of the current bucket and writes it out whenever the bucket changes and at the end
@@ -440,12 +442,13 @@ __global__ void __launch_bounds__(1024) k_scan(u32* __restrict__ counts, u32* __
 // unique, and bucket b's value is the sum of slots b + t for the chunks t its run touches.
 __global__ void __launch_bounds__(256) k_accum(const u32* __restrict__ offsets, const u32* __restrict__ sorted,
                                                const AffPt* __restrict__ pts, Xyzz* __restrict__ partials, size_t nb,
-                                               size_t nsets, size_t set_cap, size_t nchunk) {
+                                               size_t nsets, size_t set_cap, size_t nchunk, int lgc) {
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= nchunk * nsets) return;
     const size_t set = tid / nchunk, t = tid % nchunk;
     const u32* off = offsets + set * (nb + 1);
     const u32 total = off[nb];
+    const u32 CHUNK = 1u << lgc;
     const u32 base = (u32)(t * CHUNK);
     if (base >= total) return;
     const u32 end = base + CHUNK < total ? base + CHUNK : total;
@@ -487,7 +490,7 @@ __global__ void __launch_bounds__(256) k_accum(const u32* __restrict__ offsets, 
 constexpr u32 HSEG = 1024;
 __global__ void __launch_bounds__(64) k_heavy(Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
                                               const u32* __restrict__ heavy_list, const u32* __restrict__ nheavy,
-                                              u32 heavy_cap, size_t nb, size_t nchunk, u32 step, u32 span) {
+                                              u32 heavy_cap, size_t nb, size_t nchunk, u32 step, u32 span, int lgc) {
     __shared__ Xyzz sh[64];
     u32 cnt = *nheavy;
     if (cnt > heavy_cap) cnt = heavy_cap;
@@ -496,7 +499,7 @@ __global__ void __launch_bounds__(64) k_heavy(Xyzz* __restrict__ partials, const
         const size_t set = heavy_list[2 * idx], bk = heavy_list[2 * idx + 1];
         const u32* off = offsets + set * (nb + 1);
         Xyzz* pz = partials + set * (nb + nchunk) + bk;
-        const u32 t0 = off[bk] / CHUNK, t1 = (off[bk + 1] - 1) / CHUNK;
+        const u32 t0 = off[bk] >> lgc, t1 = (off[bk + 1] - 1) >> lgc;
         const u32 nelem = (t1 - t0) / step + 1;  // elements t0 + k*step, k < nelem
         const u32 nseg = span ? (nelem + span - 1) / span : 1;
         for (u32 seg = blockIdx.y; seg < nseg; seg += gridDim.y) {
@@ -526,11 +529,11 @@ __global__ void __launch_bounds__(64) k_heavy(Xyzz* __restrict__ partials, const
 
 // value of bucket bk of a set: sum of its pieces
 __device__ __forceinline__ void load_bucket(Xyzz& v, const Xyzz* __restrict__ partials, const u32* __restrict__ off,
-                                            const unsigned char* __restrict__ heavy, size_t bk) {
+                                            const unsigned char* __restrict__ heavy, size_t bk, int lgc) {
     const u32 beg = off[bk], end = off[bk + 1];
     g1::set_inf(v);
     if (end == beg) return;
-    const u32 t0 = beg / CHUNK, t1 = heavy[bk] ? t0 : (end - 1) / CHUNK;
+    const u32 t0 = beg >> lgc, t1 = heavy[bk] ? t0 : (end - 1) >> lgc;
     v = partials[bk + t0];
     for (u32 t = t0 + 1; t <= t1; ++t) {
         Xyzz pz = partials[bk + t];
@@ -549,7 +552,7 @@ __global__ void __launch_bounds__(128) k_level(const Xyzz* __restrict__ inA, con
                                                Xyzz* __restrict__ outA, Xyzz* __restrict__ outM, size_t nin, size_t nsets,
                                                int logS, const u32* __restrict__ offsets,
                                                const unsigned char* __restrict__ heavy, size_t nb, size_t nchunk,
-                                               int grp) {
+                                               int grp, int lgc) {
     const size_t nout = (nin + grp - 1) / grp;
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= nout * nsets) return;
@@ -562,7 +565,7 @@ __global__ void __launch_bounds__(128) k_level(const Xyzz* __restrict__ inA, con
     for (size_t k = hi; k-- > lo;) {
         Xyzz a;
         if (FIRST) {
-            load_bucket(a, inA + set * (nb + nchunk), offsets + set * (nb + 1), heavy + set * nb, k);
+            load_bucket(a, inA + set * (nb + nchunk), offsets + set * (nb + 1), heavy + set * nb, k, lgc);
         } else {
             a = inA[set * nin + k];
             Xyzz m = inM[set * nin + k];
@@ -1251,7 +1254,8 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     ws.counts.ensure(nsets * nb);
     ws.offsets.ensure(nsets * (nb + 1));
     ws.sorted.ensure(nsets * set_cap);
-    const size_t nchunk = (set_cap + CHUNK - 1) / CHUNK;
+    const int lgc = npoints >= ((size_t)1 << 18) ? 5 : 4;  // 8 was tried for n <= 2^14: slower (more pieces per bucket)
+    const size_t nchunk = (set_cap + ((size_t)1 << lgc) - 1) >> lgc;
     ws.buckets.ensure(nsets * (nb + nchunk));
     const size_t n1 = (nb + 1) / 2, n2 = (n1 + GRP - 1) / GRP;  // level 0 folds at least 2, later levels GRP
     ws.lvlA[0].ensure(nsets * n1);
@@ -1356,20 +1360,20 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         if (pev) HIP_TRY(hipEventRecord(pev[1], st));
         hipLaunchKernelGGL(k_accum, dim3((unsigned)((ns * nchunk + 255) / 256)), dim3(256), 0, st, (const u32*)offsets,
                            (const u32*)(ws.sorted.p + set0 * set_cap), (const AffPt*)ctx->table.p, buckets, nb, ns, set_cap,
-                           nchunk);
+                           nchunk, lgc);
         if (pev) HIP_TRY(hipEventRecord(pev[2], st));
         if (G > 1) HIP_TRY(hipEventRecord(ctx->ev_acc[g], st));
         hipLaunchKernelGGL(k_heavy, dim3(256, 16), dim3(64), 0, st, buckets, (const u32*)offsets, (const u32*)heavy_list,
-                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, 1u, HSEG);
+                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, 1u, HSEG, lgc);
         hipLaunchKernelGGL(k_heavy, dim3(1024, 1), dim3(64), 0, st, buckets, (const u32*)offsets, (const u32*)heavy_list,
-                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, HSEG, 0u);
+                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, HSEG, 0u, lgc);
         // bucket-reduction tree: GRP-ary levels while they are throughput work (nb -> nb/GRP -> ...), then the
         // B + 2 concurrent plain sums of k_top and the short per-window Horner of k_winsum
         size_t nin = nb;
         int logS = 0, lvl = 0;
         const Xyzz *inA = buckets, *inM = nullptr;
         do {
-            // level 0 also folds each bucket's pieces (entries/CHUNK + 1 of them): keep >= ~128k lanes in flight
+            // level 0 also folds each bucket's pieces (entries/chunk + 1 of them): keep >= ~128k lanes in flight
             int grp = GRP, lg = 3;
             if (lvl == 0)
                 while (grp > 2 && sets_per_group * ((nin + grp - 1) / grp) < ((size_t)1 << 17)) {
@@ -1381,10 +1385,10 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             const unsigned grid = (unsigned)((ns * nout + 127) / 128);
             if (lvl == 0)
                 hipLaunchKernelGGL(k_level<true>, dim3(grid), dim3(128), 0, st, inA, inM, oA, oM, nin, ns, logS,
-                                   (const u32*)offsets, (const unsigned char*)heavy, nb, nchunk, grp);
+                                   (const u32*)offsets, (const unsigned char*)heavy, nb, nchunk, grp, lgc);
             else
                 hipLaunchKernelGGL(k_level<false>, dim3(grid), dim3(128), 0, st, inA, inM, oA, oM, nin, ns, logS,
-                                   (const u32*)nullptr, (const unsigned char*)nullptr, nb, nchunk, grp);
+                                   (const u32*)nullptr, (const unsigned char*)nullptr, nb, nchunk, grp, lgc);
             inA = oA;
             inM = oM;
             nin = nout;
