@@ -167,6 +167,13 @@ C_KZG_RET kzgamd_compute_cells_and_kzg_proofs_batch(Cell *cells, KZGProof *proof
 /* the prepared-MSM handle behind a settings object (for kzgamd_msm_* calls) */
 void *kzgamd_settings_msm_handle(const CKZGSettings *s);
 
+/* Multi-GPU combine step of one large MSM sharded by index range over G ranks: every rank computes
+ * its partial with mult_pippenger / the device entry points over its slice of (points, scalars); the G
+ * 144-byte Jacobian partials are all-gathered and summed locally with this host-side helper (a G1 addition is
+ * not a reduction operator RCCL offers).  The reference has no multi-GPU path; its single-GPU call is
+ * blst/src/kzg_proofs.rs:47-61. */
+void kzgamd_g1_sum(blst_p1 *out, const blst_p1 in[], size_t n);
+
 /* library / device info */
 int kzgamd_device_count(void);
 const char *kzgamd_version(void);

@@ -53,7 +53,7 @@ EXPORTS = [
     "kzgamd_msm_prepared_batch_device", "kzgamd_msm_info", "kzgamd_msm_uses_wide_table", "kzgamd_msm_set_profile", "kzgamd_msm_get_profile",
     "kzgamd_device_count", "kzgamd_version", "kzgamd_msm_create_device", "kzgamd_generate_points",
     "kzgamd_ntt_new", "kzgamd_ntt_free", "ntt_fr", "das_fft_extension", "kzgamd_ntt_fr_device", "kzgamd_ntt_roots",
-    "fft_g1", "kzgamd_fft_g1_batch",
+    "fft_g1", "kzgamd_fft_g1_batch", "kzgamd_g1_sum",
     "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
     "compute_kzg_proof", "compute_blob_kzg_proof", "kzgamd_compute_blob_kzg_proof_batch", "compute_challenge",
     "bytes_to_kzg_commitment", "bytes_from_bls_field", "compute_cells_and_kzg_proofs",
@@ -120,6 +120,8 @@ def lib():
     L.das_fft_extension.argtypes = [vp, vp, vp, sz]
     L.kzgamd_ntt_fr_device.restype = C.c_int
     L.kzgamd_ntt_fr_device.argtypes = [vp, vp, vp, sz, sz, C.c_int, vp]
+    L.kzgamd_g1_sum.restype = None
+    L.kzgamd_g1_sum.argtypes = [vp, vp, sz]
     L.fft_g1.restype = C.c_int
     L.fft_g1.argtypes = [vp, vp, vp, sz, C.c_int]
     L.kzgamd_fft_g1_batch.restype = C.c_int
@@ -355,6 +357,17 @@ def generate_points(d_out, npoints, seed, stream=0):
 
 
 # ---------------------------------------------------------------- NTT plug-in (B2)
+def g1_sum(points):
+    """Sum of Jacobian blst_p1 values given as 144-byte strings (host arithmetic; the combine step of msm_sharded)."""
+    n = len(points)
+    buf = (BlstP1 * max(n, 1))()
+    for i, pt in enumerate(points):
+        C.memmove(C.byref(buf[i]), bytes(pt), 144)
+    out = BlstP1()
+    lib().kzgamd_g1_sum(C.byref(out), buf, n)
+    return bytes(out)
+
+
 class FFTSettings:
     """Mirror of FsFFTSettings (blst/src/types/fft_settings.rs:14-58) + FFTFr / DASExtension
     (blst/src/fft_fr.rs:156-165, blst/src/data_availability_sampling.rs:78-100).

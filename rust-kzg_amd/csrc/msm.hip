@@ -1614,6 +1614,20 @@ extern "C" void* kzgamd_msm_create_device(const void* d_points_affine, size_t np
     }
 }
 
+// sum of n Jacobian points on the host: the combine step of a large MSM sharded over several GPUs (each rank's
+// partial result is one 144-byte point; group addition is not a collective reduction op, so the partials are
+// all-gathered and added locally).  Pure host arithmetic, no device needed.
+extern "C" void kzgamd_g1_sum(blst_p1* out, const blst_p1* in, size_t n) {
+    kzgamd::HostJac acc;
+    acc.x = acc.y = acc.z = ff::Fp::zero();
+    for (size_t i = 0; i < n; ++i) {
+        kzgamd::HostJac p;
+        memcpy(&p, &in[i], sizeof p);
+        acc = kzgamd::host_jac_add(acc, p);
+    }
+    memcpy(out, &acc, sizeof acc);
+}
+
 extern "C" int kzgamd_device_count(void) {
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;

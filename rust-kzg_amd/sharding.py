@@ -1,4 +1,5 @@
-"""Whole-blob sharding across the GPUs of one node.
+"""Sharding across the GPUs of one node: whole blobs for batched commit / prove, index ranges
+for one large MSM.
 
 Blobs are independent units: rank r takes a contiguous slab of the batch, runs the single-GPU
 pipeline on it with its own replica of the fixed-base table, and the 48-byte results are gathered.
@@ -35,3 +36,21 @@ def commit_sharded(blobs: Sequence[bytes], commit_batch: Callable[[List[bytes]],
     if len(out) != len(blobs):
         raise RuntimeError("sharded commit lost results")
     return out
+
+
+def msm_sharded(n_points: int, msm_partial: Callable[[int, int], bytes], g1_sum: Callable[[List[bytes]], bytes],
+                dist=None) -> bytes:
+    """One large MSM split by index range: rank r computes the partial sum over points/scalars [lo, hi) with
+    `msm_partial(lo, hi)` (a 144-byte Jacobian blst_p1; the GPU engine in production), the partials are
+    all-gathered (world x 144 bytes, the only exchange step) and every rank adds them with `g1_sum`
+    (kzgamd_g1_sum: a group addition is not a reduction op a collective library offers)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return msm_partial(0, n_points)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(n_points, world, rank)
+    mine = msm_partial(lo, hi) if hi > lo else bytes(144)  # empty slice: the point at infinity (Z == 0)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    if any(len(p) != 144 for p in gathered):
+        raise RuntimeError("sharded MSM: malformed partial")
+    return g1_sum(gathered)

@@ -146,3 +146,61 @@ def test_sharded_commit_two_ranks_gloo(tmp_path):
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % rank in o
+
+
+MSM_WORKER = r'''
+import ctypes as C, os, sys, random, importlib.util
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch.distributed as dist
+from importlib import util
+spec = util.spec_from_file_location("sharding", os.path.join(ROOT, "rust-kzg_amd", "sharding.py"))
+sh = util.module_from_spec(spec); spec.loader.exec_module(sh)
+path = os.path.join(ROOT, "rust-kzg_amd", "__init__.py")
+spec = importlib.util.spec_from_file_location("rust_kzg_amd", path, submodule_search_locations=[os.path.dirname(path)])
+kzg = importlib.util.module_from_spec(spec); sys.modules["rust_kzg_amd"] = kzg; spec.loader.exec_module(kzg)
+import oracle_ffi as O
+L = O.lib()
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % PORT, rank=RANK, world_size=2)
+rnd = random.Random(9)
+n = 37
+g = O.G1(); L.og1_generator(C.byref(g))
+pts = (O.G1Affine * n)()
+for i in range(n):
+    t = O.G1(); k = O.fr_from_int(rnd.randrange(1, O.R))
+    L.og1_mul(C.byref(t), C.byref(g), C.byref(k)); L.og1_to_affine(C.byref(pts[i]), C.byref(t))
+sc = O.fr_array([rnd.randrange(O.R) for _ in range(n)])
+calls = []
+def partial(lo, hi):   # the per-rank engine: here the CPU oracle over the slice
+    calls.append((lo, hi))
+    out = O.G1()
+    L.omsm_affine(C.byref(out), C.cast(C.byref(pts, lo * 96), C.POINTER(O.G1Affine)),
+                  C.cast(C.byref(sc, lo * 32), C.POINTER(O.Fr)), hi - lo)
+    return bytes(out)
+got = sh.msm_sharded(n, partial, kzg.g1_sum, dist)   # combine step = the product's host helper
+assert calls == [sh.shard_range(n, 2, RANK)], calls
+full = O.G1(); L.omsm_affine(C.byref(full), pts, sc, n)
+a = O.G1(); C.memmove(C.byref(a), got, 144)
+assert L.og1_equal(C.byref(a), C.byref(full)) == 1
+# degenerate shapes: fewer points than ranks, and the empty sum
+one = sh.msm_sharded(1, partial, kzg.g1_sum, dist)
+b = O.G1(); C.memmove(C.byref(b), one, 144)
+exp = O.G1(); L.omsm_affine(C.byref(exp), pts, sc, 1)
+assert L.og1_equal(C.byref(b), C.byref(exp)) == 1
+assert kzg.g1_sum([]) == bytes(144)
+dist.barrier()
+dist.destroy_process_group()
+print("rank", RANK, "ok")
+'''
+
+
+def test_sharded_large_msm_two_ranks_gloo():
+    # SURVEY 8(e): one large MSM split by index range, partials all-gathered and added with kzgamd_g1_sum
+    port = 30100 + (os.getpid() % 500)
+    procs = []
+    for rank in range(2):
+        code = "ROOT=%r\nPORT=%d\nRANK=%d\n" % (ROOT, port, rank) + MSM_WORKER
+        procs.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % rank in o

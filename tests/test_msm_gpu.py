@@ -120,6 +120,27 @@ def test_glv_split_boundaries(oracle, kzg):
         check(L, kzg, one, O.fr_array([vals[i]]), 1)
 
 
+def test_index_range_partials_combine_with_g1_sum(oracle, kzg):
+    """The multi-GPU split of one MSM (sharding.msm_sharded), run here as three slices on one GPU: the
+    partials added by the library's host helper equal the whole MSM."""
+    L = oracle.lib()
+    rnd = random.Random(14)
+    n = 301
+    pts = gen_points(L, n, rnd)
+    sc = O.fr_array([rnd.randrange(O.R) for _ in range(n)])
+    parts = []
+    for lo, hi in ((0, 100), (100, 101), (101, n)):
+        sub_p = C.cast(C.byref(pts, lo * 96), C.POINTER(O.G1Affine * (hi - lo))).contents
+        sub_s = C.cast(C.byref(sc, lo * 32), C.POINTER(O.Fr * (hi - lo))).contents
+        parts.append(bytes(kzg.multi_scalar_mult(sub_p, sub_s, hi - lo)))
+    parts.append(bytes(144))  # a rank with an empty slice contributes the point at infinity
+    total = O.G1()
+    C.memmove(C.byref(total), kzg.g1_sum(parts), 144)
+    exp = O.G1()
+    L.omsm_affine(C.byref(exp), pts, sc, n)
+    assert compressed(L, total) == compressed(L, exp)
+
+
 def test_sum_of_multiples_of_generator(oracle, kzg):
     # sum (i+1)*G with scalars (i+1), n = 255 (bls12_381.rs:184-219)
     L = oracle.lib()
