@@ -311,12 +311,14 @@ __device__ __forceinline__ void glv_split(const u32 kin[8], u32 k1[8], u32 k2[8]
     neg2 = flip ? 1u : 0u;
 }
 
-// pass 0: histogram; pass 1: scatter (recomputes the digits instead of storing them)
+// pass 0: histogram — the value the atomic returns is the entry's rank inside its bucket, kept in `ranks`
+// (one word per (part, window, scalar), coalesced); pass 1: scatter to offsets[bucket] + rank with no atomics at
+// all (recomputes the digits instead of storing them)
 template <int PASS>
 __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __restrict__ scalars,
                                                 const AffPt* __restrict__ pts, u32* __restrict__ counts,
                                                 const u32* __restrict__ offsets, u32* __restrict__ sorted,
-                                                size_t set_cap) {
+                                                size_t set_cap, u32* __restrict__ ranks) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= P.n * P.nbatch) return;
     size_t b = t / P.n, i = t % P.n;
@@ -349,7 +351,16 @@ __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __rest
             bool todo = d != 0;
             const size_t set = P.prepared ? b : b * P.nwin + w;
             const size_t slot = set * P.nb + (todo ? d - 1 : 0);
-            u32 rank = 0;  // position inside the bucket (scatter pass)
+            u32* rank_slot = ranks + ((size_t)(part * P.nwin + w) * P.nbatch * P.n + t);
+            if (PASS == 1) {
+                if (todo) {
+                    const u32 pos = offsets[set * (P.nb + 1) + (d - 1)] + *rank_slot;
+                    const u32 pidx = P.prepared ? (u32)((size_t)w * P.row_stride + i) : (u32)(part ? P.row_stride + i : i);
+                    sorted[set * set_cap + pos] = pidx | ((neg ^ pneg[part]) << 31);
+                }
+                continue;
+            }
+            u32 rank = 0;  // position inside the bucket
             // Lanes of a wave that hit the same bucket share one atomic: a short top window, the carry-only
             // window and blobs of equal elements put thousands of entries on one counter, and same-address
             // atomics serialise.  Groups of fewer than 4 lanes are left to the plain per-lane atomic below, and
@@ -376,11 +387,7 @@ __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __rest
             }
             const bool mine = d != 0;
             if (todo) rank = atomicAdd(&counts[slot], 1u);
-            if (PASS == 1 && mine) {
-                const u32 pos = offsets[set * (P.nb + 1) + (d - 1)] + rank;
-                const u32 pidx = P.prepared ? (u32)((size_t)w * P.row_stride + i) : (u32)(part ? P.row_stride + i : i);
-                sorted[set * set_cap + pos] = pidx | ((neg ^ pneg[part]) << 31);
-            }
+            if (mine) *rank_slot = rank;
         }
     }
 }
@@ -1037,7 +1044,7 @@ struct DevBuf {
 };
 
 struct Workspace {
-    DevBuf<u32> counts, offsets, sorted, scalars;
+    DevBuf<u32> counts, offsets, sorted, scalars, ranks;
     DevBuf<Xyzz> buckets, lvlA[2], lvlM[2], top, win;
     DevBuf<unsigned char> heavy;
     DevBuf<u32> heavy_list, nheavy;
@@ -1046,6 +1053,7 @@ struct Workspace {
         counts.release();
         offsets.release();
         sorted.release();
+        ranks.release();
         scalars.release();
         buckets.release();
         for (int k = 0; k < 2; ++k) {
@@ -1254,6 +1262,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     ws.counts.ensure(nsets * nb);
     ws.offsets.ensure(nsets * (nb + 1));
     ws.sorted.ensure(nsets * set_cap);
+    ws.ranks.ensure((size_t)(ctx->glv ? 2 : 1) * nwin * nbatch * npoints);
     const int lgc = npoints >= ((size_t)1 << 18) ? 5 : 4;  // 8 was tried for n <= 2^14: slower (more pieces per bucket)
     const size_t nchunk = (set_cap + ((size_t)1 << lgc) - 1) >> lgc;
     ws.buckets.ensure(nsets * (nb + nchunk));
@@ -1347,12 +1356,12 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         const unsigned gdig = (unsigned)((npoints * nbatch + 255) / 256);
         // k_digits indexes sets globally (b * nwin + w): it gets the unshifted arrays
         hipLaunchKernelGGL(k_digits<0>, dim3(gdig), dim3(256), 0, st, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
-                           (const u32*)nullptr, (u32*)nullptr, set_cap);
+                           (const u32*)nullptr, (u32*)nullptr, set_cap, ws.ranks.p);
         HIP_TRY(hipMemsetAsync(nheavy, 0, sizeof(u32), st));
         hipLaunchKernelGGL(k_scan, dim3((unsigned)ns), dim3(1024), 0, st, counts, offsets, nb, heavy, heavy_list, nheavy,
                            (u32)heavy_cap);
         hipLaunchKernelGGL(k_digits<1>, dim3(gdig), dim3(256), 0, st, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
-                           (const u32*)ws.offsets.p, ws.sorted.p, set_cap);
+                           (const u32*)ws.offsets.p, ws.sorted.p, set_cap, ws.ranks.p);
         if (G > 1) {
             HIP_TRY(hipEventRecord(ctx->ev_dig[g], st));
             if (g > 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_acc[g - 1], 0));
