@@ -3,8 +3,9 @@
 //! NOT COMPILED in the build image (no rustc/cargo there); every behaviour that matters is implemented
 //! and tested on the C side of this boundary.  Mapping to the reference:
 //!   * `GpuMsm` / `msm_prepared` / `msm`  <->  blst-sppark/src/lib.rs:8-62 (same three C symbols)
-//!   * `GpuNtt::fft_fr` / `das_fft_extension`  <->  blst/src/fft_fr.rs:156-165,
-//!     blst/src/data_availability_sampling.rs:78-100
+//!   * `GpuNtt::fft_fr` / `das_fft_extension` / `fft_g1`  <->  blst/src/fft_fr.rs:156-165,
+//!     blst/src/data_availability_sampling.rs:78-100, blst/src/fft_g1.rs:54-83
+//!   * `g1_sum`  —  combine step of one MSM split over several GPUs
 use blst::{blst_fr, blst_p1, blst_p1_affine};
 use core::ffi::{c_char, c_int, c_void};
 
@@ -26,6 +27,8 @@ extern "C" {
     fn kzgamd_ntt_free(ctx: *mut c_void);
     fn ntt_fr(ctx: *mut c_void, out: *mut blst_fr, input: *const blst_fr, n: usize, inverse: c_int) -> c_int;
     fn das_fft_extension(ctx: *mut c_void, odds: *mut blst_fr, evens: *const blst_fr, half_n: usize) -> c_int;
+    fn fft_g1(ctx: *mut c_void, out: *mut blst_p1, input: *const blst_p1, n: usize, inverse: c_int) -> c_int;
+    fn kzgamd_g1_sum(out: *mut blst_p1, input: *const blst_p1, n: usize);
 }
 
 fn check(err: RustError, what: &str) -> Result<(), String> {
@@ -142,6 +145,17 @@ impl GpuNtt {
         }
     }
 
+    /// `FFTG1::fft_g1` (blst/src/fft_g1.rs:54-83); results equal the reference's as group elements.
+    pub fn fft_g1(&self, data: &[blst_p1], inverse: bool) -> Result<Vec<blst_p1>, String> {
+        let mut out = vec![blst_p1::default(); data.len()];
+        match unsafe { fft_g1(self.ctx, out.as_mut_ptr(), data.as_ptr(), data.len(), inverse as c_int) } {
+            0 => Ok(out),
+            1 => Err(String::from("Supplied list is longer than the available max width")),
+            2 => Err(String::from("A list with power-of-two length expected")),
+            e => Err(format!("GPU fft_g1 failed: {e}")),
+        }
+    }
+
     /// `DASExtension::das_fft_extension`.
     pub fn das_fft_extension(&self, evens: &[blst_fr]) -> Result<Vec<blst_fr>, String> {
         let mut out = vec![blst_fr::default(); evens.len()];
@@ -159,4 +173,11 @@ impl Drop for GpuNtt {
     fn drop(&mut self) {
         unsafe { kzgamd_ntt_free(self.ctx) }
     }
+}
+
+/// Sum of Jacobian points on the host: each rank of a multi-GPU MSM contributes one partial.
+pub fn g1_sum(partials: &[blst_p1]) -> blst_p1 {
+    let mut out = blst_p1::default();
+    unsafe { kzgamd_g1_sum(&mut out, partials.as_ptr(), partials.len()) };
+    out
 }
