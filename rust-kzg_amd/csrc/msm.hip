@@ -1248,8 +1248,19 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             hipLaunchKernelGGL(k_fbw_accum<4>, grid, dim3(256), 0, stream, P, (const u32*)d_scalars,
                                (const WidePt*)ctx->wide.p, ws.buckets.p, lanes);
         if (pev) HIP_TRY(hipEventRecord(pev[2], stream));
-        hipLaunchKernelGGL(k_blocksum, dim3((unsigned)nbatch), dim3(256), 256 * sizeof(Xyzz), stream,
-                           (const Xyzz*)ws.buckets.p, ws.lvlM[0].p, lanes);
+        if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) {
+            // a few MSMs: the one-workgroup-per-MSM fold is a latency chain (16 strided additions + 8 tree rounds);
+            // 16 workgroups per MSM and a second small fold take 9 + 6 rounds instead (single commitment call
+            // 0.83 -> 0.71 ms).  Splitting the windows of a scalar over 3 lanes as well was measured: no gain.
+            ws.lvlA[0].ensure(nbatch * 16);
+            hipLaunchKernelGGL(k_blocksum, dim3((unsigned)(nbatch * 16)), dim3(256), 256 * sizeof(Xyzz), stream,
+                               (const Xyzz*)ws.buckets.p, ws.lvlA[0].p, lanes / 16);
+            hipLaunchKernelGGL(k_blocksum, dim3((unsigned)nbatch), dim3(64), 64 * sizeof(Xyzz), stream,
+                               (const Xyzz*)ws.lvlA[0].p, ws.lvlM[0].p, (size_t)16);
+        } else {
+            hipLaunchKernelGGL(k_blocksum, dim3((unsigned)nbatch), dim3(256), 256 * sizeof(Xyzz), stream,
+                               (const Xyzz*)ws.buckets.p, ws.lvlM[0].p, lanes);
+        }
         hipLaunchKernelGGL(k_final, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)nullptr,
                            (const Xyzz*)ws.lvlM[0].p, d_out, nbatch, nwin, c, 1, out_mode);
         if (pev) {
