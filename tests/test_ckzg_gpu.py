@@ -326,3 +326,55 @@ def test_batch_256_blobs_commit_and_prove(kzg, settings, oracle, oracle_settings
     for b in range(0, n, 16):
         batch.update(cms[b] + proofs[b])
     assert singles.digest() == batch.digest()
+
+
+def test_concurrent_callers_share_one_settings_handle(kzg, settings, oracle, oracle_settings):
+    """The reference shares the settings / MSM handle through Arc and calls it from rayon workers
+    (kzg/src/eip_4844.rs:781-805): eight threads commit and prove at once on one CKZGSettings and on one prepared
+    MSM handle; every result equals the sequential one."""
+    import threading
+
+    L = oracle.lib()
+    rnd = random.Random(91)
+    nblobs = 8
+    blobs = []
+    for _ in range(nblobs):
+        b = bytearray(rnd.randbytes(BLOB))
+        for i in range(0, BLOB, 32):
+            b[i] = 0
+        blobs.append(bytes(b))
+    want_c = [kzg.blob_to_kzg_commitment(b, settings) for b in blobs]
+    want_p = [kzg.compute_blob_kzg_proof(b, c, settings) for b, c in zip(blobs, want_c)]
+    ec = C.create_string_buffer(48)
+    assert L.oblob_to_kzg_commitment(ec, blobs[0], C.byref(oracle_settings)) == 0
+    assert want_c[0] == ec.raw
+    n = 64
+    pts = (O.G1Affine * n)()
+    g = O.G1()
+    L.og1_generator(C.byref(g))
+    for i in range(n):
+        t = O.G1()
+        k = O.fr_from_int(rnd.randrange(1, O.R))
+        L.og1_mul(C.byref(t), C.byref(g), C.byref(k))
+        L.og1_to_affine(C.byref(pts[i]), C.byref(t))
+    scs = [O.fr_array([rnd.randrange(O.R) for _ in range(n)]) for _ in range(nblobs)]
+    h = kzg.prepare_multi_scalar_mult(pts, n)
+    want_m = [bytes(kzg.multi_scalar_mult_prepared(h, sc, n)) for sc in scs]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(3):
+                assert kzg.blob_to_kzg_commitment(blobs[i], settings) == want_c[i]
+                assert kzg.compute_blob_kzg_proof(blobs[i], want_c[i], settings) == want_p[i]
+                assert bytes(kzg.multi_scalar_mult_prepared(h, scs[i], n)) == want_m[i]
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(nblobs)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    h.close()
+    assert not errors, errors
