@@ -160,6 +160,13 @@ C_KZG_RET kzgamd_blob_to_kzg_commitment_device(void *d_out, void *d_status, void
 /* EIP-7594: cells (128 x 2048 B) and cell proofs (128 x 48 B) of a blob, same name
  * and signature as the reference (kzg/src/eth/c_bindings.rs:356-372); either output may be NULL, not
  * both.  The first call that asks for proofs builds a second wide table over g1_values_monomial. */
+/* compute_challenges_and_evaluate_polynomial (kzg/src/eip_4844.rs:690-719): the per-blob field work of
+ * verify_blob_kzg_proof_batch (:736-832) — z_i = Fiat-Shamir challenge of (blob_i, commitment_i), y_i = p_i(z_i),
+ * both 32-byte big-endian.  Commitments are validated (decode + subgroup) as validate_batched_input does.  The
+ * pairing side (verify_kzg_proof_batch, :380-435) stays on the caller's CPU backend. */
+C_KZG_RET kzgamd_compute_challenges_and_evaluate_batch(Bytes32 *zs_out, Bytes32 *ys_out, const Blob *blobs,
+                                                       const Bytes48 *commitments, size_t n, const CKZGSettings *s);
+
 typedef struct { uint8_t bytes[2048]; } Cell;
 C_KZG_RET compute_cells_and_kzg_proofs(Cell *cells, KZGProof *proofs, const Blob *blob, const CKZGSettings *s);
 C_KZG_RET kzgamd_compute_cells_and_kzg_proofs_batch(Cell *cells, KZGProof *proofs, const Blob *blobs, size_t n,

@@ -57,7 +57,7 @@ EXPORTS = [
     "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
     "compute_kzg_proof", "compute_blob_kzg_proof", "kzgamd_compute_blob_kzg_proof_batch", "compute_challenge",
     "bytes_to_kzg_commitment", "bytes_from_bls_field", "compute_cells_and_kzg_proofs",
-    "kzgamd_compute_cells_and_kzg_proofs_batch",
+    "kzgamd_compute_cells_and_kzg_proofs_batch", "kzgamd_compute_challenges_and_evaluate_batch",
     "kzgamd_blob_to_kzg_commitment_batch", "kzgamd_blob_to_kzg_commitment_device", "kzgamd_settings_msm_handle",
 ]
 
@@ -136,6 +136,8 @@ def lib():
     L.load_trusted_setup_file.argtypes = [sp, vp]
     L.free_trusted_setup.restype = None
     L.free_trusted_setup.argtypes = [sp]
+    L.kzgamd_compute_challenges_and_evaluate_batch.restype = C.c_int
+    L.kzgamd_compute_challenges_and_evaluate_batch.argtypes = [vp, vp, vp, vp, sz, sp]
     L.blob_to_kzg_commitment.restype = C.c_int
     L.blob_to_kzg_commitment.argtypes = [vp, vp, sp]
     L.kzgamd_blob_to_kzg_commitment_batch.restype = C.c_int
@@ -475,6 +477,16 @@ def compute_blob_kzg_proof_batch(blobs: bytes, commitments: bytes, n: int, setti
     if rc != C_KZG_OK:
         raise KzgAmdError("kzgamd_compute_blob_kzg_proof_batch: C_KZG_RET %d" % rc)
     return [out.raw[48 * i:48 * i + 48] for i in range(n)]
+
+
+def compute_challenges_and_evaluate_batch(blobs: bytes, commitments: bytes, n: int, settings: KZGSettings):
+    """compute_challenges_and_evaluate_polynomial (kzg/src/eip_4844.rs:690-719): per blob the Fiat-Shamir challenge z
+    and y = p(z), 32-byte big-endian each — the field work of verify_blob_kzg_proof_batch."""
+    zs, ys = C.create_string_buffer(32 * n), C.create_string_buffer(32 * n)
+    rc = lib().kzgamd_compute_challenges_and_evaluate_batch(zs, ys, blobs, commitments, n, C.byref(settings.c))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("kzgamd_compute_challenges_and_evaluate_batch: C_KZG_RET %d" % rc)
+    return ([zs.raw[32 * i:32 * i + 32] for i in range(n)], [ys.raw[32 * i:32 * i + 32] for i in range(n)])
 
 
 def compute_challenge(blob: bytes, commitment_p1) -> BlstFr:

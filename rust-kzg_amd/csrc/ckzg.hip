@@ -674,10 +674,11 @@ void commit_enqueue(KzgAmdSettings* dev, void* d_out, int* d_status, const void*
 
 
 // blobs + evaluation points (device) -> proofs (48 B) + y (canonical limbs), all on `stream`
-void prove_enqueue(KzgAmdSettings* dev, size_t n, hipStream_t stream) {
+void prove_enqueue(KzgAmdSettings* dev, size_t n, hipStream_t stream, bool evaluate_only = false) {
     CK_HIP(hipMemsetAsync(dev->d_status, 0, n * sizeof(int), stream));
     hipLaunchKernelGGL(k_quotient, dim3((unsigned)n), dim3(QT), 0, stream, dev->d_scalars, dev->d_y, dev->d_status,
                        (const u32*)dev->d_blobs, (const u32*)dev->d_z, (const ff::Fr*)dev->d_brp_roots);
+    if (evaluate_only) return;  // y = p(z) is all the caller wants (the field work of batched verification)
     kzgamd::msm_lock(dev->msm);
     try {
         kzgamd::msm_enqueue(dev->msm, dev->d_out, dev->d_scalars, N, n, 0, stream, kzgamd::OUT_COMPRESSED);
@@ -741,8 +742,9 @@ bool host_blob_valid(const uint8_t* blob) {
 
 // proofs for n (blob, z) pairs; z_src = explicit evaluation points or nullptr to derive them
 // from the commitments (compute_blob_kzg_proof)
+// proofs == nullptr: evaluation only (zs_out receives the derived challenges)
 void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32* zs, const Bytes48* commitments, size_t n,
-                 KzgAmdSettings* dev) {
+                 KzgAmdSettings* dev, Bytes32* zs_out = nullptr) {
     std::lock_guard<std::mutex> lk(dev->mu);
     CK_HIP(hipSetDevice(dev->device));
     dev->ensure(n);
@@ -796,12 +798,13 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
         zs = zbuf.data();
     }
     CK_HIP(hipMemcpyAsync(dev->d_z, zs, n * 32, hipMemcpyHostToDevice, dev->stream));
-    prove_enqueue(dev, n, dev->stream);
+    prove_enqueue(dev, n, dev->stream, proofs == nullptr);
     std::vector<int> status(n);
     std::vector<u32> ylimbs(n * 8);
     CK_HIP(hipMemcpyAsync(status.data(), dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
     CK_HIP(hipMemcpyAsync(ylimbs.data(), dev->d_y, n * 32, hipMemcpyDeviceToHost, dev->stream));
-    CK_HIP(hipMemcpyAsync(proofs, dev->d_out, n * 48, hipMemcpyDeviceToHost, dev->stream));
+    if (proofs) CK_HIP(hipMemcpyAsync(proofs, dev->d_out, n * 48, hipMemcpyDeviceToHost, dev->stream));
+    if (zs_out) memcpy(zs_out, zs, n * 32);
     if (host_check)
         for (size_t i = 0; i < n; ++i) {
             blst_p1 c;
@@ -981,6 +984,19 @@ extern "C" C_KZG_RET kzgamd_compute_blob_kzg_proof_batch(KZGProof* out, const Bl
     if (!dev) return C_KZG_BADARGS;
     if (n == 0) return C_KZG_OK;
     return guarded([&] { prove_batch(out, nullptr, blobs, nullptr, commitments, n, dev); });
+}
+
+// compute_challenges_and_evaluate_polynomial (kzg/src/eip_4844.rs:690-719): the per-blob field work of
+// verify_blob_kzg_proof_batch — Fiat-Shamir challenge z_i (host SHA-256) and y_i = p_i(z_i) (barycentric, on the
+// GPU).  The pairing side (verify_kzg_proof_batch, :380-435) stays with the caller.
+extern "C" C_KZG_RET kzgamd_compute_challenges_and_evaluate_batch(Bytes32* zs_out, Bytes32* ys_out, const Blob* blobs,
+                                                                  const Bytes48* commitments, size_t n,
+                                                                  const CKZGSettings* s) {
+    if (!zs_out || !ys_out || !blobs || !commitments) return C_KZG_BADARGS;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    if (n == 0) return C_KZG_OK;
+    return guarded([&] { prove_batch(nullptr, ys_out, blobs, nullptr, commitments, n, dev, zs_out); });
 }
 
 extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof* out, const Blob* blob, const Bytes48* commitment_bytes,

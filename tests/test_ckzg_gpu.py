@@ -378,3 +378,42 @@ def test_concurrent_callers_share_one_settings_handle(kzg, settings, oracle, ora
         t.join()
     h.close()
     assert not errors, errors
+
+
+def test_challenges_and_evaluations_for_batched_verification(kzg, settings, oracle, oracle_settings, golden, blob_loader):
+    """compute_challenges_and_evaluate_polynomial (kzg/src/eip_4844.rs:690-719), the field half of
+    verify_blob_kzg_proof_batch: z from the oracle's Fiat-Shamir restatement, y from the oracle's evaluation; the
+    blobs of the compute_blob_kzg_proof vectors plus random ones; batch of 1, of 3 (host-side commitment check)
+    and of 9 (device-side check)."""
+    L = oracle.lib()
+    rnd = random.Random(57)
+    blobs, cms = [], []
+    for case in golden["compute_blob_kzg_proof"]:
+        if case["output"] is None:
+            continue
+        blobs.append(blob_loader(case["blob"]))
+        cms.append(bytes.fromhex(case["commitment"][2:]))
+    while len(blobs) < 9:
+        b = bytearray(rnd.randbytes(BLOB))
+        for i in range(0, BLOB, 32):
+            b[i] = 0
+        blobs.append(bytes(b))
+        cms.append(kzg.blob_to_kzg_commitment(blobs[-1], settings))
+    for n in (1, 3, 9):
+        zs, ys = kzg.compute_challenges_and_evaluate_batch(b"".join(blobs[:n]), b"".join(cms[:n]), n, settings)
+        for i in range(n):
+            poly = (O.Fr * 4096)()
+            assert L.oblob_to_fr(poly, blobs[i]) == 0
+            z = O.Fr()
+            L.ocompute_challenge(C.byref(z), poly, cms[i])
+            zb = C.create_string_buffer(32)
+            L.ofr_to_be32(zb, C.byref(z))
+            assert zs[i] == zb.raw, (n, i)
+            ep, ey = C.create_string_buffer(48), C.create_string_buffer(32)
+            assert L.ocompute_kzg_proof(ep, ey, blobs[i], zb.raw, C.byref(oracle_settings)) == 0
+            assert ys[i] == ey.raw, (n, i)
+    # an invalid commitment is rejected, as validate_batched_input does
+    bad = bytearray(cms[0])
+    bad[5] ^= 1
+    with pytest.raises(kzg.KzgAmdError):
+        kzg.compute_challenges_and_evaluate_batch(blobs[0] + blobs[1], bytes(bad) + cms[1], 2, settings)
