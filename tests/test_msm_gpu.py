@@ -322,3 +322,59 @@ def test_msm_2p22_split_property(oracle, kzg):
     exp = O.G1()
     L.omsm_tiling_pippenger(C.byref(exp), pts, sc[:512].numpy().tobytes(), 512)
     assert compressed(L, exp) == compressed(L, outs[3])
+
+
+def test_prepared_bucket_path_without_wide_table(oracle, kzg, monkeypatch):
+    """A prepared handle whose wide table does not fit (here: disabled) runs the fixed-base-rows bucket engine:
+    one bucket set per MSM, single call and batch, skewed and edge scalars."""
+    L = oracle.lib()
+    monkeypatch.setenv("KZGAMD_FBW_MAX_GB", "0")
+    rnd = random.Random(15)
+    n = 700
+    pts = gen_points(L, n, rnd)
+    pts[13] = O.G1Affine()
+    h = kzg.prepare_multi_scalar_mult(pts, n)
+    assert not h.info()["wide_table"] and h.info()["rows"] > 1
+    vals = [rnd.randrange(O.R) for _ in range(n)]
+    vals[0], vals[1], vals[2] = 0, O.R - 1, 1
+    batches = [vals, [rnd.randrange(1 << 200) for _ in range(n)], [vals[5]] * n, [0] * n, [rnd.randrange(O.R) for _ in range(n)]]
+    for v in batches[:3]:
+        check(L, kzg, pts, O.fr_array(v), n, prepared=h, unprepared=False)
+    flat = O.fr_array([x for v in batches for x in v])
+    got = kzg.multi_scalar_mult_prepared_batch(h, flat, n, len(batches))
+    for b, v in enumerate(batches):
+        exp = O.G1()
+        L.omsm_affine(C.byref(exp), pts, O.fr_array(v), n)
+        assert compressed(L, as_oracle_g1(got[b])) == compressed(L, exp), b
+    h.close()
+
+
+@pytest.mark.parametrize("nbatch", [3, 70])
+def test_variable_base_device_handle_batched(oracle, kzg, nbatch):
+    """Several MSMs over one variable-base device handle in one launch: 3 (top-of-tree sums + limb-parallel
+    Horner, one wave per MSM) and 70 (more than 64 bucket sets: plain tree + single-lane Horner)."""
+    import torch
+
+    L = oracle.lib()
+    rnd = random.Random(16 + nbatch)
+    n = 600
+    pts = gen_points(L, n, rnd)
+    stream = torch.cuda.current_stream().cuda_stream
+    d_pts = torch.frombuffer(bytearray(bytes(pts)), dtype=torch.uint8).cuda()
+    h = kzg.DeviceMsm(d_pts.data_ptr(), n, False)
+    scal = [[rnd.randrange(O.R) for _ in range(n)] for _ in range(nbatch)]
+    scal[1] = [scal[1][0]] * n          # equal scalars: one bucket per window takes everything
+    scal[2][::3] = [0] * len(scal[2][::3])
+    raw = b"".join(v.to_bytes(32, "little") for row in scal for v in row)  # canonical little-endian
+    d_sc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+    d_out = torch.zeros(144 * nbatch, dtype=torch.uint8, device="cuda")
+    kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr(), n, nbatch, False, stream)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy().tobytes()
+    for b in range(nbatch if nbatch <= 8 else 6):
+        got = O.G1()
+        C.memmove(C.byref(got), out[144 * b:144 * b + 144], 144)
+        exp = O.G1()
+        L.omsm_affine(C.byref(exp), pts, O.fr_array(scal[b]), n)
+        assert compressed(L, got) == compressed(L, exp), b
+    h.close()
