@@ -752,8 +752,7 @@ __global__ void __launch_bounds__(64) k_winsum_wide(const Xyzz* __restrict__ top
 }
 
 // k_final_wide: Horner over the window sums of one variable-base MSM per wave
-__global__ void __launch_bounds__(64) k_final_wide(const Xyzz* __restrict__ win, void* __restrict__ out_v, int nwin, int c,
-                                                   int out_mode) {
+__global__ void __launch_bounds__(64) k_final_wide(const Xyzz* __restrict__ win, void* __restrict__ out_v, int nwin, int c) {
     __shared__ u32 sh[16];
     const int lane = threadIdx.x;
     if (lane >= 16) return;
@@ -765,17 +764,6 @@ __global__ void __launch_bounds__(64) k_final_wide(const Xyzz* __restrict__ win,
         g1w::dadd(wacc, g1w::load(win + b * nwin + w, lane), lc, sh, lane);
     }
     Xyzz acc = g1w::to_single(wacc, lc, sh, lane);
-    if (out_mode == kzgamd::OUT_COMPRESSED) {
-        unsigned char buf[48];
-        g1io::compress(buf, acc);
-        if (lane == 0) {
-            u32* o = (u32*)out_v + 12 * b;
-#pragma unroll
-            for (int k = 0; k < 12; ++k)
-                o[k] = (u32)buf[4 * k] | ((u32)buf[4 * k + 1] << 8) | ((u32)buf[4 * k + 2] << 16) | ((u32)buf[4 * k + 3] << 24);
-        }
-        return;
-    }
     ff::Fp j[3];
     g1::to_blst_jacobian(j, acc);
     if (lane == 0) {
@@ -1439,9 +1427,9 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done[g], 0));
         }
     }
-    if (wide_tail && !ctx->prepared && out_mode != OUT_WINDOWS && nwin > 1) {
+    if (wide_tail && !ctx->prepared && out_mode == OUT_JACOBIAN && nwin > 1) {
         // few independent Horner chains: one wave each, limb-parallel doublings
-        hipLaunchKernelGGL(k_final_wide, dim3((unsigned)nbatch), dim3(64), 0, stream, finM, d_out, nwin, c, out_mode);
+        hipLaunchKernelGGL(k_final_wide, dim3((unsigned)nbatch), dim3(64), 0, stream, finM, d_out, nwin, c);
     } else {
         const size_t nfinal = out_mode == OUT_WINDOWS ? nbatch * (size_t)nwin : nbatch;
         hipLaunchKernelGGL(k_final, dim3((unsigned)((nfinal + 63) / 64)), dim3(64), 0, stream, finA, finM, d_out, nbatch, nwin,
