@@ -28,6 +28,7 @@
 #include "../../include/kzg_mi355x.h"
 #include "g1_io.cuh"
 #include "g1w.cuh"
+#include "glv.cuh"
 #include "host_g1.h"
 #include "msm_internal.h"
 
@@ -175,142 +176,6 @@ __device__ __forceinline__ u32 window_bits(const u32 s[8], int bit, int c) {
     return (u32)(two >> sh) & ((1u << c) - 1);
 }
 
-// GLV split for the variable-base engine: k = +-k1 +- k2 * X2 with X2 = x^2 (x the BLS parameter, X2 ~ 2^127.4), so
-// k*P = +-k1*P +- k2*[x^2]P with [x^2]P = (beta*x, -y) one field multiplication away.  Half as many windows, and
-// the Horner chain over the window sums is ~112 doublings instead of 255.
-//   1. k > (r-1)/2 -> use r - k and flip both signs            (k <= (r-1)/2)
-//   2. q = floor(k / X2), rem = k - q*X2: division by the constant through its reciprocal
-//      M = floor(2^256 / X2), at most two corrections
-//   3. rem > X2/2 -> rem = X2 - rem (negative), q += 1
-// Both halves end below 2^126.5, so ceil(128/c) signed windows never carry out of the top one.
-__device__ __forceinline__ void glv_split(const u32 kin[8], u32 k1[8], u32 k2[8], u32& neg1, u32& neg2) {
-    constexpr u32 X2[4] = {0x00000000u, 0x00000001u, 0x0001a402u, 0xac45a401u};
-    constexpr u32 X2H[4] = {0x80000000u, 0x00000000u, 0x8000d201u, 0x5622d200u};  // X2 / 2
-    constexpr u32 M[5] = {0xf6cfee2eu, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x1u};
-    constexpr u32 RH[8] = {0x80000000u, 0x7fffffffu, 0x7fff2dffu, 0xa9ded201u,
-                           0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u};  // (r - 1) / 2
-    u32 k[8];
-    bool flip = false;
-#pragma unroll
-    for (int i = 7; i >= 0; --i) {
-        if (kin[i] != RH[i]) {
-            flip = kin[i] > RH[i];
-            break;
-        }
-    }
-    {
-        u32 bw = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            u64 v = (u64)ff::FrParams::p(i) - kin[i] - bw;
-            k[i] = flip ? (u32)v : kin[i];
-            bw = (u32)(v >> 63);
-        }
-    }
-    u32 t[13];
-#pragma unroll
-    for (int i = 0; i < 13; ++i) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        u32 carry = 0;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            u64 v = (u64)k[i] * M[j] + t[i + j] + carry;
-            t[i + j] = (u32)v;
-            carry = (u32)(v >> 32);
-        }
-        t[i + 5] = carry;
-    }
-    u32 q[4] = {t[8], t[9], t[10], t[11]};
-    // rem = k - q*X2 (160 bits are enough: rem < 3*X2)
-    u32 pr[5] = {0, 0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        u32 carry = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (i + j < 5) {
-                u64 v = (u64)q[i] * X2[j] + pr[i + j] + carry;
-                pr[i + j] = (u32)v;
-                carry = (u32)(v >> 32);
-            }
-        }
-        if (i + 4 < 5) pr[i + 4] = carry;
-    }
-    u32 rem[5];
-    u32 borrow = 0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        u64 v = (u64)k[i] - pr[i] - borrow;
-        rem[i] = (u32)v;
-        borrow = (u32)(v >> 63);
-    }
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        bool ge = rem[4] != 0;
-        if (!ge) {
-            ge = true;
-#pragma unroll
-            for (int i = 3; i >= 0; --i) {
-                if (rem[i] != X2[i]) {
-                    ge = rem[i] > X2[i];
-                    break;
-                }
-            }
-        }
-        if (ge) {
-            u32 bw = 0;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                u64 v = (u64)rem[i] - (i < 4 ? X2[i] : 0u) - bw;
-                rem[i] = (u32)v;
-                bw = (u32)(v >> 63);
-            }
-            u32 cy = 1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                u64 v = (u64)q[i] + cy;
-                q[i] = (u32)v;
-                cy = (u32)(v >> 32);
-            }
-        }
-    }
-    // balance the remainder: rem > X2/2  ->  X2 - rem, negative
-    bool big = false;
-#pragma unroll
-    for (int i = 3; i >= 0; --i) {
-        if (rem[i] != X2H[i]) {
-            big = rem[i] > X2H[i];
-            break;
-        }
-    }
-    if (big) {
-        u32 bw = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u64 v = (u64)X2[i] - rem[i] - bw;
-            rem[i] = (u32)v;
-            bw = (u32)(v >> 63);
-        }
-        u32 cy = 1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u64 v = (u64)q[i] + cy;
-            q[i] = (u32)v;
-            cy = (u32)(v >> 32);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        k1[i] = rem[i];
-        k2[i] = q[i];
-        k1[i + 4] = 0;
-        k2[i + 4] = 0;
-    }
-    neg1 = (big ? 1u : 0u) ^ (flip ? 1u : 0u);
-    neg2 = flip ? 1u : 0u;
-}
-
 // pass 0: histogram — the value the atomic returns is the entry's rank inside its bucket, kept in `ranks`
 // (one word per (part, window, scalar), coalesced); pass 1: scatter to offsets[bucket] + rank with no atomics at
 // all (recomputes the digits instead of storing them)
@@ -330,7 +195,7 @@ __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __rest
         u32 k[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) k[q] = s[q];
-        glv_split(k, s, s2, pneg[0], pneg[1]);
+        kzgamd::glv_split(k, s, s2, pneg[0], pneg[1]);
     }
     const u32 half = 1u << (P.c - 1);
     const int lane = threadIdx.x & 63;

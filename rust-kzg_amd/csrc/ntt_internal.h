@@ -27,8 +27,8 @@ struct NttCtx {
     std::mutex mu;
     Fr *d_a = nullptr, *d_b = nullptr;
     size_t cap = 0;
-    // G1-valued transforms (fftg1.hip): canonical (non-Montgomery) roots as scalars, staging and work buffers
-    ff::u32* d_kroots = nullptr;  // (W + 1) x 8 words
+    // G1-valued transforms (fftg1.hip): the roots as GLV-split scalars, staging and work buffers
+    void* d_kroots = nullptr;  // (W + 1) x RootSplit
     void *d_p1 = nullptr, *d_pts = nullptr, *d_tab = nullptr;
     size_t cap_g1 = 0, cap_tab = 0;
     ~NttCtx() {
