@@ -257,6 +257,217 @@ __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Two-level sort (default for one MSM up to n = 2^22).  The one-level sort above pays two global atomics' worth
+// of L2 traffic per entry (histogram with return value, then a scattered 4-byte write): 1.2 ms at n = 2^20.
+// Here a bucket id is split into a coarse bin (bucket >> 7) and a fine bucket (low 7 bits):
+//   k_part_count   : a workgroup counts its 1024 scalars' entries per coarse bin in LDS (<= 4096 bins) and adds
+//                    the non-zero counters to the global bin counts — ~8x fewer global atomics, all LDS otherwise
+//   k_part_scan    : exclusive scan of the bin counts
+//   k_part_scatter : same count again in LDS, one returning atomic per (workgroup, bin) reserves a run inside the
+//                    bin, entries are written there as  fine << 25 | sign << 24 | point index
+//   k_bin_sort     : one workgroup per coarse bin streams its run twice: LDS histogram of the 128 fine buckets ->
+//                    bucket offsets (+ heavy flags), then an LDS counting sort into the final order
+// Entries keep the format the accumulation expects (point index | sign << 31).
+constexpr int FINE_BITS = 7;
+constexpr u32 FINE = 1u << FINE_BITS;
+constexpr u32 MAX_BINS = 4096;     // coarse bins per launch (LDS counters)
+constexpr int PART_SCALARS = 4;    // scalars per lane in the partition kernels (1024 per workgroup)
+
+// calls emit(set, bucket, sign, point index) for every non-zero digit of scalar t in windows [w0, w1)
+template <class F>
+__device__ __forceinline__ void scalar_entries(const DigitParams& P, const u32* __restrict__ scalars,
+                                               const AffPt* __restrict__ pts, size_t t, F emit) {
+    const size_t b = t / P.n, i = t % P.n;
+    if (pts[i].flags & 1) return;  // infinity base contributes nothing (rows share the flag)
+    u32 s[8], s2[8];
+    load_scalar(s, scalars, t, P.mont);
+    u32 pneg[2] = {0, 0};
+    if (P.glv) {
+        u32 k[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) k[q] = s[q];
+        kzgamd::glv_split(k, s, s2, pneg[0], pneg[1]);
+    }
+    const u32 half = 1u << (P.c - 1);
+    for (int part = 0; part <= P.glv; ++part) {
+        const u32* sv = part ? s2 : s;
+        u32 carry = 0;
+        for (int w = 0; w < P.w1; ++w) {
+            u32 d = window_bits(sv, w * P.c, P.c) + carry;
+            u32 neg = 0;
+            carry = 0;
+            if (d > half) {
+                d = (1u << P.c) - d;
+                neg = 1;
+                carry = 1;
+            }
+            if (w < P.w0 || d == 0) continue;
+            const size_t set = P.prepared ? b : b * P.nwin + w;
+            const u32 pidx = P.prepared ? (u32)((size_t)w * P.row_stride + i) : (u32)(part ? P.row_stride + i : i);
+            emit(set, d - 1, neg ^ pneg[part], pidx);
+        }
+    }
+}
+
+// set0 = first set of this launch's group, cb = coarse bins per set; bins are numbered (set - set0) * cb + coarse
+__global__ void __launch_bounds__(256) k_part_count(DigitParams P, const u32* __restrict__ scalars,
+                                                    const AffPt* __restrict__ pts, u32* __restrict__ bin_count, u32 set0,
+                                                    u32 cb, u32 nbins) {
+    extern __shared__ u32 lds_bins[];
+    for (u32 k = threadIdx.x; k < nbins; k += 256) lds_bins[k] = 0;
+    __syncthreads();
+    const size_t total = P.n * P.nbatch;
+#pragma unroll 1
+    for (int q = 0; q < PART_SCALARS; ++q) {
+        const size_t t = ((size_t)blockIdx.x * PART_SCALARS + q) * 256 + threadIdx.x;
+        if (t < total)
+            scalar_entries(P, scalars, pts, t, [&](size_t set, u32 bucket, u32, u32) {
+                atomicAdd(&lds_bins[(u32)(set - set0) * cb + (bucket >> FINE_BITS)], 1u);
+            });
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < nbins; k += 256) {
+        const u32 v = lds_bins[k];
+        if (v) atomicAdd(&bin_count[k], v);
+    }
+}
+
+// bin_start[0..nbins] = exclusive scan of bin_count; bin_cursor zeroed
+__global__ void __launch_bounds__(1024) k_part_scan(const u32* __restrict__ bin_count, u32* __restrict__ bin_start,
+                                                    u32* __restrict__ bin_cursor, u32 nbins) {
+    __shared__ u32 wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // nbins <= 4096: four consecutive bins per lane
+    u32 v[4], tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 idx = threadIdx.x * 4 + k;
+        v[k] = idx < nbins ? bin_count[idx] : 0;
+        if (idx < nbins) bin_cursor[idx] = 0;
+        tot += v[k];
+    }
+    u32 x = tot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    u32 base = x - tot;
+    for (int w2 = 0; w2 < wave; ++w2) base += wsum[w2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32 idx = threadIdx.x * 4 + k;
+        if (idx < nbins) bin_start[idx] = base;
+        base += v[k];
+        if (idx + 1 == nbins) bin_start[nbins] = base;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_part_scatter(DigitParams P, const u32* __restrict__ scalars,
+                                                      const AffPt* __restrict__ pts, const u32* __restrict__ bin_start,
+                                                      u32* __restrict__ bin_cursor, u32* __restrict__ tmp, u32 set0, u32 cb,
+                                                      u32 nbins) {
+    extern __shared__ u32 lds_bins[];
+    u32* cnt = lds_bins;
+    u32* base = lds_bins + nbins;
+    for (u32 k = threadIdx.x; k < nbins; k += 256) cnt[k] = 0;
+    __syncthreads();
+    const size_t total = P.n * P.nbatch;
+#pragma unroll 1
+    for (int q = 0; q < PART_SCALARS; ++q) {
+        const size_t t = ((size_t)blockIdx.x * PART_SCALARS + q) * 256 + threadIdx.x;
+        if (t < total)
+            scalar_entries(P, scalars, pts, t, [&](size_t set, u32 bucket, u32, u32) {
+                atomicAdd(&cnt[(u32)(set - set0) * cb + (bucket >> FINE_BITS)], 1u);
+            });
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < nbins; k += 256) {
+        const u32 v = cnt[k];
+        base[k] = v ? bin_start[k] + atomicAdd(&bin_cursor[k], v) : 0u;
+        cnt[k] = 0;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int q = 0; q < PART_SCALARS; ++q) {
+        const size_t t = ((size_t)blockIdx.x * PART_SCALARS + q) * 256 + threadIdx.x;
+        if (t < total)
+            scalar_entries(P, scalars, pts, t, [&](size_t set, u32 bucket, u32 neg, u32 pidx) {
+                const u32 bin = (u32)(set - set0) * cb + (bucket >> FINE_BITS);
+                const u32 r = atomicAdd(&cnt[bin], 1u);
+                tmp[base[bin] + r] = ((bucket & (FINE - 1)) << 25) | (neg << 24) | pidx;
+            });
+    }
+}
+
+// offsets / heavy / sorted are the group's (already shifted to its first set); heavy buckets are listed as in k_scan
+__global__ void __launch_bounds__(256) k_bin_sort(const u32* __restrict__ tmp, const u32* __restrict__ bin_start,
+                                                  u32* __restrict__ offsets, u32* __restrict__ sorted,
+                                                  unsigned char* __restrict__ heavy, u32* __restrict__ heavy_list,
+                                                  u32* __restrict__ nheavy, u32 heavy_cap, u32 cb, size_t nb, size_t set_cap) {
+    __shared__ u32 hist[FINE], pref[FINE], cur[FINE];
+    const u32 bin = blockIdx.x, set = bin / cb, coarse = bin % cb;
+    const u32 beg = bin_start[bin], end = bin_start[bin + 1], set_start = bin_start[set * cb];
+    if (threadIdx.x < FINE) {
+        hist[threadIdx.x] = 0;
+        cur[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (u32 e = beg + threadIdx.x; e < end; e += 256) atomicAdd(&hist[tmp[e] >> 25], 1u);
+    __syncthreads();
+    if (threadIdx.x < FINE) {
+        // exclusive scan over the 128 fine buckets (two waves: wave scan + the first wave's total)
+        const int lane = threadIdx.x & 63;
+        const u32 v = hist[threadIdx.x];
+        u32 x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            u32 y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (threadIdx.x == 63) pref[0] = x;  // borrowed as a mailbox; rewritten below after the barrier
+        hist[threadIdx.x] = x - v;           // exclusive within the wave
+    }
+    __syncthreads();
+    const u32 first_wave_total = pref[0];
+    __syncthreads();
+    if (threadIdx.x < FINE) {
+        const u32 ex = hist[threadIdx.x] + (threadIdx.x >= 64 ? first_wave_total : 0u);
+        pref[threadIdx.x] = ex;
+        const size_t bucket = (size_t)coarse * FINE + threadIdx.x;
+        u32* off = offsets + (size_t)set * (nb + 1);
+        off[bucket] = (beg - set_start) + ex;
+        if (coarse + 1 == cb && threadIdx.x == FINE - 1) off[nb] = bin_start[(set + 1) * cb] - set_start;
+    }
+    __syncthreads();
+    if (threadIdx.x < FINE) {
+        // bucket size = next prefix - own prefix
+        const u32 ex = pref[threadIdx.x];
+        const u32 nx = threadIdx.x + 1 < FINE ? pref[threadIdx.x + 1] : (end - beg);
+        const u32 cntb = nx - ex;
+        const size_t bucket = (size_t)coarse * FINE + threadIdx.x;
+        const bool hv = cntb > HEAVY;
+        heavy[(size_t)set * nb + bucket] = hv ? 1 : 0;
+        if (hv) {
+            const u32 slot = atomicAdd(nheavy, 1u);
+            if (slot < heavy_cap) {
+                heavy_list[2 * slot] = set;
+                heavy_list[2 * slot + 1] = (u32)bucket;
+            }
+        }
+    }
+    u32* dst = sorted + (size_t)set * set_cap + (beg - set_start);
+    for (u32 e = beg + threadIdx.x; e < end; e += 256) {
+        const u32 w = tmp[e];
+        const u32 f = w >> 25;
+        const u32 r = atomicAdd(&cur[f], 1u);
+        dst[pref[f] + r] = (w & 0xffffffu) | (((w >> 24) & 1u) << 31);
+    }
+}
+
 // exclusive scan of counts[set][0..nb) -> offsets[set][0..nb]; zeroes counts for the scatter pass.
 // Buckets with more than HEAVY entries (> HEAVY/chunk pieces after k_accum) are flagged and listed
 // so that k_heavy can combine their pieces with a whole wave instead of one lane.
@@ -897,7 +1108,7 @@ struct DevBuf {
 };
 
 struct Workspace {
-    DevBuf<u32> counts, offsets, sorted, scalars, ranks;
+    DevBuf<u32> counts, offsets, sorted, scalars, ranks, tmp, bins;
     DevBuf<Xyzz> buckets, lvlA[2], lvlM[2], top, win;
     DevBuf<unsigned char> heavy;
     DevBuf<u32> heavy_list, nheavy;
@@ -907,6 +1118,8 @@ struct Workspace {
         offsets.release();
         sorted.release();
         ranks.release();
+        tmp.release();
+        bins.release();
         scalars.release();
         buckets.release();
         for (int k = 0; k < 2; ++k) {
@@ -1136,21 +1349,30 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     ws.lvlA[1].ensure(nsets * n2);
     ws.lvlM[1].ensure(nsets * n2);
     ws.heavy.ensure(nsets * nb);
-    // Window groups.  The digit/sort kernels are bound by L2 atomics, the accumulation by the integer VALUs and the
-    // reduction tail by latency, so a single large MSM is cut into groups of windows that run as a pipeline on
-    // their own streams: digits of group g+1 overlap the accumulation of group g, whose tail overlaps the
-    // accumulation of g+1.  Only the Horner over the window sums (k_final) joins them.
+    // Window groups (KZGAMD_GROUPS=2..4, off by default).  The sort is bound by atomics / scattered writes, the
+    // accumulation by the integer VALUs and the reduction tail by latency, so a single large MSM can be cut into
+    // groups of windows that run as a pipeline on their own streams: the sort of group g+1 overlaps the accumulation
+    // of group g, whose tail overlaps the accumulation of g+1; only the Horner over the window sums joins them.
+    // With the one-level sort (1.2 ms at n = 2^20) two groups gained 6 % (5.83 -> 5.47 ms; four were slower: every
+    // group pays the scalar load + split again); with the two-level sort (0.5 ms) there is nothing left to hide:
+    // 6.17 vs 6.22 ms on the same box.
     int G = 1;
-    if (!ctx->prepared && nbatch == 1 && !ctx->profile && npoints >= ((size_t)1 << 19) && nwin >= 4) {
-        // measured at n = 2^20: 1 group 5.83 ms, 2 groups 5.47 ms, 4 groups slower (every group pays the scalar
-        // load + split again, and the tail of the last group is not hidden by anything)
-        G = 2;
+    if (!ctx->prepared && nbatch == 1 && !ctx->profile && npoints >= 4096 && nwin >= 4) {
         if (const char* e = getenv("KZGAMD_GROUPS")) {
             int v = atoi(e);
             if (v >= 1 && v <= MsmContext::MAXG && v <= nwin) G = v;
         }
     }
     const size_t sets_per_group = (nsets + G - 1) / G;
+    // two-level sort: coarse bins must fit the LDS counters and a point index 24 bits
+    const size_t max_pidx = ctx->prepared ? (size_t)ctx->rows * ctx->n : (ctx->glv ? 2 * ctx->n : ctx->n);
+    const bool two_level = !getenv("KZGAMD_ONE_LEVEL_SORT") && nb >= FINE &&
+                           (nb >> FINE_BITS) * sets_per_group <= MAX_BINS && max_pidx <= ((size_t)1 << 24) &&
+                           npoints * nbatch >= ((size_t)1 << 15);  // below: four more launches than they save
+    if (two_level) {
+        ws.tmp.ensure(nsets * set_cap);
+        ws.bins.ensure((size_t)G * (3 * MAX_BINS + 8));
+    }
     const size_t heavy_cap = sets_per_group * set_cap / HEAVY + 1;  // a heavy bucket holds > HEAVY entries
     ws.heavy_list.ensure(2 * heavy_cap * G);
     ws.nheavy.ensure(G);
@@ -1216,6 +1438,24 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         u32* heavy_list = ws.heavy_list.p + 2 * heavy_cap * g;
         u32* nheavy = ws.nheavy.p + g;
         Xyzz* buckets = ws.buckets.p + set0 * (nb + nchunk);
+        if (two_level) {
+            const u32 cb = (u32)(nb >> FINE_BITS), nbins = (u32)ns * cb;
+            u32* bin_count = ws.bins.p + (size_t)g * (3 * MAX_BINS + 8);
+            u32* bin_start = bin_count + MAX_BINS;
+            u32* bin_cursor = bin_start + MAX_BINS + 8;
+            u32* tmp = ws.tmp.p + set0 * set_cap;
+            const unsigned gpart = (unsigned)((npoints * nbatch + 256 * PART_SCALARS - 1) / (256 * PART_SCALARS));
+            HIP_TRY(hipMemsetAsync(bin_count, 0, nbins * sizeof(u32), st));
+            hipLaunchKernelGGL(k_part_count, dim3(gpart), dim3(256), nbins * sizeof(u32), st, P, (const u32*)d_scalars,
+                               (const AffPt*)ctx->table.p, bin_count, (u32)set0, cb, nbins);
+            hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, st, (const u32*)bin_count, bin_start, bin_cursor, nbins);
+            hipLaunchKernelGGL(k_part_scatter, dim3(gpart), dim3(256), 2 * nbins * sizeof(u32), st, P,
+                               (const u32*)d_scalars, (const AffPt*)ctx->table.p, (const u32*)bin_start, bin_cursor, tmp,
+                               (u32)set0, cb, nbins);
+            HIP_TRY(hipMemsetAsync(nheavy, 0, sizeof(u32), st));
+            hipLaunchKernelGGL(k_bin_sort, dim3(nbins), dim3(256), 0, st, (const u32*)tmp, (const u32*)bin_start, offsets,
+                               ws.sorted.p + set0 * set_cap, heavy, heavy_list, nheavy, (u32)heavy_cap, cb, nb, set_cap);
+        } else {
         HIP_TRY(hipMemsetAsync(counts, 0, ns * nb * sizeof(u32), st));
         const unsigned gdig = (unsigned)((npoints * nbatch + 255) / 256);
         // k_digits indexes sets globally (b * nwin + w): it gets the unshifted arrays
@@ -1226,6 +1466,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                            (u32)heavy_cap);
         hipLaunchKernelGGL(k_digits<1>, dim3(gdig), dim3(256), 0, st, P, (const u32*)d_scalars, ctx->table.p, ws.counts.p,
                            (const u32*)ws.offsets.p, ws.sorted.p, set_cap, ws.ranks.p);
+        }
         if (G > 1) {
             HIP_TRY(hipEventRecord(ctx->ev_dig[g], st));
             if (g > 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_acc[g - 1], 0));

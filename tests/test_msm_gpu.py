@@ -378,3 +378,37 @@ def test_variable_base_device_handle_batched(oracle, kzg, nbatch):
         L.omsm_affine(C.byref(exp), pts, O.fr_array(scal[b]), n)
         assert compressed(L, got) == compressed(L, exp), b
     h.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"KZGAMD_GROUPS": "2"}, {"KZGAMD_ONE_LEVEL_SORT": "1"},
+                                 {"KZGAMD_GROUPS": "3", "KZGAMD_ONE_LEVEL_SORT": "1"}, {"KZGAMD_NO_WIDE_TAIL": "1"}])
+def test_variable_base_engine_variants(oracle, kzg, monkeypatch, env):
+    """Every selectable shape of the variable-base engine (two-level / one-level sort, window groups on their own
+    streams, limb-parallel / single-lane tails) on the same 40 000-point MSM with a skewed scalar distribution."""
+    import torch
+
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    L = oracle.lib()
+    n = 40000
+    stream = torch.cuda.current_stream().cuda_stream
+    d_pts = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    kzg.generate_points(d_pts.data_ptr(), n, 21, stream)
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(23)
+    sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=gen)
+    sc[:, 31] &= 0x3F
+    sc[::7] = sc[3]        # one scalar repeated 5 700 times: heavy buckets in every window
+    sc[1::50, 8:] = 0      # short scalars
+    d_sc = sc.cuda()
+    d_out = torch.zeros(144, dtype=torch.uint8, device="cuda")
+    h = kzg.DeviceMsm(d_pts.data_ptr(), n, False)
+    kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr(), n, 1, False, stream)
+    torch.cuda.synchronize()
+    got = O.G1()
+    C.memmove(C.byref(got), d_out.cpu().numpy().tobytes(), 144)
+    pts = (O.G1Affine * n).from_buffer_copy(d_pts.cpu().numpy().tobytes())
+    exp = O.G1()
+    L.omsm_tiling_pippenger(C.byref(exp), pts, sc.numpy().tobytes(), n)
+    assert compressed(L, got) == compressed(L, exp)
+    h.close()
