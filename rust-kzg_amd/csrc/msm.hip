@@ -1477,7 +1477,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                            nchunk, lgc);
         if (pev) HIP_TRY(hipEventRecord(pev[2], st));
         if (G > 1) HIP_TRY(hipEventRecord(ctx->ev_acc[g], st));
-        hipLaunchKernelGGL(k_heavy, dim3(256, 16), dim3(64), 0, st, buckets, (const u32*)offsets, (const u32*)heavy_list,
+        hipLaunchKernelGGL(k_heavy, dim3(256, 64), dim3(64), 0, st, buckets, (const u32*)offsets, (const u32*)heavy_list,
                            (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, 1u, HSEG, lgc);
         hipLaunchKernelGGL(k_heavy, dim3(1024, 1), dim3(64), 0, st, buckets, (const u32*)offsets, (const u32*)heavy_list,
                            (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, HSEG, 0u, lgc);

@@ -1,0 +1,20 @@
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import extra_bench as eb
+import torch
+kzg = eb.load_pkg()
+dev = torch.device("cuda", 0)
+stream = torch.cuda.current_stream().cuda_stream
+n = 1 << 20
+pts = torch.empty(n * 96, dtype=torch.uint8, device=dev)
+kzg.generate_points(pts.data_ptr(), n, 2, stream)
+g = torch.Generator(device="cpu"); g.manual_seed(2)
+base = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g); base[:, 31] &= 0x3F
+eq = base.clone(); eq[:] = base[0]
+d = eq.to(dev)
+out = torch.zeros(144, dtype=torch.uint8, device=dev)
+h = kzg.DeviceMsm(pts.data_ptr(), n, False)
+for _ in range(3):
+    kzg.msm_prepared_batch_device(h, out.data_ptr(), d.data_ptr(), n, 1, False, stream)
+torch.cuda.synchronize()
