@@ -129,7 +129,7 @@ constexpr int QE = (int)(N / QT);  // elements per thread (8), element index i =
 // Outputs: q as canonical little-endian scalars (ready for the MSM), y canonical.
 __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* __restrict__ y_out, int* __restrict__ status,
                                                  const u32* __restrict__ blobs, const u32* __restrict__ z_be,
-                                                 const ff::Fr* __restrict__ roots_brp) {
+                                                 const ff::Fr* __restrict__ roots_brp, ff::Fr ninv) {
     __shared__ ff::Fr sh_a[QT];
     __shared__ ff::Fr sh_b[QT];
     __shared__ ff::Fr sh_misc[4];  // 0: total^-1, 1: y, 2: z^-1 (domain case)
@@ -215,10 +215,7 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
             // out = sum / N * (z^N - 1)
             ff::Fr zn = z;
             for (int k = 0; k < 12; ++k) zn = ff::sqr(zn);
-            ff::Fr nfr = ff::Fr::zero();
-            nfr.v[0] = (u32)N;
-            ff::Fr ninv = fr_inverse(ff::to_mont(nfr));
-            y = ff::mul(ff::mul(sh_a[0], ninv), ff::sub(zn, ff::Fr::one()));
+            y = ff::mul(ff::mul(sh_a[0], ninv), ff::sub(zn, ff::Fr::one()));  // ninv = 1/N, computed once on the host
         }
         sh_misc[1] = y;
         ff::Fr yc = ff::from_mont(y);
@@ -465,7 +462,7 @@ struct KzgAmdSettings {
         CK_HIP(hipMalloc(&d_blobs, nblobs * BYTES_PER_BLOB));
         CK_HIP(hipMalloc(&d_scalars, nblobs * BYTES_PER_BLOB));
         CK_HIP(hipMalloc(&d_status, nblobs * sizeof(int)));
-        CK_HIP(hipMalloc(&d_out, nblobs * 48));
+        CK_HIP(hipMalloc(&d_out, nblobs * 144));  // 48-byte compressed results, or Jacobian for the small-batch path
         CK_HIP(hipMalloc(&d_z, nblobs * 32));
         CK_HIP(hipMalloc(&d_y, nblobs * 32));
         CK_HIP(hipMalloc(&d_commit, nblobs * 48));
@@ -657,14 +654,23 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
 }
 
 // device pipeline: blobs (device) -> 48-byte commitments (device)
+// A compressed result costs the GPU a field inversion in one lane (~0.15 ms of latency whatever the batch); for a
+// handful of results the host-buffer entry points fetch Jacobian points instead and compress them on the host
+// (~20 us each): a single blob_to_kzg_commitment call 0.71 -> 0.5 ms.
+constexpr size_t HOST_COMPRESS_MAX = 4;
+
+void compress_on_host(uint8_t* out48, const blst_p1* jac, size_t n) {
+    for (size_t i = 0; i < n; ++i) kzgamd::host_p1_compress(out48 + 48 * i, &jac[i]);
+}
+
 void commit_enqueue(KzgAmdSettings* dev, void* d_out, int* d_status, const void* d_blobs, u32* d_scalars, size_t n,
-                    hipStream_t stream) {
+                    hipStream_t stream, int out_mode = kzgamd::OUT_COMPRESSED) {
     CK_HIP(hipMemsetAsync(d_status, 0, n * sizeof(int), stream));
     hipLaunchKernelGGL(k_blob_to_scalars, dim3((unsigned)((n * N + 255) / 256)), dim3(256), 0, stream, d_scalars, d_status,
                        (const u32*)d_blobs, n);
     kzgamd::msm_lock(dev->msm);
     try {
-        kzgamd::msm_enqueue(dev->msm, d_out, d_scalars, N, n, 0, stream, kzgamd::OUT_COMPRESSED);
+        kzgamd::msm_enqueue(dev->msm, d_out, d_scalars, N, n, 0, stream, out_mode);
     } catch (...) {
         kzgamd::msm_unlock(dev->msm);
         throw;
@@ -673,15 +679,26 @@ void commit_enqueue(KzgAmdSettings* dev, void* d_out, int* d_status, const void*
 }
 
 
+// 1 / FIELD_ELEMENTS_PER_BLOB in Montgomery form (the barycentric formula's 1/N)
+static ff::Fr n_inverse() {
+    static const ff::Fr v = [] {
+        ff::Fr nfr = ff::Fr::zero();
+        nfr.v[0] = (u32)N;
+        return ff::inverse_bgcd(ff::to_mont(nfr));
+    }();
+    return v;
+}
+
 // blobs + evaluation points (device) -> proofs (48 B) + y (canonical limbs), all on `stream`
-void prove_enqueue(KzgAmdSettings* dev, size_t n, hipStream_t stream, bool evaluate_only = false) {
+void prove_enqueue(KzgAmdSettings* dev, size_t n, hipStream_t stream, bool evaluate_only = false,
+                   int out_mode = kzgamd::OUT_COMPRESSED) {
     CK_HIP(hipMemsetAsync(dev->d_status, 0, n * sizeof(int), stream));
     hipLaunchKernelGGL(k_quotient, dim3((unsigned)n), dim3(QT), 0, stream, dev->d_scalars, dev->d_y, dev->d_status,
-                       (const u32*)dev->d_blobs, (const u32*)dev->d_z, (const ff::Fr*)dev->d_brp_roots);
+                       (const u32*)dev->d_blobs, (const u32*)dev->d_z, (const ff::Fr*)dev->d_brp_roots, n_inverse());
     if (evaluate_only) return;  // y = p(z) is all the caller wants (the field work of batched verification)
     kzgamd::msm_lock(dev->msm);
     try {
-        kzgamd::msm_enqueue(dev->msm, dev->d_out, dev->d_scalars, N, n, 0, stream, kzgamd::OUT_COMPRESSED);
+        kzgamd::msm_enqueue(dev->msm, dev->d_out, dev->d_scalars, N, n, 0, stream, out_mode);
     } catch (...) {
         kzgamd::msm_unlock(dev->msm);
         throw;
@@ -798,12 +815,15 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
         zs = zbuf.data();
     }
     CK_HIP(hipMemcpyAsync(dev->d_z, zs, n * 32, hipMemcpyHostToDevice, dev->stream));
-    prove_enqueue(dev, n, dev->stream, proofs == nullptr);
+    const bool host_compress = proofs && n <= HOST_COMPRESS_MAX;
+    prove_enqueue(dev, n, dev->stream, proofs == nullptr, host_compress ? kzgamd::OUT_JACOBIAN : kzgamd::OUT_COMPRESSED);
     std::vector<int> status(n);
     std::vector<u32> ylimbs(n * 8);
+    blst_p1 jac[HOST_COMPRESS_MAX];
     CK_HIP(hipMemcpyAsync(status.data(), dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
     CK_HIP(hipMemcpyAsync(ylimbs.data(), dev->d_y, n * 32, hipMemcpyDeviceToHost, dev->stream));
-    if (proofs) CK_HIP(hipMemcpyAsync(proofs, dev->d_out, n * 48, hipMemcpyDeviceToHost, dev->stream));
+    if (host_compress) CK_HIP(hipMemcpyAsync(jac, dev->d_out, n * 144, hipMemcpyDeviceToHost, dev->stream));
+    else if (proofs) CK_HIP(hipMemcpyAsync(proofs, dev->d_out, n * 48, hipMemcpyDeviceToHost, dev->stream));
     if (zs_out) memcpy(zs_out, zs, n * 32);
     if (host_check)
         for (size_t i = 0; i < n; ++i) {
@@ -816,6 +836,7 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
         for (size_t i = 0; i < n; ++i) CK_REQUIRE(cstat[i] == 0, "Invalid commitment");
     }
     for (size_t i = 0; i < n; ++i) CK_REQUIRE(status[i] == 0, "Invalid scalar");
+    if (host_compress) compress_on_host(proofs[0].bytes, jac, n);
     if (ys)
         for (size_t i = 0; i < n; ++i) fr_limbs_to_be32(ys[i].bytes, &ylimbs[8 * i]);
 }
@@ -947,12 +968,17 @@ extern "C" C_KZG_RET kzgamd_blob_to_kzg_commitment_batch(KZGCommitment* out, con
         CK_HIP(hipSetDevice(dev->device));
         dev->ensure(n);
         CK_HIP(hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream));
-        commit_enqueue(dev, dev->d_out, dev->d_status, dev->d_blobs, dev->d_scalars, n, dev->stream);
+        const bool host_compress = n <= HOST_COMPRESS_MAX;
+        commit_enqueue(dev, dev->d_out, dev->d_status, dev->d_blobs, dev->d_scalars, n, dev->stream,
+                       host_compress ? kzgamd::OUT_JACOBIAN : kzgamd::OUT_COMPRESSED);
         std::vector<int> status(n);
+        blst_p1 jac[HOST_COMPRESS_MAX];
         CK_HIP(hipMemcpyAsync(status.data(), dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
-        CK_HIP(hipMemcpyAsync(out, dev->d_out, n * 48, hipMemcpyDeviceToHost, dev->stream));
+        if (host_compress) CK_HIP(hipMemcpyAsync(jac, dev->d_out, n * 144, hipMemcpyDeviceToHost, dev->stream));
+        else CK_HIP(hipMemcpyAsync(out, dev->d_out, n * 48, hipMemcpyDeviceToHost, dev->stream));
         CK_HIP(hipStreamSynchronize(dev->stream));
         for (size_t i = 0; i < n; ++i) CK_REQUIRE(status[i] == 0, "Invalid scalar");
+        if (host_compress) compress_on_host(out[0].bytes, jac, n);
     });
 }
 
