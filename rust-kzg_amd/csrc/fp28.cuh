@@ -2,9 +2,10 @@
 // Montgomery radix R' = 2^392.
 //
 // Why not blst's 12 x 32 layout on the device: gfx950 issues v_mad_u64_u32 at
-// nearly the rate of a plain 32-bit add (tools/ffbench.hip: 5.5 vs 4.3 cycles
-// per wave-instruction), so the cheapest multiplier is the one with the fewest
-// instructions overall, not the fewest multiplies.  With 28-bit limbs a whole
+// the rate of any other VALU instruction (one per SIMD per 4 cycles by the SQ
+// counters; tools/ffbench.hip sees 1.3x the wall time of a plain add because the
+// chip clocks lower under a multiply-heavy stream), so the cheapest multiplier
+// is the one with the fewest instructions overall, not the fewest multiplies.  With 28-bit limbs a whole
 // column of partial products (<= 28 terms of < 2^58) fits a 64-bit accumulator,
 // so the 381-bit Montgomery product is a carry-free stream of 392 mads plus
 // ~100 shifts/masks (measured 58 G mul/s on MI355X against 35 G mul/s for the

@@ -34,7 +34,8 @@ def main():
                     out.setdefault(k, {})[cn] = {"launches": len(full), "avg_full_batch": sum(full) / len(full)}
             tag = os.path.basename(d[:-1])[4:]
             shutil.copy(f, os.path.join(R, "profiles", "%s_pmc_%s_counter_collection.csv" % (TAG, tag)))
-    name = [k for k in out if k.startswith("k_fbw_accum")][0]
+    # the instantiation that ran the full-batch launches (k_fbw_accum<4> at 1024 blobs): the one with the most work
+    name = max((k for k in out if k.startswith("k_fbw_accum")), key=lambda k: out[k].get("FETCH_SIZE", {}).get("avg_full_batch", 0))
     ka = out[name]
     fetch_kb, write_kb = ka["FETCH_SIZE"]["avg_full_batch"], ka["WRITE_SIZE"]["avg_full_batch"]
     summary = {
@@ -53,6 +54,24 @@ def main():
         },
         "all": out,
     }
+    # VALU utilisation from the counters alone (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count quad-cycles; effective
+    # clock = GRBM_GUI_ACTIVE / kernel wall time, the counter being summed over the 8 XCDs): duration of the same
+    # launches inside the GRBM pass
+    durs = []
+    for f in glob.glob(os.path.join(R, "gpurun_out", "pmc_GRBM_GUI_ACTIVE", "*kernel_trace.csv")):
+        for row in csv.DictReader(open(f)):
+            if short(row["Kernel_Name"]) == name:
+                durs.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    if durs and "GRBM_GUI_ACTIVE" in ka and "SQ_ACTIVE_INST_VALU" in ka:
+        full = [d for d in durs if d > 0.5 * max(durs)]
+        dur_s = sum(full) / len(full) * 1e-9
+        xcd_cycles = ka["GRBM_GUI_ACTIVE"]["avg_full_batch"] / 8
+        summary["k_fbw_accum"]["kernel_s_in_grbm_pass"] = dur_s
+        summary["k_fbw_accum"]["effective_clock_ghz"] = xcd_cycles / dur_s / 1e9
+        summary["k_fbw_accum"]["valu_busy_frac"] = ka["SQ_ACTIVE_INST_VALU"]["avg_full_batch"] * 4 / (1024 * xcd_cycles)
+        summary["k_fbw_accum"]["valu_note"] = ("valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): "
+                                               "share of the kernel's cycles in which a SIMD's VALU is executing, at the clock the chip "
+                                               "sustained under this load")
     json.dump(summary, open(os.path.join(R, "profiles", TAG + "_pmc_summary.json"), "w"), indent=1)
     shutil.copy(os.path.join(R, "gpurun_out", "prof_final", "r01_kernel_stats.csv"),
                 os.path.join(R, "profiles", TAG + "_bench_kernel_stats.csv"))
