@@ -62,7 +62,7 @@ __device__ __forceinline__ void lds_stages(u32* sh, int cnt, int stages, TwFn tw
             const int j = b & (half - 1);
             const int i0 = ((b >> s) << (s + 1)) | j, i1 = i0 + half;
             Fe x = lds_get(sh, cnt, i0), y = lds_get(sh, cnt, i1);
-            Fe t = fr29::mul(y, fr29::unpack(tw(s, j, i0)));
+            Fe t = fr29::mul(y, tw(s, j, i0));
             fr29::butterfly(x, y, t);
             lds_put(sh, cnt, i0, x);
             lds_put(sh, cnt, i1, y);
@@ -82,7 +82,7 @@ struct NttParams {
 // Pass 1 (and the whole transform when n <= TILE): block `blk` of min(n,TILE) consecutive
 // positions of the bit-reversed sequence; stages 0 .. min(logn,12)-1.
 __global__ void __launch_bounds__(NT) k_ntt_low(Fr* __restrict__ out, const Fr* __restrict__ in,
-                                                const Fr* __restrict__ roots, NttParams P, u32 blocks_per_xform) {
+                                                const Fe* __restrict__ roots, NttParams P, u32 blocks_per_xform) {
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     const u32 xf = blockIdx.x / blocks_per_xform, blk = blockIdx.x % blocks_per_xform;
     const int cnt = P.n < (u32)TILE ? (int)P.n : TILE;
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(NT) k_ntt_low(Fr* __restrict__ out, const Fr* 
     __syncthreads();
     // stage s: half = 2^s, twiddle w_n^(j * n / 2^(s+1)) = roots[j * (W / 2^(s+1))]
     const bool last_pass = P.logn <= LOG_TILE;
-    lds_stages(sh, cnt, stages, [&](int s, int j, int) -> Fr {
+    lds_stages(sh, cnt, stages, [&](int s, int j, int) -> Fe {
         const u32 idx = (u32)j * (P.W >> (s + 1));
         return roots[P.inverse ? P.W - idx : idx];
     });
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(NT) k_ntt_low(Fr* __restrict__ out, const Fr* 
 // View the bit-reversed-order array as [hi][r][lo] with lo < 2^stage0, r < R = 2^logR: stage stage0+s pairs
 // rows r and r + 2^s.  A workgroup takes C = 4096 / R consecutive lo positions of one hi block
 // (C * 32 B contiguous per row: coalesced while R <= 256), runs the logR stages in LDS, writes back.
-__global__ void __launch_bounds__(NT) k_ntt_high(Fr* __restrict__ data, const Fr* __restrict__ roots, NttParams P,
+__global__ void __launch_bounds__(NT) k_ntt_high(Fr* __restrict__ data, const Fe* __restrict__ roots, NttParams P,
                                                  u32 tiles_per_xform, int stage0, int logR, int last) {
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     const u32 xf = blockIdx.x / tiles_per_xform, tile = blockIdx.x % tiles_per_xform;
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(NT) k_ntt_high(Fr* __restrict__ data, const Fr
         lds_put(sh, TILE, c * R + r, fr29::unpack(base[origin + ((size_t)r << stage0) + c]));
     }
     __syncthreads();
-    lds_stages(sh, TILE, logR, [&](int s, int j, int i0) -> Fr {
+    lds_stages(sh, TILE, logR, [&](int s, int j, int i0) -> Fe {
         // global stage stage0+s: half = 2^(stage0+s); position mod half = (r mod 2^s) * 2^stage0 + lo
         const u32 lo = lo0 + (u32)(i0 >> logR);
         const u32 jg = ((u32)j << stage0) + lo;
@@ -138,12 +138,12 @@ __global__ void __launch_bounds__(NT) k_ntt_high(Fr* __restrict__ data, const Fr
 }
 
 // DAS helper: data[i] *= roots[i * stride]  (the shift by the 2n-th root between the two NTTs)
-__global__ void __launch_bounds__(256) k_twist(Fr* __restrict__ data, const Fr* __restrict__ roots, u32 n, u32 stride,
+__global__ void __launch_bounds__(256) k_twist(Fr* __restrict__ data, const Fe* __restrict__ roots, u32 n, u32 stride,
                                                size_t total) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     u32 i = (u32)(t % n);
-    data[t] = fr29::finish(fr29::unpack(data[t]), fr29::unpack(roots[(size_t)i * stride]));
+    data[t] = fr29::finish(fr29::unpack(data[t]), roots[(size_t)i * stride]);
 }
 
 }  // namespace
@@ -185,14 +185,14 @@ void ntt_enqueue(NttCtx* ctx, Fr* d_out, const Fr* d_in, size_t n, size_t nbatch
     const size_t lds = (n < (size_t)TILE ? n : (size_t)TILE) * sizeof(u32) * fr29::L;
     const u32 blocks = n <= (size_t)TILE ? 1u : (u32)(n >> LOG_TILE);
     hipLaunchKernelGGL(k_ntt_low, dim3((unsigned)(blocks * nbatch)), dim3(NT), lds, stream, d_out, d_in,
-                       (const Fr*)ctx->d_roots, P, blocks);
+                       (const Fe*)ctx->d_roots, P, blocks);
     // remaining stages, up to 12 per pass: 12..23, then 24..30
     for (int stage0 = LOG_TILE; stage0 < P.logn; stage0 += LOG_TILE) {
         const int logR = P.logn - stage0 < LOG_TILE ? P.logn - stage0 : LOG_TILE;
         const int last = stage0 + logR == P.logn;
         const u32 tiles = (u32)(n >> LOG_TILE);
         hipLaunchKernelGGL(k_ntt_high, dim3((unsigned)(tiles * nbatch)), dim3(NT), (size_t)TILE * sizeof(u32) * fr29::L, stream,
-                           d_out, (const Fr*)ctx->d_roots, P, tiles, stage0, logR, last);
+                           d_out, (const Fe*)ctx->d_roots, P, tiles, stage0, logR, last);
     }
     NTT_TRY(hipGetLastError());
 }
@@ -213,11 +213,12 @@ extern "C" void* kzgamd_ntt_new(unsigned scale) {
         ctx->scale = scale;
         ctx->W = (size_t)1 << scale;
         kzgamd::expand_roots(ctx->roots, scale);
-        // device twiddles in the 2^261 domain: w*2^261 = (w*2^256) * 2^5
-        std::vector<Fr> tw(ctx->W + 1);
-        for (size_t i = 0; i <= ctx->W; ++i) tw[i] = times32(ctx->roots[i]);
-        NTT_TRY(hipMalloc(&ctx->d_roots, (ctx->W + 1) * sizeof(Fr)));
-        NTT_TRY(hipMemcpy(ctx->d_roots, tw.data(), (ctx->W + 1) * sizeof(Fr), hipMemcpyHostToDevice));
+        // device twiddles in the 2^261 domain, w*2^261 = (w*2^256) * 2^5, already sliced into the 9 x 29-bit limbs
+        // the butterflies multiply with (36 bytes per root instead of 32, ~27 instructions less per butterfly)
+        std::vector<Fe> tw(ctx->W + 1);
+        for (size_t i = 0; i <= ctx->W; ++i) tw[i] = fr29::unpack(times32(ctx->roots[i]));
+        NTT_TRY(hipMalloc(&ctx->d_roots, (ctx->W + 1) * sizeof(Fe)));
+        NTT_TRY(hipMemcpy(ctx->d_roots, tw.data(), (ctx->W + 1) * sizeof(Fe), hipMemcpyHostToDevice));
     } catch (...) {
         delete ctx;
         return nullptr;
@@ -278,7 +279,7 @@ extern "C" int das_fft_extension(void* vctx, blst_fr* odds, const blst_fr* evens
         NTT_TRY(hipMemcpyAsync(ctx->d_a, evens, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
         ntt_enqueue(ctx, ctx->d_b, ctx->d_a, n, 1, true, ctx->stream);
         hipLaunchKernelGGL(k_twist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_b,
-                           (const Fr*)ctx->d_roots, (u32)n, (u32)(ctx->W / (2 * n)), n);
+                           (const Fe*)ctx->d_roots, (u32)n, (u32)(ctx->W / (2 * n)), n);
         ntt_enqueue(ctx, ctx->d_a, ctx->d_b, n, 1, false, ctx->stream);
         NTT_TRY(hipMemcpyAsync(odds, ctx->d_a, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
         NTT_TRY(hipStreamSynchronize(ctx->stream));

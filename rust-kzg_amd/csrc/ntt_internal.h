@@ -21,7 +21,7 @@ struct NttCtx {
     int device = 0;
     unsigned scale = 0;
     size_t W = 0;
-    Fr* d_roots = nullptr;  // W + 1 twiddles in the 2^261 domain (Fr transforms)
+    void* d_roots = nullptr;  // W + 1 twiddles in the 2^261 domain as 9 x 29-bit limbs (Fr transforms)
     std::vector<Fr> roots;  // host copy, blst Montgomery form
     hipStream_t stream = nullptr;
     std::mutex mu;
