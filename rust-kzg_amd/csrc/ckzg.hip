@@ -179,6 +179,7 @@ class WorkerPool {
 };
 
 constexpr int QT = 512;            // threads per blob
+constexpr size_t QSPLIT_MAX = 4;   // up to this many blobs run the multi-workgroup variant (k_quotient_a/b)
 constexpr int QE = (int)(N / QT);  // elements per thread (8), element index i = k*QT + t
 
 // compute_kzg_proof_rust up to the MSM (kzg/src/eip_4844.rs:437-510): y = p(z) by the barycentric
@@ -314,6 +315,138 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
             for (int l = 0; l < 8; ++l) q_out[(blob * N + m) * 8 + l] = qc.v[l];
         }
     }
+}
+
+// The same computation for a handful of blobs (single compute_kzg_proof / compute_blob_kzg_proof calls), where one
+// workgroup per blob is a latency chain: QS workgroups per blob, one element per lane, in two phases.
+//   k_quotient_a : d_i = z - w_i, inverses by a product scan per workgroup (one binary-Euclid inversion each, all
+//                  concurrent), partial barycentric sums, inv_i kept in `scratch`
+//   k_quotient_b : y from the QS partial sums, q_i = (y - p_i) * inv_i; in the z-inside-the-domain case the column
+//                  sum is finished by the last workgroup of the blob to arrive (atomic ticket)
+// scratch per blob: N inverses, QS partial sums, QS partial column sums (Fr), then m (int) and a ticket (u32).
+constexpr int QS = (int)(N / QT);  // workgroups per blob (8)
+constexpr size_t QSCR_FR = N + 2 * QS;                   // Fr slots per blob
+constexpr size_t QSCR_BYTES = QSCR_FR * sizeof(ff::Fr) + 16;  // + m, ticket
+
+__global__ void __launch_bounds__(QT) k_quotient_a(unsigned char* __restrict__ scratch, int* __restrict__ status,
+                                                   const u32* __restrict__ blobs, const u32* __restrict__ z_be,
+                                                   const ff::Fr* __restrict__ roots_brp) {
+    __shared__ ff::Fr sh_a[QT];
+    __shared__ ff::Fr sh_b[QT];
+    __shared__ ff::Fr sh_inv;
+    const int t = threadIdx.x;
+    const size_t blob = blockIdx.x / QS;
+    const int blk = (int)(blockIdx.x % QS);
+    const int i = blk * QT + t;
+    unsigned char* sc = scratch + blob * QSCR_BYTES;
+    ff::Fr* sc_fr = reinterpret_cast<ff::Fr*>(sc);
+    int* sc_m = reinterpret_cast<int*>(sc + QSCR_FR * sizeof(ff::Fr));
+    bool zok;
+    const ff::Fr z = ff::to_mont(fr_load_be(z_be + blob * 8, &zok));
+    const ff::Fr w = roots_brp[i];
+    ff::Fr d = ff::sub(z, w);
+    if (d.is_zero()) {
+        *sc_m = i;  // at most one lane of one workgroup
+        d = ff::Fr::one();
+    }
+    sh_a[t] = d;
+    sh_b[t] = d;
+    __syncthreads();
+    for (int off = 1; off < QT; off <<= 1) {
+        ff::Fr pa = sh_a[t], pb = sh_b[t];
+        if (t >= off) pa = ff::mul(sh_a[t - off], pa);
+        if (t + off < QT) pb = ff::mul(pb, sh_b[t + off]);
+        __syncthreads();
+        sh_a[t] = pa;
+        sh_b[t] = pb;
+        __syncthreads();
+    }
+    if (t == 0) sh_inv = fr_inverse(sh_a[QT - 1]);
+    __syncthreads();
+    ff::Fr inv = sh_inv;
+    if (t > 0) inv = ff::mul(inv, sh_a[t - 1]);
+    if (t + 1 < QT) inv = ff::mul(inv, sh_b[t + 1]);  // 1 / d_i
+    __syncthreads();
+    bool ok;
+    const ff::Fr p = ff::to_mont(fr_load_be(blobs + (blob * N + (size_t)i) * 8, &ok));
+    if (!ok || !zok) status[blob] = 1;
+    sc_fr[i] = inv;
+    sh_a[t] = ff::mul(ff::mul(inv, w), p);
+    __syncthreads();
+    for (int off = QT / 2; off > 0; off >>= 1) {
+        if (t < off) sh_a[t] = ff::add(sh_a[t], sh_a[t + off]);
+        __syncthreads();
+    }
+    if (t == 0) sc_fr[N + blk] = sh_a[0];
+}
+
+__global__ void __launch_bounds__(QT) k_quotient_b(u32* __restrict__ q_out, u32* __restrict__ y_out,
+                                                   unsigned char* __restrict__ scratch, const u32* __restrict__ blobs,
+                                                   const u32* __restrict__ z_be, const ff::Fr* __restrict__ roots_brp,
+                                                   ff::Fr ninv) {
+    __shared__ ff::Fr sh_a[QT];
+    __shared__ ff::Fr sh_y, sh_zinv;
+    __shared__ u32 sh_ticket;
+    const int t = threadIdx.x;
+    const size_t blob = blockIdx.x / QS;
+    const int blk = (int)(blockIdx.x % QS);
+    const int i = blk * QT + t;
+    unsigned char* sc = scratch + blob * QSCR_BYTES;
+    ff::Fr* sc_fr = reinterpret_cast<ff::Fr*>(sc);
+    const int m = *reinterpret_cast<const int*>(sc + QSCR_FR * sizeof(ff::Fr));
+    u32* ticket = reinterpret_cast<u32*>(sc + QSCR_FR * sizeof(ff::Fr) + 4);
+    const u32* bw = blobs + blob * (N * 8);
+    bool ok;
+    const ff::Fr z = ff::to_mont(fr_load_be(z_be + blob * 8, &ok));
+    if (t == 0) {
+        ff::Fr y;
+        if (m >= 0) {
+            y = ff::to_mont(fr_load_be(bw + (size_t)m * 8, &ok));
+        } else {
+            ff::Fr sum = sc_fr[N];
+            for (int k = 1; k < QS; ++k) sum = ff::add(sum, sc_fr[N + k]);
+            ff::Fr zn = z;
+            for (int k = 0; k < 12; ++k) zn = ff::sqr(zn);
+            y = ff::mul(ff::mul(sum, ninv), ff::sub(zn, ff::Fr::one()));  // sum / N * (z^N - 1)
+        }
+        sh_y = y;
+        if (blk == 0) {
+            const ff::Fr yc = ff::from_mont(y);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y_out[blob * 8 + k] = yc.v[k];
+        }
+    }
+    __syncthreads();
+    const ff::Fr y = sh_y;
+    const ff::Fr inv = sc_fr[i];
+    const ff::Fr p = ff::to_mont(fr_load_be(bw + (size_t)i * 8, &ok));
+    const ff::Fr ymp = ff::sub(y, p);
+    if (i != m) {
+        const ff::Fr qc = ff::from_mont(ff::mul(ymp, inv));
+#pragma unroll
+        for (int l = 0; l < 8; ++l) q_out[(blob * N + i) * 8 + l] = qc.v[l];
+    }
+    if (m < 0) return;  // (uniform over the blob)
+    // domain case: column m gets  sum_{i != m} (p_i - y) * w_i / (z * (z - w_i))
+    sh_a[t] = i == m ? ff::Fr::zero() : ff::mul(ff::mul(ff::neg(ymp), roots_brp[i]), inv);
+    __syncthreads();
+    for (int off = QT / 2; off > 0; off >>= 1) {
+        if (t < off) sh_a[t] = ff::add(sh_a[t], sh_a[t + off]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        sc_fr[N + QS + blk] = sh_a[0];
+        __threadfence();
+        sh_ticket = atomicAdd(ticket, 1u);
+    }
+    __syncthreads();
+    if (sh_ticket != (u32)QS - 1 || t != 0) return;
+    __threadfence();
+    ff::Fr col = sc_fr[N + QS];
+    for (int k = 1; k < QS; ++k) col = ff::add(col, sc_fr[N + QS + k]);
+    const ff::Fr qc = ff::from_mont(ff::mul(col, fr_inverse(z)));
+#pragma unroll
+    for (int l = 0; l < 8; ++l) q_out[(blob * N + m) * 8 + l] = qc.v[l];
 }
 
 // commitment bytes -> status: 0 ok (valid encoding, and infinity or in the r-torsion subgroup), 1 bad
@@ -455,6 +588,7 @@ struct KzgAmdSettings {
     u32* d_z = nullptr;              // n x 32 B big-endian evaluation points
     u32* d_y = nullptr;              // n x 8 u32 canonical y
     unsigned char* d_commit = nullptr;  // n x 48 B
+    unsigned char* d_qscratch = nullptr;  // k_quotient_a/b scratch for up to QSPLIT_MAX blobs
     size_t cap_blobs = 0;
     std::unique_ptr<WorkerPool> pool;  // created by the first batched proof call
     std::vector<ff::Fr> brp_roots;  // brp_roots_of_unity[0..8192) (host copy, Montgomery)
@@ -463,6 +597,7 @@ struct KzgAmdSettings {
         if (d_z) (void)hipFree(d_z);
         if (d_y) (void)hipFree(d_y);
         if (d_commit) (void)hipFree(d_commit);
+        if (d_qscratch) (void)hipFree(d_qscratch);
         if (d_brp_roots) (void)hipFree(d_brp_roots);
         if (d_monomial) (void)hipFree(d_monomial);
         if (msm_monomial) kzgamd::msm_destroy(msm_monomial);
@@ -754,8 +889,23 @@ static ff::Fr n_inverse() {
 void prove_enqueue(KzgAmdSettings* dev, size_t n, hipStream_t stream, bool evaluate_only = false,
                    int out_mode = kzgamd::OUT_COMPRESSED) {
     CK_HIP(hipMemsetAsync(dev->d_status, 0, n * sizeof(int), stream));
-    hipLaunchKernelGGL(k_quotient, dim3((unsigned)n), dim3(QT), 0, stream, dev->d_scalars, dev->d_y, dev->d_status,
-                       (const u32*)dev->d_blobs, (const u32*)dev->d_z, (const ff::Fr*)dev->d_brp_roots, n_inverse());
+    if (n <= QSPLIT_MAX) {
+        // a few blobs: QS workgroups per blob, two phases (k_quotient alone is 0.4 ms of latency per call)
+        if (!dev->d_qscratch) CK_HIP(hipMalloc(&dev->d_qscratch, QSPLIT_MAX * QSCR_BYTES));
+        for (size_t b = 0; b < n; ++b) {
+            const int init[4] = {-1, 0, 0, 0};  // m = -1, ticket = 0
+            CK_HIP(hipMemcpyAsync(dev->d_qscratch + b * QSCR_BYTES + QSCR_FR * sizeof(ff::Fr), init, 16, hipMemcpyHostToDevice,
+                                  stream));
+        }
+        hipLaunchKernelGGL(k_quotient_a, dim3((unsigned)(n * QS)), dim3(QT), 0, stream, dev->d_qscratch, dev->d_status,
+                           (const u32*)dev->d_blobs, (const u32*)dev->d_z, (const ff::Fr*)dev->d_brp_roots);
+        hipLaunchKernelGGL(k_quotient_b, dim3((unsigned)(n * QS)), dim3(QT), 0, stream, dev->d_scalars, dev->d_y,
+                           dev->d_qscratch, (const u32*)dev->d_blobs, (const u32*)dev->d_z,
+                           (const ff::Fr*)dev->d_brp_roots, n_inverse());
+    } else {
+        hipLaunchKernelGGL(k_quotient, dim3((unsigned)n), dim3(QT), 0, stream, dev->d_scalars, dev->d_y, dev->d_status,
+                           (const u32*)dev->d_blobs, (const u32*)dev->d_z, (const ff::Fr*)dev->d_brp_roots, n_inverse());
+    }
     if (evaluate_only) return;  // y = p(z) is all the caller wants (the field work of batched verification)
     kzgamd::msm_lock(dev->msm);
     try {
@@ -885,6 +1035,12 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
     CK_HIP(hipMemcpyAsync(dev->d_z, zs, n * 32, hipMemcpyHostToDevice, dev->stream));
     const bool host_compress = proofs && n <= HOST_COMPRESS_MAX;
     prove_enqueue(dev, n, dev->stream, proofs == nullptr, host_compress ? kzgamd::OUT_JACOBIAN : kzgamd::OUT_COMPRESSED);
+    // commitment check on the host, while the GPU works (the copies below block until it is done)
+    if (host_check)
+        for (size_t i = 0; i < n; ++i) {
+            blst_p1 c;
+            if (!kzgamd::host_p1_uncompress(&c, commitments[i].bytes) || !kzgamd::host_p1_in_g1(&c)) cstat[i] = 1;
+        }
     std::vector<int> status(n);
     std::vector<u32> ylimbs(n * 8);
     blst_p1 jac[HOST_COMPRESS_MAX];
@@ -893,11 +1049,6 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
     if (host_compress) CK_HIP(hipMemcpyAsync(jac, dev->d_out, n * 144, hipMemcpyDeviceToHost, dev->stream));
     else if (proofs) CK_HIP(hipMemcpyAsync(proofs, dev->d_out, n * 48, hipMemcpyDeviceToHost, dev->stream));
     if (zs_out) memcpy(zs_out, zs, n * 32);
-    if (host_check)
-        for (size_t i = 0; i < n; ++i) {
-            blst_p1 c;
-            if (!kzgamd::host_p1_uncompress(&c, commitments[i].bytes) || !kzgamd::host_p1_in_g1(&c)) cstat[i] = 1;
-        }
     CK_HIP(hipStreamSynchronize(dev->stream));
     if (derive) {
         if (!host_check) {
