@@ -1,0 +1,20 @@
+import os, sys, random, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import extra_bench as eb
+kzg = eb.load_pkg()
+s = kzg.KZGSettings.from_file(eb.SETUP)
+rnd = random.Random(5)
+b = bytearray(rnd.randbytes(131072))
+for i in range(0, len(b), 32):
+    b[i] = 0
+b = bytes(b)
+c = kzg.blob_to_kzg_commitment(b, s)
+for name, fn in (("commit", lambda: kzg.blob_to_kzg_commitment(b, s)), ("blob proof", lambda: kzg.compute_blob_kzg_proof(b, c, s))):
+    for _ in range(5):
+        fn()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        fn()
+    print("%-10s %.3f ms" % (name, (time.perf_counter() - t0) / 50 * 1e3), os.environ.get("KZGAMD_WSPLIT", "default"))
+s.close()
