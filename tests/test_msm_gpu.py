@@ -412,3 +412,43 @@ def test_variable_base_engine_variants(oracle, kzg, monkeypatch, env):
     L.omsm_tiling_pippenger(C.byref(exp), pts, sc.numpy().tobytes(), n)
     assert compressed(L, got) == compressed(L, exp)
     h.close()
+
+
+@pytest.mark.parametrize("sign", [1, -1])
+def test_horner_exceptional_additions(oracle, kzg, sign):
+    """Window sums that collide in the Horner recombination: Q = +-2^16 * P with scalars (2^16, 1) makes the last
+    addition of the limb-parallel chain a doubling (+) or a cancellation to infinity (-); c = 16 is forced so that
+    the digits fall on window boundaries whatever the size-dependent default."""
+    import torch
+
+    L = oracle.lib()
+    rnd = random.Random(31)
+    n = 40000  # large enough for the default 16-bit windows of the variable-base engine
+    pts = gen_points(L, n, rnd)
+    p = O.G1()
+    L.og1_from_affine(C.byref(p), C.byref(pts[0]))
+    q = O.G1()
+    k = O.fr_from_int((sign * (1 << 16)) % O.R)
+    L.og1_mul(C.byref(q), C.byref(p), C.byref(k))
+    L.og1_to_affine(C.byref(pts[1]), C.byref(q))
+    vals = [0] * n
+    vals[0], vals[1] = 1 << 16, 1
+    sc = O.fr_array(vals)
+    check(L, kzg, pts, sc, n)  # host entry point (host-side Horner)
+    stream = torch.cuda.current_stream().cuda_stream
+    d_pts = torch.frombuffer(bytearray(bytes(pts)), dtype=torch.uint8).cuda()
+    raw = b"".join(v.to_bytes(32, "little") for v in vals)
+    d_sc = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+    d_out = torch.ones(144, dtype=torch.uint8, device="cuda")
+    h = kzg.DeviceMsm(d_pts.data_ptr(), n, False)
+    assert h.info()["window_bits"] == 16
+    kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr(), n, 1, False, stream)
+    torch.cuda.synchronize()
+    h.close()
+    got = O.G1()
+    C.memmove(C.byref(got), d_out.cpu().numpy().tobytes(), 144)
+    exp = O.G1()
+    L.omsm_affine(C.byref(exp), pts, sc, n)
+    assert compressed(L, got) == compressed(L, exp)
+    if sign < 0:
+        assert compressed(L, got) == b"\xc0" + bytes(47)
