@@ -1338,10 +1338,8 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         HIP_TRY(hipGetLastError());
         return;
     }
-    ws.counts.ensure(nsets * nb);
     ws.offsets.ensure(nsets * (nb + 1));
     ws.sorted.ensure(nsets * set_cap);
-    ws.ranks.ensure((size_t)(ctx->glv ? 2 : 1) * nwin * nbatch * npoints);
     const int lgc = npoints >= ((size_t)1 << 18) ? 5 : 4;  // 8 was tried for n <= 2^14: slower (more pieces per bucket)
     const size_t nchunk = (set_cap + ((size_t)1 << lgc) - 1) >> lgc;
     ws.buckets.ensure(nsets * (nb + nchunk));
@@ -1374,6 +1372,9 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     if (two_level) {
         ws.tmp.ensure(nsets * set_cap);
         ws.bins.ensure((size_t)G * (3 * MAX_BINS + 8));
+    } else {
+        ws.counts.ensure(nsets * nb);
+        ws.ranks.ensure((size_t)(ctx->glv ? 2 : 1) * nwin * nbatch * npoints);
     }
     const size_t heavy_cap = sets_per_group * set_cap / HEAVY + 1;  // a heavy bucket holds > HEAVY entries
     ws.heavy_list.ensure(2 * heavy_cap * G);
@@ -1434,7 +1435,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         // with groups, sets are windows (nbatch == 1): group g emits windows [set0, set0 + ns)
         DigitParams P{npoints, nbatch, c, nwin, ctx->prepared ? 1 : 0, mont, nb, ctx->n, ctx->glv ? 1 : 0,
                       G > 1 ? (int)set0 : 0, G > 1 ? (int)(set0 + ns) : nwin};
-        u32* counts = ws.counts.p + set0 * nb;
+        u32* counts = two_level ? nullptr : ws.counts.p + set0 * nb;
         u32* offsets = ws.offsets.p + set0 * (nb + 1);
         unsigned char* heavy = ws.heavy.p + set0 * nb;
         u32* heavy_list = ws.heavy_list.p + 2 * heavy_cap * g;
