@@ -1326,7 +1326,12 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             hipLaunchKernelGGL(k_blocksum, dim3((unsigned)nbatch), dim3(64), 64 * sizeof(Xyzz), stream,
                                (const Xyzz*)ws.lvlA[0].p, ws.lvlM[0].p, (size_t)16);
         } else {
-            hipLaunchKernelGGL(k_blocksum, dim3((unsigned)nbatch), dim3(256), 256 * sizeof(Xyzz), stream,
+            // many MSMs: two waves per MSM instead of four — fewer mostly-idle tree rounds per partial sum
+            // (256 / 128 / 64 threads: 87.7 k / 88.9 k / 87.6 k commitments/s at 1024 blobs, same box)
+            int bs = 256;
+            if (nbatch >= 256) bs = 128;
+            if (const char* e = getenv("KZGAMD_BLOCKSUM_THREADS")) bs = atoi(e) == 64 || atoi(e) == 128 || atoi(e) == 256 ? atoi(e) : bs;
+            hipLaunchKernelGGL(k_blocksum, dim3((unsigned)nbatch), dim3(bs), bs * sizeof(Xyzz), stream,
                                (const Xyzz*)ws.buckets.p, ws.lvlM[0].p, lanes);
         }
         hipLaunchKernelGGL(k_final, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)nullptr,
