@@ -1149,6 +1149,25 @@ struct kzgamd::MsmContext {
     DevBuf<WidePt> wide;  // wide fixed-base table: (rows x n) x 2^(c-1) 128-byte slots, when it fits the budget
     bool fbw = false;
     Workspace ws;
+    // One workspace per stream the handle is used on (up to 4): independent batches enqueued on different streams
+    // may overlap on the GPU — the low-occupancy tail of one batch under the accumulation of the next.  `ws` serves
+    // the handle's own stream and the first caller stream; further streams get their own.
+    hipStream_t ws_owner = nullptr;
+    bool ws_owned = false;
+    std::vector<std::pair<hipStream_t, Workspace*>> ws_extra;
+    Workspace& workspace_for(hipStream_t st) {
+        if (st == stream) return ws;  // host-buffer entry points (synchronised internally)
+        if (!ws_owned) {
+            ws_owned = true;
+            ws_owner = st;
+        }
+        if (st == ws_owner) return ws;
+        for (auto& e : ws_extra)
+            if (e.first == st) return *e.second;
+        if (ws_extra.size() >= 3) return ws;  // more streams than slots: the caller keeps them ordered (header note)
+        ws_extra.emplace_back(st, new Workspace());
+        return *ws_extra.back().second;
+    }
     hipStream_t stream = nullptr;
     // window-group pipeline of the variable-base engine: one auxiliary stream per group, events to fork from /
     // join into the caller's stream and to order the digit and accumulation kernels across groups
@@ -1164,6 +1183,10 @@ struct kzgamd::MsmContext {
         table.release();
         wide.release();
         ws.release();
+        for (auto& e : ws_extra) {
+            e.second->release();
+            delete e.second;
+        }
         for (auto& e : ev)
             if (e) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
@@ -1280,7 +1303,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         return;
     }
     if (set_cap >= ((size_t)1 << 31) || nsets * nb >= ((size_t)1 << 40)) throw HipErr{hipErrorInvalidValue, "MSM too large"};
-    Workspace& ws = ctx->ws;
+    Workspace& ws = ctx->workspace_for(stream);
     if (ctx->fbw) {
         // wide-table path: gather + add, then one block-sum per MSM
         // scalars per lane: 4 for large batches — a quarter of the partial sums for k_blocksum to fold against one

@@ -417,3 +417,35 @@ def test_challenges_and_evaluations_for_batched_verification(kzg, settings, orac
     bad[5] ^= 1
     with pytest.raises(kzg.KzgAmdError):
         kzg.compute_challenges_and_evaluate_batch(blobs[0] + blobs[1], bytes(bad) + cms[1], 2, settings)
+
+
+def test_device_entry_point_on_two_streams(kzg, settings):
+    """Independent batches on two streams share the settings' MSM handle (one workspace per stream): results equal
+    the host-buffer path whatever the interleaving."""
+    import torch
+
+    rnd = random.Random(101)
+    nb = 24
+    dev = torch.device("cuda", 0)
+    host = []
+    for _ in range(2):
+        b = bytearray(rnd.randbytes(nb * BLOB))
+        for i in range(0, nb * BLOB, 32):
+            b[i] = 0
+        host.append(bytes(b))
+    want = [kzg.blob_to_kzg_commitment_batch(h, nb, settings) for h in host]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    d_blobs = [torch.frombuffer(bytearray(h), dtype=torch.uint8).to(dev) for h in host]
+    outs = [torch.zeros(nb * 48, dtype=torch.uint8, device=dev) for _ in range(2)]
+    stats = [torch.zeros(nb, dtype=torch.int32, device=dev) for _ in range(2)]
+    scratch = [torch.empty(nb * BLOB, dtype=torch.uint8, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(6):  # interleaved launches, no synchronisation in between
+        k = rep % 2
+        kzg.blob_to_kzg_commitment_device(outs[k].data_ptr(), stats[k].data_ptr(), scratch[k].data_ptr(),
+                                          d_blobs[k].data_ptr(), nb, settings, streams[k].cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert int(stats[k].sum().item()) == 0
+        got = outs[k].cpu().numpy().tobytes()
+        assert [got[48 * i:48 * i + 48] for i in range(nb)] == want[k]
