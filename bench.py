@@ -103,7 +103,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="blobs per GPU per step")
-    ap.add_argument("--streams", type=int, default=2, help="1: batches back to back on one stream; 2: alternate two streams")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="1: batches back to back on one stream; 2-4: consecutive batches rotate over that many streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large", action="store_true", help="skip the 2^20-point MSM latency line")
     args = ap.parse_args()
@@ -131,10 +132,10 @@ def main():
 
     B = args.batch
     blobs = make_blobs(torch, B, 4844 + rank, dev)
-    # Two streams, alternating: every step is one whole batch (bytes in HBM -> commitments in HBM) on one stream;
+    # A few streams, in rotation: every step is one whole batch (bytes in HBM -> commitments in HBM) on one stream;
     # consecutive batches are independent, so the low-occupancy tail of step i (block sums, compression) runs under
     # the accumulation kernel of step i + 1.  Each stream has its own outputs and scratch.
-    NS = 1 if args.streams < 2 else 2
+    NS = max(1, min(args.streams, 4))
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
     outs = [torch.zeros(B * 48, dtype=torch.uint8, device=dev) for _ in range(NS)]
     stats = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NS)]
@@ -163,7 +164,7 @@ def main():
         step(i)
     sync_all()
     wall = time.perf_counter() - t0
-    prof = kzg.msm_get_profile(handle)  # over the timed region (with two streams: while sharing the GPU)
+    prof = kzg.msm_get_profile(handle)  # over the timed region (with several streams: while sharing the GPU)
     # the same kernel on a few launches that run alone, after the timed region: its own duration, which is what the
     # committed rocprofv3 summary measures and what the VALU utilisation is quoted on
     kzg.msm_set_profile(handle, True)
@@ -173,8 +174,8 @@ def main():
     prof_alone = kzg.msm_get_profile(handle)
     kzg.msm_set_profile(handle, False)
     assert all(int(st.sum().item()) == 0 for st in stats)
-    if NS == 2 and args.steps >= 2:
-        assert torch.equal(outs[0], outs[1])  # the same blobs on both streams
+    if NS >= 2 and args.steps >= 2:
+        assert all(torch.equal(outs[0], o) for o in outs[1:min(NS, args.steps)])  # the same blobs on every stream
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
