@@ -206,7 +206,11 @@ def main():
     if prof is not None:
         accum_ms, total_ms, cnt = prof
         alg_bytes = ALG_BYTES_PER_COMMIT * B
-        ach = alg_bytes / (accum_ms * 1e-3) / 1e9
+        # with several streams the launches of the timed region share the GPU, so an individual launch lasts ~NS times
+        # its own duration; the roofline is quoted on the kernel's own duration (launches that run alone, measured
+        # with the same HIP events right after the timed region; `bench.py --streams 1` times them inside it)
+        own_ms = prof_alone[0] if (prof_alone and NS > 1) else accum_ms
+        ach = alg_bytes / (own_ms * 1e-3) / 1e9
         traffic = None
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same window), scaled to B
             pm = json.load(open(PMC_SUMMARY))
@@ -216,7 +220,7 @@ def main():
             pass
         res["roofline"] = {"bound": "hbm", "kernel": "k_fbw_accum" if info.get("wide_table") else "k_accum", "achieved": ach,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                           "kernel_ms": accum_ms, "kernel_ms_alone": prof_alone[0] if prof_alone else None,
+                           "kernel_ms": own_ms, "kernel_ms_in_timed_region_sharing_the_gpu": accum_ms,
                            "pipeline_ms": total_ms, "launches_averaged": cnt,
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "note": "MSM is integer-VALU bound, not HBM bound (SURVEY §8d); see `valu`"}

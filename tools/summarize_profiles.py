@@ -40,7 +40,7 @@ def main():
     fetch_kb, write_kb = ka["FETCH_SIZE"]["avg_full_batch"], ka["WRITE_SIZE"]["avg_full_batch"]
     summary = {
         "run": "rocprofv3 --pmc <one counter group per pass> --kernel-trace -- python bench.py --steps 4 --warmup 1 "
-               "--no-cpu-baseline --no-large",
+               "--streams 1 --no-cpu-baseline --no-large",
         "batch": B, "window_bits": c, "table_rows": rows,
         "k_fbw_accum": {
             "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
