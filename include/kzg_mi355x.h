@@ -50,7 +50,8 @@ RustError mult_pippenger_prepared_batch(void *msm, blst_p1 out[], size_t npoints
  * synchronised.  scalars_mont != 0: blst_fr Montgomery limbs; 0: canonical little-endian 256-bit.
  * A handle keeps one workspace per stream it is used on, for up to four streams: calls enqueued on the same
  * stream are serialised by stream order, calls on different streams may overlap on the GPU (the low-occupancy
- * tail of one batch under the accumulation of the next).  With more than four streams, order them yourself.
+ * tail of one batch under the accumulation of the next).  With more streams than workspaces the library makes a
+ * stream wait (on the GPU) for the previous use of the workspace it is handed: still correct, no longer overlapped.
  * The host-buffer entry points above synchronise internally and may be called from any thread. */
 RustError kzgamd_msm_prepared_batch_device(void *msm, void *d_out, const void *d_scalars, size_t npoints,
                                            size_t nbatch, int scalars_mont, void *stream);

@@ -1113,7 +1113,12 @@ struct Workspace {
     DevBuf<unsigned char> heavy;
     DevBuf<u32> heavy_list, nheavy;
     DevBuf<ff::Fp> out;
+    // the last enqueue that used this workspace: another stream that is handed the same workspace waits for it
+    hipEvent_t last_done = nullptr;
+    hipStream_t last_stream = nullptr;
     void release() {
+        if (last_done) (void)hipEventDestroy(last_done);
+        last_done = nullptr;
         counts.release();
         offsets.release();
         sorted.release();
@@ -1304,6 +1309,20 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     }
     if (set_cap >= ((size_t)1 << 31) || nsets * nb >= ((size_t)1 << 40)) throw HipErr{hipErrorInvalidValue, "MSM too large"};
     Workspace& ws = ctx->workspace_for(stream);
+    // Workspaces are per stream, but streams can outnumber them (and the handle's own stream shares the first one):
+    // whoever gets a workspace last used on another stream first waits for that use to finish on the GPU.
+    struct WsUse {
+        Workspace& w;
+        hipStream_t st;
+        WsUse(Workspace& w_, hipStream_t st_) : w(w_), st(st_) {
+            if (w.last_done && w.last_stream != st) (void)hipStreamWaitEvent(st, w.last_done, 0);
+        }
+        ~WsUse() {
+            if (!w.last_done && hipEventCreateWithFlags(&w.last_done, hipEventDisableTiming) != hipSuccess) w.last_done = nullptr;
+            if (w.last_done) (void)hipEventRecord(w.last_done, st);
+            w.last_stream = st;
+        }
+    } ws_use(ws, stream);
     if (ctx->fbw) {
         // wide-table path: gather + add, then one block-sum per MSM
         // scalars per lane: 4 for large batches — a quarter of the partial sums for k_blocksum to fold against one
