@@ -22,6 +22,7 @@
 #include "host_g1.h"
 #include "msm_internal.h"
 #include "sha256.h"
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -179,6 +180,7 @@ class WorkerPool {
 };
 
 constexpr int QT = 512;            // threads per blob
+constexpr size_t PROVE_CHUNK = 64;  // blobs per pipeline stage of a large compute_blob_kzg_proof batch
 constexpr size_t QSPLIT_MAX = 4;   // up to this many blobs run the multi-workgroup variant (k_quotient_a/b)
 constexpr int QE = (int)(N / QT);  // elements per thread (8), element index i = k*QT + t
 
@@ -591,6 +593,29 @@ struct KzgAmdSettings {
     unsigned char* d_qscratch = nullptr;  // k_quotient_a/b scratch for up to QSPLIT_MAX blobs
     size_t cap_blobs = 0;
     std::unique_ptr<WorkerPool> pool;  // created by the first batched proof call
+    // extra streams for the chunk pipeline of large proof batches (created on first use); chunk k runs on
+    // pipe_stream(k), `stream` waits for all of them in pipe_join()
+    static constexpr int NPIPE = 3;
+    hipStream_t pipe[NPIPE] = {nullptr, nullptr, nullptr};
+    hipEvent_t pipe_ev[NPIPE] = {nullptr, nullptr, nullptr};
+    hipStream_t pipe_stream(size_t k) {
+        const int j = (int)(k % NPIPE);
+        if (!pipe[j]) {
+            if (hipStreamCreateWithFlags(&pipe[j], hipStreamNonBlocking) != hipSuccess) {
+                pipe[j] = nullptr;
+                return stream;
+            }
+            (void)hipEventCreateWithFlags(&pipe_ev[j], hipEventDisableTiming);
+        }
+        return pipe[j];
+    }
+    void pipe_join() {
+        for (int j = 0; j < NPIPE; ++j)
+            if (pipe[j] && pipe_ev[j]) {
+                (void)hipEventRecord(pipe_ev[j], pipe[j]);
+                (void)hipStreamWaitEvent(stream, pipe_ev[j], 0);
+            }
+    }
     std::vector<ff::Fr> brp_roots;  // brp_roots_of_unity[0..8192) (host copy, Montgomery)
     ff::Fr* d_brp_roots = nullptr;  // first 4096 = the blob evaluation domain
     ~KzgAmdSettings() {
@@ -598,6 +623,10 @@ struct KzgAmdSettings {
         if (d_y) (void)hipFree(d_y);
         if (d_commit) (void)hipFree(d_commit);
         if (d_qscratch) (void)hipFree(d_qscratch);
+        for (int j = 0; j < NPIPE; ++j) {
+            if (pipe_ev[j]) (void)hipEventDestroy(pipe_ev[j]);
+            if (pipe[j]) (void)hipStreamDestroy(pipe[j]);
+        }
         if (d_brp_roots) (void)hipFree(d_brp_roots);
         if (d_monomial) (void)hipFree(d_monomial);
         if (msm_monomial) kzgamd::msm_destroy(msm_monomial);
@@ -886,9 +915,15 @@ static ff::Fr n_inverse() {
 }
 
 // blobs + evaluation points (device) -> proofs (48 B) + y (canonical limbs), all on `stream`
-void prove_enqueue(KzgAmdSettings* dev, size_t n, hipStream_t stream, bool evaluate_only = false,
+void prove_enqueue(KzgAmdSettings* dev, size_t off, size_t n, hipStream_t stream, bool evaluate_only = false,
                    int out_mode = kzgamd::OUT_COMPRESSED) {
-    CK_HIP(hipMemsetAsync(dev->d_status, 0, n * sizeof(int), stream));
+    // blobs [off, off + n) of the staging buffers
+    u32* scal = dev->d_scalars + off * N * 8;
+    u32* yv = dev->d_y + off * 8;
+    int* stat = dev->d_status + off;
+    const u32* bl = (const u32*)(dev->d_blobs + off * BYTES_PER_BLOB);
+    const u32* zv = (const u32*)(dev->d_z + off * 8);
+    CK_HIP(hipMemsetAsync(stat, 0, n * sizeof(int), stream));
     if (n <= QSPLIT_MAX) {
         // a few blobs: QS workgroups per blob, two phases (k_quotient alone is 0.4 ms of latency per call)
         if (!dev->d_qscratch) CK_HIP(hipMalloc(&dev->d_qscratch, QSPLIT_MAX * QSCR_BYTES));
@@ -897,19 +932,19 @@ void prove_enqueue(KzgAmdSettings* dev, size_t n, hipStream_t stream, bool evalu
             CK_HIP(hipMemcpyAsync(dev->d_qscratch + b * QSCR_BYTES + QSCR_FR * sizeof(ff::Fr), init, 16, hipMemcpyHostToDevice,
                                   stream));
         }
-        hipLaunchKernelGGL(k_quotient_a, dim3((unsigned)(n * QS)), dim3(QT), 0, stream, dev->d_qscratch, dev->d_status,
-                           (const u32*)dev->d_blobs, (const u32*)dev->d_z, (const ff::Fr*)dev->d_brp_roots);
-        hipLaunchKernelGGL(k_quotient_b, dim3((unsigned)(n * QS)), dim3(QT), 0, stream, dev->d_scalars, dev->d_y,
-                           dev->d_qscratch, (const u32*)dev->d_blobs, (const u32*)dev->d_z,
+        hipLaunchKernelGGL(k_quotient_a, dim3((unsigned)(n * QS)), dim3(QT), 0, stream, dev->d_qscratch, stat, bl, zv,
+                           (const ff::Fr*)dev->d_brp_roots);
+        hipLaunchKernelGGL(k_quotient_b, dim3((unsigned)(n * QS)), dim3(QT), 0, stream, scal, yv, dev->d_qscratch, bl, zv,
                            (const ff::Fr*)dev->d_brp_roots, n_inverse());
     } else {
-        hipLaunchKernelGGL(k_quotient, dim3((unsigned)n), dim3(QT), 0, stream, dev->d_scalars, dev->d_y, dev->d_status,
-                           (const u32*)dev->d_blobs, (const u32*)dev->d_z, (const ff::Fr*)dev->d_brp_roots, n_inverse());
+        hipLaunchKernelGGL(k_quotient, dim3((unsigned)n), dim3(QT), 0, stream, scal, yv, stat, bl, zv,
+                           (const ff::Fr*)dev->d_brp_roots, n_inverse());
     }
     if (evaluate_only) return;  // y = p(z) is all the caller wants (the field work of batched verification)
     kzgamd::msm_lock(dev->msm);
     try {
-        kzgamd::msm_enqueue(dev->msm, dev->d_out, dev->d_scalars, N, n, 0, stream, out_mode);
+        kzgamd::msm_enqueue(dev->msm, dev->d_out + off * (out_mode == kzgamd::OUT_JACOBIAN ? 144 : 48), scal, N, n, 0, stream,
+                            out_mode);
     } catch (...) {
         kzgamd::msm_unlock(dev->msm);
         throw;
@@ -997,44 +1032,109 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
             // thread until the kernel is done (1.7 ms for 256 commitments), and nothing below depends on it
         }
         zbuf.resize(n);
-        std::vector<char> blob_ok(n, 1);
-        unsigned nth = std::thread::hardware_concurrency();
-        if (nth == 0) nth = 1;
-        if (nth > 16) nth = 16;
-        if (nth > n) nth = (unsigned)n;
-        auto work = [&, nth](unsigned w) {
-            for (size_t i = w; i < n; i += nth) {
-                blob_ok[i] = host_blob_valid(blobs[i].bytes) ? 1 : 0;
-                if (blob_ok[i]) challenge_bytes(zbuf[i].bytes, blobs[i].bytes, commitments[i].bytes);
-            }
-        };
-        if (nth == 1) {
-            CK_HIP(hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream));
-            work(0);
-        } else {
-            // hash on the pool while this thread stages the blobs (pageable memory: the copy call returns when the
-            // bytes are staged, ~0.7 ms for 256 blobs)
-            if (!dev->pool) dev->pool.reset(new WorkerPool(16));
-            hipError_t ce = hipSuccess;
-            std::thread copier([&] {
-                (void)hipSetDevice(dev->device);
-                ce = hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream);
-            });
-            dev->pool->run(nth, work);
-            copier.join();
-            CK_HIP(ce);
-        }
-        for (size_t i = 0; i < n; ++i)
-            if (!blob_ok[i]) {
-                (void)hipStreamSynchronize(dev->stream2);
-                (void)hipStreamSynchronize(dev->stream);
-                throw CkErr{C_KZG_BADARGS, "Invalid scalar"};
-            }
         zs = zbuf.data();
     }
-    CK_HIP(hipMemcpyAsync(dev->d_z, zs, n * 32, hipMemcpyHostToDevice, dev->stream));
     const bool host_compress = proofs && n <= HOST_COMPRESS_MAX;
-    prove_enqueue(dev, n, dev->stream, proofs == nullptr, host_compress ? kzgamd::OUT_JACOBIAN : kzgamd::OUT_COMPRESSED);
+    const int out_mode = host_compress ? kzgamd::OUT_JACOBIAN : kzgamd::OUT_COMPRESSED;
+    unsigned nth = std::thread::hardware_concurrency();
+    if (nth == 0) nth = 1;
+    if (nth > 16) nth = 16;
+    if (nth > n) nth = (unsigned)n;
+    if (derive && nth > 1 && n >= 2 * PROVE_CHUNK) {
+        // Large batch: a pipeline of PROVE_CHUNK-blob chunks on rotating streams.  The pool hashes the blobs in
+        // index order, a copier thread stages chunk after chunk (pageable memory: each copy call blocks until the
+        // bytes are staged), and this thread enqueues the kernels of a chunk as soon as its challenges and its
+        // blobs are there: the GPU proves chunk k while the host is still hashing chunk k+1, and the low-occupancy
+        // tails of neighbouring chunks overlap (one MSM workspace per stream).
+        const size_t nchunks = (n + PROVE_CHUNK - 1) / PROVE_CHUNK;
+        std::vector<char> blob_ok(n, 1);
+        std::vector<std::atomic<unsigned>> hashed(nchunks);
+        for (auto& h : hashed) h.store(0);
+        std::atomic<size_t> copied{0};
+        std::atomic<int> copy_err{0};
+        if (!dev->pool) dev->pool.reset(new WorkerPool(16));
+        std::vector<hipStream_t> cs(nchunks);
+        for (size_t k = 0; k < nchunks; ++k) cs[k] = dev->pipe_stream(k);
+        std::thread copier([&] {
+            (void)hipSetDevice(dev->device);
+            for (size_t k = 0; k < nchunks; ++k) {
+                const size_t off = k * PROVE_CHUNK, cn = off + PROVE_CHUNK <= n ? PROVE_CHUNK : n - off;
+                if (hipMemcpyAsync(dev->d_blobs + off * BYTES_PER_BLOB, blobs + off, cn * BYTES_PER_BLOB, hipMemcpyHostToDevice,
+                                   cs[k]) != hipSuccess)
+                    copy_err.store(1);
+                copied.store(k + 1, std::memory_order_release);
+            }
+        });
+        std::thread hasher([&] {
+            dev->pool->run(nth, [&, nth](unsigned w) {
+                for (size_t i = w; i < n; i += nth) {
+                    blob_ok[i] = host_blob_valid(blobs[i].bytes) ? 1 : 0;
+                    if (blob_ok[i]) challenge_bytes(zbuf[i].bytes, blobs[i].bytes, commitments[i].bytes);
+                    hashed[i / PROVE_CHUNK].fetch_add(1, std::memory_order_release);
+                }
+            });
+        });
+        struct Joiner {
+            std::thread &a, &b;
+            ~Joiner() {
+                if (a.joinable()) a.join();
+                if (b.joinable()) b.join();
+            }
+        } joiner{copier, hasher};
+        bool all_ok = true;
+        for (size_t k = 0; k < nchunks && all_ok; ++k) {
+            const size_t off = k * PROVE_CHUNK, cn = off + PROVE_CHUNK <= n ? PROVE_CHUNK : n - off;
+            while (hashed[k].load(std::memory_order_acquire) < cn || copied.load(std::memory_order_acquire) <= k)
+                std::this_thread::yield();
+            for (size_t i = off; i < off + cn; ++i) all_ok = all_ok && blob_ok[i];
+            if (!all_ok || copy_err.load()) break;
+            CK_HIP(hipMemcpyAsync(dev->d_z + off * 8, zs + off, cn * 32, hipMemcpyHostToDevice, cs[k]));
+            prove_enqueue(dev, off, cn, cs[k], proofs == nullptr, out_mode);
+        }
+        copier.join();
+        hasher.join();
+        dev->pipe_join();  // dev->stream now waits for every chunk
+        if (!all_ok || copy_err.load()) {
+            (void)hipStreamSynchronize(dev->stream2);
+            (void)hipStreamSynchronize(dev->stream);
+            if (copy_err.load()) throw CkErr{C_KZG_ERROR, "host-to-device copy failed"};
+            throw CkErr{C_KZG_BADARGS, "Invalid scalar"};
+        }
+    } else {
+        if (derive) {
+            std::vector<char> blob_ok(n, 1);
+            auto work = [&, nth](unsigned w) {
+                for (size_t i = w; i < n; i += nth) {
+                    blob_ok[i] = host_blob_valid(blobs[i].bytes) ? 1 : 0;
+                    if (blob_ok[i]) challenge_bytes(zbuf[i].bytes, blobs[i].bytes, commitments[i].bytes);
+                }
+            };
+            if (nth == 1) {
+                CK_HIP(hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream));
+                work(0);
+            } else {
+                // hash on the pool while this thread stages the blobs (pageable memory: the copy call returns when
+                // the bytes are staged)
+                if (!dev->pool) dev->pool.reset(new WorkerPool(16));
+                hipError_t ce = hipSuccess;
+                std::thread copier([&] {
+                    (void)hipSetDevice(dev->device);
+                    ce = hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream);
+                });
+                dev->pool->run(nth, work);
+                copier.join();
+                CK_HIP(ce);
+            }
+            for (size_t i = 0; i < n; ++i)
+                if (!blob_ok[i]) {
+                    (void)hipStreamSynchronize(dev->stream2);
+                    (void)hipStreamSynchronize(dev->stream);
+                    throw CkErr{C_KZG_BADARGS, "Invalid scalar"};
+                }
+        }
+        CK_HIP(hipMemcpyAsync(dev->d_z, zs, n * 32, hipMemcpyHostToDevice, dev->stream));
+        prove_enqueue(dev, 0, n, dev->stream, proofs == nullptr, out_mode);
+    }
     // commitment check on the host, while the GPU works (the copies below block until it is done)
     if (host_check)
         for (size_t i = 0; i < n; ++i) {

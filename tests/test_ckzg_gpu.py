@@ -326,6 +326,17 @@ def test_batch_256_blobs_commit_and_prove(kzg, settings, oracle, oracle_settings
     for b in range(0, n, 16):
         batch.update(cms[b] + proofs[b])
     assert singles.digest() == batch.digest()
+    # the pipelined large-batch path rejects a bad blob (element >= r) and a bad commitment wherever they sit
+    for pos in (3, 200):
+        bad = bytearray(blobs)
+        bad[pos * BLOB + 64:pos * BLOB + 96] = b"\xff" * 32
+        with pytest.raises(kzg.KzgAmdError):
+            kzg.compute_blob_kzg_proof_batch(bytes(bad), b"".join(cms), n, settings)
+        badc = list(cms)
+        badc[pos] = b"\x9f" + b"\xff" * 47  # compressed flag set, x >= p: not a field element
+        with pytest.raises(kzg.KzgAmdError):
+            kzg.compute_blob_kzg_proof_batch(blobs, b"".join(badc), n, settings)
+    assert kzg.compute_blob_kzg_proof_batch(blobs, b"".join(cms), n, settings) == proofs  # and recovers afterwards
 
 
 def test_concurrent_callers_share_one_settings_handle(kzg, settings, oracle, oracle_settings):
