@@ -48,7 +48,7 @@ RustError mult_pippenger_prepared_batch(void *msm, blst_p1 out[], size_t npoints
 /* Device-resident form used by the batched blob pipeline and bench.py: d_scalars / d_out are
  * device pointers, work is enqueued on `stream` (a hipStream_t, NULL = default stream) and NOT
  * synchronised.  scalars_mont != 0: blst_fr Montgomery limbs; 0: canonical little-endian 256-bit.
- * A handle keeps one workspace per stream it is used on, for up to four streams: calls enqueued on the same
+ * A handle keeps one workspace per stream it is used on, for up to eight streams: calls enqueued on the same
  * stream are serialised by stream order, calls on different streams may overlap on the GPU (the low-occupancy
  * tail of one batch under the accumulation of the next).  With more streams than workspaces the library makes a
  * stream wait (on the GPU) for the previous use of the workspace it is handed: still correct, no longer overlapped.

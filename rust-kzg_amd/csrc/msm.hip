@@ -1154,7 +1154,7 @@ struct kzgamd::MsmContext {
     DevBuf<WidePt> wide;  // wide fixed-base table: (rows x n) x 2^(c-1) 128-byte slots, when it fits the budget
     bool fbw = false;
     Workspace ws;
-    // One workspace per stream the handle is used on (up to 4): independent batches enqueued on different streams
+    // One workspace per stream the handle is used on (up to 8): independent batches enqueued on different streams
     // may overlap on the GPU — the low-occupancy tail of one batch under the accumulation of the next.  `ws` serves
     // the handle's own stream and the first caller stream; further streams get their own.
     hipStream_t ws_owner = nullptr;
@@ -1169,7 +1169,7 @@ struct kzgamd::MsmContext {
         if (st == ws_owner) return ws;
         for (auto& e : ws_extra)
             if (e.first == st) return *e.second;
-        if (ws_extra.size() >= 3) return ws;  // more streams than slots: the caller keeps them ordered (header note)
+        if (ws_extra.size() >= 7) return ws;  // more streams than workspaces: shared, see WsUse in msm_enqueue
         ws_extra.emplace_back(st, new Workspace());
         return *ws_extra.back().second;
     }
