@@ -290,13 +290,16 @@ def test_msm_2p20_matches_oracle(oracle, kzg):
     h.close()
 
 
-def test_msm_2p22_split_property(oracle, kzg):
-    # BASELINE configs[2] upper size (n = 2^22): a size-independent property instead of a CPU recomputation:
-    # MSM over all points == MSM(first half) + MSM(second half), plus one oracle-checked small prefix
+@pytest.mark.parametrize("logn", [22, 23, 24])
+def test_msm_2p22_split_property(oracle, kzg, logn):
+    # BASELINE configs[2] upper size (n = 2^22) and beyond: a size-independent property instead of a CPU recomputation:
+    # MSM over all points == MSM(first half) + MSM(second half), plus one oracle-checked small prefix.
+    # 2^23 is the largest size of the two-level sort (24-bit point indices for P_i and [x^2]P_i), 2^24 runs the
+    # one-level sort again.
     import torch
 
     L = oracle.lib()
-    n = 1 << 22
+    n = 1 << logn
     stream = torch.cuda.current_stream().cuda_stream
     d_pts = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
     kzg.generate_points(d_pts.data_ptr(), n, 22, stream)
