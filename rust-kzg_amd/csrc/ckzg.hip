@@ -17,8 +17,8 @@
 
 #include "../../include/kzg_mi355x.h"
 #include "ckzg_internal.h"
-#include "fr_host.h"
-#include "g1_io.cuh"
+#include "ff.hip.h"
+#include "g1_io.hip.h"
 #include "host_g1.h"
 #include "msm_internal.h"
 #include "sha256.h"
@@ -119,7 +119,7 @@ __device__ __forceinline__ ff::Fr fr_load_be(const u32* __restrict__ w8, bool* o
     *ok = borrow != 0;
     return a;
 }
-// Montgomery inverse by binary Euclid (ff.cuh); 0 -> 0 like blst_fr_eucl_inverse
+// Montgomery inverse by binary Euclid (ff.hip.h); 0 -> 0 like blst_fr_eucl_inverse
 __device__ ff::Fr fr_inverse(const ff::Fr& a) { return ff::inverse_bgcd(a); }
 
 // Host worker threads for the per-blob SHA-256 challenges of a batch, kept alive between calls: spawning 16

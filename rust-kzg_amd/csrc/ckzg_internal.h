@@ -3,7 +3,7 @@
 #include <vector>
 
 #include "../../include/kzg_mi355x.h"
-#include "ff.cuh"
+#include "ff.hip.h"
 
 struct KzgAmdSettings;
 

@@ -3,7 +3,7 @@
 // handling at all, so the multiplier is a pure v_mad_u64_u32 stream.
 // Candidate measured by tools/ffbench.hip against the saturated 12x32 form.
 #pragma once
-#include "ff.cuh"
+#include "ff.hip.h"
 
 namespace ff28 {
 using ff::u32;

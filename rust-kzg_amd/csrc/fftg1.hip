@@ -5,14 +5,14 @@
 // The reference recurses (even/odd split) and spends its time in FsG1::mul, a 255-bit scalar
 // multiplication per butterfly: n/2 * log2(n) of them.  Here the same butterfly network runs iteratively,
 // one kernel per stage, TWO lanes per butterfly (all transforms of a batch in one launch).  The root w^j is split
-// on the host, once per settings object, into w^j = +-k1 +- k2 * x^2 with 127-bit halves (glv.cuh), so
+// on the host, once per settings object, into w^j = +-k1 +- k2 * x^2 with 127-bit halves (glv.hip.h), so
 //     lane 0:  a = k1 * (+-y)          lane 1:  b = k2 * (+-[x^2]y),  [x^2](X, Y, ZZZ, ZZ) = (beta*X, -Y, ZZZ, ZZ)
 //              fixed 4-bit windows, the 15 multiples in a per-lane table in HBM
 //              (32 windows: 124 doublings + <= 32 additions + 14 for the table, XYZZ coordinates)
 //     t = a + b (exchanged by lane shuffles),   lane 0 writes x + t,  lane 1 writes x - t
 // — half the dependent chain of the plain 255-bit double-and-add, on twice the lanes (a stage of a 2^15-point
 // transform has 16 384 butterflies: a quarter of the chip's lanes).
-// Points live in HBM as XYZZ over the 14 x 28-bit field (g1_28.cuh) between stages; blst Jacobian at the
+// Points live in HBM as XYZZ over the 14 x 28-bit field (g1_28.hip.h) between stages; blst Jacobian at the
 // boundary.  The work is integer-VALU bound; HBM traffic is negligible next to it.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,9 +20,9 @@
 #include <string.h>
 
 #include "../../include/kzg_mi355x.h"
-#include "ff.cuh"
-#include "g1_28.cuh"
-#include "glv.cuh"
+#include "ff.hip.h"
+#include "g1_28.hip.h"
+#include "glv.hip.h"
 #include "ntt_internal.h"
 
 using ff::Fr;

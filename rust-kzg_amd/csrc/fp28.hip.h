@@ -19,7 +19,7 @@
 // Values are only ever reduced to [0,p) at the I/O boundary (to_blst) and inside
 // the rare exact zero test.
 #pragma once
-#include "ff.cuh"
+#include "ff.hip.h"
 
 namespace fp28 {
 using ff::u32;

@@ -1,4 +1,4 @@
-// Fp spread over the lanes of a 16-lane DPP row: limb i of the 14 x 28-bit form (fp28.cuh) lives in lane i,
+// Fp spread over the lanes of a 16-lane DPP row: limb i of the 14 x 28-bit form (fp28.hip.h) lives in lane i,
 // lanes 14 and 15 hold zero.  One element per wave (lanes 0..15 active, the rest idle).
 //
 // Why: the tails of the MSM (Horner over the window sums, the short per-window chains) are single dependency
@@ -13,7 +13,7 @@
 // (one lazy add of normalized values) and return normalized limbs, value < 2p under the same product bound as
 // fp28::mul.  Subtractions add a multiple of p whose low limbs are >= 2^29 - 2, so they never go negative.
 #pragma once
-#include "fp28.cuh"
+#include "fp28.hip.h"
 
 namespace fpw {
 using ff::u32;

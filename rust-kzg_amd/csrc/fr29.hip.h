@@ -1,12 +1,12 @@
 // Fr for the NTT butterflies: 9 limbs of 29 bits, Montgomery radix R' = 2^261 — the same idea as
-// fp28.cuh (carry-free columns of v_mad_u64_u32: 18 partial products < 2^58 per 64-bit column).
+// fp28.hip.h (carry-free columns of v_mad_u64_u32: 18 partial products < 2^58 per 64-bit column).
 //
 // Data elements keep blst's Montgomery form d*2^256 (only re-sliced 32 -> 29 bits); twiddles are
 // stored as w*2^261, so  mul(D, W) = d*w*2^256  stays in blst form without any domain conversion.
 // Butterfly outputs are lazy (value < 64r, limbs renormalised each stage); a pass ends with one
 // multiplication by 2^261 mod r (or by the inverse-transform scale) that brings the value below 2r.
 #pragma once
-#include "ff.cuh"
+#include "ff.hip.h"
 
 namespace fr29 {
 using ff::u32;

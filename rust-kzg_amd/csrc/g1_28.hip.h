@@ -5,9 +5,9 @@
 // restate (pippenger_utils.rs:90-210), with the same exceptional cases
 // (infinity, P == Q -> double, P == -Q -> infinity).
 //
-// Value bounds carried between calls (see fp28.cuh): X < 10p, Y < 6p, ZZ, ZZZ < 2p.
+// Value bounds carried between calls (see fp28.hip.h): X < 10p, Y < 6p, ZZ, ZZZ < 2p.
 #pragma once
-#include "fp28.cuh"
+#include "fp28.hip.h"
 
 namespace g1 {
 using fp28::Fe;

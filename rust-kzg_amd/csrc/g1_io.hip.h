@@ -3,7 +3,7 @@
 // FsG1::from_bytes / to_bytes (blst/src/types/g1.rs:65-100); flag semantics as stated
 // in-tree at zkcrypto/bls12_381/src/g1.rs:337-392.
 #pragma once
-#include "g1_28.cuh"
+#include "g1_28.hip.h"
 
 namespace g1io {
 using ff::u32;

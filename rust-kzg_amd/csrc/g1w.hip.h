@@ -1,9 +1,9 @@
-// G1 points with every coordinate spread over the lanes of a 16-lane row (fpw.cuh): XYZZ coordinates as in
-// g1_28.cuh, one point operation per wave, for the serial tails of the MSM where no other parallelism is left.
+// G1 points with every coordinate spread over the lanes of a 16-lane row (fpw.hip.h): XYZZ coordinates as in
+// g1_28.hip.h, one point operation per wave, for the serial tails of the MSM where no other parallelism is left.
 // Coordinate bounds between calls: X, Y < 18p, ZZ, ZZZ < 2p, limbs <= 2^28.
 #pragma once
-#include "fpw.cuh"
-#include "g1_28.cuh"
+#include "fpw.hip.h"
+#include "g1_28.hip.h"
 
 namespace g1w {
 using ff::u32;

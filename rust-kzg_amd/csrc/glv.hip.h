@@ -1,6 +1,6 @@
 // GLV scalar split on BLS12-381 G1, shared by the variable-base MSM (device) and fft_g1 (host, per root).
 #pragma once
-#include "ff.cuh"
+#include "ff.hip.h"
 
 namespace kzgamd {
 using ff::u32;

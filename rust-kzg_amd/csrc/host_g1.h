@@ -1,12 +1,12 @@
 // Host-side G1 (de)serialisation on blst-layout values, for the few single-point conversions the
 // c-kzg helpers need (compute_challenge takes a blst_p1; bytes_to_kzg_commitment returns one).
-// Bulk work goes through the device kernels in g1_io.cuh instead.
+// Bulk work goes through the device kernels in g1_io.hip.h instead.
 #pragma once
 #include <stdint.h>
 #include <string.h>
 
 #include "../../include/kzg_mi355x.h"
-#include "ff.cuh"
+#include "ff.hip.h"
 
 namespace kzgamd {
 

@@ -26,9 +26,9 @@
 #include <vector>
 
 #include "../../include/kzg_mi355x.h"
-#include "g1_io.cuh"
-#include "g1w.cuh"
-#include "glv.cuh"
+#include "g1_io.hip.h"
+#include "g1w.hip.h"
+#include "glv.hip.h"
 #include "host_g1.h"
 #include "msm_internal.h"
 
@@ -805,7 +805,7 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, co
     out[3 * b + 2] = j[2];
 }
 
-// The serial tails with limb-parallel arithmetic (fpw.cuh / g1w.cuh): one point operation per wave, ~3x shorter
+// The serial tails with limb-parallel arithmetic (fpw.hip.h / g1w.hip.h): one point operation per wave, ~3x shorter
 // instruction streams than the single-lane code.  Used when there are only a few chains (one large MSM).
 //
 // k_winsum_wide: one wave per set,  window sum = A + M + 2^logS * sum_q 2^q R_q

@@ -11,7 +11,7 @@
 //               stages per pass on strided tiles (C positions x R rows = 4096 elements per workgroup): two
 //               passes up to 2^24, three up to the 2^31 the roots table allows; every element crosses HBM
 //               once per pass (64*n algorithmic bytes each).
-// Field arithmetic: 9 x 29-bit Montgomery with lazy butterflies (fr29.cuh); integer VALU only.
+// Field arithmetic: 9 x 29-bit Montgomery with lazy butterflies (fr29.hip.h); integer VALU only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -21,8 +21,8 @@
 
 #include "../../include/kzg_mi355x.h"
 #include "ckzg_internal.h"
-#include "ff.cuh"
-#include "fr29.cuh"
+#include "ff.hip.h"
+#include "fr29.hip.h"
 #include "ntt_internal.h"
 
 using ff::Fr;

@@ -5,7 +5,7 @@
 #include <mutex>
 #include <vector>
 
-#include "ff.cuh"
+#include "ff.hip.h"
 
 struct NttErr {
     hipError_t e;

@@ -6,8 +6,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#include "../rust-kzg_amd/csrc/ff.cuh"
-#include "../rust-kzg_amd/csrc/ff28.cuh"
+#include "../rust-kzg_amd/csrc/ff.hip.h"
+#include "../rust-kzg_amd/csrc/ff28.hip.h"
 
 #define CK(x)                                                                      \
     do {                                                                           \
