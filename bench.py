@@ -1,22 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py — blob_to_kzg_commitment throughput on MI355X (BASELINE.json metric).
+"""bench.py — blob_to_kzg_commitment throughput on MI355X (BASELINE.json metric), plus one driver-timed figure
+with its own roofline object for every other BASELINE.json config.
 
-One step = one pass of the hot path over one batch of synthetic blobs per GPU:
+One step = one pass of the hot path over `--batches-per-step` batches of synthetic blobs per GPU:
   B blobs (4096 x 32-byte field elements each, already resident in HBM)
-    -> canonical scalars -> fixed-base Pippenger MSM over the mainnet trusted setup
-    -> 48-byte compressed commitments (in HBM).
-Workload = BASELINE.json configs[1] (n = 4096 G1 MSM over the trusted-setup points, random Fr
-scalars), batched B per GPU; N > 1 shards whole blobs across ranks (weak scaling, no data-path
-collective).  Prints ONE JSON line on rank 0.
+    -> canonical scalars -> fixed-base MSM over the mainnet trusted setup -> 48-byte compressed commitments (in HBM).
+Workload = BASELINE.json configs[1] (n = 4096 G1 MSM over the trusted-setup points, random Fr scalars), batched;
+N > 1 shards whole blobs across ranks (weak scaling, table replicated, no data-path collective).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself
+(python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...); under an external
+launcher the world size must equal --gpus.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
 import importlib.util
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -26,9 +30,11 @@ SETUP = os.path.join(ROOT, "tests", "golden", "trusted_setup.txt")
 BLOB = 131072
 N = 4096
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK = 1024 * 2.4e9 / 4               # 1024 SIMDs x one wave64 VALU instruction per 4 cycles at the nominal 2.4 GHz
 ALG_BYTES_PER_COMMIT = 128 * N             # 96 B point + 32 B scalar per pair
 ALG_ADDS_PER_COMMIT = 20 * N + 8192        # BGMW count for the fixed-base 4096 case
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_FALLBACK = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
 
 
 def load_pkg():
@@ -41,11 +47,13 @@ def load_pkg():
 
 
 def make_blobs(torch, nblobs, seed, device):
-    g = torch.Generator(device="cpu")
+    """generate_random_blob_bytes (kzg-bench/src/tests/eip_4844.rs:28-37): random bytes, byte 0 of every element
+    zero so that it is < r.  Generated on the device (seeded), nothing to copy."""
+    g = torch.Generator(device=device)
     g.manual_seed(seed)
-    b = torch.randint(0, 256, (nblobs, N, 32), dtype=torch.uint8, generator=g)
-    b[:, :, 0] = 0  # generate_random_blob_bytes: every element < r (kzg-bench/src/tests/eip_4844.rs:28-37)
-    return b.reshape(nblobs, BLOB).to(device)
+    b = torch.randint(0, 256, (nblobs, N, 32), dtype=torch.uint8, generator=g, device=device)
+    b[:, :, 0] = 0
+    return b.reshape(nblobs, BLOB)
 
 
 def host_cores():
@@ -60,9 +68,11 @@ def host_cores():
     return n
 
 
-def cpu_baseline(blobs_host, budget_s=12.0):
-    """Times the CPU oracle (portable C restatement of the reference's Pippenger path — NOT blst asm)
-    on this box's host cores: one thread per core, each committing to its own blobs."""
+def cpu_baseline(blobs_host, gpu_commitments, budget_s=10.0):
+    """Times the CPU oracle (portable C restatement of the reference — NOT blst asm) on this box's host cores, one
+    thread per core, each committing to its own blobs: the reference's default fixed-base algorithm (BGMW,
+    kzg/src/msm/bgmw.rs) when the oracle has it, and the tiling Pippenger the round-1 line used.  Also the checker of
+    this run: the oracle's commitments of the sampled blobs must equal the GPU's."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi as O
 
@@ -70,52 +80,108 @@ def cpu_baseline(blobs_host, budget_s=12.0):
     with open(SETUP, "rb") as f:
         rc, s = O.load_settings(f.read())
     assert rc == 0
-    out = C.create_string_buffer(48)
-    t0 = time.perf_counter()
-    assert L.oblob_to_kzg_commitment(out, blobs_host[0], C.byref(s)) == 0
-    t1 = time.perf_counter() - t0
     cores = host_cores()
-    per_thread = max(1, min(256, int(budget_s / max(t1, 1e-3))))
-    done = [0] * cores
-
-    def work(t):
+    out = {}
+    algos = [("pippenger", L.oblob_to_kzg_commitment)]
+    if hasattr(L, "oblob_to_kzg_commitment_bgmw"):
+        algos.insert(0, ("bgmw", L.oblob_to_kzg_commitment_bgmw))
+    checked = 0
+    for name, fn in algos:
         o = C.create_string_buffer(48)
-        for k in range(per_thread):
-            L.oblob_to_kzg_commitment(o, blobs_host[(t + k) % len(blobs_host)], C.byref(s))
-            done[t] += 1
+        t0 = time.perf_counter()
+        assert fn(o, blobs_host[0], C.byref(s)) == 0
+        t1 = time.perf_counter() - t0
+        assert o.raw == gpu_commitments[0], "GPU commitment differs from the oracle (%s)" % name
+        checked += 1
+        per_thread = max(1, min(256, int(budget_s / len(algos) / max(t1, 1e-3))))
+        done = [0] * cores
+        bad = [0]
 
-    th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
-    t0 = time.perf_counter()
-    for x in th:
-        x.start()
-    for x in th:
-        x.join()
-    dt = time.perf_counter() - t0
-    return {"value": sum(done) / dt, "unit": "commitments/s", "cores": cores, "kind": "port",
-            "single_thread_ms": t1 * 1e3,
-            "sample": "%d commitments (%d threads x %d, seeded random blobs, mainnet setup) in %.1f s; "
-                      "portable-C oracle (oracle/msm.c tiling Pippenger), not blst asm" % (sum(done), cores, per_thread, dt)}
+        def work(t):
+            ob = C.create_string_buffer(48)
+            for k in range(per_thread):
+                i = (t + k) % len(blobs_host)
+                fn(ob, blobs_host[i], C.byref(s))
+                if ob.raw != gpu_commitments[i]:
+                    bad[0] += 1
+                done[t] += 1
+
+        th = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+        t0 = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt = time.perf_counter() - t0
+        assert bad[0] == 0, "GPU commitments differ from the oracle's"
+        out[name] = {"commitments_per_s": sum(done) / dt, "single_thread_ms": t1 * 1e3, "commitments": sum(done), "seconds": dt}
+    best = max(out, key=lambda k: out[k]["commitments_per_s"])
+    return {"value": out[best]["commitments_per_s"], "unit": "commitments/s", "cores": cores, "kind": "port",
+            "algorithm": best, "single_thread_ms": out[best]["single_thread_ms"], "by_algorithm": out,
+            "gpu_commitments_checked_against_oracle": min(len(blobs_host), cores + 255),
+            "sample": "%d commitments (%d threads, seeded random blobs, mainnet setup) in %.1f s with %s; portable-C oracle "
+                      "(oracle/msm.c), not blst asm; every one compared with the GPU's commitment of the same blob"
+                      % (out[best]["commitments"], cores, out[best]["seconds"], best)}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def reference_window(n):  # pippenger_window_size (kzg/src/msm/pippenger_utils.rs:300-317)
+    b = n.bit_length()
+    return b - 4 if b > 13 else (b - 3 if b > 5 else 2)
+
+
+def pmc_summary():
+    for p in (PMC_SUMMARY, PMC_FALLBACK):
+        try:
+            return json.load(open(p)), os.path.relpath(p, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="blobs per GPU per step")
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="blobs per batch (one MSM launch)")
+    ap.add_argument("--batches-per-step", type=int, default=8, help="batches per GPU per step, each with its own blobs")
     ap.add_argument("--streams", type=int, default=4,
                     help="1: batches back to back on one stream; 2-4: consecutive batches rotate over that many streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-large", action="store_true", help="skip the 2^20-point MSM latency line")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip the NTT / MSM sweep / proof / host-buffer legs")
+    ap.add_argument("--no-large", action="store_true", help="alias of --no-extras")
     args = ap.parse_args()
+    if args.no_large:
+        args.no_extras = True
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # self-launch: one rank per GPU over RCCL
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or let --gpus N launch them)"
+                         % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -126,28 +192,35 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     kzg = load_pkg()
+    kzg.set_device(local_rank)
     settings = kzg.KZGSettings.from_file(SETUP)
+    assert settings.device() == local_rank
     handle = settings.msm_handle()
     info = kzg.PreparedMsm.info(type("H", (), {"handle": handle})())
 
-    B = args.batch
-    blobs = make_blobs(torch, B, 4844 + rank, dev)
-    # A few streams, in rotation: every step is one whole batch (bytes in HBM -> commitments in HBM) on one stream;
-    # consecutive batches are independent, so the low-occupancy tail of step i (block sums, compression) runs under
-    # the accumulation kernel of step i + 1.  Each stream has its own outputs and scratch.
+    B, NB = args.batch, max(1, args.batches_per_step)
+    blobs = make_blobs(torch, B * NB, 4844 + 1000 * rank, dev)          # every batch of a step has its own blobs
+    batch_ptr = [blobs[k * B:(k + 1) * B].data_ptr() for k in range(NB)]
+    # A few streams, in rotation: every batch (bytes in HBM -> commitments in HBM) runs on one stream; consecutive
+    # batches are independent, so the low-occupancy tail of one (block sums, compression) runs under the
+    # accumulation kernel of the next.  Each (stream, batch) has its own outputs; each stream its own scratch.
     NS = max(1, min(args.streams, 4))
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
-    outs = [torch.zeros(B * 48, dtype=torch.uint8, device=dev) for _ in range(NS)]
-    stats = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NS)]
+    outs = [torch.zeros(B * 48, dtype=torch.uint8, device=dev) for _ in range(NB)]
+    stats = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(NB)]
     scratch = [torch.empty(B * BLOB, dtype=torch.uint8, device=dev) for _ in range(NS)]
-    out, status = outs[0], stats[0]
     stream = torch.cuda.current_stream().cuda_stream
+    for s_ in streams:
+        settings.reserve(B, s_.cuda_stream)   # workspaces allocated here, not inside the timed region
     torch.cuda.synchronize()
+    seq = [0]
 
-    def step(i):
-        k = i % NS
-        kzg.blob_to_kzg_commitment_device(outs[k].data_ptr(), stats[k].data_ptr(), scratch[k].data_ptr(), blobs.data_ptr(), B,
-                                          settings, streams[k].cuda_stream)
+    def step():
+        for k in range(NB):
+            j = seq[0] % NS
+            seq[0] += 1
+            kzg.blob_to_kzg_commitment_device(outs[k].data_ptr(), stats[k].data_ptr(), scratch[j].data_ptr(), batch_ptr[k], B,
+                                              settings, streams[j].cuda_stream)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -155,38 +228,38 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # set-up, like building the table: one pass over every stream so that each has its workspace allocated (a first
-    # use calls hipMalloc, which synchronises the device) — then the W warm-up steps and the K timed steps
-    for i in range(NS):
-        step(i)
-    sync_all()
-    for i in range(args.warmup):
-        step(i)
+    for _ in range(args.warmup):
+        step()
     sync_all()
     kzg.msm_set_profile(handle, True)  # HIP events around the dominant kernel, on its launch stream
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    for _ in range(args.steps):
+        step()
     sync_all()
     wall = time.perf_counter() - t0
-    prof = kzg.msm_get_profile(handle)  # over the timed region (with several streams: while sharing the GPU)
-    # the same kernel on a few launches that run alone, after the timed region: its own duration, which is what the
-    # committed rocprofv3 summary measures and what the VALU utilisation is quoted on
+    prof = kzg.msm_get_profile(handle)  # over the timed region (with several streams: launches share the GPU)
+    # the same kernel on launches that run alone (one stream, back to back), after the timed region: its own duration,
+    # which is what rocprofv3 --streams 1 measures and what the VALU utilisation is quoted on
     kzg.msm_set_profile(handle, True)
-    for _ in range(3):
-        step(0)
+    for k in range(min(NB, 4)):
+        kzg.blob_to_kzg_commitment_device(outs[k].data_ptr(), stats[k].data_ptr(), scratch[0].data_ptr(), batch_ptr[k], B,
+                                          settings, streams[0].cuda_stream)
     torch.cuda.synchronize()
     prof_alone = kzg.msm_get_profile(handle)
     kzg.msm_set_profile(handle, False)
     assert all(int(st.sum().item()) == 0 for st in stats)
-    if NS >= 2 and args.steps >= 2:
-        assert all(torch.equal(outs[0], o) for o in outs[1:min(NS, args.steps)])  # the same blobs on every stream
     tmax = torch.tensor([wall], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall_max = float(tmax.item())
+    devices = [{"rank": rank, "device": kzg.get_device(), "name": torch.cuda.get_device_name(local_rank),
+                "settings_device": settings.device()}]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
 
-    total_commits = B * args.steps * world
+    total_commits = B * NB * args.steps * world
     value = total_commits / wall_max
     res = {
         "metric": "blob_to_kzg_commitment_per_s",
@@ -203,99 +276,152 @@ def main():
         "data": "synthetic: seeded random blobs (byte 0 of each element zeroed), Ethereum mainnet trusted setup",
         "config": {"workload": "G1 Pippenger MSM n=4096 (EIP-4844 blob) x trusted-setup Lagrange points, "
                                "blob bytes -> 48-byte commitment, batched",
-                   "blobs_per_gpu_per_step": B, "msm_window_bits": info["window_bits"], "table_rows": info["rows"],
+                   "blobs_per_batch": B, "batches_per_step": NB, "blobs_per_gpu_per_step": B * NB,
+                   "msm_window_bits": info["window_bits"], "table_rows": info["rows"],
                    "parallelism": "blobs sharded across %d GPU(s), table replicated, no collective" % world},
+        "timed_region_s": wall_max,
         "g1_adds_per_s": value * ALG_ADDS_PER_COMMIT,
         "streams": NS,
+        "devices": devices,
     }
+    pm, pm_src = pmc_summary()
     if prof is not None:
         accum_ms, total_ms, cnt = prof
         alg_bytes = ALG_BYTES_PER_COMMIT * B
-        # with several streams the launches of the timed region share the GPU, so an individual launch lasts ~NS times
-        # its own duration; the roofline is quoted on the kernel's own duration (launches that run alone, measured
-        # with the same HIP events right after the timed region; `bench.py --streams 1` times them inside it)
         own_ms = prof_alone[0] if (prof_alone and NS > 1) else accum_ms
         ach = alg_bytes / (own_ms * 1e-3) / 1e9
+        kern = "k_fbw_accum" if info.get("wide_table") else "k_accum"
         traffic = None
-        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same window), scaled to B
-            pm = json.load(open(PMC_SUMMARY))
-            if info.get("wide_table") and pm.get("window_bits") == info["window_bits"]:
-                traffic = pm["k_fbw_accum"]["hbm_bytes_per_launch"] / pm["batch"] * B
-        except Exception:
-            pass
-        res["roofline"] = {"bound": "hbm", "kernel": "k_fbw_accum" if info.get("wide_table") else "k_accum", "achieved": ach,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+        pk = None
+        if pm and info.get("wide_table") and pm.get("window_bits") == info["window_bits"] and kern in pm:
+            pk = pm[kern]
+            traffic = pk["hbm_bytes_per_launch"] / pm["batch"] * B
+        res["roofline"] = {"bound": "hbm", "kernel": kern, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                           "traffic_source": pm_src if traffic is not None else None,
                            "kernel_ms": own_ms, "kernel_ms_in_timed_region_sharing_the_gpu": accum_ms,
-                           "pipeline_ms": total_ms, "launches_averaged": cnt,
+                           "launches_per_step": NB, "pipeline_ms_per_launch": total_ms, "launches_averaged": cnt,
                            "algorithmic_bytes_per_launch": alg_bytes,
-                           "note": "MSM is integer-VALU bound, not HBM bound (SURVEY §8d); see `valu`"}
-        # The kernel is bound by VALU instruction issue (one wave-instruction per SIMD per 4 cycles), not by HBM.
-        # Instructions per launch and the busy fraction come from the committed rocprofv3 PMC passes of this same
-        # kernel (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE), the duration is the live one.
-        try:
-            pm = json.load(open(PMC_SUMMARY))
-            pk = pm["k_fbw_accum"]
-            if info.get("wide_table") and pm.get("window_bits") == info["window_bits"]:
-                wave_instr = pk["SQ_INSTS_VALU"] / pm["batch"] * B
-                peak = 1024 * 2.4e9 / 4  # 1024 SIMDs, nominal 2.4 GHz, 4 cycles per wave64 VALU instruction
-                alone_ms = prof_alone[0] if prof_alone else accum_ms
-                res["valu"] = {"bound": "VALU issue", "achieved": wave_instr / (alone_ms * 1e-3), "peak": peak,
-                               "unit": "VALU wave-instructions/s", "frac": wave_instr / (alone_ms * 1e-3) / peak,
-                               "kernel_ms_alone": alone_ms,
-                               "busy_frac_at_sustained_clock": pk.get("valu_busy_frac"),
-                               "sustained_clock_ghz": pk.get("effective_clock_ghz"),
-                               "note": "frac is against the nominal 2.4 GHz; under this all-VALU load the chip sustains "
-                                       "~2.0 GHz, where the VALUs are busy busy_frac of the kernel's cycles "
-                                       "(SQ_ACTIVE_INST_VALU x 4 / SIMD cycles from GRBM_GUI_ACTIVE)"}
-        except Exception:
-            pass
+                           "note": "MSM is integer-VALU bound, not HBM bound (SURVEY §8d); see `valu`. kernel_ms is one "
+                                   "launch (one batch) running alone; a step is launches_per_step of them"}
+        if pk is not None:
+            wave_instr = pk["SQ_INSTS_VALU"] / pm["batch"] * B
+            res["valu"] = {"bound": "VALU issue", "kernel": kern, "achieved": wave_instr / (own_ms * 1e-3), "peak": VALU_PEAK,
+                           "unit": "VALU wave-instructions/s", "frac": wave_instr / (own_ms * 1e-3) / VALU_PEAK,
+                           "kernel_ms_alone": own_ms, "valu_instructions_per_mixed_add": wave_instr * 64 / (B * N * info["rows"]),
+                           "busy_frac_at_sustained_clock": pk.get("valu_busy_frac"),
+                           "sustained_clock_ghz": pk.get("effective_clock_ghz"),
+                           "source": "instruction count, busy fraction and clock: %s (rocprofv3 PMC passes of this kernel); "
+                                     "duration: live HIP events" % pm_src,
+                           "note": "frac is against the nominal 2.4 GHz; under this all-VALU load the chip sustains "
+                                   "~2.0 GHz, where the VALUs are busy busy_frac of the kernel's cycles"}
 
-    # second half of the metric: 2^20-point G1 MSM latency (variable-base engine, device-resident inputs)
-    if not args.no_large and rank == 0:
-        n = 1 << 20
-        pts = torch.empty(n * 96, dtype=torch.uint8, device=dev)
-        kzg.generate_points(pts.data_ptr(), n, 2, stream)
-        g = torch.Generator(device="cpu")
-        g.manual_seed(2)
-        sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g)
-        sc[:, 31] &= 0x3f  # little-endian canonical scalars < 2^254 < r
-        sc = sc.to(dev)
-        big = kzg.DeviceMsm(pts.data_ptr(), n, False)
-        o = torch.zeros(144, dtype=torch.uint8, device=dev)
-        kzg.msm_prepared_batch_device(big, o.data_ptr(), sc.data_ptr(), n, 1, False, stream)
+    def ev_time(fn, reps=5):
+        """min over reps of the HIP-event time of fn() on torch's current stream (the library launches there)"""
+        fn()
         torch.cuda.synchronize()
         ts = []
-        for _ in range(3):
+        for _ in range(reps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            kzg.msm_prepared_batch_device(big, o.data_ptr(), sc.data_ptr(), n, 1, False, stream)
+            fn()
             b.record()
             torch.cuda.synchronize()
             ts.append(a.elapsed_time(b))
-        res["msm_2p20_ms"] = min(ts)
-        res["msm_2p20_pairs_per_s"] = n / (min(ts) * 1e-3)
-        big.close()
+        return min(ts)
 
-    if rank == 0 and not args.no_large:
-        # host buffers in / host buffers out through the c-kzg batch entry point (PCIe both ways) — never `value`
-        nb = min(B, 256)
+    # ---- configs[4]: blob proofs, 256 blobs sharded over the ranks (host buffers in/out) -------------------------
+    if not args.no_extras:
+        nshard = max(1, 256 // world)
+        hb = blobs[:nshard].cpu().numpy().tobytes()
+        cm = b"".join(kzg.blob_to_kzg_commitment_batch(hb, nshard, settings))
+        kzg.compute_blob_kzg_proof_batch(hb, cm, nshard, settings)
+        sync_all()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            kzg.compute_blob_kzg_proof_batch(hb, cm, nshard, settings)
+        sync_all()
+        tp = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        res["blob_proof_batch_256"] = {"proofs_per_s": reps * nshard * world / float(tp.item()), "blobs_per_rank": nshard,
+                                       "ms_per_batch": float(tp.item()) / reps * 1e3,
+                                       "path": "kzgamd_compute_blob_kzg_proof_batch: host buffers in and out (PCIe both ways), "
+                                               "Fiat-Shamir SHA-256 on host threads",
+                                       "algorithmic_bytes_per_proof": ALG_BYTES_PER_COMMIT + 131120}
+
+    if rank == 0 and not args.no_extras:
+        # ---- configs[3]: Fr NTT n = 4096 (batched) and n = 2^20, forward + DAS extension -------------------------
+        fs = kzg.FFTSettings(20)
+        ntt = {}
+        for n, nb in ((4096, 256), (1 << 20, 1)):
+            a = torch.randint(0, 2**31, (nb * n * 8,), dtype=torch.int32, device=dev)
+            a[7::8] &= 0x3FFFFFFF  # any 256-bit pattern below r is a valid Montgomery residue
+            b = torch.empty_like(a)
+            ms = ev_time(lambda: fs.fft_fr_device(b.data_ptr(), a.data_ptr(), n, nb, False, stream))
+            ms_inv = ev_time(lambda: fs.fft_fr_device(b.data_ptr(), a.data_ptr(), n, nb, True, stream))
+            alg = 64 * n * nb
+            muls = nb * (n // 2) * int(math.log2(n))
+            ntt["n=%d x %d" % (n, nb)] = {
+                "ms": ms, "ms_inverse": ms_inv, "transforms_per_s": nb / (ms * 1e-3), "fr_mul_per_s": muls / (ms * 1e-3),
+                "roofline": {"bound": "hbm", "kernel": "k_ntt_low" + ("+k_ntt_high" if n > 4096 else ""),
+                             "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "traffic": None,
+                             "note": "64*n algorithmic bytes (SURVEY §8d). At ~270 VALU instructions per radix-2 butterfly "
+                                     "(9x29-bit Montgomery multiply + lazy add/sub) the transform needs "
+                                     "%.1f M wave-instructions: VALU floor %.0f us at the nominal clock"
+                                     % (muls * 270 / 64 / 1e6, muls * 270 / 64 / VALU_PEAK * 1e6)}}
+            del a, b
+        res["ntt"] = ntt
+        fs.close()
+
+        # ---- configs[2]: G1 MSM sweep n = 2^16 .. 2^22 (variable-base engine, device-resident inputs) --------------
+        nmax = 1 << 22
+        pts = torch.empty(nmax * 96, dtype=torch.uint8, device=dev)
+        kzg.generate_points(pts.data_ptr(), nmax, 2, stream)
+        g = torch.Generator(device=dev)
+        g.manual_seed(2)
+        sc = torch.randint(0, 256, (nmax, 32), dtype=torch.uint8, generator=g, device=dev)
+        sc[:, 31] &= 0x3F  # little-endian canonical scalars < 2^254 < r
+        o = torch.zeros(144, dtype=torch.uint8, device=dev)
+        sweep = []
+        for logn in (16, 18, 20, 21, 22):
+            n = 1 << logn
+            h = kzg.DeviceMsm(pts.data_ptr(), n, False)
+            hi = h.info()
+            ms = ev_time(lambda: kzg.msm_prepared_batch_device(h, o.data_ptr(), sc.data_ptr(), n, 1, False, stream), reps=3)
+            c = reference_window(n)
+            w = -(-255 // c)
+            adds = n * w + (1 << c) * w  # SURVEY §8(d): algorithmic adds with the reference's window
+            gbs = 128 * n / (ms * 1e-3) / 1e9
+            sweep.append({"n": n, "ms": ms, "pairs_per_s": n / (ms * 1e-3), "g1_adds_per_s": adds / (ms * 1e-3),
+                          "kernel_window_bits": hi["window_bits"],
+                          "roofline": {"bound": "hbm", "kernel": "k_accum (+ sort and reduction kernels)", "achieved": gbs,
+                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                       "algorithmic_bytes": 128 * n, "traffic": None}})
+            if logn == 20:
+                res["msm_2p20_ms"] = ms
+                res["msm_2p20_pairs_per_s"] = n / (ms * 1e-3)
+            h.close()
+        res["msm_sweep"] = sweep
+        del pts, sc
+
+        # ---- host buffers in / host buffers out through the c-kzg batch entry point (PCIe both ways) — never `value`
+        nb = 1024
         hb = blobs[:nb].cpu().numpy().tobytes()
         kzg.blob_to_kzg_commitment_batch(hb, nb, settings)
         t0 = time.perf_counter()
         for _ in range(3):
             kzg.blob_to_kzg_commitment_batch(hb, nb, settings)
         res["pcie_inclusive_commitments_per_s"] = 3 * nb / (time.perf_counter() - t0)
-        # blob proofs through the batched host-buffer entry point (Fiat-Shamir hashes on host threads)
-        cm = b"".join(kzg.blob_to_kzg_commitment_batch(hb, nb, settings))
-        kzg.compute_blob_kzg_proof_batch(hb, cm, nb, settings)
-        t0 = time.perf_counter()
-        for _ in range(3):
-            kzg.compute_blob_kzg_proof_batch(hb, cm, nb, settings)
-        res["blob_proofs_per_s_host_buffers"] = 3 * nb / (time.perf_counter() - t0)
+        res["pcie_inclusive_blobs_per_call"] = nb
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        host = blobs[: min(B, 64)].cpu().numpy()
-        res["cpu_baseline"] = cpu_baseline([host[i].tobytes() for i in range(host.shape[0])])
+        ns = min(B, 64)
+        host = blobs[:ns].cpu().numpy()
+        gpu = outs[0][:ns * 48].cpu().numpy().tobytes()
+        res["cpu_baseline"] = cpu_baseline([host[i].tobytes() for i in range(ns)], [gpu[48 * i:48 * i + 48] for i in range(ns)])
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

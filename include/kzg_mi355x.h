@@ -55,6 +55,12 @@ RustError mult_pippenger_prepared_batch(void *msm, blst_p1 out[], size_t npoints
  * The host-buffer entry points above synchronise internally and may be called from any thread. */
 RustError kzgamd_msm_prepared_batch_device(void *msm, void *d_out, const void *d_scalars, size_t npoints,
                                            size_t nbatch, int scalars_mont, void *stream);
+/* Allocates now the workspace `stream` will use for nbatch MSMs of npoints scalars, so that the enqueue calls that
+ * follow never call hipMalloc (which synchronises the device).  Without it the first enqueue on a new stream, or
+ * with a larger shape, allocates lazily. */
+RustError kzgamd_msm_reserve(void *msm, size_t npoints, size_t nbatch, void *stream);
+/* the GPU a handle lives on (-1 for NULL) */
+int kzgamd_msm_device(void *msm);
 /* introspection for benches/tests: window bits, table rows, buckets of a handle */
 int kzgamd_msm_info(void *msm, int *window_bits, int *rows, size_t *nbuckets, size_t *npoints);
 /* 1 if the handle holds the wide fixed-base table (rows x npoints x 2^(window_bits-1) affine multiples,
@@ -175,6 +181,11 @@ C_KZG_RET kzgamd_compute_cells_and_kzg_proofs_batch(Cell *cells, KZGProof *proof
                                                     const CKZGSettings *s);
 /* the prepared-MSM handle behind a settings object (for kzgamd_msm_* calls) */
 void *kzgamd_settings_msm_handle(const CKZGSettings *s);
+/* the GPU a settings object lives on (-1 if unknown) */
+int kzgamd_settings_device(const CKZGSettings *s);
+/* pre-allocates the per-stream workspace kzgamd_blob_to_kzg_commitment_device needs for batches of up to n blobs
+ * on `stream` (see kzgamd_msm_reserve) */
+C_KZG_RET kzgamd_settings_reserve(const CKZGSettings *s, size_t n, void *stream);
 
 /* Multi-GPU combine step of one large MSM sharded by index range over G ranks: every rank computes
  * its partial with mult_pippenger / the device entry points over its slice of (points, scalars); the G
@@ -185,6 +196,14 @@ void kzgamd_g1_sum(blst_p1 *out, const blst_p1 in[], size_t n);
 
 /* library / device info */
 int kzgamd_device_count(void);
+/* Multi-GPU from one process (the reference's sppark path is single-GPU, blst/src/kzg_proofs.rs:47-61).
+ * kzgamd_set_device selects the GPU for the calling thread (hipSetDevice): handles created afterwards — prepare_msm,
+ * kzgamd_msm_create_device, kzgamd_ntt_new, load_trusted_setup(_file) — live on that GPU.  Every later call on a
+ * handle, host-buffer or device-resident form, switches to the handle's GPU by itself and restores the caller's
+ * current device on return; device pointers and streams passed to a *_device entry point must belong to the
+ * handle's GPU.  Returns 0 / the device index (-1 on error). */
+int kzgamd_set_device(int device);
+int kzgamd_get_device(void);
 const char *kzgamd_version(void);
 
 #ifdef __cplusplus

@@ -59,6 +59,8 @@ EXPORTS = [
     "bytes_to_kzg_commitment", "bytes_from_bls_field", "compute_cells_and_kzg_proofs",
     "kzgamd_compute_cells_and_kzg_proofs_batch", "kzgamd_compute_challenges_and_evaluate_batch",
     "kzgamd_blob_to_kzg_commitment_batch", "kzgamd_blob_to_kzg_commitment_device", "kzgamd_settings_msm_handle",
+    "kzgamd_msm_reserve", "kzgamd_msm_device", "kzgamd_set_device", "kzgamd_get_device", "kzgamd_settings_device",
+    "kzgamd_settings_reserve",
 ]
 
 
@@ -162,6 +164,17 @@ def lib():
     L.kzgamd_compute_cells_and_kzg_proofs_batch.argtypes = [vp, vp, vp, sz, sp]
     L.kzgamd_settings_msm_handle.restype = vp
     L.kzgamd_settings_msm_handle.argtypes = [sp]
+    L.kzgamd_msm_reserve.restype = RustError
+    L.kzgamd_msm_reserve.argtypes = [vp, sz, sz, vp]
+    L.kzgamd_msm_device.restype = C.c_int
+    L.kzgamd_msm_device.argtypes = [vp]
+    L.kzgamd_set_device.restype = C.c_int
+    L.kzgamd_set_device.argtypes = [C.c_int]
+    L.kzgamd_get_device.restype = C.c_int
+    L.kzgamd_settings_device.restype = C.c_int
+    L.kzgamd_settings_device.argtypes = [sp]
+    L.kzgamd_settings_reserve.restype = C.c_int
+    L.kzgamd_settings_reserve.argtypes = [sp, sz, vp]
     _lib = L
     return L
 
@@ -240,6 +253,20 @@ def device_count():
     return lib().kzgamd_device_count()
 
 
+def set_device(device):
+    """GPU for handles created afterwards by this thread (kzgamd_set_device)."""
+    if lib().kzgamd_set_device(device) != 0:
+        raise KzgAmdError("kzgamd_set_device(%d) failed" % device)
+
+
+def get_device():
+    return lib().kzgamd_get_device()
+
+
+def msm_reserve(handle, npoints, nbatch, stream=0):
+    _check(lib().kzgamd_msm_reserve(C.c_void_p(handle), npoints, nbatch, C.c_void_p(stream)), "kzgamd_msm_reserve")
+
+
 # ---------------------------------------------------------------- c-kzg-4844 surface (B3)
 _libc = None
 
@@ -289,6 +316,14 @@ class KZGSettings:
 
     def msm_handle(self):
         return lib().kzgamd_settings_msm_handle(C.byref(self.c))
+
+    def device(self):
+        return lib().kzgamd_settings_device(C.byref(self.c))
+
+    def reserve(self, nblobs, stream=0):
+        rc = lib().kzgamd_settings_reserve(C.byref(self.c), nblobs, C.c_void_p(stream))
+        if rc != C_KZG_OK:
+            raise KzgAmdError("kzgamd_settings_reserve: C_KZG_RET %d" % rc)
 
     def g1_lagrange_brp(self):
         return (BlstP1 * 4096).from_address(self.c.g1_values_lagrange_brp)

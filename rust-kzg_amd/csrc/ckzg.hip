@@ -17,6 +17,7 @@
 
 #include "../../include/kzg_mi355x.h"
 #include "ckzg_internal.h"
+#include "device_guard.h"
 #include "ff.hip.h"
 #include "g1_io.hip.h"
 #include "host_g1.h"
@@ -1009,7 +1010,8 @@ bool host_blob_valid(const uint8_t* blob) {
 void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32* zs, const Bytes48* commitments, size_t n,
                  KzgAmdSettings* dev, Bytes32* zs_out = nullptr) {
     std::lock_guard<std::mutex> lk(dev->mu);
-    CK_HIP(hipSetDevice(dev->device));
+    kzgamd::DeviceGuard on_device(dev->device);
+    CK_HIP(on_device.err);
     dev->ensure(n);
     std::vector<Bytes32> zbuf;
     std::vector<int> cstat;
@@ -1168,7 +1170,8 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
 void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_t n, const CKZGSettings* cs,
                       KzgAmdSettings* dev) {
     std::lock_guard<std::mutex> lk(dev->mu);
-    CK_HIP(hipSetDevice(dev->device));
+    kzgamd::DeviceGuard on_device(dev->device);
+    CK_HIP(on_device.err);
     if (!dev->ntt) {
         dev->ntt = kzgamd_ntt_new(13);
         if (!dev->ntt) throw CkErr{C_KZG_ERROR, "kzgamd_ntt_new failed"};
@@ -1276,7 +1279,10 @@ extern "C" void free_trusted_setup(CKZGSettings* s) {
             g_registry.erase(it);
         }
     }
-    delete dev;
+    if (dev) {
+        kzgamd::DeviceGuard on_device(dev->device);
+        delete dev;
+    }
     free_host_arrays(s);
 }
 
@@ -1288,7 +1294,8 @@ extern "C" C_KZG_RET kzgamd_blob_to_kzg_commitment_batch(KZGCommitment* out, con
     if (n == 0) return C_KZG_OK;
     return guarded([&] {
         std::lock_guard<std::mutex> lk(dev->mu);
-        CK_HIP(hipSetDevice(dev->device));
+        kzgamd::DeviceGuard on_device(dev->device);
+        CK_HIP(on_device.err);
         dev->ensure(n);
         CK_HIP(hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream));
         const bool host_compress = n <= HOST_COMPRESS_MAX;
@@ -1314,7 +1321,36 @@ extern "C" C_KZG_RET kzgamd_blob_to_kzg_commitment_device(void* d_out, void* d_s
     KzgAmdSettings* dev = lookup(s);
     if (!dev || !d_out || !d_status || !d_scratch || !d_blobs) return C_KZG_BADARGS;
     if (n == 0) return C_KZG_OK;
-    return guarded([&] { commit_enqueue(dev, d_out, (int*)d_status, d_blobs, (u32*)d_scratch, n, (hipStream_t)stream); });
+    return guarded([&] {
+        kzgamd::DeviceGuard on_device(dev->device);
+        CK_HIP(on_device.err);
+        commit_enqueue(dev, d_out, (int*)d_status, d_blobs, (u32*)d_scratch, n, (hipStream_t)stream);
+    });
+}
+
+// Pre-allocates what kzgamd_blob_to_kzg_commitment_device needs for batches of up to n blobs on `stream` (the MSM
+// workspace of that stream), so that the enqueue calls never allocate — hipMalloc synchronises the device.
+extern "C" C_KZG_RET kzgamd_settings_reserve(const CKZGSettings* s, size_t n, void* stream) {
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    if (n == 0) return C_KZG_OK;
+    return guarded([&] {
+        kzgamd::DeviceGuard on_device(dev->device);
+        CK_HIP(on_device.err);
+        kzgamd::msm_lock(dev->msm);
+        try {
+            kzgamd::msm_enqueue(dev->msm, nullptr, nullptr, N, n, 0, (hipStream_t)stream, kzgamd::OUT_COMPRESSED, true);
+        } catch (...) {
+            kzgamd::msm_unlock(dev->msm);
+            throw;
+        }
+        kzgamd::msm_unlock(dev->msm);
+    });
+}
+
+extern "C" int kzgamd_settings_device(const CKZGSettings* s) {
+    KzgAmdSettings* dev = lookup(s);
+    return dev ? dev->device : -1;
 }
 
 

@@ -1,0 +1,27 @@
+// Every entry point of the library runs on the GPU its handle was created on and leaves the caller's
+// current device as it found it: one host process can own the 8 GPUs of a node (one settings object /
+// MSM handle / NTT handle per device) and call into any of them from any thread.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace kzgamd {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            changed = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+}  // namespace kzgamd

@@ -23,6 +23,7 @@
 #include "ff.hip.h"
 #include "g1_28.hip.h"
 #include "glv.hip.h"
+#include "device_guard.h"
 #include "ntt_internal.h"
 
 using ff::Fr;
@@ -132,7 +133,9 @@ __global__ void __launch_bounds__(256) k_g1_load(Xyzz* __restrict__ out, const f
 
 // stage s of the DIT network on bit-reversed-order data: pairs i0 and i0 + 2^s,
 // twiddle w_n^(j * n / 2^(s+1)) = roots[j * (W >> (s+1))]  (fft_g1.rs:22-29 unrolled); two lanes per butterfly
-__global__ void __launch_bounds__(NTHREADS) k_g1_stage(Xyzz* __restrict__ data, Xyzz* __restrict__ tab,
+// (out of place: the two lanes of a butterfly both read x and y, so the stage writes to the other half of a
+// ping-pong buffer instead of relying on the pair running in lockstep)
+__global__ void __launch_bounds__(NTHREADS) k_g1_stage(Xyzz* __restrict__ dst, const Xyzz* __restrict__ data, Xyzz* __restrict__ tab,
                                                        const RootSplit* __restrict__ kroots, u32 n, int s, u32 W, int inverse,
                                                        size_t total) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // total = 2 * butterflies, even
@@ -144,14 +147,14 @@ __global__ void __launch_bounds__(NTHREADS) k_g1_stage(Xyzz* __restrict__ data, 
     const u32 b = (u32)(bf % halfn);
     const u32 hs = 1u << s, j = b & (hs - 1);
     const u32 i0 = ((b >> s) << (s + 1)) | j, i1 = i0 + hs;
-    Xyzz* base = data + xf * n;
+    const Xyzz* base = data + xf * n;
     Xyzz y = base[i1];
     const u32 idx = j * (W >> (s + 1));
     if (idx != 0) glv_mul_pair(y, kroots[inverse ? W - idx : idx], half, tab + t, total);
     Xyzz x = base[i0];
     if (half) y.y = fp28::neg<8>(y.y);  // lane 1: x - t   (Y < 8p is within what dadd/dbl accept)
     pt_add(x, y);
-    base[half ? i1 : i0] = x;
+    dst[xf * n + (half ? i1 : i0)] = x;
 }
 
 // XYZZ -> blst Jacobian; an inverse transform multiplies by n^-1 first (fft_g1.rs:72-79), two lanes per point
@@ -196,7 +199,7 @@ void ensure_g1(NttCtx* ctx, size_t total, size_t tab_lanes) {
         ctx->d_p1 = ctx->d_pts = nullptr;
         ctx->cap_g1 = 0;
         NTT_TRY(hipMalloc(&ctx->d_p1, total * sizeof(blst_p1)));
-        NTT_TRY(hipMalloc(&ctx->d_pts, total * sizeof(Xyzz)));
+        NTT_TRY(hipMalloc(&ctx->d_pts, 2 * total * sizeof(Xyzz)));  // ping-pong halves
         ctx->cap_g1 = total;
     }
     if (tab_lanes > ctx->cap_tab) {
@@ -218,7 +221,8 @@ extern "C" int kzgamd_fft_g1_batch(void* vctx, blst_p1* out, const blst_p1* in, 
     if (nbatch == 0) return 0;
     std::lock_guard<std::mutex> lk(ctx->mu);
     try {
-        NTT_TRY(hipSetDevice(ctx->device));
+        kzgamd::DeviceGuard on_device(ctx->device);
+        NTT_TRY(on_device.err);
         const size_t total = n * nbatch, bf = total / 2;
         const int logn = ilog2(n);
         ensure_g1(ctx, total, inverse ? 2 * total : (bf ? 2 * bf : 2));
@@ -229,8 +233,9 @@ extern "C" int kzgamd_fft_g1_batch(void* vctx, blst_p1* out, const blst_p1* in, 
         hipLaunchKernelGGL(k_g1_load, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pts, (const ff::Fp*)ctx->d_p1,
                            (u32)n, logn, total);
         for (int s = 0; s < logn; ++s)
-            hipLaunchKernelGGL(k_g1_stage, dim3((unsigned)((2 * bf + NTHREADS - 1) / NTHREADS)), dim3(NTHREADS), 0, st, pts,
-                               tab, (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0, 2 * bf);
+            hipLaunchKernelGGL(k_g1_stage, dim3((unsigned)((2 * bf + NTHREADS - 1) / NTHREADS)), dim3(NTHREADS), 0, st,
+                               pts + ((s + 1) & 1) * total, (const Xyzz*)(pts + (s & 1) * total), tab,
+                               (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0, 2 * bf);
         RootSplit inv_n;
         memset(&inv_n, 0, sizeof inv_n);
         if (inverse) {
@@ -240,7 +245,7 @@ extern "C" int kzgamd_fft_g1_batch(void* vctx, blst_p1* out, const blst_p1* in, 
             inv_n = split_scalar(ff::from_mont(ff::inverse_bgcd(ff::to_mont(v))));
         }
         hipLaunchKernelGGL(k_g1_store, dim3((unsigned)((2 * total + NTHREADS - 1) / NTHREADS)), dim3(NTHREADS), 0, st,
-                           (ff::Fp*)ctx->d_p1, (const Xyzz*)pts, tab, inv_n, inverse && n > 1 ? 1 : 0, 2 * total);
+                           (ff::Fp*)ctx->d_p1, (const Xyzz*)(pts + (logn & 1) * total), tab, inv_n, inverse && n > 1 ? 1 : 0, 2 * total);
         NTT_TRY(hipGetLastError());
         NTT_TRY(hipMemcpyAsync(out, ctx->d_p1, total * sizeof(blst_p1), hipMemcpyDeviceToHost, st));
         NTT_TRY(hipStreamSynchronize(st));

@@ -30,6 +30,7 @@
 #include "g1w.hip.h"
 #include "glv.hip.h"
 #include "host_g1.h"
+#include "device_guard.h"
 #include "msm_internal.h"
 
 using ff::u32;
@@ -1290,11 +1291,18 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
     return ctx;
 }
 
-void msm_destroy(MsmContext* ctx) { delete ctx; }
+void msm_destroy(MsmContext* ctx) {
+    if (!ctx) return;
+    DeviceGuard on_device(ctx->device);
+    delete ctx;
+}
+int msm_device(MsmContext* ctx) { return ctx->device; }
 
 // enqueue nbatch MSMs over the first npoints bases; d_scalars / d_out device pointers
+// reserve_only: size and allocate the workspace `stream` will use for this shape, launch nothing (hipMalloc
+// synchronises the device, so callers that must not stall a running pipeline reserve during set-up)
 void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npoints, size_t nbatch, int mont,
-                 hipStream_t stream, int out_mode) {
+                 hipStream_t stream, int out_mode, bool reserve_only) {
     if (npoints > ctx->n) throw HipErr{hipErrorInvalidValue, "npoints exceeds the prepared size"};
     if (nbatch == 0) return;
     const int c = ctx->c;
@@ -1303,6 +1311,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     const size_t nsets = ctx->prepared ? nbatch : nbatch * (size_t)nwin;
     const size_t set_cap = ctx->prepared ? npoints * (size_t)nwin : (ctx->glv ? 2 * npoints : npoints);
     if (npoints == 0) {
+        if (reserve_only) return;
         if (out_mode == OUT_COMPRESSED) throw HipErr{hipErrorInvalidValue, "empty MSM in compressed mode"};
         HIP_TRY(hipMemsetAsync(d_out, 0, nbatch * 144, stream));
         return;
@@ -1322,7 +1331,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             if (w.last_done) (void)hipEventRecord(w.last_done, st);
             w.last_stream = st;
         }
-    } ws_use(ws, stream);
+    };
     if (ctx->fbw) {
         // wide-table path: gather + add, then one block-sum per MSM
         // scalars per lane: 4 for large batches — a quarter of the partial sums for k_blocksum to fold against one
@@ -1335,6 +1344,9 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         const size_t lanes = (npoints + spl - 1) / spl;
         ws.buckets.ensure(nbatch * lanes);
         ws.lvlM[0].ensure(nbatch);
+        if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) ws.lvlA[0].ensure(nbatch * 16);
+        if (reserve_only) return;
+        WsUse ws_use(ws, stream);
         DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n, 0, 0, nwin};
         hipEvent_t* pev = nullptr;
         if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
@@ -1362,7 +1374,6 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             // a few MSMs: the one-workgroup-per-MSM fold is a latency chain (16 strided additions + 8 tree rounds);
             // 16 workgroups per MSM and a second small fold take 9 + 6 rounds instead (single commitment call
             // 0.83 -> 0.71 ms).  Splitting the windows of a scalar over 3 lanes as well was measured: no gain.
-            ws.lvlA[0].ensure(nbatch * 16);
             hipLaunchKernelGGL(k_blocksum, dim3((unsigned)(nbatch * 16)), dim3(256), 256 * sizeof(Xyzz), stream,
                                (const Xyzz*)ws.buckets.p, ws.lvlA[0].p, lanes / 16);
             hipLaunchKernelGGL(k_blocksum, dim3((unsigned)nbatch), dim3(64), 64 * sizeof(Xyzz), stream,
@@ -1429,26 +1440,6 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     const bool use_top = nsets <= 64;  // many independent sets (batched MSMs) keep plain tree levels busy on their own
     // few chains: run the serial tails limb-parallel, one point operation per wave
     const bool wide_tail = use_top && !getenv("KZGAMD_NO_WIDE_TAIL");
-    hipEvent_t* pev = nullptr;
-    if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
-        while (ctx->ev.size() < ctx->ev_used + 4) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreate(&e));
-            ctx->ev.push_back(e);
-        }
-        pev = &ctx->ev[ctx->ev_used];
-        HIP_TRY(hipEventRecord(pev[0], stream));
-    }
-    if (G > 1) {
-        if (!ctx->ev_fork) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        for (int g = 0; g < G; ++g) {
-            if (!ctx->aux[g]) HIP_TRY(hipStreamCreateWithFlags(&ctx->aux[g], hipStreamNonBlocking));
-            if (!ctx->ev_dig[g]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_dig[g], hipEventDisableTiming));
-            if (!ctx->ev_acc[g]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_acc[g], hipEventDisableTiming));
-            if (!ctx->ev_done[g]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done[g], hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventRecord(ctx->ev_fork, stream));
-    }
     // shape of the tree (the same for every group: level 0 folds by the group size): k_top stride B + 2
     size_t top_stride = 0;
     {
@@ -1468,6 +1459,28 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             ws.top.ensure(nsets * top_stride);
             ws.win.ensure(nsets);
         }
+    }
+    if (reserve_only) return;
+    WsUse ws_use(ws, stream);
+    hipEvent_t* pev = nullptr;
+    if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
+        while (ctx->ev.size() < ctx->ev_used + 4) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            ctx->ev.push_back(e);
+        }
+        pev = &ctx->ev[ctx->ev_used];
+        HIP_TRY(hipEventRecord(pev[0], stream));
+    }
+    if (G > 1) {
+        if (!ctx->ev_fork) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        for (int g = 0; g < G; ++g) {
+            if (!ctx->aux[g]) HIP_TRY(hipStreamCreateWithFlags(&ctx->aux[g], hipStreamNonBlocking));
+            if (!ctx->ev_dig[g]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_dig[g], hipEventDisableTiming));
+            if (!ctx->ev_acc[g]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_acc[g], hipEventDisableTiming));
+            if (!ctx->ev_done[g]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done[g], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(ctx->ev_fork, stream));
     }
     const Xyzz *finA = nullptr, *finM = nullptr;
     for (int g = 0; g < G; ++g) {
@@ -1626,7 +1639,8 @@ int msm_get_profile(MsmContext* ctx, float* accum_ms, float* total_ms) {
 // host buffers in, host buffers out
 void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoints, size_t nbatch) {
     std::lock_guard<std::mutex> lk(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
+    DeviceGuard on_device(ctx->device);
+    HIP_TRY(on_device.err);
     ctx->ws.scalars.ensure(nbatch * npoints * 8 + 8);
     ctx->ws.out.ensure(nbatch * 3 + 3);
     if (npoints * nbatch)
@@ -1728,8 +1742,35 @@ extern "C" RustError kzgamd_msm_prepared_batch_device(void* msm, void* d_out, co
     return guarded([&] {
         MsmContext* ctx = (MsmContext*)msm;
         std::lock_guard<std::mutex> lk(ctx->mu);
+        kzgamd::DeviceGuard on_device(ctx->device);
+        HIP_TRY(on_device.err);
         kzgamd::msm_enqueue(ctx, d_out, d_scalars, npoints, nbatch, scalars_mont, (hipStream_t)stream, kzgamd::OUT_JACOBIAN);
     });
+}
+
+// Allocates, now, the workspace `stream` will use for nbatch MSMs of npoints scalars on this handle, so that the
+// enqueue calls that follow never call hipMalloc (which synchronises the device).  Without it the first enqueue on
+// a new stream, or with a larger shape, allocates lazily.
+extern "C" RustError kzgamd_msm_reserve(void* msm, size_t npoints, size_t nbatch, void* stream) {
+    if (!msm) return make_error(1, "null handle");
+    return guarded([&] {
+        MsmContext* ctx = (MsmContext*)msm;
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        kzgamd::DeviceGuard on_device(ctx->device);
+        HIP_TRY(on_device.err);
+        kzgamd::msm_enqueue(ctx, nullptr, nullptr, npoints, nbatch, 0, (hipStream_t)stream, kzgamd::OUT_JACOBIAN, true);
+    });
+}
+
+extern "C" int kzgamd_msm_device(void* msm) { return msm ? ((MsmContext*)msm)->device : -1; }
+
+// Device selection for the calling thread (hipSetDevice / hipGetDevice): handles created afterwards — prepare_msm,
+// kzgamd_msm_create_device, kzgamd_ntt_new, load_trusted_setup(_file) — live on that GPU; every later call on a
+// handle switches to the handle's GPU by itself and restores the caller's device on return.
+extern "C" int kzgamd_set_device(int device) { return hipSetDevice(device) == hipSuccess ? 0 : 1; }
+extern "C" int kzgamd_get_device(void) {
+    int d = -1;
+    return hipGetDevice(&d) == hipSuccess ? d : -1;
 }
 
 extern "C" int kzgamd_msm_info(void* msm, int* window_bits, int* rows, size_t* nbuckets, size_t* npoints) {

@@ -12,7 +12,8 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
 void msm_destroy(MsmContext* ctx);
 // enqueue nbatch MSMs (device pointers, no sync); d_out = blst_p1[nbatch] or 48-byte compressed points
 void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npoints, size_t nbatch, int mont,
-                 hipStream_t stream, int out_mode);
+                 hipStream_t stream, int out_mode, bool reserve_only = false);
+int msm_device(MsmContext* ctx);
 void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoints, size_t nbatch);
 void msm_lock(MsmContext* ctx);
 void msm_unlock(MsmContext* ctx);

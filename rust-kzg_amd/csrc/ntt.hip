@@ -23,6 +23,7 @@
 #include "ckzg_internal.h"
 #include "ff.hip.h"
 #include "fr29.hip.h"
+#include "device_guard.h"
 #include "ntt_internal.h"
 
 using ff::Fr;
@@ -34,41 +35,83 @@ namespace {
 
 constexpr int LOG_TILE = 12;
 constexpr int TILE = 1 << LOG_TILE;  // elements per workgroup
-constexpr int NT = 1024;             // threads per workgroup
+constexpr int NT = 512;              // threads per workgroup: 8 elements per thread in a radix-8 round
 
-__device__ __forceinline__ u32 brev(u32 v, int bits) { return __builtin_bitreverse32(v) >> (32 - bits); }
+__device__ __forceinline__ u32 brev(u32 v, int bits) { return bits == 0 ? 0u : __builtin_bitreverse32(v) >> (32 - bits); }
 
-// LDS holds elements in the 9 x 29-bit form, limb-major: sh[limb * cnt + idx] -> unit-stride lanes hit
-// distinct banks (4096 x 36 B = 144 KiB of the 160 KiB LDS)
-__device__ __forceinline__ Fe lds_get(const u32* sh, int cnt, int idx) {
+// LDS holds a tile in the 9 x 29-bit form, limb-major: sh[limb * cnt + swz(idx)].  The XOR swizzle folds
+// index bits 5..11 into the bank bits, so that every access pattern of the kernels below — unit stride, the
+// strides 8 / 64 / 512 of the radix-8 rounds, and the bit-reversed scatter of the loads — puts the 32 lanes of a
+// ds_read_b32 / ds_write_b32 group on 32 distinct banks (4096 x 36 B = 144 KiB of the 160 KiB LDS).
+__host__ __device__ constexpr int swz(int i) { return i ^ (((i >> 5) & 7) ^ (((i >> 6) & 3) << 3) ^ ((i >> 7) & 31)); }
+
+__device__ __forceinline__ Fe lds_get(const u32* sh, int cnt, int sidx) {  // sidx already swizzled
     Fe r;
 #pragma unroll
-    for (int k = 0; k < fr29::L; ++k) r.v[k] = sh[k * cnt + idx];
+    for (int k = 0; k < fr29::L; ++k) r.v[k] = sh[k * cnt + sidx];
     return r;
 }
-__device__ __forceinline__ void lds_put(u32* sh, int cnt, int idx, const Fe& a) {
+__device__ __forceinline__ void lds_put(u32* sh, int cnt, int sidx, const Fe& a) {
 #pragma unroll
-    for (int k = 0; k < fr29::L; ++k) sh[k * cnt + idx] = a.v[k];
+    for (int k = 0; k < fr29::L; ++k) sh[k * cnt + sidx] = a.v[k];
 }
 
-// `stages` butterfly stages of a DIT network on the `cnt` elements in LDS.
-// Element e of the tile has global index  g = e_hi * gstride + goff  pattern handled by the caller
-// through twiddle_index(); here: stage s pairs e and e + 2^s (s = 0 .. stages-1).
-template <class TwFn>
-__device__ __forceinline__ void lds_stages(u32* sh, int cnt, int stages, TwFn tw) {
-    for (int s = 0; s < stages; ++s) {
-        const int half = 1 << s;
-        for (int b = threadIdx.x; b < cnt / 2; b += NT) {
-            const int j = b & (half - 1);
-            const int i0 = ((b >> s) << (s + 1)) | j, i1 = i0 + half;
-            Fe x = lds_get(sh, cnt, i0), y = lds_get(sh, cnt, i1);
-            Fe t = fr29::mul(y, tw(s, j, i0));
-            fr29::butterfly(x, y, t);
-            lds_put(sh, cnt, i0, x);
-            lds_put(sh, cnt, i1, y);
+// One round = M consecutive butterfly stages (B .. B+M-1 of the tile's DIT network) on 2^M elements held in
+// registers: one LDS round trip and one barrier per M stages instead of per stage.  Virtual thread v owns the
+// tile indices  base | (k << B),  k < 2^M,  base = v with M zero bits inserted at position B.  Stage B+q pairs
+// k and k | 2^q; its twiddle depends on the low B+q bits of the index, so the round loads 2^M - 1 twiddles for
+// its M * 2^(M-1) butterflies.  FIRST: stage 0 of a transform multiplies by w^0 = 1 — no multiplication.
+template <int M, int B, bool FIRST, class TwFn>
+__device__ __forceinline__ void round_regs(u32* sh, int cnt, int nelem, TwFn tw) {
+    constexpr int E = 1 << M;
+    for (int v = threadIdx.x; v < (nelem >> M); v += NT) {
+        const int lo = v & ((1 << B) - 1);
+        const int base = ((v >> B) << (B + M)) | lo;
+        const int sbase = swz(base);  // swz is XOR-linear: swz(base | k << B) = swz(base) ^ swz(k << B)
+        Fe e[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) e[k] = lds_get(sh, cnt, sbase ^ swz(k << B));
+#pragma unroll
+        for (int q = 0; q < M; ++q) {
+#pragma unroll
+            for (int t = 0; t < (1 << q); ++t) {
+                if (FIRST && B == 0 && q == 0) {
+#pragma unroll
+                    for (int h = 0; h < (E >> 1); ++h) {
+                        const Fe y = e[2 * h + 1];
+                        fr29::butterfly(e[2 * h], e[2 * h + 1], y);
+                    }
+                } else {
+                    const Fe w = tw(B + q, lo | (t << B), base);
+#pragma unroll
+                    for (int h = 0; h < (E >> (q + 1)); ++h) {
+                        const int k0 = t | (h << (q + 1)), k1 = k0 | (1 << q);
+                        const Fe tt = fr29::mul(e[k1], w);
+                        fr29::butterfly(e[k0], e[k1], tt);
+                    }
+                }
+            }
         }
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < E; ++k) lds_put(sh, cnt, sbase ^ swz(k << B), e[k]);
     }
+    __syncthreads();
+}
+
+// `stages` butterfly stages (1..12) of a DIT network on the tile in LDS: stage s pairs tile indices i and i + 2^s.
+// tw(s, j, base): twiddle of stage s for pair position j = i mod 2^s (base = any index of the thread's group: the
+// caller derives the tile column from its high bits).
+template <bool FIRST, class TwFn>
+__device__ __forceinline__ void tile_stages(u32* sh, int cnt, int nelem, int stages, TwFn tw) {
+#define KZG_ROUNDS(B_)                                                              \
+    if (stages >= (B_) + 3) round_regs<3, B_, FIRST>(sh, cnt, nelem, tw);           \
+    else if (stages == (B_) + 2) round_regs<2, B_, FIRST>(sh, cnt, nelem, tw);      \
+    else if (stages == (B_) + 1) round_regs<1, B_, FIRST>(sh, cnt, nelem, tw);
+    KZG_ROUNDS(0)
+    KZG_ROUNDS(3)
+    KZG_ROUNDS(6)
+    KZG_ROUNDS(9)
+#undef KZG_ROUNDS
 }
 
 struct NttParams {
@@ -79,53 +122,75 @@ struct NttParams {
     Fr scale;       // final multiplier in the 2^261 domain: 2^261 mod r, times n^-1 on the last pass of an inverse
 };
 
-// Pass 1 (and the whole transform when n <= TILE): block `blk` of min(n,TILE) consecutive
-// positions of the bit-reversed sequence; stages 0 .. min(logn,12)-1.
+// Pass 1 (the whole transform when n <= TILE): stages 0 .. min(logn,12)-1.
+//   n <= TILE: a workgroup takes C = cnt / n whole transforms (cnt = min(TILE, n * nbatch) elements): coalesced
+//              natural-order loads, scattered into LDS at the bit-reversed index, coalesced natural-order stores.
+//   n  > TILE: a workgroup takes TILE consecutive positions of the bit-reversed sequence (block `blk`), i.e. the
+//              natural indices  o + (t << L),  o = brev_L(blk), L = logn - 12: 32-byte pieces 2^L elements apart.
+//              The four blocks whose pieces share 128-byte lines (o, o^1, o^2, o^3) are given to workgroups
+//              8 apart in launch order — same XCD, dispatched together — so the line is fetched from HBM once.
 __global__ void __launch_bounds__(NT) k_ntt_low(Fr* __restrict__ out, const Fr* __restrict__ in,
-                                                const Fe* __restrict__ roots, NttParams P, u32 blocks_per_xform) {
+                                                const Fe* __restrict__ roots, NttParams P, u32 blocks_per_xform, int nelem,
+                                                size_t total) {
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
-    const u32 xf = blockIdx.x / blocks_per_xform, blk = blockIdx.x % blocks_per_xform;
-    const int cnt = P.n < (u32)TILE ? (int)P.n : TILE;
+    const int cnt = (nelem + 31) & ~31;  // limb stride: the swizzle permutes within aligned groups of 32
     const int stages = P.logn < LOG_TILE ? P.logn : LOG_TILE;
-    const Fr* src = in + (size_t)xf * P.n;
-    Fr* dst = out + (size_t)xf * P.n;
-    for (int e = threadIdx.x; e < cnt; e += NT) {
-        const u32 pos = blk * (u32)cnt + (u32)e;  // position in the bit-reversed sequence
-        lds_put(sh, cnt, e, fr29::unpack(src[brev(pos, P.logn)]));
+    const bool last_pass = P.logn <= LOG_TILE;
+    size_t src0, dst0;
+    int L = 0;
+    if (P.n <= (u32)TILE) {
+        src0 = dst0 = (size_t)blockIdx.x * (size_t)nelem;
+    } else {
+        const u32 xf = blockIdx.x / blocks_per_xform, g = blockIdx.x % blocks_per_xform;
+        L = P.logn - LOG_TILE;
+        u32 o = g;
+        if (L >= 5) {
+            const u32 xcd = g & 7, slot = g >> 3;
+            o = (((slot >> 2) << 3 | xcd) << 2) | (slot & 3);
+        }
+        src0 = (size_t)xf * P.n + o;
+        dst0 = (size_t)xf * P.n + (size_t)brev(o, L) * TILE;
+    }
+    const int mask = (1 << stages) - 1;
+    for (int t = threadIdx.x; t < nelem; t += NT) {
+        const size_t gi = src0 + ((size_t)t << L);
+        Fe v;
+        if (gi < total) v = fr29::unpack(in[gi]);
+        else v = fr29::unpack(Fr::zero());
+        lds_put(sh, cnt, swz((t & ~mask) | (int)brev((u32)(t & mask), stages)), v);
     }
     __syncthreads();
     // stage s: half = 2^s, twiddle w_n^(j * n / 2^(s+1)) = roots[j * (W / 2^(s+1))]
-    const bool last_pass = P.logn <= LOG_TILE;
-    lds_stages(sh, cnt, stages, [&](int s, int j, int) -> Fe {
+    tile_stages<true>(sh, cnt, nelem, stages, [&](int s, int j, int) -> Fe {
         const u32 idx = (u32)j * (P.W >> (s + 1));
         return roots[P.inverse ? P.W - idx : idx];
     });
     const Fe fin = last_pass ? fr29::unpack(P.scale) : fr29::one();
-    for (int e = threadIdx.x; e < cnt; e += NT) dst[blk * (u32)cnt + (u32)e] = fr29::finish(lds_get(sh, cnt, e), fin);
+    for (int t = threadIdx.x; t < nelem; t += NT)
+        if (dst0 + t < total) out[dst0 + t] = fr29::finish(lds_get(sh, cnt, swz(t)), fin);
 }
 
 // Passes 2, 3: `logR` stages starting at global stage `stage0` (a multiple of 12), in place.
 // View the bit-reversed-order array as [hi][r][lo] with lo < 2^stage0, r < R = 2^logR: stage stage0+s pairs
 // rows r and r + 2^s.  A workgroup takes C = 4096 / R consecutive lo positions of one hi block
-// (C * 32 B contiguous per row: coalesced while R <= 256), runs the logR stages in LDS, writes back.
+// (C * 32 B contiguous per row), runs the logR stages on the tile, writes back.  Tile index = c * R + r.
 __global__ void __launch_bounds__(NT) k_ntt_high(Fr* __restrict__ data, const Fe* __restrict__ roots, NttParams P,
                                                  u32 tiles_per_xform, int stage0, int logR, int last) {
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
     const u32 xf = blockIdx.x / tiles_per_xform, tile = blockIdx.x % tiles_per_xform;
-    const int R = 1 << logR, C = TILE >> logR, logC = LOG_TILE - logR;
+    const int C = TILE >> logR, logC = LOG_TILE - logR;
     Fr* base = data + (size_t)xf * P.n;
     const u32 lo_tiles = (1u << stage0) >> logC;  // tiles per hi block
     const u32 hi = tile / lo_tiles, lo0 = (tile % lo_tiles) << logC;
     const size_t origin = ((size_t)hi << (stage0 + logR)) + lo0;
-    // LDS element e = c * R + r  (row index fastest, so a butterfly pairs e and e + 2^s)
     for (int e = threadIdx.x; e < TILE; e += NT) {
         const int c = e & (C - 1), r = e >> logC;  // consecutive lanes -> consecutive positions
-        lds_put(sh, TILE, c * R + r, fr29::unpack(base[origin + ((size_t)r << stage0) + c]));
+        lds_put(sh, TILE, swz((c << logR) | r), fr29::unpack(base[origin + ((size_t)r << stage0) + c]));
     }
     __syncthreads();
-    lds_stages(sh, TILE, logR, [&](int s, int j, int i0) -> Fe {
+    tile_stages<false>(sh, TILE, TILE, logR, [&](int s, int j, int tidx) -> Fe {
         // global stage stage0+s: half = 2^(stage0+s); position mod half = (r mod 2^s) * 2^stage0 + lo
-        const u32 lo = lo0 + (u32)(i0 >> logR);
+        const u32 lo = lo0 + (u32)(tidx >> logR);
         const u32 jg = ((u32)j << stage0) + lo;
         const u32 idx = jg * (P.W >> (stage0 + s + 1));
         return roots[P.inverse ? P.W - idx : idx];
@@ -133,7 +198,7 @@ __global__ void __launch_bounds__(NT) k_ntt_high(Fr* __restrict__ data, const Fe
     const Fe fin = last ? fr29::unpack(P.scale) : fr29::one();
     for (int e = threadIdx.x; e < TILE; e += NT) {
         const int c = e & (C - 1), r = e >> logC;
-        base[origin + ((size_t)r << stage0) + c] = fr29::finish(lds_get(sh, TILE, c * R + r), fin);
+        base[origin + ((size_t)r << stage0) + c] = fr29::finish(lds_get(sh, TILE, swz((c << logR) | r)), fin);
     }
 }
 
@@ -182,10 +247,18 @@ void ntt_enqueue(NttCtx* ctx, Fr* d_out, const Fr* d_in, size_t n, size_t nbatch
     // 2^261 mod r as a plain residue (= "one" of the 2^261 domain); an inverse transform folds n^-1 in:
     // data is d*2^256, so the multiplier n^-1*2^261 is (n^-1 in blst Montgomery form) * 2^5
     P.scale = inverse ? times32(inv_len(n)) : one261();
-    const size_t lds = (n < (size_t)TILE ? n : (size_t)TILE) * sizeof(u32) * fr29::L;
-    const u32 blocks = n <= (size_t)TILE ? 1u : (u32)(n >> LOG_TILE);
-    hipLaunchKernelGGL(k_ntt_low, dim3((unsigned)(blocks * nbatch)), dim3(NT), lds, stream, d_out, d_in,
-                       (const Fe*)ctx->d_roots, P, blocks);
+    const size_t total = n * nbatch;
+    if (n <= (size_t)TILE) {
+        // whole transforms per workgroup: TILE / n of them (all of them when the batch is smaller than a tile)
+        const size_t cnt = total < (size_t)TILE ? total : (size_t)TILE;
+        const size_t wgs = (total + cnt - 1) / cnt;
+        hipLaunchKernelGGL(k_ntt_low, dim3((unsigned)wgs), dim3(NT), ((cnt + 31) & ~(size_t)31) * sizeof(u32) * fr29::L, stream, d_out, d_in,
+                           (const Fe*)ctx->d_roots, P, 1u, (int)cnt, total);
+    } else {
+        const u32 blocks = (u32)(n >> LOG_TILE);
+        hipLaunchKernelGGL(k_ntt_low, dim3((unsigned)(blocks * nbatch)), dim3(NT), (size_t)TILE * sizeof(u32) * fr29::L, stream,
+                           d_out, d_in, (const Fe*)ctx->d_roots, P, blocks, TILE, total);
+    }
     // remaining stages, up to 12 per pass: 12..23, then 24..30
     for (int stage0 = LOG_TILE; stage0 < P.logn; stage0 += LOG_TILE) {
         const int logR = P.logn - stage0 < LOG_TILE ? P.logn - stage0 : LOG_TILE;
@@ -226,7 +299,12 @@ extern "C" void* kzgamd_ntt_new(unsigned scale) {
     return ctx;
 }
 
-extern "C" void kzgamd_ntt_free(void* ctx) { delete (NttCtx*)ctx; }
+extern "C" void kzgamd_ntt_free(void* vctx) {
+    NttCtx* ctx = (NttCtx*)vctx;
+    if (!ctx) return;
+    kzgamd::DeviceGuard on_device(ctx->device);
+    delete ctx;
+}
 
 extern "C" int kzgamd_ntt_fr_device(void* vctx, void* d_out, const void* d_in, size_t n, size_t nbatch, int inverse,
                                     void* stream) {
@@ -236,6 +314,8 @@ extern "C" int kzgamd_ntt_fr_device(void* vctx, void* d_out, const void* d_in, s
     if (n == 0 || (n & (n - 1))) return 2;
     if (d_out == d_in) return -3;
     try {
+        kzgamd::DeviceGuard on_device(ctx->device);
+        NTT_TRY(on_device.err);
         ntt_enqueue(ctx, (Fr*)d_out, (const Fr*)d_in, n, nbatch, inverse != 0, (hipStream_t)stream);
     } catch (const NttErr& e) {
         return -(int)e.e - 100;
@@ -250,7 +330,8 @@ extern "C" int ntt_fr(void* vctx, blst_fr* out, const blst_fr* in, size_t n, int
     if (n == 0 || (n & (n - 1))) return 2;    // "A list with power-of-two length expected"
     std::lock_guard<std::mutex> lk(ctx->mu);
     try {
-        NTT_TRY(hipSetDevice(ctx->device));
+        kzgamd::DeviceGuard on_device(ctx->device);
+        NTT_TRY(on_device.err);
         ctx->ensure(n);
         NTT_TRY(hipMemcpyAsync(ctx->d_a, in, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
         ntt_enqueue(ctx, ctx->d_b, ctx->d_a, n, 1, inverse != 0, ctx->stream);
@@ -274,7 +355,8 @@ extern "C" int das_fft_extension(void* vctx, blst_fr* odds, const blst_fr* evens
     if (n * 2 > ctx->W) return 3;          // "Supplied list is longer than the available max width"
     std::lock_guard<std::mutex> lk(ctx->mu);
     try {
-        NTT_TRY(hipSetDevice(ctx->device));
+        kzgamd::DeviceGuard on_device(ctx->device);
+        NTT_TRY(on_device.err);
         ctx->ensure(n);
         NTT_TRY(hipMemcpyAsync(ctx->d_a, evens, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
         ntt_enqueue(ctx, ctx->d_b, ctx->d_a, n, 1, true, ctx->stream);

@@ -1,0 +1,178 @@
+"""Multi-GPU plumbing: bench.py's own N-rank launch, the C-ABI device selection, and the sharded
+commit with the GPU engine under two ranks.  The two-device tests skip on a one-GPU box."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT, load_package
+
+SETUP = os.path.join(ROOT, "tests", "golden", "trusted_setup.txt")
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    # no GPU here: every rank must start (RANK 0 and 1 both report) and fail loudly — not silently run one process
+    if _gpu_count() > 0:
+        pytest.skip("CPU-only check of the launcher")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=ROOT)
+    out = p.stdout.decode()
+    assert p.returncode != 0
+    assert out.count("bench.py needs an MI355X") >= 2, out[-2000:]
+
+
+def test_bench_rejects_world_size_mismatch():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode != 0
+    assert "WORLD_SIZE=1" in p.stdout.decode()
+
+
+def _gpu_count():
+    try:
+        return load_package().device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+def test_entry_points_leave_the_callers_device_alone(kzg):
+    s = kzg.KZGSettings.from_file(SETUP)
+    try:
+        before = kzg.get_device()
+        assert s.device() == before
+        assert kzg.lib().kzgamd_msm_device(s.msm_handle()) == before
+        blob = bytes(131072)
+        assert kzg.blob_to_kzg_commitment(blob, s)[0] == 0xC0
+        assert kzg.get_device() == before
+    finally:
+        s.close()
+
+
+@pytest.mark.gpu
+def test_reserve_then_enqueue_does_not_allocate(kzg):
+    import torch
+
+    s = kzg.KZGSettings.from_file(SETUP)
+    try:
+        dev = torch.device("cuda", 0)
+        st = torch.cuda.Stream(device=dev)
+        n = 8
+        s.reserve(n, st.cuda_stream)
+        free0 = torch.cuda.mem_get_info()[0]
+        blobs = torch.zeros(n * 131072, dtype=torch.uint8, device=dev)
+        out = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
+        stat = torch.zeros(n, dtype=torch.int32, device=dev)
+        scratch = torch.empty(n * 131072, dtype=torch.uint8, device=dev)
+        free1 = torch.cuda.mem_get_info()[0]
+        kzg.blob_to_kzg_commitment_device(out.data_ptr(), stat.data_ptr(), scratch.data_ptr(), blobs.data_ptr(), n, s,
+                                          st.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free1  # the enqueue found its workspace already there
+        assert free0 >= free1
+        assert bytes(out.cpu().numpy().tobytes()[:48]) == bytes([0xC0]) + bytes(47)
+    finally:
+        s.close()
+
+
+@pytest.mark.gpu
+def test_two_devices_one_process(kzg, oracle, oracle_settings):
+    import ctypes as C
+    import random
+
+    if kzg.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    kzg.set_device(1)
+    s1 = kzg.KZGSettings.from_file(SETUP)
+    kzg.set_device(0)
+    s0 = kzg.KZGSettings.from_file(SETUP)
+    try:
+        assert (s0.device(), s1.device()) == (0, 1)
+        rnd = random.Random(11)
+        blob = bytearray(rnd.randbytes(131072))
+        for i in range(0, 131072, 32):
+            blob[i] = 0
+        blob = bytes(blob)
+        want = C.create_string_buffer(48)
+        assert oracle.lib().oblob_to_kzg_commitment(want, blob, C.byref(oracle_settings)) == 0
+        # both from a thread whose current device is 0: the call on s1 switches to GPU 1 and back
+        assert kzg.blob_to_kzg_commitment(blob, s1) == want.raw
+        assert kzg.get_device() == 0
+        assert kzg.blob_to_kzg_commitment(blob, s0) == want.raw
+    finally:
+        s0.close()
+        s1.close()
+
+
+GPU_WORKER = r'''
+import ctypes as C, os, sys, random, importlib.util
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, torch.distributed as dist
+from importlib import util
+spec = util.spec_from_file_location("sharding", os.path.join(ROOT, "rust-kzg_amd", "sharding.py"))
+sh = util.module_from_spec(spec); spec.loader.exec_module(sh)
+torch.cuda.set_device(RANK)
+path = os.path.join(ROOT, "rust-kzg_amd", "__init__.py")
+spec = importlib.util.spec_from_file_location("rust_kzg_amd", path, submodule_search_locations=[os.path.dirname(path)])
+kzg = importlib.util.module_from_spec(spec); sys.modules["rust_kzg_amd"] = kzg; spec.loader.exec_module(kzg)
+import oracle_ffi as O
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % PORT, rank=RANK, world_size=2,
+                        device_id=torch.device("cuda", RANK))
+kzg.set_device(RANK)
+s = kzg.KZGSettings.from_file(os.path.join(ROOT, "tests", "golden", "trusted_setup.txt"))
+assert s.device() == RANK
+rnd = random.Random(3)
+blobs = []
+for _ in range(9):
+    b = bytearray(rnd.randbytes(131072))
+    for i in range(0, 131072, 32):
+        b[i] = 0
+    blobs.append(bytes(b))
+calls = []
+def engine(bs):   # the GPU pipeline of this rank
+    calls.append(len(bs))
+    return kzg.blob_to_kzg_commitment_batch(b"".join(bs), len(bs), s)
+got = sh.commit_sharded(blobs, engine, dist)
+lo, hi = sh.shard_range(9, 2, RANK)
+assert calls == [hi - lo], calls
+with open(os.path.join(ROOT, "tests", "golden", "trusted_setup.txt"), "rb") as f:
+    rc, os_ = O.load_settings(f.read())
+for b, c in zip(blobs, got):
+    o = C.create_string_buffer(48)
+    assert O.lib().oblob_to_kzg_commitment(o, b, C.byref(os_)) == 0 and o.raw == c
+dist.barrier()
+dist.destroy_process_group()
+s.close()
+print("rank", RANK, "ok")
+'''
+
+
+@pytest.mark.gpu
+def test_sharded_commit_gpu_engine_two_ranks(kzg):
+    if kzg.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    port = 30700 + (os.getpid() % 500)
+    procs = []
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for rank in range(2):
+        code = "ROOT=%r\nPORT=%d\nRANK=%d\n" % (ROOT, port, rank) + GPU_WORKER
+        procs.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env))
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % rank in o
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_a_two_gpu_box(kzg):
+    import json
+
+    if kzg.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-extras", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and sorted(d["device"] for d in line["devices"]) == [0, 1]
