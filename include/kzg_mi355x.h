@@ -175,6 +175,20 @@ C_KZG_RET kzgamd_blob_to_kzg_commitment_device(void *d_out, void *d_status, void
 C_KZG_RET kzgamd_compute_challenges_and_evaluate_batch(Bytes32 *zs_out, Bytes32 *ys_out, const Blob *blobs,
                                                        const Bytes48 *commitments, size_t n, const CKZGSettings *s);
 
+/* verify_kzg_proof_batch (kzg/src/eip_4844.rs:380-435) up to the pairing: r = Fiat-Shamir scalar of the n tuples
+ * (compute_r_powers, :328-378);  proof_lincomb = sum r^i proof_i;  rhs = sum r^i (C_i - [y_i]G) + sum r^i z_i proof_i.
+ * Commitments and proofs are decoded and subgroup-checked on the GPU (validate_batched_input, :721-734), z_i / y_i must
+ * be canonical (< r); any violation -> C_KZG_BADARGS.  The caller (its CPU backend) finishes with the one pairing check
+ *     e(proof_lincomb, g2_values_monomial[1]) == e(rhs, G2_generator).
+ * n == 0 yields two points at infinity.  kzgamd_verify_blob_kzg_proof_batch_g1 is verify_blob_kzg_proof_batch
+ * (:736-832) up to the same point: it derives z_i, y_i from the blobs first. */
+C_KZG_RET kzgamd_verify_kzg_proof_batch_g1(blst_p1 *proof_lincomb_out, blst_p1 *rhs_out, const Bytes48 *commitments,
+                                           const Bytes32 *zs, const Bytes32 *ys, const Bytes48 *proofs, size_t n,
+                                           const CKZGSettings *s);
+C_KZG_RET kzgamd_verify_blob_kzg_proof_batch_g1(blst_p1 *proof_lincomb_out, blst_p1 *rhs_out, const Blob *blobs,
+                                                const Bytes48 *commitments, const Bytes48 *proofs, size_t n,
+                                                const CKZGSettings *s);
+
 typedef struct { uint8_t bytes[2048]; } Cell;
 C_KZG_RET compute_cells_and_kzg_proofs(Cell *cells, KZGProof *proofs, const Blob *blob, const CKZGSettings *s);
 C_KZG_RET kzgamd_compute_cells_and_kzg_proofs_batch(Cell *cells, KZGProof *proofs, const Blob *blobs, size_t n,

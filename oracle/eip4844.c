@@ -326,3 +326,85 @@ int ocompute_cell_proof(uint8_t proof[48], const uint8_t *blob, size_t k, const 
     free(q);
     return rc;
 }
+
+/* ---- batched verification, G1 half ----
+ * compute_r_powers (kzg/src/eip_4844.rs:328-378) and the three linear combinations of
+ * verify_kzg_proof_batch (:380-435), up to the pairing:  returns
+ *     proof_lincomb = sum r^i * proof_i
+ *     rhs           = sum r^i * (C_i - [y_i]G)  +  sum (r^i z_i) * proof_i
+ * i.e. the two G1 inputs of the final  e(proof_lincomb, [tau]G2) == e(rhs, G2)  check.  Inputs are validated the way
+ * verify_blob_kzg_proof_batch's callers do (bytes_to_* + validate_batched_input, :721-734): 1 = BadArgs. */
+int ocompute_r_powers(ofr_t *out, const uint8_t *commitments, const uint8_t *zs, const uint8_t *ys, const uint8_t *proofs, size_t n) {
+    size_t sz = 32 + n * (48 + 32 + 32 + 48), off = 32;
+    uint8_t *buf = calloc(sz, 1), h[32];
+    memcpy(buf, "RCKZGBATCH___V1_", 16);
+    uint64_t fe = N, nn = n;
+    for (int i = 0; i < 8; ++i) {
+        buf[16 + 7 - i] = (uint8_t)(fe >> (8 * i));
+        buf[24 + 7 - i] = (uint8_t)(nn >> (8 * i));
+    }
+    for (size_t i = 0; i < n; ++i) {
+        memcpy(buf + off, commitments + 48 * i, 48); /* G1::to_bytes of a decoded valid point = its input bytes */
+        off += 48;
+        memcpy(buf + off, zs + 32 * i, 32);
+        off += 32;
+        memcpy(buf + off, ys + 32 * i, 32);
+        off += 32;
+        memcpy(buf + off, proofs + 48 * i, 48);
+        off += 48;
+    }
+    osha256(h, buf, sz);
+    free(buf);
+    ofr_t r;
+    ofr_from_be32_unchecked(&r, h);
+    /* compute_powers (:309-326) */
+    if (n > 0) ofr_one(&out[0]);
+    for (size_t i = 1; i < n; ++i) ofr_mul(&out[i], &out[i - 1], &r);
+    return 0;
+}
+
+int overify_kzg_proof_batch_g1(og1_t *proof_lincomb, og1_t *rhs, const uint8_t *commitments, const uint8_t *zs,
+                               const uint8_t *ys, const uint8_t *proofs, size_t n) {
+    og1_t *c = malloc((n + 1) * sizeof(og1_t)), *p = malloc((n + 1) * sizeof(og1_t)), *cmy = malloc((n + 1) * sizeof(og1_t));
+    ofr_t *z = malloc((n + 1) * sizeof(ofr_t)), *y = malloc((n + 1) * sizeof(ofr_t)), *rp = malloc((n + 1) * sizeof(ofr_t)),
+          *rz = malloc((n + 1) * sizeof(ofr_t));
+    int rc = 0;
+    for (size_t i = 0; !rc && i < n; ++i) {
+        og1_affine_t a;
+        if (!og1_uncompress(&a, commitments + 48 * i)) rc = 1;
+        else {
+            og1_from_affine(&c[i], &a);
+            if (!og1_is_inf(&c[i]) && !og1_in_subgroup(&c[i])) rc = 1;
+        }
+        if (!rc && !og1_uncompress(&a, proofs + 48 * i)) rc = 1;
+        if (!rc) {
+            og1_from_affine(&p[i], &a);
+            if (!og1_is_inf(&p[i]) && !og1_in_subgroup(&p[i])) rc = 1;
+        }
+        if (!rc && (!ofr_from_be32(&z[i], zs + 32 * i) || !ofr_from_be32(&y[i], ys + 32 * i))) rc = 1;
+    }
+    if (!rc) {
+        ocompute_r_powers(rp, commitments, zs, ys, proofs, n);
+        og1_lincomb(proof_lincomb, p, rp, n);
+        og1_t g, t;
+        og1_generator(&g);
+        for (size_t i = 0; i < n; ++i) {
+            og1_mul(&t, &g, &y[i]);          /* [y_i] */
+            og1_neg(&t, &t);
+            og1_add_or_dbl(&cmy[i], &c[i], &t); /* C_i - [y_i] */
+            ofr_mul(&rz[i], &rp[i], &z[i]);
+        }
+        og1_t a, b;
+        og1_lincomb(&a, p, rz, n);
+        og1_lincomb(&b, cmy, rp, n);
+        og1_add_or_dbl(rhs, &b, &a);
+    }
+    free(c);
+    free(p);
+    free(cmy);
+    free(z);
+    free(y);
+    free(rp);
+    free(rz);
+    return rc;
+}

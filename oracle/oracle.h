@@ -150,6 +150,11 @@ int  ocompute_cells(uint8_t *cells_out, const uint8_t *blob, const osettings_t *
 /* KZG multiproof of cell k (0..127), by definition: quotient by X^64 - h_k^64, MSM over the monomial setup */
 int  ocompute_cell_proof(uint8_t proof[48], const uint8_t *blob, size_t k, const osettings_t *s);
 
+/* batched verification up to the pairing (kzg/src/eip_4844.rs:328-435): r-powers and the two G1 pairing inputs */
+int  ocompute_r_powers(ofr_t *out, const uint8_t *commitments, const uint8_t *zs, const uint8_t *ys, const uint8_t *proofs, size_t n);
+int  overify_kzg_proof_batch_g1(og1_t *proof_lincomb, og1_t *rhs, const uint8_t *commitments, const uint8_t *zs,
+                                const uint8_t *ys, const uint8_t *proofs, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

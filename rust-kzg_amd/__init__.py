@@ -60,7 +60,7 @@ EXPORTS = [
     "kzgamd_compute_cells_and_kzg_proofs_batch", "kzgamd_compute_challenges_and_evaluate_batch",
     "kzgamd_blob_to_kzg_commitment_batch", "kzgamd_blob_to_kzg_commitment_device", "kzgamd_settings_msm_handle",
     "kzgamd_msm_reserve", "kzgamd_msm_device", "kzgamd_set_device", "kzgamd_get_device", "kzgamd_settings_device",
-    "kzgamd_settings_reserve",
+    "kzgamd_settings_reserve", "kzgamd_verify_kzg_proof_batch_g1", "kzgamd_verify_blob_kzg_proof_batch_g1",
 ]
 
 
@@ -175,6 +175,10 @@ def lib():
     L.kzgamd_settings_device.argtypes = [sp]
     L.kzgamd_settings_reserve.restype = C.c_int
     L.kzgamd_settings_reserve.argtypes = [sp, sz, vp]
+    L.kzgamd_verify_kzg_proof_batch_g1.restype = C.c_int
+    L.kzgamd_verify_kzg_proof_batch_g1.argtypes = [vp, vp, vp, vp, vp, vp, sz, sp]
+    L.kzgamd_verify_blob_kzg_proof_batch_g1.restype = C.c_int
+    L.kzgamd_verify_blob_kzg_proof_batch_g1.argtypes = [vp, vp, vp, vp, vp, sz, sp]
     _lib = L
     return L
 
@@ -522,6 +526,24 @@ def compute_challenges_and_evaluate_batch(blobs: bytes, commitments: bytes, n: i
     if rc != C_KZG_OK:
         raise KzgAmdError("kzgamd_compute_challenges_and_evaluate_batch: C_KZG_RET %d" % rc)
     return ([zs.raw[32 * i:32 * i + 32] for i in range(n)], [ys.raw[32 * i:32 * i + 32] for i in range(n)])
+
+
+def verify_kzg_proof_batch_g1(commitments: bytes, zs: bytes, ys: bytes, proofs: bytes, n: int, settings: KZGSettings):
+    """verify_kzg_proof_batch (kzg/src/eip_4844.rs:380-435) up to the pairing -> (proof_lincomb, rhs) as BlstP1."""
+    a, b = BlstP1(), BlstP1()
+    rc = lib().kzgamd_verify_kzg_proof_batch_g1(C.byref(a), C.byref(b), commitments, zs, ys, proofs, n, C.byref(settings.c))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("kzgamd_verify_kzg_proof_batch_g1: C_KZG_RET %d" % rc)
+    return a, b
+
+
+def verify_blob_kzg_proof_batch_g1(blobs: bytes, commitments: bytes, proofs: bytes, n: int, settings: KZGSettings):
+    """verify_blob_kzg_proof_batch (kzg/src/eip_4844.rs:736-832) up to the pairing -> (proof_lincomb, rhs)."""
+    a, b = BlstP1(), BlstP1()
+    rc = lib().kzgamd_verify_blob_kzg_proof_batch_g1(C.byref(a), C.byref(b), blobs, commitments, proofs, n, C.byref(settings.c))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("kzgamd_verify_blob_kzg_proof_batch_g1: C_KZG_RET %d" % rc)
+    return a, b
 
 
 def compute_challenge(blob: bytes, commitment_p1) -> BlstFr:

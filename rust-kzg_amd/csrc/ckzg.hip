@@ -1384,6 +1384,165 @@ extern "C" C_KZG_RET kzgamd_compute_challenges_and_evaluate_batch(Bytes32* zs_ou
     return guarded([&] { prove_batch(nullptr, ys_out, blobs, nullptr, commitments, n, dev, zs_out); });
 }
 
+namespace {
+
+bool fr_from_be32_checked(ff::Fr& out, const uint8_t* in) {  // FsFr::from_bytes: canonical limbs, false if >= r
+    for (int i = 0; i < 8; ++i) {
+        const uint8_t* q = in + (7 - i) * 4;
+        out.v[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+    }
+    u64 borrow = 0;
+    for (int k = 0; k < 8; ++k) {
+        u64 d = (u64)out.v[k] - ff::FrParams::p(k) - borrow;
+        borrow = (d >> 32) & 1;
+    }
+    return borrow != 0;
+}
+
+// verify_kzg_proof_batch (kzg/src/eip_4844.rs:380-435) up to the pairing.  Host: the Fiat-Shamir scalar r
+// (compute_r_powers, :328-378) and the three scalar vectors; GPU: decoding + subgroup checks of the 2n points
+// (validate_batched_input, :721-734) and the linear combinations — as ONE two-row MSM over [proofs | commitments | G]:
+//     row 0:  r^i           0      0                 -> proof_lincomb
+//     row 1:  r^i z_i       r^i    -sum r^i y_i      -> rhs  ( = sum r^i (C_i - [y_i]G) + sum r^i z_i proof_i )
+void verify_batch_g1(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commitments, const Bytes32* zs, const Bytes32* ys,
+                     const Bytes48* proofs, size_t n, KzgAmdSettings* dev) {
+    std::vector<ff::Fr> z(n), y(n);
+    for (size_t i = 0; i < n; ++i) {
+        CK_REQUIRE(fr_from_be32_checked(z[i], zs[i].bytes), "Invalid scalar");
+        CK_REQUIRE(fr_from_be32_checked(y[i], ys[i].bytes), "Invalid scalar");
+        z[i] = ff::to_mont(z[i]);
+        y[i] = ff::to_mont(y[i]);
+    }
+    std::lock_guard<std::mutex> lk(dev->mu);
+    kzgamd::DeviceGuard on_device(dev->device);
+    CK_HIP(on_device.err);
+    const size_t np = 2 * n + 1;
+    unsigned char* d_bytes = nullptr;
+    AffPt* d_pts = nullptr;
+    int *d_bad = nullptr, *d_stat = nullptr;
+    kzgamd::MsmContext* msm = nullptr;
+    struct Cleanup {
+        unsigned char*& a;
+        AffPt*& b;
+        int *&c, *&d;
+        kzgamd::MsmContext*& m;
+        ~Cleanup() {
+            if (a) (void)hipFree(a);
+            if (b) (void)hipFree(b);
+            if (c) (void)hipFree(c);
+            if (d) (void)hipFree(d);
+            if (m) kzgamd::msm_destroy(m);
+        }
+    } cleanup{d_bytes, d_pts, d_bad, d_stat, msm};
+    // device: [proofs | commitments | generator], decoded and checked
+    std::vector<uint8_t> stage(np * 48);
+    memcpy(stage.data(), proofs, n * 48);
+    memcpy(stage.data() + n * 48, commitments, n * 48);
+    static const uint8_t G1_GENERATOR_COMPRESSED[48] = {
+        0x97, 0xf1, 0xd3, 0xa7, 0x31, 0x97, 0xd7, 0x94, 0x26, 0x95, 0x63, 0x8c, 0x4f, 0xa9, 0xac, 0x0f,
+        0xc3, 0x68, 0x8c, 0x4f, 0x97, 0x74, 0xb9, 0x05, 0xa1, 0x4e, 0x3a, 0x3f, 0x17, 0x1b, 0xac, 0x58,
+        0x6c, 0x55, 0xe8, 0x3f, 0xf9, 0x7a, 0x1a, 0xef, 0xfb, 0x3a, 0xf0, 0x0a, 0xdb, 0x22, 0xc6, 0xbb};
+    memcpy(stage.data() + 2 * n * 48, G1_GENERATOR_COMPRESSED, 48);
+    CK_HIP(hipMalloc(&d_bytes, stage.size()));
+    CK_HIP(hipMalloc(&d_pts, np * sizeof(AffPt)));
+    CK_HIP(hipMalloc(&d_bad, sizeof(int)));
+    CK_HIP(hipMalloc(&d_stat, np * sizeof(int)));
+    hipStream_t st = dev->stream;
+    CK_HIP(hipMemcpyAsync(d_bytes, stage.data(), stage.size(), hipMemcpyHostToDevice, st));
+    CK_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), st));
+    CK_HIP(hipMemsetAsync(d_stat, 0, np * sizeof(int), st));
+    hipLaunchKernelGGL(k_uncompress, dim3((unsigned)((np + 127) / 128)), dim3(128), 0, st, d_pts, d_bad, d_bytes, np);
+    hipLaunchKernelGGL(k_check_commitments, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st, d_stat,
+                       (const unsigned char*)d_bytes, np);
+    // host, meanwhile: r = hash_to_bls_field(sha256(domain | 4096 | n | (C_i | z_i | y_i | proof_i)...)), powers of r
+    std::vector<ff::Fr> sc(2 * np, ff::Fr::zero());
+    {
+        kzgamd::Sha256 h;
+        uint8_t head[32] = {0};
+        memcpy(head, "RCKZGBATCH___V1_", 16);
+        const uint64_t nfe = N, nn = n;
+        for (int i = 0; i < 8; ++i) {
+            head[16 + 7 - i] = (uint8_t)(nfe >> (8 * i));
+            head[24 + 7 - i] = (uint8_t)(nn >> (8 * i));
+        }
+        h.update(head, 32);
+        for (size_t i = 0; i < n; ++i) {
+            h.update(commitments[i].bytes, 48);
+            h.update(zs[i].bytes, 32);
+            h.update(ys[i].bytes, 32);
+            h.update(proofs[i].bytes, 48);
+        }
+        uint8_t digest[32];
+        h.finish(digest);
+        ff::Fr v;
+        for (int i = 0; i < 8; ++i) {
+            const uint8_t* q = digest + (7 - i) * 4;
+            v.v[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+        }
+        const ff::Fr r = ff::mul(v, ff::Fr::r2());  // Montgomery form of (v mod r)
+        ff::Fr pw = ff::Fr::one(), sy = ff::Fr::zero();
+        for (size_t i = 0; i < n; ++i) {
+            sc[i] = pw;                          // row 0: proofs
+            sc[np + i] = ff::mul(pw, z[i]);      // row 1: proofs
+            sc[np + n + i] = pw;                 // row 1: commitments
+            sy = ff::add(sy, ff::mul(pw, y[i]));
+            pw = ff::mul(pw, r);
+        }
+        sc[np + 2 * n] = ff::neg(sy);            // row 1: generator
+    }
+    int bad = 0;
+    std::vector<int> stat(np);
+    CK_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    CK_HIP(hipMemcpyAsync(stat.data(), d_stat, np * sizeof(int), hipMemcpyDeviceToHost, st));
+    CK_HIP(hipStreamSynchronize(st));
+    CK_REQUIRE(bad == 0, "Invalid G1 encoding");
+    for (size_t i = 0; i < n; ++i) CK_REQUIRE(stat[i] == 0, "Invalid proof");
+    for (size_t i = n; i < 2 * n; ++i) CK_REQUIRE(stat[i] == 0, "Invalid commitment");
+    msm = kzgamd::msm_create(d_pts, np, true, false, true);
+    blst_p1 out[2];
+    kzgamd::msm_run_host(msm, out, sc.data(), np, 2);
+    *proof_lincomb = out[0];
+    *rhs = out[1];
+}
+
+}  // namespace
+
+extern "C" C_KZG_RET kzgamd_verify_kzg_proof_batch_g1(blst_p1* proof_lincomb_out, blst_p1* rhs_out, const Bytes48* commitments,
+                                                      const Bytes32* zs, const Bytes32* ys, const Bytes48* proofs, size_t n,
+                                                      const CKZGSettings* s) {
+    if (!proof_lincomb_out || !rhs_out) return C_KZG_BADARGS;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    if (n == 0) {
+        memset(proof_lincomb_out, 0, sizeof *proof_lincomb_out);
+        memset(rhs_out, 0, sizeof *rhs_out);
+        return C_KZG_OK;
+    }
+    if (!commitments || !zs || !ys || !proofs) return C_KZG_BADARGS;
+    return guarded([&] { verify_batch_g1(proof_lincomb_out, rhs_out, commitments, zs, ys, proofs, n, dev); });
+}
+
+// verify_blob_kzg_proof_batch (kzg/src/eip_4844.rs:736-832) up to the pairing: challenges + evaluations on the GPU
+// (:690-719), then the G1 half above.  The caller finishes with  e(proof_lincomb, [tau]G2) == e(rhs, G2).
+extern "C" C_KZG_RET kzgamd_verify_blob_kzg_proof_batch_g1(blst_p1* proof_lincomb_out, blst_p1* rhs_out, const Blob* blobs,
+                                                           const Bytes48* commitments, const Bytes48* proofs, size_t n,
+                                                           const CKZGSettings* s) {
+    if (!proof_lincomb_out || !rhs_out) return C_KZG_BADARGS;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    if (n == 0) {
+        memset(proof_lincomb_out, 0, sizeof *proof_lincomb_out);
+        memset(rhs_out, 0, sizeof *rhs_out);
+        return C_KZG_OK;
+    }
+    if (!blobs || !commitments || !proofs) return C_KZG_BADARGS;
+    return guarded([&] {
+        std::vector<Bytes32> zs(n), ys(n);
+        prove_batch(nullptr, ys.data(), blobs, nullptr, commitments, n, dev, zs.data());
+        verify_batch_g1(proof_lincomb_out, rhs_out, commitments, zs.data(), ys.data(), proofs, n, dev);
+    });
+}
+
 extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof* out, const Blob* blob, const Bytes48* commitment_bytes,
                                             const CKZGSettings* s) {
     return kzgamd_compute_blob_kzg_proof_batch(out, blob, commitment_bytes, 1, s);

@@ -35,7 +35,10 @@ namespace {
 
 constexpr int LOG_TILE = 12;
 constexpr int TILE = 1 << LOG_TILE;  // elements per workgroup
-constexpr int NT = 512;              // threads per workgroup: 8 elements per thread in a radix-8 round
+// threads per workgroup = TILE >> MAXM: 2^MAXM elements per thread in a round of MAXM stages
+//   MAXM = 3 (radix-8 rounds, 512 threads, 2 waves per SIMD: the 144 KiB tile allows one workgroup per CU)
+//   MAXM = 2 (radix-4 rounds, 1024 threads, 4 waves per SIMD, half the registers, 1.5x the LDS traffic) was measured
+//            7 % slower (98.8 vs 92.4 us for 256 transforms of 4096) and is not instantiated
 
 __device__ __forceinline__ u32 brev(u32 v, int bits) { return bits == 0 ? 0u : __builtin_bitreverse32(v) >> (32 - bits); }
 
@@ -61,7 +64,7 @@ __device__ __forceinline__ void lds_put(u32* sh, int cnt, int sidx, const Fe& a)
 // tile indices  base | (k << B),  k < 2^M,  base = v with M zero bits inserted at position B.  Stage B+q pairs
 // k and k | 2^q; its twiddle depends on the low B+q bits of the index, so the round loads 2^M - 1 twiddles for
 // its M * 2^(M-1) butterflies.  FIRST: stage 0 of a transform multiplies by w^0 = 1 — no multiplication.
-template <int M, int B, bool FIRST, class TwFn>
+template <int NT, int M, int B, bool FIRST, class TwFn>
 __device__ __forceinline__ void round_regs(u32* sh, int cnt, int nelem, TwFn tw) {
     constexpr int E = 1 << M;
     for (int v = threadIdx.x; v < (nelem >> M); v += NT) {
@@ -71,27 +74,82 @@ __device__ __forceinline__ void round_regs(u32* sh, int cnt, int nelem, TwFn tw)
         Fe e[E];
 #pragma unroll
         for (int k = 0; k < E; ++k) e[k] = lds_get(sh, cnt, sbase ^ swz(k << B));
-#pragma unroll
-        for (int q = 0; q < M; ++q) {
-#pragma unroll
-            for (int t = 0; t < (1 << q); ++t) {
-                if (FIRST && B == 0 && q == 0) {
-#pragma unroll
-                    for (int h = 0; h < (E >> 1); ++h) {
-                        const Fe y = e[2 * h + 1];
-                        fr29::butterfly(e[2 * h], e[2 * h + 1], y);
-                    }
-                } else {
-                    const Fe w = tw(B + q, lo | (t << B), base);
-#pragma unroll
-                    for (int h = 0; h < (E >> (q + 1)); ++h) {
-                        const int k0 = t | (h << (q + 1)), k1 = k0 | (1 << q);
-                        const Fe tt = fr29::mul(e[k1], w);
-                        fr29::butterfly(e[k0], e[k1], tt);
-                    }
-                }
+        // butterflies written out per stage (no loop nests for the compiler to leave rolled: a rolled loop would
+        // index e[] dynamically and push it to scratch)
+        // limbs are renormalised after the second stage of a round and at its end, not after every stage
+#define KZG_BF(K0, K1, W)                                \
+    {                                                    \
+        const Fe tt_ = fr29::mul(e[K1], W);              \
+        fr29::butterfly_lazy(e[K0], e[K1], tt_);         \
+    }
+#define KZG_BF1(K0, K1)                                  \
+    {                                                    \
+        const Fe y_ = e[K1];                             \
+        fr29::butterfly_lazy(e[K0], e[K1], y_);          \
+    }
+#define KZG_NORM_ALL                  \
+    _Pragma("unroll") for (int k_ = 0; k_ < E; ++k_) fr29::norm(e[k_]);
+        if constexpr (M == 1) {
+            if constexpr (FIRST && B == 0) {
+                KZG_BF1(0, 1)
+            } else {
+                const Fe w = tw(B, lo, base);
+                KZG_BF(0, 1, w)
             }
+            KZG_NORM_ALL
+        } else if constexpr (M == 2) {
+            if constexpr (FIRST && B == 0) {
+                KZG_BF1(0, 1)
+                KZG_BF1(2, 3)
+            } else {
+                const Fe w = tw(B, lo, base);
+                KZG_BF(0, 1, w)
+                KZG_BF(2, 3, w)
+            }
+            {
+                const Fe w0 = tw(B + 1, lo, base);
+                KZG_BF(0, 2, w0)
+                const Fe w1 = tw(B + 1, lo | (1 << B), base);
+                KZG_BF(1, 3, w1)
+            }
+            KZG_NORM_ALL
+        } else {
+            if constexpr (FIRST && B == 0) {
+                KZG_BF1(0, 1)
+                KZG_BF1(2, 3)
+                KZG_BF1(4, 5)
+                KZG_BF1(6, 7)
+            } else {
+                const Fe w = tw(B, lo, base);
+                KZG_BF(0, 1, w)
+                KZG_BF(2, 3, w)
+                KZG_BF(4, 5, w)
+                KZG_BF(6, 7, w)
+            }
+            {
+                const Fe w0 = tw(B + 1, lo, base);
+                KZG_BF(0, 2, w0)
+                KZG_BF(4, 6, w0)
+                const Fe w1 = tw(B + 1, lo | (1 << B), base);
+                KZG_BF(1, 3, w1)
+                KZG_BF(5, 7, w1)
+            }
+            KZG_NORM_ALL
+            {
+                const Fe w0 = tw(B + 2, lo, base);
+                KZG_BF(0, 4, w0)
+                const Fe w1 = tw(B + 2, lo | (1 << B), base);
+                KZG_BF(1, 5, w1)
+                const Fe w2 = tw(B + 2, lo | (2 << B), base);
+                KZG_BF(2, 6, w2)
+                const Fe w3 = tw(B + 2, lo | (3 << B), base);
+                KZG_BF(3, 7, w3)
+            }
+            KZG_NORM_ALL
         }
+#undef KZG_BF
+#undef KZG_BF1
+#undef KZG_NORM_ALL
 #pragma unroll
         for (int k = 0; k < E; ++k) lds_put(sh, cnt, sbase ^ swz(k << B), e[k]);
     }
@@ -101,17 +159,31 @@ __device__ __forceinline__ void round_regs(u32* sh, int cnt, int nelem, TwFn tw)
 // `stages` butterfly stages (1..12) of a DIT network on the tile in LDS: stage s pairs tile indices i and i + 2^s.
 // tw(s, j, base): twiddle of stage s for pair position j = i mod 2^s (base = any index of the thread's group: the
 // caller derives the tile column from its high bits).
-template <bool FIRST, class TwFn>
+template <bool FIRST, int MAXM, class TwFn>
 __device__ __forceinline__ void tile_stages(u32* sh, int cnt, int nelem, int stages, TwFn tw) {
-#define KZG_ROUNDS(B_)                                                              \
-    if (stages >= (B_) + 3) round_regs<3, B_, FIRST>(sh, cnt, nelem, tw);           \
-    else if (stages == (B_) + 2) round_regs<2, B_, FIRST>(sh, cnt, nelem, tw);      \
-    else if (stages == (B_) + 1) round_regs<1, B_, FIRST>(sh, cnt, nelem, tw);
-    KZG_ROUNDS(0)
-    KZG_ROUNDS(3)
-    KZG_ROUNDS(6)
-    KZG_ROUNDS(9)
+    constexpr int NT = TILE >> MAXM;
+    if constexpr (MAXM == 3) {
+#define KZG_ROUNDS(B_)                                                                  \
+    if (stages >= (B_) + 3) round_regs<NT, 3, B_, FIRST>(sh, cnt, nelem, tw);           \
+    else if (stages == (B_) + 2) round_regs<NT, 2, B_, FIRST>(sh, cnt, nelem, tw);      \
+    else if (stages == (B_) + 1) round_regs<NT, 1, B_, FIRST>(sh, cnt, nelem, tw);
+        KZG_ROUNDS(0)
+        KZG_ROUNDS(3)
+        KZG_ROUNDS(6)
+        KZG_ROUNDS(9)
 #undef KZG_ROUNDS
+    } else {
+#define KZG_ROUNDS(B_)                                                                  \
+    if (stages >= (B_) + 2) round_regs<NT, 2, B_, FIRST>(sh, cnt, nelem, tw);           \
+    else if (stages == (B_) + 1) round_regs<NT, 1, B_, FIRST>(sh, cnt, nelem, tw);
+        KZG_ROUNDS(0)
+        KZG_ROUNDS(2)
+        KZG_ROUNDS(4)
+        KZG_ROUNDS(6)
+        KZG_ROUNDS(8)
+        KZG_ROUNDS(10)
+#undef KZG_ROUNDS
+    }
 }
 
 struct NttParams {
@@ -120,6 +192,7 @@ struct NttParams {
     u32 W;          // roots table width (max_width)
     int inverse;
     Fr scale;       // final multiplier in the 2^261 domain: 2^261 mod r, times n^-1 on the last pass of an inverse
+    int dbg;        // timing experiments only (KZGAMD_NTT_DBG): 1 = skip the butterfly stages, 2 = every twiddle = roots[0]
 };
 
 // Pass 1 (the whole transform when n <= TILE): stages 0 .. min(logn,12)-1.
@@ -129,10 +202,12 @@ struct NttParams {
 //              natural indices  o + (t << L),  o = brev_L(blk), L = logn - 12: 32-byte pieces 2^L elements apart.
 //              The four blocks whose pieces share 128-byte lines (o, o^1, o^2, o^3) are given to workgroups
 //              8 apart in launch order — same XCD, dispatched together — so the line is fetched from HBM once.
-__global__ void __launch_bounds__(NT) k_ntt_low(Fr* __restrict__ out, const Fr* __restrict__ in,
+template <int MAXM>
+__global__ void __launch_bounds__(TILE >> MAXM) k_ntt_low(Fr* __restrict__ out, const Fr* __restrict__ in,
                                                 const Fe* __restrict__ roots, NttParams P, u32 blocks_per_xform, int nelem,
                                                 size_t total) {
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    constexpr int NT = TILE >> MAXM;
     const int cnt = (nelem + 31) & ~31;  // limb stride: the swizzle permutes within aligned groups of 32
     const int stages = P.logn < LOG_TILE ? P.logn : LOG_TILE;
     const bool last_pass = P.logn <= LOG_TILE;
@@ -161,22 +236,32 @@ __global__ void __launch_bounds__(NT) k_ntt_low(Fr* __restrict__ out, const Fr* 
     }
     __syncthreads();
     // stage s: half = 2^s, twiddle w_n^(j * n / 2^(s+1)) = roots[j * (W / 2^(s+1))]
-    tile_stages<true>(sh, cnt, nelem, stages, [&](int s, int j, int) -> Fe {
-        const u32 idx = (u32)j * (P.W >> (s + 1));
-        return roots[P.inverse ? P.W - idx : idx];
+    // `roots` is the stage-major table of this direction: entry (2^s - 1) + j = w_{2^(s+1)}^(+-j), so the twiddles a
+    // wave asks for are neighbours in memory whatever the ratio between the table width and n
+    tile_stages<true, MAXM>(sh, cnt, nelem, (P.dbg & 1) ? 0 : stages, [&](int s, int j, int) -> Fe {
+        return roots[(P.dbg & 2) ? 0u : ((1u << s) - 1u) + (u32)j];
     });
-    const Fe fin = last_pass ? fr29::unpack(P.scale) : fr29::one();
-    for (int t = threadIdx.x; t < nelem; t += NT)
-        if (dst0 + t < total) out[dst0 + t] = fr29::finish(lds_get(sh, cnt, swz(t)), fin);
+    // an inverse transform multiplies by n^-1 at the end of its last pass; everything else only needs the lazy value
+    // (< 64r) brought back to [0, r)
+    if (last_pass && P.inverse) {
+        const Fe fin = fr29::unpack(P.scale);
+        for (int t = threadIdx.x; t < nelem; t += NT)
+            if (dst0 + t < total) out[dst0 + t] = fr29::finish(lds_get(sh, cnt, swz(t)), fin);
+    } else {
+        for (int t = threadIdx.x; t < nelem; t += NT)
+            if (dst0 + t < total) out[dst0 + t] = fr29::reduce_lazy(lds_get(sh, cnt, swz(t)));
+    }
 }
 
 // Passes 2, 3: `logR` stages starting at global stage `stage0` (a multiple of 12), in place.
 // View the bit-reversed-order array as [hi][r][lo] with lo < 2^stage0, r < R = 2^logR: stage stage0+s pairs
 // rows r and r + 2^s.  A workgroup takes C = 4096 / R consecutive lo positions of one hi block
 // (C * 32 B contiguous per row), runs the logR stages on the tile, writes back.  Tile index = c * R + r.
-__global__ void __launch_bounds__(NT) k_ntt_high(Fr* __restrict__ data, const Fe* __restrict__ roots, NttParams P,
+template <int MAXM>
+__global__ void __launch_bounds__(TILE >> MAXM) k_ntt_high(Fr* __restrict__ data, const Fe* __restrict__ roots, NttParams P,
                                                  u32 tiles_per_xform, int stage0, int logR, int last) {
     extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    constexpr int NT = TILE >> MAXM;
     const u32 xf = blockIdx.x / tiles_per_xform, tile = blockIdx.x % tiles_per_xform;
     const int C = TILE >> logR, logC = LOG_TILE - logR;
     Fr* base = data + (size_t)xf * P.n;
@@ -188,17 +273,23 @@ __global__ void __launch_bounds__(NT) k_ntt_high(Fr* __restrict__ data, const Fe
         lds_put(sh, TILE, swz((c << logR) | r), fr29::unpack(base[origin + ((size_t)r << stage0) + c]));
     }
     __syncthreads();
-    tile_stages<false>(sh, TILE, TILE, logR, [&](int s, int j, int tidx) -> Fe {
+    tile_stages<false, MAXM>(sh, TILE, TILE, (P.dbg & 1) ? 0 : logR, [&](int s, int j, int tidx) -> Fe {
         // global stage stage0+s: half = 2^(stage0+s); position mod half = (r mod 2^s) * 2^stage0 + lo
         const u32 lo = lo0 + (u32)(tidx >> logR);
         const u32 jg = ((u32)j << stage0) + lo;
-        const u32 idx = jg * (P.W >> (stage0 + s + 1));
-        return roots[P.inverse ? P.W - idx : idx];
+        return roots[(P.dbg & 2) ? 0u : ((1u << (stage0 + s)) - 1u) + jg];
     });
-    const Fe fin = last ? fr29::unpack(P.scale) : fr29::one();
-    for (int e = threadIdx.x; e < TILE; e += NT) {
-        const int c = e & (C - 1), r = e >> logC;
-        base[origin + ((size_t)r << stage0) + c] = fr29::finish(lds_get(sh, TILE, swz((c << logR) | r)), fin);
+    if (last && P.inverse) {
+        const Fe fin = fr29::unpack(P.scale);
+        for (int e = threadIdx.x; e < TILE; e += NT) {
+            const int c = e & (C - 1), r = e >> logC;
+            base[origin + ((size_t)r << stage0) + c] = fr29::finish(lds_get(sh, TILE, swz((c << logR) | r)), fin);
+        }
+    } else {
+        for (int e = threadIdx.x; e < TILE; e += NT) {
+            const int c = e & (C - 1), r = e >> logC;
+            base[origin + ((size_t)r << stage0) + c] = fr29::reduce_lazy(lds_get(sh, TILE, swz((c << logR) | r)));
+        }
     }
 }
 
@@ -244,28 +335,32 @@ void ntt_enqueue(NttCtx* ctx, Fr* d_out, const Fr* d_in, size_t n, size_t nbatch
     P.logn = ilog2(n);
     P.W = (u32)ctx->W;
     P.inverse = inverse ? 1 : 0;
+    static const int dbg = getenv("KZGAMD_NTT_DBG") ? atoi(getenv("KZGAMD_NTT_DBG")) : 0;
+    P.dbg = dbg;
     // 2^261 mod r as a plain residue (= "one" of the 2^261 domain); an inverse transform folds n^-1 in:
     // data is d*2^256, so the multiplier n^-1*2^261 is (n^-1 in blst Montgomery form) * 2^5
     P.scale = inverse ? times32(inv_len(n)) : one261();
     const size_t total = n * nbatch;
+    const Fe* tw = (const Fe*)(inverse ? ctx->d_tw_inv : ctx->d_tw_fwd);
     if (n <= (size_t)TILE) {
         // whole transforms per workgroup: TILE / n of them (all of them when the batch is smaller than a tile)
         const size_t cnt = total < (size_t)TILE ? total : (size_t)TILE;
         const size_t wgs = (total + cnt - 1) / cnt;
-        hipLaunchKernelGGL(k_ntt_low, dim3((unsigned)wgs), dim3(NT), ((cnt + 31) & ~(size_t)31) * sizeof(u32) * fr29::L, stream, d_out, d_in,
-                           (const Fe*)ctx->d_roots, P, 1u, (int)cnt, total);
+        const size_t lds = ((cnt + 31) & ~(size_t)31) * sizeof(u32) * fr29::L;
+        hipLaunchKernelGGL(k_ntt_low<3>, dim3((unsigned)wgs), dim3(TILE >> 3), lds, stream, d_out, d_in,
+                               tw, P, 1u, (int)cnt, total);
     } else {
         const u32 blocks = (u32)(n >> LOG_TILE);
-        hipLaunchKernelGGL(k_ntt_low, dim3((unsigned)(blocks * nbatch)), dim3(NT), (size_t)TILE * sizeof(u32) * fr29::L, stream,
-                           d_out, d_in, (const Fe*)ctx->d_roots, P, blocks, TILE, total);
+        hipLaunchKernelGGL(k_ntt_low<3>, dim3((unsigned)(blocks * nbatch)), dim3(TILE >> 3), (size_t)TILE * sizeof(u32) * fr29::L,
+                               stream, d_out, d_in, tw, P, blocks, TILE, total);
     }
     // remaining stages, up to 12 per pass: 12..23, then 24..30
     for (int stage0 = LOG_TILE; stage0 < P.logn; stage0 += LOG_TILE) {
         const int logR = P.logn - stage0 < LOG_TILE ? P.logn - stage0 : LOG_TILE;
         const int last = stage0 + logR == P.logn;
         const u32 tiles = (u32)(n >> LOG_TILE);
-        hipLaunchKernelGGL(k_ntt_high, dim3((unsigned)(tiles * nbatch)), dim3(NT), (size_t)TILE * sizeof(u32) * fr29::L, stream,
-                           d_out, (const Fe*)ctx->d_roots, P, tiles, stage0, logR, last);
+        hipLaunchKernelGGL(k_ntt_high<3>, dim3((unsigned)(tiles * nbatch)), dim3(TILE >> 3), (size_t)TILE * sizeof(u32) * fr29::L,
+                               stream, d_out, tw, P, tiles, stage0, logR, last);
     }
     NTT_TRY(hipGetLastError());
 }
@@ -292,6 +387,21 @@ extern "C" void* kzgamd_ntt_new(unsigned scale) {
         for (size_t i = 0; i <= ctx->W; ++i) tw[i] = fr29::unpack(times32(ctx->roots[i]));
         NTT_TRY(hipMalloc(&ctx->d_roots, (ctx->W + 1) * sizeof(Fe)));
         NTT_TRY(hipMemcpy(ctx->d_roots, tw.data(), (ctx->W + 1) * sizeof(Fe), hipMemcpyHostToDevice));
+        // stage-major copies for the butterfly kernels: [(2^s - 1) + j] = w_{2^(s+1)}^j = roots[j * (W >> (s+1))],
+        // s < scale, and the same with the inverse roots (roots[W - idx]); W - 1 entries each
+        if (scale > 0) {
+            std::vector<Fe> sm(ctx->W), smi(ctx->W);
+            for (unsigned s = 0; s < scale; ++s)
+                for (size_t j = 0; j < ((size_t)1 << s); ++j) {
+                    const size_t idx = j * (ctx->W >> (s + 1));
+                    sm[((size_t)1 << s) - 1 + j] = tw[idx];
+                    smi[((size_t)1 << s) - 1 + j] = tw[ctx->W - idx];
+                }
+            NTT_TRY(hipMalloc(&ctx->d_tw_fwd, ctx->W * sizeof(Fe)));
+            NTT_TRY(hipMalloc(&ctx->d_tw_inv, ctx->W * sizeof(Fe)));
+            NTT_TRY(hipMemcpy(ctx->d_tw_fwd, sm.data(), ctx->W * sizeof(Fe), hipMemcpyHostToDevice));
+            NTT_TRY(hipMemcpy(ctx->d_tw_inv, smi.data(), ctx->W * sizeof(Fe), hipMemcpyHostToDevice));
+        }
     } catch (...) {
         delete ctx;
         return nullptr;

@@ -21,7 +21,8 @@ struct NttCtx {
     int device = 0;
     unsigned scale = 0;
     size_t W = 0;
-    void* d_roots = nullptr;  // W + 1 twiddles in the 2^261 domain as 9 x 29-bit limbs (Fr transforms)
+    void* d_roots = nullptr;  // W + 1 twiddles in the 2^261 domain as 9 x 29-bit limbs (Fr transforms), natural order
+    void *d_tw_fwd = nullptr, *d_tw_inv = nullptr;  // the same, stage-major (forward roots / inverse roots)
     std::vector<Fr> roots;  // host copy, blst Montgomery form
     hipStream_t stream = nullptr;
     std::mutex mu;
@@ -33,6 +34,8 @@ struct NttCtx {
     size_t cap_g1 = 0, cap_tab = 0;
     ~NttCtx() {
         if (d_roots) (void)hipFree(d_roots);
+        if (d_tw_fwd) (void)hipFree(d_tw_fwd);
+        if (d_tw_inv) (void)hipFree(d_tw_inv);
         if (d_a) (void)hipFree(d_a);
         if (d_b) (void)hipFree(d_b);
         if (d_kroots) (void)hipFree(d_kroots);

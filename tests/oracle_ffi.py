@@ -101,6 +101,8 @@ def lib():
         "ocompute_blob_kzg_proof": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Settings)]),
         "ocompute_cells": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(Settings)]),
         "ocompute_cell_proof": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(Settings)]),
+        "ocompute_r_powers": (C.c_int, [frp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+        "overify_kzg_proof_batch_g1": (C.c_int, [g1p, g1p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
