@@ -11,6 +11,7 @@
  */
 #ifndef KZG_MI355X_H
 #define KZG_MI355X_H
+#include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -117,20 +118,21 @@ typedef struct { uint8_t bytes[BYTES_PER_BLOB]; } Blob;
 typedef Bytes48 KZGCommitment;
 typedef Bytes48 KZGProof;
 
-typedef struct { uint8_t opaque[288]; } blst_p2;       /* 3 x Fp2, never dereferenced by this library */
+typedef struct { blst_fp fp[2]; } blst_fp2;
+typedef struct { blst_fp2 x, y, z; } blst_p2;          /* Jacobian over Fp2; infinity = Z == 0 */
 
 /* Same layout as the reference's CKZGSettings (kzg/src/eth/c_bindings.rs:55-108).  The host arrays are
  * owned by the library and freed by free_trusted_setup; the device-resident state (fixed-base MSM table)
  * is found through a registry keyed by g1_values_lagrange_brp, as the reference does for its tables
- * (kzg/src/eip_4844.rs:64-146).  g2_values_monomial / x_ext_fft_columns / tables stay NULL: pairing
- * (verify_*) and FK20 are outside this library's path. */
+ * (kzg/src/eip_4844.rs:64-146).  x_ext_fft_columns / tables stay NULL (FK20 state, outside this library's path:
+ * cell proofs are computed as fixed-base MSMs instead). */
 typedef struct {
     blst_fr *roots_of_unity;          /* 8193 */
     blst_fr *brp_roots_of_unity;      /* 8192 */
     blst_fr *reverse_roots_of_unity;  /* 8193 */
     blst_p1 *g1_values_monomial;      /* 4096 */
     blst_p1 *g1_values_lagrange_brp;  /* 4096 */
-    blst_p2 *g2_values_monomial;      /* NULL */
+    blst_p2 *g2_values_monomial;      /* 65 */
     blst_p1 **x_ext_fft_columns;      /* NULL */
     blst_p1_affine **tables;          /* NULL */
     size_t wbits;
@@ -149,6 +151,15 @@ C_KZG_RET compute_kzg_proof(KZGProof *proof_out, Bytes32 *y_out, const Blob *blo
                             const CKZGSettings *s);                                            /* eip_4844.rs:476-496 */
 C_KZG_RET compute_blob_kzg_proof(KZGProof *out, const Blob *blob, const Bytes48 *commitment_bytes,
                                  const CKZGSettings *s);                                       /* eip_4844.rs:274-291 */
+/* Verification (eip_4844.rs:383-471).  The field work (challenge, evaluation) and, for batches, the G1 linear
+ * combinations run on the GPU; the pairing check itself runs on the host, as in the reference (its GPU backend moves
+ * only g1_lincomb; blst/src/kzg_proofs.rs:73-100 is CPU code).  *ok is the verdict; malformed input -> C_KZG_BADARGS. */
+C_KZG_RET verify_kzg_proof(bool *ok, const Bytes48 *commitment_bytes, const Bytes32 *z_bytes, const Bytes32 *y_bytes,
+                           const Bytes48 *proof_bytes, const CKZGSettings *s);                 /* eip_4844.rs:383-405 */
+C_KZG_RET verify_blob_kzg_proof(bool *ok, const Blob *blob, const Bytes48 *commitment_bytes, const Bytes48 *proof_bytes,
+                                const CKZGSettings *s);                                        /* eip_4844.rs:410-430 */
+C_KZG_RET verify_blob_kzg_proof_batch(bool *ok, const Blob *blobs, const Bytes48 *commitments_bytes,
+                                      const Bytes48 *proofs_bytes, size_t n, const CKZGSettings *s); /* eip_4844.rs:435-471 */
 /* helpers the reference exports for the binding test-suites (eip_4844.rs:501-530) */
 void compute_challenge(blst_fr *eval_challenge_out, const Blob *blob, const blst_p1 *commitment);
 C_KZG_RET bytes_to_kzg_commitment(blst_p1 *out, const Bytes48 *b);
@@ -188,6 +199,16 @@ C_KZG_RET kzgamd_verify_kzg_proof_batch_g1(blst_p1 *proof_lincomb_out, blst_p1 *
 C_KZG_RET kzgamd_verify_blob_kzg_proof_batch_g1(blst_p1 *proof_lincomb_out, blst_p1 *rhs_out, const Blob *blobs,
                                                 const Bytes48 *commitments, const Bytes48 *proofs, size_t n,
                                                 const CKZGSettings *s);
+
+/* Host-only helpers over blst_p2 and the pairing (no GPU involved): pairings_verify = blst/src/kzg_proofs.rs:73-100
+ * (1 if e(a1,a2) == e(b1,b2), 0 if not, -1 on NULL); uncompress = FsG2::from_bytes (0 ok, 1 invalid encoding /
+ * not on the curve); mult takes a Montgomery blst_fr like G2Mul (blst/src/types/g2.rs:24-39). */
+int kzgamd_pairings_verify(const blst_p1 *a1, const blst_p2 *a2, const blst_p1 *b1, const blst_p2 *b2);
+int kzgamd_p2_uncompress(blst_p2 *out, const uint8_t in[96]);
+void kzgamd_p2_compress(uint8_t out[96], const blst_p2 *in);
+void kzgamd_p2_generator(blst_p2 *out);
+void kzgamd_p2_mult(blst_p2 *out, const blst_p2 *in, const blst_fr *scalar);
+void kzgamd_p2_add(blst_p2 *out, const blst_p2 *a, const blst_p2 *b);
 
 typedef struct { uint8_t bytes[2048]; } Cell;
 C_KZG_RET compute_cells_and_kzg_proofs(Cell *cells, KZGProof *proofs, const Blob *blob, const CKZGSettings *s);

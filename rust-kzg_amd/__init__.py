@@ -45,6 +45,14 @@ class BlstP1(C.Structure):
     _fields_ = [("x", BlstFp), ("y", BlstFp), ("z", BlstFp)]
 
 
+class BlstFp2(C.Structure):
+    _fields_ = [("fp", BlstFp * 2)]
+
+
+class BlstP2(C.Structure):
+    _fields_ = [("x", BlstFp2), ("y", BlstFp2), ("z", BlstFp2)]
+
+
 _lib = None
 
 # every symbol include/kzg_mi355x.h declares; tests check the library exports all of them
@@ -61,6 +69,8 @@ EXPORTS = [
     "kzgamd_blob_to_kzg_commitment_batch", "kzgamd_blob_to_kzg_commitment_device", "kzgamd_settings_msm_handle",
     "kzgamd_msm_reserve", "kzgamd_msm_device", "kzgamd_set_device", "kzgamd_get_device", "kzgamd_settings_device",
     "kzgamd_settings_reserve", "kzgamd_verify_kzg_proof_batch_g1", "kzgamd_verify_blob_kzg_proof_batch_g1",
+    "verify_kzg_proof", "verify_blob_kzg_proof", "verify_blob_kzg_proof_batch", "kzgamd_pairings_verify",
+    "kzgamd_p2_uncompress", "kzgamd_p2_compress", "kzgamd_p2_generator", "kzgamd_p2_mult", "kzgamd_p2_add",
 ]
 
 
@@ -179,6 +189,25 @@ def lib():
     L.kzgamd_verify_kzg_proof_batch_g1.argtypes = [vp, vp, vp, vp, vp, vp, sz, sp]
     L.kzgamd_verify_blob_kzg_proof_batch_g1.restype = C.c_int
     L.kzgamd_verify_blob_kzg_proof_batch_g1.argtypes = [vp, vp, vp, vp, vp, sz, sp]
+    bp = C.POINTER(C.c_bool)
+    L.verify_kzg_proof.restype = C.c_int
+    L.verify_kzg_proof.argtypes = [bp, vp, vp, vp, vp, sp]
+    L.verify_blob_kzg_proof.restype = C.c_int
+    L.verify_blob_kzg_proof.argtypes = [bp, vp, vp, vp, sp]
+    L.verify_blob_kzg_proof_batch.restype = C.c_int
+    L.verify_blob_kzg_proof_batch.argtypes = [bp, vp, vp, vp, sz, sp]
+    L.kzgamd_pairings_verify.restype = C.c_int
+    L.kzgamd_pairings_verify.argtypes = [vp, vp, vp, vp]
+    L.kzgamd_p2_uncompress.restype = C.c_int
+    L.kzgamd_p2_uncompress.argtypes = [vp, vp]
+    L.kzgamd_p2_compress.restype = None
+    L.kzgamd_p2_compress.argtypes = [vp, vp]
+    L.kzgamd_p2_generator.restype = None
+    L.kzgamd_p2_generator.argtypes = [vp]
+    L.kzgamd_p2_mult.restype = None
+    L.kzgamd_p2_mult.argtypes = [vp, vp, vp]
+    L.kzgamd_p2_add.restype = None
+    L.kzgamd_p2_add.argtypes = [vp, vp, vp]
     _lib = L
     return L
 
@@ -544,6 +573,79 @@ def verify_blob_kzg_proof_batch_g1(blobs: bytes, commitments: bytes, proofs: byt
     if rc != C_KZG_OK:
         raise KzgAmdError("kzgamd_verify_blob_kzg_proof_batch_g1: C_KZG_RET %d" % rc)
     return a, b
+
+
+def _verdict(rc, ok, what):
+    if rc != C_KZG_OK:
+        raise KzgAmdError("%s: C_KZG_RET %d" % (what, rc))
+    return bool(ok.value)
+
+
+def verify_kzg_proof(commitment: bytes, z: bytes, y: bytes, proof: bytes, settings: KZGSettings) -> bool:
+    """blst/src/eip_4844.rs:383-405"""
+    if len(commitment) != 48 or len(z) != 32 or len(y) != 32 or len(proof) != 48:
+        raise KzgAmdError("verify_kzg_proof: C_KZG_RET %d" % C_KZG_BADARGS)
+    ok = C.c_bool(False)
+    return _verdict(lib().verify_kzg_proof(C.byref(ok), commitment, z, y, proof, C.byref(settings.c)), ok, "verify_kzg_proof")
+
+
+def verify_blob_kzg_proof(blob: bytes, commitment: bytes, proof: bytes, settings: KZGSettings) -> bool:
+    """blst/src/eip_4844.rs:410-430"""
+    if len(blob) != BYTES_PER_BLOB or len(commitment) != 48 or len(proof) != 48:
+        raise KzgAmdError("verify_blob_kzg_proof: C_KZG_RET %d" % C_KZG_BADARGS)
+    ok = C.c_bool(False)
+    return _verdict(lib().verify_blob_kzg_proof(C.byref(ok), blob, commitment, proof, C.byref(settings.c)), ok,
+                    "verify_blob_kzg_proof")
+
+
+def verify_blob_kzg_proof_batch(blobs, commitments, proofs, settings: KZGSettings) -> bool:
+    """blst/src/eip_4844.rs:435-471; lists of bytes.  Length mismatches are the reference's 'Invalid amount of arguments'."""
+    n = len(blobs)
+    if len(commitments) != n or len(proofs) != n or any(len(b) != BYTES_PER_BLOB for b in blobs) or \
+            any(len(c) != 48 for c in commitments) or any(len(p) != 48 for p in proofs):
+        raise KzgAmdError("verify_blob_kzg_proof_batch: C_KZG_RET %d" % C_KZG_BADARGS)
+    ok = C.c_bool(False)
+    return _verdict(lib().verify_blob_kzg_proof_batch(C.byref(ok), b"".join(blobs), b"".join(commitments), b"".join(proofs), n,
+                                                      C.byref(settings.c)), ok, "verify_blob_kzg_proof_batch")
+
+
+def pairings_verify(a1, a2, b1, b2) -> bool:
+    """blst/src/kzg_proofs.rs:73-100 on BlstP1 / BlstP2 values (host arithmetic, no GPU)."""
+    rc = lib().kzgamd_pairings_verify(C.byref(a1), C.byref(a2), C.byref(b1), C.byref(b2))
+    if rc < 0:
+        raise KzgAmdError("kzgamd_pairings_verify")
+    return rc == 1
+
+
+def p2_uncompress(b: bytes) -> BlstP2:
+    out = BlstP2()
+    if len(b) != 96 or lib().kzgamd_p2_uncompress(C.byref(out), b) != 0:
+        raise KzgAmdError("kzgamd_p2_uncompress: invalid G2 encoding")
+    return out
+
+
+def p2_compress(p) -> bytes:
+    out = C.create_string_buffer(96)
+    lib().kzgamd_p2_compress(out, C.byref(p))
+    return out.raw
+
+
+def p2_generator() -> BlstP2:
+    out = BlstP2()
+    lib().kzgamd_p2_generator(C.byref(out))
+    return out
+
+
+def p2_mult(p, fr) -> BlstP2:
+    out = BlstP2()
+    lib().kzgamd_p2_mult(C.byref(out), C.byref(p), C.byref(fr))
+    return out
+
+
+def p2_add(a, b) -> BlstP2:
+    out = BlstP2()
+    lib().kzgamd_p2_add(C.byref(out), C.byref(a), C.byref(b))
+    return out
 
 
 def compute_challenge(blob: bytes, commitment_p1) -> BlstFr:

@@ -21,6 +21,7 @@
 #include "ff.hip.h"
 #include "g1_io.hip.h"
 #include "host_g1.h"
+#include "host_pairing.h"
 #include "msm_internal.h"
 #include "sha256.h"
 #include <atomic>
@@ -617,6 +618,7 @@ struct KzgAmdSettings {
                 (void)hipStreamWaitEvent(stream, pipe_ev[j], 0);
             }
     }
+    std::vector<kzgamd::pairing::G2Jac> g2_monomial;  // [tau^i]G2, i < 65 (host; the pairing checks use [1])
     std::vector<ff::Fr> brp_roots;  // brp_roots_of_unity[0..8192) (host copy, Montgomery)
     ff::Fr* d_brp_roots = nullptr;  // first 4096 = the blob evaluation domain
     ~KzgAmdSettings() {
@@ -788,9 +790,11 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
     CK_REQUIRE(n2 / 96 == NUM_G2 && n2 % 96 == 0, "Invalid number of G2 points");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw CkErr{C_KZG_ERROR, "no gfx950 device visible"};
-    // G2 points are only consumed by the pairing-based verifiers, which are outside this
-    // library's path; the encoding flags are sanity-checked, the points are not decoded.
-    for (size_t i = 0; i < NUM_G2; ++i) CK_REQUIRE((g2_mono[96 * i] & 0x80) != 0, "Invalid G2 point");
+    // G2 points: decoded and checked to be on the twist (TG2::from_bytes = blst_p2_uncompress, blst/src/types/g2.rs:52-75)
+    // on the host; they feed the pairing checks of the verify_* entry points and the Lagrange-form check below
+    std::vector<kzgamd::pairing::G2Jac> g2(NUM_G2);
+    for (size_t i = 0; i < NUM_G2; ++i)
+        CK_REQUIRE(kzgamd::pairing::g2_uncompress(g2[i], g2_mono + 96 * i), "Failed to uncompress G2 point");
 
     auto* dev = new KzgAmdSettings();
     unsigned char* d_bytes = nullptr;
@@ -831,16 +835,15 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
         CK_HIP(hipMalloc(&dev->d_monomial, N * sizeof(AffPt)));
         CK_HIP(hipMemcpy(dev->d_monomial, d_pts, N * sizeof(AffPt), hipMemcpyDeviceToDevice));
 
-        // Lagrange-form sanity check.  The reference compares two pairings
-        // (is_trusted_setup_in_lagrange_form, eip_4844.rs:1005-1020); the pairing is outside this
-        // path, so the equivalent group identity is used instead: the Lagrange basis sums to one,
-        // i.e. sum_i L_i(tau)*G == G == g1_monomial[0].  A monomial-form file fails it.
-        {
-            std::vector<ff::Fr> ones(N, ff::Fr::one());
-            blst_p1 sum;
-            kzgamd::msm_run_host(dev->msm, &sum, ones.data(), N, 1);
-            CK_REQUIRE(kzgamd::host_p1_equal(&sum, &out->g1_values_monomial[0]), "Trusted setup is not in Lagrange form");
-        }
+        // is_trusted_setup_in_lagrange_form (eip_4844.rs:1005-1020), the reference's own test: a file whose
+        // "Lagrange" section is the monomial setup satisfies e(L_1, G2_0) == e(L_0, G2_1) (L_1 = tau * L_0).
+        // L_0, L_1 are the first two points in FILE order: positions 0 and brp(1) = N/2 of the bit-reversed array.
+        out->g2_values_monomial = leak_array<blst_p2>(NUM_G2);
+        memcpy(out->g2_values_monomial, g2.data(), NUM_G2 * sizeof(blst_p2));
+        dev->g2_monomial = g2;
+        CK_REQUIRE(!kzgamd::pairing::pairings_verify(&out->g1_values_lagrange_brp[N / 2], &out->g2_values_monomial[0],
+                                                     &out->g1_values_lagrange_brp[0], &out->g2_values_monomial[1]),
+                   "Trusted setup is not in Lagrange form");
 
         // FsFFTSettings::new(13) (blst/src/types/fft_settings.rs:30-58)
         const size_t W = 2 * N;
@@ -860,8 +863,8 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
         }
         CK_HIP(hipMalloc(&dev->d_brp_roots, N * sizeof(ff::Fr)));
         CK_HIP(hipMemcpy(dev->d_brp_roots, dev->brp_roots.data(), N * sizeof(ff::Fr), hipMemcpyHostToDevice));
-        // g2_values_monomial / x_ext_fft_columns / tables stay NULL: pairing and FK20 state are not
-        // part of this path (blst/src/eip_4844.rs:140-142 leaves tables/wbits/scratch_size empty too)
+        // x_ext_fft_columns / tables stay NULL: FK20 state is not part of this path
+        // (blst/src/eip_4844.rs:140-142 leaves tables/wbits/scratch_size empty too)
         (void)hipFree(d_bytes);
         (void)hipFree(d_pts);
         (void)hipFree(d_bad);
@@ -1541,6 +1544,163 @@ extern "C" C_KZG_RET kzgamd_verify_blob_kzg_proof_batch_g1(blst_p1* proof_lincom
         prove_batch(nullptr, ys.data(), blobs, nullptr, commitments, n, dev, zs.data());
         verify_batch_g1(proof_lincomb_out, rhs_out, commitments, zs.data(), ys.data(), proofs, n, dev);
     });
+}
+
+namespace {
+
+// check_proof_single (blst/src/types/kzg_settings.rs:178-196) on decoded, validated inputs:
+//     e(C - [y]G, G2) == e(proof, [tau]G2 - [z]G2)
+// One pairing-product check on the host (see host_pairing.h: the reference keeps the pairing on the CPU too).
+bool check_proof_single(const blst_p1& commitment, const blst_p1& proof, const ff::Fr& z_plain, const ff::Fr& y_plain,
+                        KzgAmdSettings* dev) {
+    using namespace kzgamd::pairing;
+    const G2Jac g2gen = g2_generator();
+    const G2Jac s_minus_x = g2_add(dev->g2_monomial[1], g2_neg(g2_mul(g2gen, z_plain.v)));
+    // [y]G on the host: 255 doublings of one point
+    kzgamd::HostJac g;
+    {
+        const uint64_t GX[6] = {0x5cb38790fd530c16ull, 0x7817fc679976fff5ull, 0x154f95c7143ba1c1ull,
+                                0xf0ae6acdf3d0e747ull, 0xedce6ecc21dbf440ull, 0x120177419e0bfb75ull};
+        const uint64_t GY[6] = {0xbaac93d50ce72271ull, 0x8c22631a7918fd8eull, 0xdd595f13570725ceull,
+                                0x51ac582950405194ull, 0x0e1c8c3fad0059c0ull, 0x0bbc3efc5008a26aull};
+        for (int k = 0; k < 6; ++k) {
+            g.x.v[2 * k] = (u32)GX[k];
+            g.x.v[2 * k + 1] = (u32)(GX[k] >> 32);
+            g.y.v[2 * k] = (u32)GY[k];
+            g.y.v[2 * k + 1] = (u32)(GY[k] >> 32);
+        }
+        g.z = ff::Fp::one();
+    }
+    kzgamd::HostJac yg;
+    yg.x = yg.y = yg.z = ff::Fp::zero();
+    for (int bit = 254; bit >= 0; --bit) {
+        yg = kzgamd::host_jac_dbl(yg);
+        if ((y_plain.v[bit >> 5] >> (bit & 31)) & 1) yg = kzgamd::host_jac_add(yg, g);
+    }
+    yg.y = ff::neg(yg.y);
+    kzgamd::HostJac c;
+    memcpy(&c, &commitment, sizeof c);
+    const kzgamd::HostJac cmy = kzgamd::host_jac_add(c, yg);
+    blst_p1 a1;
+    memcpy(&a1, &cmy, sizeof a1);
+    blst_p2 b2, a2;
+    memcpy(&b2, &s_minus_x, sizeof b2);
+    memcpy(&a2, &g2gen, sizeof a2);
+    return pairings_verify(&a1, &a2, &proof, &b2);
+}
+
+// FsG1::from_bytes + the is_inf / is_valid test of verify_kzg_proof_rust (kzg/src/eip_4844.rs:603-608)
+void decode_valid_g1(blst_p1& out, const uint8_t* bytes, const char* what) {
+    CK_REQUIRE(kzgamd::host_p1_uncompress(&out, bytes), std::string("Invalid ") + what);
+    CK_REQUIRE(kzgamd::host_p1_in_g1(&out), std::string("Invalid ") + what);
+}
+
+}  // namespace
+
+// blst/src/eip_4844.rs:383-405 -> verify_kzg_proof_raw (kzg/src/eip_4844.rs:613-637)
+extern "C" C_KZG_RET verify_kzg_proof(bool* ok, const Bytes48* commitment_bytes, const Bytes32* z_bytes, const Bytes32* y_bytes,
+                                      const Bytes48* proof_bytes, const CKZGSettings* s) {
+    if (!ok || !commitment_bytes || !z_bytes || !y_bytes || !proof_bytes) return C_KZG_BADARGS;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    return guarded([&] {
+        blst_p1 c, pr;
+        ff::Fr z, y;
+        CK_REQUIRE(kzgamd::host_p1_uncompress(&c, commitment_bytes->bytes), "Invalid commitment");
+        CK_REQUIRE(fr_from_be32_checked(z, z_bytes->bytes), "Invalid scalar");
+        CK_REQUIRE(fr_from_be32_checked(y, y_bytes->bytes), "Invalid scalar");
+        CK_REQUIRE(kzgamd::host_p1_uncompress(&pr, proof_bytes->bytes), "Invalid proof");
+        CK_REQUIRE(kzgamd::host_p1_in_g1(&c), "Invalid commitment");
+        CK_REQUIRE(kzgamd::host_p1_in_g1(&pr), "Invalid proof");
+        *ok = check_proof_single(c, pr, z, y, dev);
+    });
+}
+
+// blst/src/eip_4844.rs:410-430 -> verify_blob_kzg_proof_raw (kzg/src/eip_4844.rs:667-688): challenge and evaluation
+// on the GPU, one pairing check on the host
+extern "C" C_KZG_RET verify_blob_kzg_proof(bool* ok, const Blob* blob, const Bytes48* commitment_bytes,
+                                           const Bytes48* proof_bytes, const CKZGSettings* s) {
+    if (!ok || !blob || !commitment_bytes || !proof_bytes) return C_KZG_BADARGS;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    return guarded([&] {
+        blst_p1 c, pr;
+        CK_REQUIRE(host_blob_valid(blob->bytes), "Invalid scalar");           // bytes_to_blob
+        CK_REQUIRE(kzgamd::host_p1_uncompress(&c, commitment_bytes->bytes), "Invalid commitment");
+        CK_REQUIRE(kzgamd::host_p1_uncompress(&pr, proof_bytes->bytes), "Invalid proof");
+        Bytes32 zb, yb;
+        prove_batch(nullptr, &yb, blob, nullptr, commitment_bytes, 1, dev, &zb);  // also validates the commitment
+        CK_REQUIRE(kzgamd::host_p1_in_g1(&pr), "Invalid proof");
+        ff::Fr z, y;
+        CK_REQUIRE(fr_from_be32_checked(z, zb.bytes) && fr_from_be32_checked(y, yb.bytes), "Invalid scalar");
+        *ok = check_proof_single(c, pr, z, y, dev);
+    });
+}
+
+// blst/src/eip_4844.rs:435-471 -> verify_blob_kzg_proof_batch_raw (kzg/src/eip_4844.rs:736-866): n == 0 is true,
+// n == 1 the single verification, otherwise challenges, evaluations and the three linear combinations on the GPU
+// and ONE pairing check e(sum r^i proof_i, [tau]G2) == e(rhs, G2) on the host
+extern "C" C_KZG_RET verify_blob_kzg_proof_batch(bool* ok, const Blob* blobs, const Bytes48* commitments_bytes,
+                                                 const Bytes48* proofs_bytes, size_t n, const CKZGSettings* s) {
+    if (!ok) return C_KZG_BADARGS;
+    *ok = false;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    if (n == 0) {
+        *ok = true;
+        return C_KZG_OK;
+    }
+    if (!blobs || !commitments_bytes || !proofs_bytes) return C_KZG_BADARGS;
+    if (n == 1) return verify_blob_kzg_proof(ok, blobs, commitments_bytes, proofs_bytes, s);
+    return guarded([&] {
+        blst_p1 pl, rhs;
+        std::vector<Bytes32> zs(n), ys(n);
+        prove_batch(nullptr, ys.data(), blobs, nullptr, commitments_bytes, n, dev, zs.data());
+        verify_batch_g1(&pl, &rhs, commitments_bytes, zs.data(), ys.data(), proofs_bytes, n, dev);
+        blst_p2 g2gen, g2tau;
+        const kzgamd::pairing::G2Jac gen = kzgamd::pairing::g2_generator();
+        memcpy(&g2gen, &gen, sizeof g2gen);
+        memcpy(&g2tau, &dev->g2_monomial[1], sizeof g2tau);
+        *ok = kzgamd::pairing::pairings_verify(&pl, &g2tau, &rhs, &g2gen);
+    });
+}
+
+// ---- host-only helpers over blst_p2 / the pairing (no GPU needed): what a binding test-suite or a caller that
+// wants to finish kzgamd_verify_*_g1 itself uses.  pairings_verify = blst/src/kzg_proofs.rs:73-100.
+extern "C" int kzgamd_pairings_verify(const blst_p1* a1, const blst_p2* a2, const blst_p1* b1, const blst_p2* b2) {
+    if (!a1 || !a2 || !b1 || !b2) return -1;
+    return kzgamd::pairing::pairings_verify(a1, a2, b1, b2) ? 1 : 0;
+}
+extern "C" int kzgamd_p2_uncompress(blst_p2* out, const uint8_t in[96]) {
+    kzgamd::pairing::G2Jac p;
+    if (!out || !in || !kzgamd::pairing::g2_uncompress(p, in)) return 1;
+    memcpy(out, &p, sizeof p);
+    return 0;
+}
+extern "C" void kzgamd_p2_compress(uint8_t out[96], const blst_p2* in) {
+    kzgamd::pairing::G2Jac p;
+    memcpy(&p, in, sizeof p);
+    kzgamd::pairing::g2_compress(out, p);
+}
+extern "C" void kzgamd_p2_generator(blst_p2* out) {
+    const kzgamd::pairing::G2Jac g = kzgamd::pairing::g2_generator();
+    memcpy(out, &g, sizeof g);
+}
+extern "C" void kzgamd_p2_mult(blst_p2* out, const blst_p2* in, const blst_fr* scalar_mont) {
+    kzgamd::pairing::G2Jac p;
+    memcpy(&p, in, sizeof p);
+    ff::Fr k;
+    memcpy(&k, scalar_mont, 32);
+    k = ff::from_mont(k);
+    const kzgamd::pairing::G2Jac r = kzgamd::pairing::g2_mul(p, k.v);
+    memcpy(out, &r, sizeof r);
+}
+extern "C" void kzgamd_p2_add(blst_p2* out, const blst_p2* a, const blst_p2* b) {
+    kzgamd::pairing::G2Jac x, y;
+    memcpy(&x, a, sizeof x);
+    memcpy(&y, b, sizeof y);
+    const kzgamd::pairing::G2Jac r = kzgamd::pairing::g2_add(x, y);
+    memcpy(out, &r, sizeof r);
 }
 
 extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof* out, const Blob* blob, const Bytes48* commitment_bytes,

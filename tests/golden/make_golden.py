@@ -108,6 +108,38 @@ def main():
                              "proof0": o[1][0], "proof1": o[1][1], "proof127": o[1][127]}})
     out["compute_cells_and_kzg_proofs"] = v
 
+    # verification vectors (pin the pairing side and the batched-verification G1 work): expected = true / false / None
+    v = []
+    for name, y in cases("verify_kzg_proof"):
+        i = y["input"]
+        v.append({"name": name, "commitment": i["commitment"], "z": i["z"], "y": i["y"], "proof": i["proof"], "output": y["output"]})
+    out["verify_kzg_proof"] = v
+    v = []
+    for name, y in cases("verify_blob_kzg_proof"):
+        i = y["input"]
+        v.append({"name": name, "blob": blob_ref(unhex(i["blob"])), "commitment": i["commitment"], "proof": i["proof"],
+                  "output": y["output"]})
+    out["verify_blob_kzg_proof"] = v
+    v = []
+    for name, y in cases("verify_blob_kzg_proof_batch"):
+        i = y["input"]
+        v.append({"name": name, "blobs": [blob_ref(unhex(b)) for b in i["blobs"]], "commitments": i["commitments"],
+                  "proofs": i["proofs"], "output": y["output"]})
+    out["verify_blob_kzg_proof_batch"] = v
+
+    # trusted-setup text fixtures of the binding test-suite (kzg-bench/src/tests/c_bindings.rs:344-489): data files,
+    # stored gzipped with the outcome load_trusted_setup_file must give
+    fx = os.path.join(REF, "kzg-bench/src/tests/fixtures")
+    os.makedirs(os.path.join(OUT, "setup_fixtures"), exist_ok=True)
+    fixtures = {}
+    for name in sorted(os.listdir(fx)):
+        data = open(os.path.join(fx, name, "trusted_setup_fixture.txt"), "rb").read()
+        with gzip.GzipFile(os.path.join(OUT, "setup_fixtures", name + ".txt.gz"), "wb", mtime=0) as f:
+            f.write(data)
+        fixtures[name] = {"expect": "ok" if name.startswith("valid_") else "badargs", "bytes": len(data),
+                          "sha256": hashlib.sha256(data).hexdigest()}
+    out["setup_fixtures"] = {"cite": "kzg-bench/src/tests/c_bindings.rs:344-489", "files": fixtures}
+
     for h, b in blobs.items():
         with gzip.GzipFile(os.path.join(OUT, "blobs", h + ".bin.gz"), "wb", mtime=0) as f:
             f.write(b)
