@@ -103,8 +103,10 @@ def test_batch_g1_half_matches_oracle(kzg, settings, golden, blob_loader, oracle
         g2 = (kzg.BlstP2 * 65).from_address(settings.c.g2_values_monomial)
         assert kzg.pairings_verify(a, g2[1], b, kzg.p2_generator())
     # a proof that does not belong: the G1 half still computes, the pairing says no
-    blobs = triples[0][0] + triples[1][0]
-    cs, ps = triples[0][1] + triples[1][1], triples[1][2] + triples[0][2]
+    t0 = triples[0]
+    t1 = next(t for t in triples if t[2] != t0[2] and t[2][0] != 0xC0 and t0[2] != t[2])
+    blobs = t0[0] + t1[0]
+    cs, ps = t0[1] + t1[1], t1[2] + t0[2]
     a, b = kzg.verify_blob_kzg_proof_batch_g1(blobs, cs, ps, 2, settings)
     g2 = (kzg.BlstP2 * 65).from_address(settings.c.g2_values_monomial)
     assert not kzg.pairings_verify(a, g2[1], b, kzg.p2_generator())
