@@ -277,7 +277,8 @@ def main():
         "config": {"workload": "G1 Pippenger MSM n=4096 (EIP-4844 blob) x trusted-setup Lagrange points, "
                                "blob bytes -> 48-byte commitment, batched",
                    "blobs_per_batch": B, "batches_per_step": NB, "blobs_per_gpu_per_step": B * NB,
-                   "msm_window_bits": info["window_bits"], "table_rows": info["rows"],
+                   "msm_window_bits": info["window_bits"], "table_rows": info["rows"], "glv_split": info["wide_glv"],
+                   "mixed_adds_per_scalar": info["adds_per_scalar"],
                    "parallelism": "blobs sharded across %d GPU(s), table replicated, no collective" % world},
         "timed_region_s": wall_max,
         "g1_adds_per_s": value * ALG_ADDS_PER_COMMIT,
@@ -308,7 +309,7 @@ def main():
             wave_instr = pk["SQ_INSTS_VALU"] / pm["batch"] * B
             res["valu"] = {"bound": "VALU issue", "kernel": kern, "achieved": wave_instr / (own_ms * 1e-3), "peak": VALU_PEAK,
                            "unit": "VALU wave-instructions/s", "frac": wave_instr / (own_ms * 1e-3) / VALU_PEAK,
-                           "kernel_ms_alone": own_ms, "valu_instructions_per_mixed_add": wave_instr * 64 / (B * N * info["rows"]),
+                           "kernel_ms_alone": own_ms, "valu_instructions_per_mixed_add": wave_instr * 64 / (B * N * info["adds_per_scalar"]),
                            "busy_frac_at_sustained_clock": pk.get("valu_busy_frac"),
                            "sustained_clock_ghz": pk.get("effective_clock_ghz"),
                            "source": "instruction count, busy fraction and clock: %s (rocprofv3 PMC passes of this kernel); "

@@ -64,8 +64,10 @@ RustError kzgamd_msm_reserve(void *msm, size_t npoints, size_t nbatch, void *str
 int kzgamd_msm_device(void *msm);
 /* introspection for benches/tests: window bits, table rows, buckets of a handle */
 int kzgamd_msm_info(void *msm, int *window_bits, int *rows, size_t *nbuckets, size_t *npoints);
-/* 1 if the handle holds the wide fixed-base table (rows x npoints x 2^(window_bits-1) affine multiples,
- * built when it fits KZGAMD_FBW_MAX_GB (default 160, capped by free HBM); 0 disables) and so runs the gather-and-add path */
+/* non-zero if the handle holds the wide fixed-base table (rows x npoints x 2^(window_bits-1) affine multiples,
+ * built when it fits KZGAMD_FBW_MAX_GB (default 160, capped by free HBM); 0 disables) and so runs the gather-and-add
+ * path: 1 = rows cover the 255-bit scalar (rows additions per scalar), 2 = GLV form, rows cover a 128-bit half
+ * (2 x rows additions per scalar; chosen only when every base passed the r-torsion test at prepare time) */
 int kzgamd_msm_uses_wide_table(void *msm);
 /* HIP-event timing of the bucket-accumulation kernel (k_accum) and of the whole enqueue, recorded on
  * the launch stream; set(on) resets; get returns the number of enqueues averaged (-1 if none) */

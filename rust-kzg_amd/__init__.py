@@ -18,7 +18,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libkzg_mi355x.so")
+LIB_PATH = os.environ.get("KZGAMD_LIB") or os.path.join(HERE, "csrc", "libkzg_mi355x.so")  # KZGAMD_LIB: A/B builds
 
 
 class KzgAmdError(RuntimeError):
@@ -234,8 +234,10 @@ class PreparedMsm:
     def info(self):
         c, rows, nb, n = C.c_int(), C.c_int(), C.c_size_t(), C.c_size_t()
         lib().kzgamd_msm_info(self.handle, C.byref(c), C.byref(rows), C.byref(nb), C.byref(n))
+        wide = lib().kzgamd_msm_uses_wide_table(self.handle)
         return {"window_bits": c.value, "rows": rows.value, "nbuckets": nb.value, "npoints": n.value,
-                "wide_table": bool(lib().kzgamd_msm_uses_wide_table(self.handle))}
+                "wide_table": bool(wide), "wide_glv": wide == 2,
+                "adds_per_scalar": rows.value * (2 if wide == 2 else 1)}
 
     def close(self):
         if self.handle:

@@ -919,15 +919,52 @@ __global__ void __launch_bounds__(128) k_fbw_affine(WidePt* __restrict__ wide, c
     }
 }
 
+// r-torsion test of a table base by the endomorphism identity phi(P) == -[x^2]P (the check k_check_commitments
+// applies to commitments): decides whether a prepared handle may use the GLV form of the wide table
+__global__ void __launch_bounds__(64) k_bases_in_g1(const AffPt* __restrict__ pts, size_t n, int* __restrict__ bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const AffPt p = pts[i];
+    if (p.flags & 1) return;
+    const unsigned long long BLS_X = 0xd201000000010000ull;
+    Xyzz q1, q2;
+    g1::set_inf(q1);
+    for (int bit = 63; bit >= 0; --bit) {
+        if (!g1::is_inf(q1)) g1::dbl(q1);
+        if ((BLS_X >> bit) & 1) g1::madd(q1, p.x, p.y);
+    }
+    g1::set_inf(q2);
+    for (int bit = 63; bit >= 0; --bit) {
+        if (!g1::is_inf(q2)) g1::dbl(q2);
+        if ((BLS_X >> bit) & 1) g1::dadd(q2, q1);
+    }
+    if (g1::is_inf(q2)) {
+        atomicAdd(bad, 1);
+        return;
+    }
+    fp28::Fe dx = fp28::sub<16>(fp28::mul(fp28::mul(beta28(), p.x), q2.zz), q2.x);
+    fp28::Fe dy = fp28::addn(fp28::mul(p.y, q2.zzz), q2.y);
+    if (!fp28::is_zero_mod_p(dx) || !fp28::is_zero_mod_p(dy)) atomicAdd(bad, 1);
+}
+
 // one lane per (MSM, `spl` consecutive scalars): all windows of those scalars against the wide table.
 // spl > 1 (large batches) leaves fewer partial sums for k_blocksum to fold.
-template <int SPL>
+// GLV: the table holds rows for 128-bit scalars only (2^(c j) m P_i, j < ceil(128/c)); a scalar is split
+// k = +-k1 +- k2 x^2 and the k2 half is accumulated against the SAME table entries: psi(x, y) = (beta x, -y) = [x^2](x, y)
+// is a group endomorphism, so  sum k2_digit * psi(T) = psi(sum k2_digit * T)  — the lane that sums the k2 digits of its
+// scalars applies psi to its partial sum once (one multiplication); its neighbour sums the k1 digits.  16 additions per scalar
+// at c = 16 from a 137 GB table, against 18 at c = 15 from 154 GB without the split.
+template <int SPL, bool GLV>
 __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __restrict__ scalars,
                                                    const WidePt* __restrict__ wide, Xyzz* __restrict__ partial,
                                                    size_t lanes_per_msm) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= lanes_per_msm * P.nbatch) return;
-    const size_t b = t / lanes_per_msm, l = t % lanes_per_msm;
+    const size_t b = t / lanes_per_msm;
+    size_t l = t % lanes_per_msm;
+    // GLV: neighbouring lanes take the two halves of the same scalars (k1 digits / k2 digits)
+    const u32 part = GLV ? (u32)(l & 1) : 0u;
+    if (GLV) l >>= 1;
     Xyzz acc;
     g1::set_inf(acc);
     const u32 half = 1u << (P.c - 1);
@@ -938,14 +975,24 @@ __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __r
         if (SPL > 1 && i >= P.n) break;
         u32 s[8];
         load_scalar(s, scalars, b * P.n + i, P.mont);
+        u32 pneg = 0;
+        if (GLV) {
+            u32 kk[8], s1[8], s2[8], n1, n2;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) kk[q] = s[q];
+            kzgamd::glv_split(kk, s1, s2, n1, n2);
+            pneg = part ? n2 : n1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s[q] = part ? s2[q] : s1[q];
+        }
         u32 carry = 0;
         for (int w = 0; w < P.nwin; ++w) {
             u32 d = window_bits(s, w * P.c, P.c) + carry;
-            u32 neg = 0;
+            u32 neg = pneg;
             carry = 0;
             if (d > half) {
                 d = (1u << P.c) - d;
-                neg = 1;
+                neg ^= 1;
                 carry = 1;
             }
             if (d == 0) continue;
@@ -955,6 +1002,10 @@ __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __r
             if (neg) y = fp28::neg<2>(y);
             g1::madd(acc, x, y);
         }
+    }
+    if (GLV && part && !g1::is_inf(acc)) {
+        acc.x = fp28::mul(acc.x, beta28());                     // psi(X, Y, ZZ, ZZZ) = (beta X, -Y, ZZ, ZZZ)
+        acc.y = fp28::mul(fp28::neg<8>(acc.y), fp28::one());    // -Y, back under the 2p bound
     }
     partial[t] = acc;
 }
@@ -1053,20 +1104,37 @@ double fbw_budget_gb() {
     return budget_gb;
 }
 
+// wide-table shape for a prepared handle: the (window, split) pair with the fewest additions per scalar whose table
+// fits the HBM budget.  Without the split a scalar costs rows = ceil(256/c) additions from a table of
+// rows * n * 2^(c-1) slots; with the GLV split (bases must be in the r-torsion subgroup) 2 * ceil(128/c) additions from
+// a table of ceil(128/c) * n * 2^(c-1) slots.  Returns 0 when nothing fits.
+int choose_wide_window(size_t n, bool glv_allowed, bool* use_glv) {
+    const double budget_gb = fbw_budget_gb();
+    int best_c = 0, best_adds = 1 << 30;
+    double best_gb = 0;
+    bool best_glv = false;
+    for (int g = 0; g <= (glv_allowed ? 1 : 0); ++g)
+        for (int c = 10; c <= 18; ++c) {
+            const int rows = g ? (127 + c) / c : 255 / c + 1, adds = g ? 2 * rows : rows;
+            const double gb = (double)rows * (double)n * (double)((size_t)1 << (c - 1)) * 128.0 / 1e9;
+            if (gb > budget_gb) continue;
+            if (adds < best_adds || (adds == best_adds && gb < best_gb)) {
+                best_adds = adds;
+                best_c = c;
+                best_gb = gb;
+                best_glv = g != 0;
+            }
+        }
+    *use_glv = best_glv;
+    return best_c;
+}
+
 int choose_window(size_t n, bool prepared, bool glv) {
     // minimise adds: prepared  n*ceil(256/c) + 3*2^(c-1);  unprepared  ceil(256/c) * (n + 3*2^(c-1));
     // unprepared with the GLV split: (128/c + 1) bucket sets fed by 2n half-scalars
     if (const char* e = getenv(prepared ? "KZGAMD_WINDOW_PREPARED" : "KZGAMD_WINDOW")) {
         int c = atoi(e);
         if (c >= 2 && c <= 22) return c;
-    }
-    if (prepared) {
-        // wide-table path: fewest table rows (= fewest adds per scalar) that fit the HBM budget
-        const double budget_gb = fbw_budget_gb();
-        for (int c = 16; c >= 10 && budget_gb > 0; --c) {
-            double gb = (double)(255 / c + 1) * (double)n * (double)((size_t)1 << (c - 1)) * 128.0 / 1e9;
-            if (gb <= budget_gb) return c;
-        }
     }
     if (glv) {
         // measured on MI355X (tools/sweep_window.py, device-resident inputs): c = 16 wins from n = 2^15 up to at
@@ -1154,6 +1222,7 @@ struct kzgamd::MsmContext {
     DevBuf<AffPt> table;  // rows x n (prepared) or n
     DevBuf<WidePt> wide;  // wide fixed-base table: (rows x n) x 2^(c-1) 128-byte slots, when it fits the budget
     bool fbw = false;
+    bool fbw_glv = false;  // the wide table covers 128-bit half-scalars (rows = ceil(128 / c)); scalars are GLV-split
     Workspace ws;
     // One workspace per stream the handle is used on (up to 8): independent batches enqueued on different streams
     // may overlap on the GPU — the low-occupancy tail of one batch under the accumulation of the next.  `ws` serves
@@ -1257,16 +1326,14 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         ctx->prepared = prepare;
         ctx->glv = !prepare;
         if (const char* e = getenv("KZGAMD_GLV")) ctx->glv = ctx->glv && atoi(e) != 0;
-        ctx->c = choose_window(n, prepare, ctx->glv);
-        ctx->rows = prepare ? (255 / ctx->c + 1) : 1;
-        ctx->nwin = ctx->glv ? (127 + ctx->c) / ctx->c : 255 / ctx->c + 1;
-        ctx->nb = (size_t)1 << (ctx->c - 1);
-        ctx->table.ensure(ctx->glv ? 2 * n : (size_t)ctx->rows * n);
+        // the bases first (row 0 of the table; the variable-base engine appends the [x^2]P images)
+        DevBuf<AffPt> row0;
+        row0.ensure(ctx->glv ? 2 * n : n);
         DevBuf<ff::Fp> staging;
         const ff::Fp* src = (const ff::Fp*)points;
         if (points_are_affpt) {
             if (!points_on_device) throw HipErr{hipErrorInvalidValue, "AffPt input must be device-resident"};
-            hipLaunchKernelGGL(k_copy_affpt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->table.p,
+            hipLaunchKernelGGL(k_copy_affpt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, row0.p,
                                (const AffPt*)points, n, ctx->glv ? 1 : 0);
         } else {
             if (!points_on_device) {
@@ -1274,9 +1341,49 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
                 HIP_TRY(hipMemcpyAsync(staging.p, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
                 src = staging.p;
             }
-            hipLaunchKernelGGL(k_points_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->table.p, src,
-                               n, ctx->glv ? 1 : 0);
+            hipLaunchKernelGGL(k_points_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, row0.p, src, n,
+                               ctx->glv ? 1 : 0);
         }
+        // shape of the engine
+        bool wide_glv = false;
+        int cw = 0;
+        if (prepare && !getenv("KZGAMD_WINDOW_PREPARED")) {
+            bool dummy;
+            if (choose_wide_window(n, true, &dummy) != 0) {
+                // a wide table fits: its GLV form needs every base in the r-torsion subgroup (psi(P) = [x^2]P holds only
+                // there; FsG1::from_bytes does not check it, blst/src/types/g1.rs:65-87) — test the bases, once
+                bool in_g1 = false;
+                const char* e = getenv("KZGAMD_FBW_GLV");
+                if (!e || atoi(e) != 0) {
+                    DevBuf<int> bad;
+                    bad.ensure(1);
+                    HIP_TRY(hipMemsetAsync(bad.p, 0, sizeof(int), ctx->stream));
+                    hipLaunchKernelGGL(k_bases_in_g1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream,
+                                       (const AffPt*)row0.p, n, bad.p);
+                    int nbad = 1;
+                    HIP_TRY(hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_TRY(hipStreamSynchronize(ctx->stream));
+                    bad.release();
+                    in_g1 = nbad == 0;
+                }
+                cw = choose_wide_window(n, in_g1, &wide_glv);
+            }
+        }
+        if (cw) {
+            ctx->c = cw;
+            ctx->fbw_glv = wide_glv;
+            ctx->rows = wide_glv ? (127 + cw) / cw : 255 / cw + 1;
+            ctx->nwin = ctx->rows;
+        } else {
+            ctx->c = choose_window(n, prepare, ctx->glv);
+            ctx->rows = prepare ? (255 / ctx->c + 1) : 1;
+            ctx->nwin = ctx->glv ? (127 + ctx->c) / ctx->c : 255 / ctx->c + 1;
+        }
+        ctx->nb = (size_t)1 << (ctx->c - 1);
+        ctx->table.ensure(ctx->glv ? 2 * n : (size_t)ctx->rows * n);
+        HIP_TRY(hipMemcpyAsync(ctx->table.p, row0.p, (ctx->glv ? 2 * n : n) * sizeof(AffPt), hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        row0.release();
         if (prepare && ctx->rows > 1)
             hipLaunchKernelGGL(k_table_rows, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, ctx->table.p, n,
                                ctx->rows, ctx->c);
@@ -1284,6 +1391,7 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         staging.release();
         if (prepare) build_wide_table(ctx);
+        if (ctx->fbw_glv && !ctx->fbw) throw HipErr{hipErrorOutOfMemory, "wide GLV table did not fit the HBM budget it was sized for"};
     } catch (...) {
         delete ctx;
         throw;
@@ -1341,7 +1449,8 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         int spl = nbatch >= 256 ? 4 : 1;
         if (const char* e = getenv("KZGAMD_SPL")) spl = atoi(e) > 0 ? atoi(e) : spl;
         if (spl == 3 || spl > 4) spl = 4;
-        const size_t lanes = (npoints + spl - 1) / spl;
+        if (ctx->fbw_glv) spl *= 2;  // two lanes (k1 / k2 digits) per scalar group: the same number of partial sums
+        const size_t lanes = (npoints + spl - 1) / spl * (ctx->fbw_glv ? 2 : 1);
         ws.buckets.ensure(nbatch * lanes);
         ws.lvlM[0].ensure(nbatch);
         if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) ws.lvlA[0].ensure(nbatch * 16);
@@ -1360,15 +1469,19 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             HIP_TRY(hipEventRecord(pev[1], stream));
         }
         const dim3 grid((unsigned)((lanes * nbatch + 255) / 256));
-        if (spl == 1)
-            hipLaunchKernelGGL(k_fbw_accum<1>, grid, dim3(256), 0, stream, P, (const u32*)d_scalars,
-                               (const WidePt*)ctx->wide.p, ws.buckets.p, lanes);
-        else if (spl == 2)
-            hipLaunchKernelGGL(k_fbw_accum<2>, grid, dim3(256), 0, stream, P, (const u32*)d_scalars,
-                               (const WidePt*)ctx->wide.p, ws.buckets.p, lanes);
-        else
-            hipLaunchKernelGGL(k_fbw_accum<4>, grid, dim3(256), 0, stream, P, (const u32*)d_scalars,
-                               (const WidePt*)ctx->wide.p, ws.buckets.p, lanes);
+#define KZG_FBW_LAUNCH(SPL_, GLV_)                                                                           \
+    hipLaunchKernelGGL((k_fbw_accum<SPL_, GLV_>), grid, dim3(256), 0, stream, P, (const u32*)d_scalars,          \
+                       (const WidePt*)ctx->wide.p, ws.buckets.p, lanes)
+        if (ctx->fbw_glv) {
+            if (spl == 2) KZG_FBW_LAUNCH(2, true);
+            else if (spl == 4) KZG_FBW_LAUNCH(4, true);
+            else KZG_FBW_LAUNCH(8, true);
+        } else {
+            if (spl == 1) KZG_FBW_LAUNCH(1, false);
+            else if (spl == 2) KZG_FBW_LAUNCH(2, false);
+            else KZG_FBW_LAUNCH(4, false);
+        }
+#undef KZG_FBW_LAUNCH
         if (pev) HIP_TRY(hipEventRecord(pev[2], stream));
         if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) {
             // a few MSMs: the one-workgroup-per-MSM fold is a latency chain (16 strided additions + 8 tree rounds);
@@ -1783,7 +1896,10 @@ extern "C" int kzgamd_msm_info(void* msm, int* window_bits, int* rows, size_t* n
     return 0;
 }
 
-extern "C" int kzgamd_msm_uses_wide_table(void* msm) { return msm && ((MsmContext*)msm)->fbw ? 1 : 0; }
+extern "C" int kzgamd_msm_uses_wide_table(void* msm) {
+    if (!msm || !((MsmContext*)msm)->fbw) return 0;
+    return ((MsmContext*)msm)->fbw_glv ? 2 : 1;
+}
 
 extern "C" int kzgamd_msm_set_profile(void* msm, int on) {
     if (!msm) return 1;

@@ -171,7 +171,8 @@ def test_trusted_setup_4096_random_scalars_and_batch(oracle, oracle_settings, kz
     pts = oracle_settings.g1_lagrange_brp
     h = kzg.prepare_multi_scalar_mult(pts, n)
     info = h.info()
-    assert info["npoints"] == n and info["rows"] == 255 // info["window_bits"] + 1
+    c = info["window_bits"]
+    assert info["npoints"] == n and info["rows"] == ((127 + c) // c if info["wide_glv"] else 255 // c + 1)
     nb = 3
     vals = [rnd.randrange(O.R) for _ in range(nb * n)]
     sc = O.fr_array(vals)
