@@ -178,6 +178,15 @@ C_KZG_RET kzgamd_compute_blob_kzg_proof_batch(KZGProof *out, const Blob *blobs, 
  * d_scratch = n x 131072 B of workspace. */
 C_KZG_RET kzgamd_blob_to_kzg_commitment_device(void *d_out, void *d_status, void *d_scratch, const void *d_blobs,
                                                size_t n, const CKZGSettings *s, void *stream);
+/* Device-resident compute_blob_kzg_proof (kzg/src/eip_4844.rs:541-584) for n blobs, enqueued on `stream` without
+ * synchronising: d_blobs = n x 131072 B, d_commitments = n x 48 B, d_proofs = n x 48 B, d_status = n x int32
+ * (non-zero: blob i has an element >= r or commitment i is not a valid G1 element — the reference fails the call;
+ * here the other proofs of the batch stay valid), d_scratch = n x KZGAMD_PROOF_SCRATCH_BYTES of workspace.
+ * The Fiat-Shamir SHA-256 runs on the device too (one lane per blob: ~9 ms of latency per batch and about a percent
+ * of the chip — pipeline batches on a few streams); kzgamd_settings_reserve covers the MSM workspace. */
+#define KZGAMD_PROOF_SCRATCH_BYTES (131072 + 64)
+C_KZG_RET kzgamd_compute_blob_kzg_proof_device(void *d_proofs, void *d_status, void *d_scratch, const void *d_blobs,
+                                               const void *d_commitments, size_t n, const CKZGSettings *s, void *stream);
 /* EIP-7594: cells (128 x 2048 B) and cell proofs (128 x 48 B) of a blob, same name
  * and signature as the reference (kzg/src/eth/c_bindings.rs:356-372); either output may be NULL, not
  * both.  The first call that asks for proofs builds a second wide table over g1_values_monomial. */

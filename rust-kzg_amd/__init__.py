@@ -70,6 +70,7 @@ EXPORTS = [
     "kzgamd_msm_reserve", "kzgamd_msm_device", "kzgamd_set_device", "kzgamd_get_device", "kzgamd_settings_device",
     "kzgamd_settings_reserve", "kzgamd_verify_kzg_proof_batch_g1", "kzgamd_verify_blob_kzg_proof_batch_g1",
     "verify_kzg_proof", "verify_blob_kzg_proof", "verify_blob_kzg_proof_batch", "kzgamd_pairings_verify",
+    "kzgamd_compute_blob_kzg_proof_device",
     "kzgamd_p2_uncompress", "kzgamd_p2_compress", "kzgamd_p2_generator", "kzgamd_p2_mult", "kzgamd_p2_add",
 ]
 
@@ -160,6 +161,8 @@ def lib():
     L.compute_kzg_proof.argtypes = [vp, vp, vp, vp, sp]
     L.compute_blob_kzg_proof.restype = C.c_int
     L.compute_blob_kzg_proof.argtypes = [vp, vp, vp, sp]
+    L.kzgamd_compute_blob_kzg_proof_device.restype = C.c_int
+    L.kzgamd_compute_blob_kzg_proof_device.argtypes = [vp, vp, vp, vp, vp, sz, sp, vp]
     L.kzgamd_compute_blob_kzg_proof_batch.restype = C.c_int
     L.kzgamd_compute_blob_kzg_proof_batch.argtypes = [vp, vp, vp, sz, sp]
     L.compute_challenge.restype = None
@@ -399,6 +402,18 @@ def blob_to_kzg_commitment_device(d_out, d_status, d_scratch, d_blobs, n, settin
                                                     C.c_void_p(d_blobs), n, C.byref(settings.c), C.c_void_p(stream))
     if rc != C_KZG_OK:
         raise KzgAmdError("kzgamd_blob_to_kzg_commitment_device: C_KZG_RET %d" % rc)
+
+
+PROOF_SCRATCH_BYTES = 131072 + 64
+
+
+def compute_blob_kzg_proof_device(d_proofs, d_status, d_scratch, d_blobs, d_commitments, n, settings, stream=0):
+    """device pointers (ints); d_scratch = n * PROOF_SCRATCH_BYTES; enqueued on `stream`, not synchronised"""
+    rc = lib().kzgamd_compute_blob_kzg_proof_device(C.c_void_p(d_proofs), C.c_void_p(d_status), C.c_void_p(d_scratch),
+                                                    C.c_void_p(d_blobs), C.c_void_p(d_commitments), n, C.byref(settings.c),
+                                                    C.c_void_p(stream))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("kzgamd_compute_blob_kzg_proof_device: C_KZG_RET %d" % rc)
 
 
 def msm_set_profile(handle, on=True):

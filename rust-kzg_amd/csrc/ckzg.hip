@@ -183,6 +183,7 @@ class WorkerPool {
 
 constexpr int QT = 512;            // threads per blob
 constexpr size_t PROVE_CHUNK = 64;  // blobs per pipeline stage of a large compute_blob_kzg_proof batch
+constexpr size_t COMMIT_CHUNK = 256;  // blobs per pipeline stage of a large blob_to_kzg_commitment batch
 constexpr size_t QSPLIT_MAX = 4;   // up to this many blobs run the multi-workgroup variant (k_quotient_a/b)
 constexpr int QE = (int)(N / QT);  // elements per thread (8), element index i = k*QT + t
 
@@ -453,6 +454,117 @@ __global__ void __launch_bounds__(QT) k_quotient_b(u32* __restrict__ q_out, u32*
     for (int l = 0; l < 8; ++l) q_out[(blob * N + m) * 8 + l] = qc.v[l];
 }
 
+// ---- Fiat-Shamir challenge on the device (compute_challenge_rust, kzg/src/eip_4844.rs:920-945) ----
+// SHA-256 is a serial chain over the 2050 blocks of  domain | 0 | 4096 | blob | commitment : one lane per blob, ~9 ms
+// of latency whatever the batch, a percent of the chip's VALU time.  It pays when batches are pipelined on several
+// streams (the hash of one batch runs under the MSM of another) and when host cores are scarce (eight ranks per node);
+// the host-buffer entry points keep hashing small batches on the host's SHA units, where one blob takes 75 us.
+__device__ __forceinline__ u32 sha_rotr(u32 x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+__device__ __forceinline__ void sha256_block(u32 h[8], u32 w[16]) {
+    constexpr u32 K[64] = {
+        0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u,
+        0x12835b01u, 0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u,
+        0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u,
+        0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u,
+        0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u,
+        0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au,
+        0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u,
+        0xc67178f2u};
+    u32 a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int t = 0; t < 64; ++t) {
+        if (t >= 16) {
+            const u32 w15 = w[(t - 15) & 15], w2 = w[(t - 2) & 15];
+            const u32 s0 = sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3);
+            const u32 s1 = sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10);
+            w[t & 15] += s0 + w[(t - 7) & 15] + s1;
+        }
+        const u32 S1 = sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25);
+        const u32 ch = (e & f) ^ (~e & g);
+        const u32 t1 = hh + S1 + ch + K[t] + w[t & 15];
+        const u32 S0 = sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22);
+        const u32 maj = (a & b) ^ (a & c) ^ (b & c);
+        const u32 t2 = S0 + maj;
+        hh = g;
+        g = f;
+        f = e;
+        e = d + t1;
+        d = c;
+        c = b;
+        b = a;
+        a = t1 + t2;
+    }
+    h[0] += a;
+    h[1] += b;
+    h[2] += c;
+    h[3] += d;
+    h[4] += e;
+    h[5] += f;
+    h[6] += g;
+    h[7] += hh;
+}
+
+// z_be[b] = hash_to_bls_field(sha256("FSBLOBVERIFY_V1_" | u64_be(0) | u64_be(4096) | blob_b | commitment_b)), 32 bytes
+// big-endian.  Message = 8 + 32768 + 12 words; 2049 full blocks + one block of 4 words, padding and the bit length.
+__global__ void __launch_bounds__(64) k_challenge_sha256(u32* __restrict__ z_be, const u32* __restrict__ blobs,
+                                                         const u32* __restrict__ commitments, size_t n) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    __builtin_amdgcn_s_setprio(3);  // a handful of long serial waves next to throughput kernels: never starve them
+    const u32* blob = blobs + b * (N * 8);
+    const u32* cm = commitments + b * 12;
+    u32 h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    u32 w[16];
+    // block 0: the 32-byte header and the first 8 words of the blob
+    w[0] = 0x4653424cu;  // "FSBL"
+    w[1] = 0x4f425645u;  // "OBVE"
+    w[2] = 0x52494659u;  // "RIFY"
+    w[3] = 0x5f56315fu;  // "_V1_"
+    w[4] = 0;
+    w[5] = 0;
+    w[6] = 0;
+    w[7] = (u32)N;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[8 + k] = __builtin_bswap32(blob[k]);
+    sha256_block(h, w);
+    // blocks 1 .. 2047: blob words 16 blk - 8 .. 16 blk + 7
+#pragma unroll 1
+    for (int blk = 1; blk < 2048; ++blk) {
+        const uint4* src = reinterpret_cast<const uint4*>(blob + 16 * blk - 8);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 v = src[q];
+            w[4 * q] = __builtin_bswap32(v.x);
+            w[4 * q + 1] = __builtin_bswap32(v.y);
+            w[4 * q + 2] = __builtin_bswap32(v.z);
+            w[4 * q + 3] = __builtin_bswap32(v.w);
+        }
+        sha256_block(h, w);
+    }
+    // block 2048: the last 8 words of the blob and the first 8 of the commitment
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = __builtin_bswap32(blob[N * 8 - 8 + k]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[8 + k] = __builtin_bswap32(cm[k]);
+    sha256_block(h, w);
+    // block 2049: the last 4 words of the commitment, 0x80, zeros, the length in bits (131152 * 8)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = __builtin_bswap32(cm[8 + k]);
+    w[4] = 0x80000000u;
+#pragma unroll
+    for (int k = 5; k < 15; ++k) w[k] = 0;
+    w[14] = 0;
+    w[15] = (u32)((32 + BYTES_PER_BLOB + 48) * 8);
+    sha256_block(h, w);
+    // hash_to_bls_field: the digest as a big-endian integer, reduced mod r
+    ff::Fr v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v.v[i] = h[7 - i];
+    const ff::Fr red = ff::from_mont(ff::mul(v, ff::Fr::r2()));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z_be[b * 8 + i] = __builtin_bswap32(red.v[7 - i]);
+}
+
 // commitment bytes -> status: 0 ok (valid encoding, and infinity or in the r-torsion subgroup), 1 bad
 // (FsG1::from_bytes + `!is_inf && !is_valid`, kzg/src/eip_4844.rs:556-558,577)
 __global__ void __launch_bounds__(64) k_check_commitments(int* __restrict__ status, const unsigned char* __restrict__ in,
@@ -597,9 +709,9 @@ struct KzgAmdSettings {
     std::unique_ptr<WorkerPool> pool;  // created by the first batched proof call
     // extra streams for the chunk pipeline of large proof batches (created on first use); chunk k runs on
     // pipe_stream(k), `stream` waits for all of them in pipe_join()
-    static constexpr int NPIPE = 3;
-    hipStream_t pipe[NPIPE] = {nullptr, nullptr, nullptr};
-    hipEvent_t pipe_ev[NPIPE] = {nullptr, nullptr, nullptr};
+    static constexpr int NPIPE = 4;
+    hipStream_t pipe[NPIPE] = {};
+    hipEvent_t pipe_ev[NPIPE] = {};
     hipStream_t pipe_stream(size_t k) {
         const int j = (int)(k % NPIPE);
         if (!pipe[j]) {
@@ -1300,10 +1412,26 @@ extern "C" C_KZG_RET kzgamd_blob_to_kzg_commitment_batch(KZGCommitment* out, con
         kzgamd::DeviceGuard on_device(dev->device);
         CK_HIP(on_device.err);
         dev->ensure(n);
-        CK_HIP(hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream));
         const bool host_compress = n <= HOST_COMPRESS_MAX;
-        commit_enqueue(dev, dev->d_out, dev->d_status, dev->d_blobs, dev->d_scalars, n, dev->stream,
-                       host_compress ? kzgamd::OUT_JACOBIAN : kzgamd::OUT_COMPRESSED);
+        if (n >= 2 * COMMIT_CHUNK) {
+            // Large batch: chunks on rotating streams.  The blobs are in pageable memory, so a copy call returns when
+            // its chunk is staged — while this thread stages chunk k + 1 the GPU commits to chunk k, and the tails of
+            // neighbouring chunks overlap (one MSM workspace per stream).  PCIe and compute run concurrently instead
+            // of back to back.
+            const size_t nchunks = (n + COMMIT_CHUNK - 1) / COMMIT_CHUNK;
+            for (size_t k = 0; k < nchunks; ++k) {
+                const size_t off = k * COMMIT_CHUNK, cn = off + COMMIT_CHUNK <= n ? COMMIT_CHUNK : n - off;
+                hipStream_t cs = dev->pipe_stream(k);
+                CK_HIP(hipMemcpyAsync(dev->d_blobs + off * BYTES_PER_BLOB, blobs + off, cn * BYTES_PER_BLOB, hipMemcpyHostToDevice, cs));
+                commit_enqueue(dev, dev->d_out + off * 48, dev->d_status + off, dev->d_blobs + off * BYTES_PER_BLOB,
+                               dev->d_scalars + off * N * 8, cn, cs, kzgamd::OUT_COMPRESSED);
+            }
+            dev->pipe_join();
+        } else {
+            CK_HIP(hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream));
+            commit_enqueue(dev, dev->d_out, dev->d_status, dev->d_blobs, dev->d_scalars, n, dev->stream,
+                           host_compress ? kzgamd::OUT_JACOBIAN : kzgamd::OUT_COMPRESSED);
+        }
         std::vector<int> status(n);
         blst_p1 jac[HOST_COMPRESS_MAX];
         CK_HIP(hipMemcpyAsync(status.data(), dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
@@ -1356,6 +1484,43 @@ extern "C" int kzgamd_settings_device(const CKZGSettings* s) {
     return dev ? dev->device : -1;
 }
 
+
+// Device-resident compute_blob_kzg_proof for n blobs, enqueued on `stream` without synchronising: challenge (SHA-256
+// on the device), commitment validation, barycentric evaluation + quotient, fixed-base MSM, compression.
+// d_scratch: n x KZGAMD_PROOF_SCRATCH_BYTES.  d_status[i] != 0: blob i has an element >= r or commitment i is not a
+// valid G1 element (the reference returns BadArgs for the call; here the other proofs of the batch are still valid).
+extern "C" C_KZG_RET kzgamd_compute_blob_kzg_proof_device(void* d_proofs, void* d_status, void* d_scratch, const void* d_blobs,
+                                                          const void* d_commitments, size_t n, const CKZGSettings* s,
+                                                          void* stream) {
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev || !d_proofs || !d_status || !d_scratch || !d_blobs || !d_commitments) return C_KZG_BADARGS;
+    if (n == 0) return C_KZG_OK;
+    return guarded([&] {
+        kzgamd::DeviceGuard on_device(dev->device);
+        CK_HIP(on_device.err);
+        hipStream_t st = (hipStream_t)stream;
+        u32* scal = (u32*)d_scratch;
+        u32* z = scal + n * N * 8;
+        u32* y = z + n * 8;
+        int* stat = (int*)d_status;
+        CK_HIP(hipMemsetAsync(stat, 0, n * sizeof(int), st));
+        hipLaunchKernelGGL(k_challenge_sha256, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, z, (const u32*)d_blobs,
+                           (const u32*)d_commitments, n);
+        hipLaunchKernelGGL(k_check_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, stat,
+                           (const unsigned char*)d_commitments, n);
+        hipLaunchKernelGGL(k_quotient, dim3((unsigned)n), dim3(QT), 0, st, scal, y, stat, (const u32*)d_blobs, (const u32*)z,
+                           (const ff::Fr*)dev->d_brp_roots, n_inverse());
+        kzgamd::msm_lock(dev->msm);
+        try {
+            kzgamd::msm_enqueue(dev->msm, d_proofs, scal, N, n, 0, st, kzgamd::OUT_COMPRESSED);
+        } catch (...) {
+            kzgamd::msm_unlock(dev->msm);
+            throw;
+        }
+        kzgamd::msm_unlock(dev->msm);
+        CK_HIP(hipGetLastError());
+    });
+}
 
 extern "C" C_KZG_RET compute_kzg_proof(KZGProof* proof_out, Bytes32* y_out, const Blob* blob, const Bytes32* z_bytes,
                                        const CKZGSettings* s) {

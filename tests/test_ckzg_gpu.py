@@ -460,3 +460,50 @@ def test_device_entry_point_on_two_streams(kzg, settings):
         assert int(stats[k].sum().item()) == 0
         got = outs[k].cpu().numpy().tobytes()
         assert [got[48 * i:48 * i + 48] for i in range(nb)] == want[k]
+
+
+def test_device_resident_blob_proofs_match_the_host_buffer_path(kzg, settings, golden, blob_loader):
+    """kzgamd_compute_blob_kzg_proof_device (SHA-256 challenge on the GPU) against the reference vectors and against
+    the host-buffer entry point on random blobs; bad blobs / commitments only flag their own slot."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    cases = [c for c in golden["compute_blob_kzg_proof"] if c["output"] is not None]
+    rnd = random.Random(21)
+    blobs, cms, want = [], [], []
+    for c in cases:
+        blobs.append(blob_loader(c["blob"]))
+        cms.append(bytes.fromhex(c["commitment"][2:]))
+        want.append(bytes.fromhex(c["output"][2:]))
+    for _ in range(70 - len(cases)):
+        b = bytearray(rnd.randbytes(BLOB))
+        for i in range(0, BLOB, 32):
+            b[i] = 0
+        blobs.append(bytes(b))
+    extra = blobs[len(cases):]
+    ecm = kzg.blob_to_kzg_commitment_batch(b"".join(extra), len(extra), settings)
+    cms += ecm
+    want += kzg.compute_blob_kzg_proof_batch(b"".join(extra), b"".join(ecm), len(extra), settings)
+    n = len(blobs)
+    # slot n: blob with an element == r; slot n + 1: commitment that is no G1 element
+    bad_blob = bytearray(blobs[-1])
+    bad_blob[32:64] = O.R.to_bytes(32, "big")
+    blobs.append(bytes(bad_blob))
+    cms.append(cms[-1])
+    blobs.append(blobs[0])
+    cms.append(bytes.fromhex("8123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef"))
+    m = len(blobs)
+    d_blobs = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).to(dev)
+    d_cms = torch.frombuffer(bytearray(b"".join(cms)), dtype=torch.uint8).to(dev)
+    d_out = torch.zeros(m * 48, dtype=torch.uint8, device=dev)
+    d_stat = torch.zeros(m, dtype=torch.int32, device=dev)
+    d_scr = torch.empty(m * kzg.PROOF_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    kzg.compute_blob_kzg_proof_device(d_out.data_ptr(), d_stat.data_ptr(), d_scr.data_ptr(), d_blobs.data_ptr(),
+                                      d_cms.data_ptr(), m, settings, st.cuda_stream)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy().tobytes()
+    stat = d_stat.cpu().tolist()
+    assert stat[:n] == [0] * n and stat[n] != 0 and stat[n + 1] != 0
+    for i in range(n):
+        assert out[48 * i:48 * i + 48] == want[i], i
