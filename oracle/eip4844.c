@@ -84,6 +84,10 @@ int oload_trusted_setup_text(osettings_t *s, const char *text, size_t len) {
 }
 
 void ofree_trusted_setup(osettings_t *s) {
+    if (s->bgmw) {
+        obgmw_table_free(s->bgmw);
+        free(s->bgmw);
+    }
     free(s->g1_lagrange_brp);
     free(s->g1_monomial);
     free(s->g2_monomial_bytes);
@@ -111,6 +115,27 @@ int oblob_to_kzg_commitment(uint8_t out[48], const uint8_t *blob, const osetting
     og1_t c;
     lincomb_setup(&c, poly, s);
     og1_compress(out, &c);
+    free(poly);
+    return 0;
+}
+
+int oblob_to_kzg_commitment_bgmw(uint8_t out[48], const uint8_t *blob, osettings_t *s) {
+    if (!s->bgmw) {
+        obgmw_table_t *t = calloc(1, sizeof *t);
+        if (!t || obgmw_table_new(t, s->g1_lagrange_brp, N)) return 1;
+        s->bgmw = t;
+    }
+    ofr_t *poly = malloc(N * sizeof *poly);
+    if (oblob_to_fr(poly, blob)) {
+        free(poly);
+        return 1;
+    }
+    uint8_t *le = malloc(32 * N);
+    for (size_t i = 0; i < N; ++i) ofr_to_scalar_le(le + 32 * i, &poly[i]);
+    og1_t c;
+    obgmw_multiply(&c, s->bgmw, le, N);
+    og1_compress(out, &c);
+    free(le);
     free(poly);
     return 0;
 }

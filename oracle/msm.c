@@ -200,3 +200,75 @@ void omsm_affine_mt(og1_t *out, const og1_affine_t *points, const ofr_t *scalars
     free(th);
     *out = acc;
 }
+
+/* ---- BGMW fixed-base MSM: the reference's DEFAULT algorithm for the 4096-point setup when built with the `bgmw`
+ * feature (kzg/src/msm/bgmw.rs; precomputation :206-232, evaluation multiply_sequential :381-439).  Restated for the
+ * CPU baseline and pinned on the same commitment vectors as the tiling Pippenger above. */
+
+/* bgmw.rs:89-129 */
+size_t obgmw_window_size(size_t npoints) {
+    size_t wbits = 0;
+    for (size_t v = npoints; v; v >>= 1) ++wbits;
+    static const unsigned char tab[38] = {0, 4, 5, 5, 6, 7, 8, 8, 9, 10, 10, 11, 12, 13, 13, 15, 15, 16, 17, 17, 19, 20, 20, 22,
+                                          22, 24, 24, 26, 26, 26, 29, 29, 29, 32, 32, 32, 32, 32};
+    return wbits <= 37 ? (wbits == 0 ? 4 : tab[wbits]) : 37;
+}
+
+/* get_table_dimensions (bgmw.rs:49-69): rows = ceil(255 / w) + (255 % w == 0) */
+static size_t bgmw_rows(size_t w) { return (255 + w - 1) / w + (255 % w == 0 ? 1 : 0); }
+
+/* BgmwTable::new (bgmw.rs:206-232): table[j * n + i] = affine(2^(w j) * P_i), j < rows */
+int obgmw_table_new(obgmw_table_t *t, const og1_affine_t *points, size_t n) {
+    t->n = n;
+    t->window = obgmw_window_size(n);
+    t->h = bgmw_rows(t->window);
+    t->table = malloc(n * t->h * sizeof(og1_affine_t));
+    if (!t->table) return 1;
+    for (size_t i = 0; i < n; ++i) {
+        og1_t p;
+        og1_from_affine(&p, &points[i]);
+        for (size_t j = 0; j < t->h; ++j) {
+            og1_to_affine(&t->table[j * n + i], &p);
+            for (size_t k = 0; k < t->window; ++k) og1_dbl(&p, &p); /* tmp_point.mul(q), q = 2^w */
+        }
+    }
+    return 0;
+}
+
+void obgmw_table_free(obgmw_table_t *t) {
+    free(t->table);
+    memset(t, 0, sizeof *t);
+}
+
+/* p1_tile_bgmw (bgmw.rs:601-680): the digit of window [bit0, bit0 + wbits) of every scalar selects a bucket of ONE
+ * shared set; the point comes from the table row of that window */
+static void tile_bgmw(const og1_affine_t *points, const uint8_t *scalars, size_t n, og1_xyzz_t *buckets, size_t bit0,
+                      size_t wbits, size_t cbits) {
+    uint64_t wmask = ((uint64_t)1 << (wbits + 1)) - 1;
+    uint64_t z = (bit0 == 0);
+    bit0 -= (size_t)(z ^ 1);
+    wbits += (size_t)(z ^ 1);
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t wval = (get_wval_limb(scalars + 32 * i, bit0, wbits) << z) & wmask;
+        wval = booth_encode(wval, cbits);
+        booth_decode(buckets, wval, cbits, &points[i]);
+    }
+}
+
+/* multiply_sequential_raw (bgmw.rs:381-425): scalars are canonical 32-byte little-endian, n of them (n <= t->n) */
+void obgmw_multiply(og1_t *out, const obgmw_table_t *t, const uint8_t *scalars_le, size_t n) {
+    size_t window = t->window;
+    og1_xyzz_t *buckets = calloc((size_t)1 << (window - 1), sizeof *buckets);
+    size_t wbits = 255 % window, cbits = wbits + 1, bit0 = 255, q_idx = t->h;
+    for (;;) {
+        bit0 -= wbits;
+        q_idx -= 1;
+        if (bit0 == 0) break;
+        tile_bgmw(t->table + q_idx * t->n, scalars_le, n, buckets, bit0, wbits, cbits);
+        cbits = window;
+        wbits = window;
+    }
+    tile_bgmw(t->table, scalars_le, n, buckets, 0, wbits, cbits);
+    integrate_buckets(out, buckets, wbits - 1);
+    free(buckets);
+}

@@ -104,6 +104,16 @@ void omsm_naive(og1_t *out, const og1_affine_t *points, const ofr_t *scalars, si
 /* nthreads-way split of omsm_affine over point ranges (CPU baseline only) */
 void omsm_affine_mt(og1_t *out, const og1_affine_t *points, const ofr_t *scalars, size_t n, int nthreads);
 
+/* BGMW fixed-base MSM (kzg/src/msm/bgmw.rs): table[j * n + i] = affine(2^(window j) P_i), j < h */
+typedef struct {
+    size_t n, window, h;
+    og1_affine_t *table;
+} obgmw_table_t;
+size_t obgmw_window_size(size_t npoints);
+int  obgmw_table_new(obgmw_table_t *t, const og1_affine_t *points, size_t n);
+void obgmw_table_free(obgmw_table_t *t);
+void obgmw_multiply(og1_t *out, const obgmw_table_t *t, const uint8_t *scalars_le, size_t n);
+
 /* ---- NTT (fft.c) ---- */
 typedef struct {
     size_t max_width;
@@ -135,12 +145,16 @@ typedef struct {
     og1_affine_t *g1_monomial;      /* 4096 */
     uint8_t *g2_monomial_bytes;     /* 65 * 96 raw */
     offt_settings_t fs;             /* scale 13 */
+    obgmw_table_t *bgmw;            /* over g1_lagrange_brp; built by the first oblob_to_kzg_commitment_bgmw call */
 } osettings_t;
 /* text format: kzg/src/eip_4844.rs:151-228.  0 ok, nonzero = BadArgs */
 int  oload_trusted_setup_text(osettings_t *s, const char *text, size_t len);
 void ofree_trusted_setup(osettings_t *s);
 int  oblob_to_fr(ofr_t *out, const uint8_t *blob);                       /* 0 ok */
 int  oblob_to_kzg_commitment(uint8_t out[48], const uint8_t *blob, const osettings_t *s);
+/* the same through the BGMW table (the reference's default with feature `bgmw`; FsKZGSettings::new builds the table,
+ * blst/src/types/kzg_settings.rs:109-123).  Builds the table on first use (~1 s); not thread-safe on that first call. */
+int  oblob_to_kzg_commitment_bgmw(uint8_t out[48], const uint8_t *blob, osettings_t *s);
 void ocompute_challenge(ofr_t *out, const ofr_t *blob_fr, const uint8_t commitment[48]);
 int  oevaluate_polynomial_in_evaluation_form(ofr_t *out, const ofr_t *poly, const ofr_t *x, const osettings_t *s);
 int  ocompute_kzg_proof(uint8_t proof[48], uint8_t y[32], const uint8_t *blob, const uint8_t z[32], const osettings_t *s);

@@ -96,6 +96,42 @@ impl GpuMsm {
     }
 }
 
+/// Raw-handle forms for callers that keep the table behind `kzg::msm::precompute::PrecomputationTable`
+/// (an opaque `*mut c_void`, kzg/src/msm/sppark.rs:5-22) instead of a `GpuMsm`.
+///
+/// # Safety
+/// `handle` must come from [`prepare_raw`] (or `GpuMsm`) and not have been freed.
+pub unsafe fn msm_prepared_raw(handle: *mut c_void, scalars: &[blst_fr]) -> Result<blst_p1, String> {
+    let mut out = blst_p1::default();
+    check(mult_pippenger_prepared(handle, &mut out, scalars.len(), scalars.as_ptr()), "mult_pippenger_prepared")?;
+    Ok(out)
+}
+
+/// # Safety
+/// as [`msm_prepared_raw`]; `scalars` is nbatch x npoints, row-major.
+pub unsafe fn msm_prepared_batch_raw(handle: *mut c_void, scalars: &[blst_fr], npoints: usize) -> Result<Vec<blst_p1>, String> {
+    if npoints == 0 || scalars.len() % npoints != 0 {
+        return Err("bad batch shape".into());
+    }
+    let nbatch = scalars.len() / npoints;
+    let mut out = vec![blst_p1::default(); nbatch];
+    check(mult_pippenger_prepared_batch(handle, out.as_mut_ptr(), npoints, nbatch, scalars.as_ptr()),
+          "mult_pippenger_prepared_batch")?;
+    Ok(out)
+}
+
+/// `prepare_multi_scalar_mult` of blst-sppark/src/lib.rs:8-17: the handle is leaked into the settings object like
+/// the reference's (release it with [`free_raw`] when the settings go away).
+pub fn prepare_raw(points: &[blst_p1_affine]) -> *mut c_void {
+    unsafe { prepare_msm(points.as_ptr(), points.len()) }
+}
+
+/// # Safety
+/// `handle` must come from [`prepare_raw`]; it is dead afterwards.
+pub unsafe fn free_raw(handle: *mut c_void) {
+    free_msm(handle)
+}
+
 impl Drop for GpuMsm {
     fn drop(&mut self) {
         unsafe { free_msm(self.handle) }

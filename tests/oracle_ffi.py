@@ -30,7 +30,7 @@ class FFTSettings(C.Structure):
 
 class Settings(C.Structure):
     _fields_ = [("g1_lagrange_brp", C.POINTER(G1Affine)), ("g1_monomial", C.POINTER(G1Affine)),
-                ("g2_monomial_bytes", C.POINTER(C.c_uint8)), ("fs", FFTSettings)]
+                ("g2_monomial_bytes", C.POINTER(C.c_uint8)), ("fs", FFTSettings), ("bgmw", C.c_void_p)]
 
 
 _lib = None
@@ -101,6 +101,8 @@ def lib():
         "ocompute_blob_kzg_proof": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(Settings)]),
         "ocompute_cells": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(Settings)]),
         "ocompute_cell_proof": (C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(Settings)]),
+        "oblob_to_kzg_commitment_bgmw": (C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(Settings)]),
+        "obgmw_window_size": (C.c_size_t, [C.c_size_t]),
         "ocompute_r_powers": (C.c_int, [frp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
         "overify_kzg_proof_batch_g1": (C.c_int, [g1p, g1p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     }

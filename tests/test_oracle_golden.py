@@ -249,6 +249,24 @@ def test_vectors_blob_to_kzg_commitment(oracle, oracle_settings, golden, blob_lo
     assert nvalid == 7
 
 
+def test_vectors_blob_to_kzg_commitment_bgmw(oracle, oracle_settings, golden, blob_loader):
+    """The BGMW fixed-base path (kzg/src/msm/bgmw.rs — the reference's default with feature `bgmw`, and the algorithm
+    bench.py's cpu_baseline times) on the same vectors: window 13, 20 table rows for the 4096-point setup."""
+    L = oracle.lib()
+    assert L.obgmw_window_size(4096) == 13 and L.obgmw_window_size(1 << 20) == 20 and L.obgmw_window_size(8) == 6
+    nvalid = 0
+    for case in golden["blob_to_kzg_commitment"]:
+        blob = blob_loader(case["blob"])
+        out = C.create_string_buffer(48)
+        rc = 1 if len(blob) != BLOB else L.oblob_to_kzg_commitment_bgmw(out, blob, C.byref(oracle_settings))
+        if case["output"] is None:
+            assert rc != 0, case["name"]
+        else:
+            assert rc == 0 and hx(out.raw) == case["output"], case["name"]
+            nvalid += 1
+    assert nvalid == 7
+
+
 def test_vectors_compute_challenge(oracle, golden, blob_loader):
     L = oracle.lib()
     n = 0
