@@ -126,8 +126,8 @@ typedef struct { blst_fp2 x, y, z; } blst_p2;          /* Jacobian over Fp2; inf
 /* Same layout as the reference's CKZGSettings (kzg/src/eth/c_bindings.rs:55-108).  The host arrays are
  * owned by the library and freed by free_trusted_setup; the device-resident state (fixed-base MSM table)
  * is found through a registry keyed by g1_values_lagrange_brp, as the reference does for its tables
- * (kzg/src/eip_4844.rs:64-146).  x_ext_fft_columns / tables stay NULL (FK20 state, outside this library's path:
- * cell proofs are computed as fixed-base MSMs instead). */
+ * (kzg/src/eip_4844.rs:64-146).  tables / wbits / scratch_size stay empty like the reference's
+ * (blst/src/eip_4844.rs:140-142). */
 typedef struct {
     blst_fr *roots_of_unity;          /* 8193 */
     blst_fr *brp_roots_of_unity;      /* 8192 */
@@ -135,7 +135,7 @@ typedef struct {
     blst_p1 *g1_values_monomial;      /* 4096 */
     blst_p1 *g1_values_lagrange_brp;  /* 4096 */
     blst_p2 *g2_values_monomial;      /* 65 */
-    blst_p1 **x_ext_fft_columns;      /* NULL */
+    blst_p1 **x_ext_fft_columns;      /* 128 rows x 64 (FK20 columns, blst/src/types/kzg_settings.rs:84-101) */
     blst_p1_affine **tables;          /* NULL */
     size_t wbits;
     size_t scratch_size;

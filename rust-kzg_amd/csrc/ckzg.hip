@@ -52,6 +52,8 @@ struct CkErr {
 
 constexpr size_t N = FIELD_ELEMENTS_PER_BLOB;
 constexpr size_t NUM_G2 = 65;
+constexpr size_t CELL_SIZE = 64;                 // FIELD_ELEMENTS_PER_CELL
+constexpr size_t CELLS_PER_BLOB = N / CELL_SIZE;  // 64; the extended blob has 128 cells
 
 // ---------------------------------------------------------------- kernels
 
@@ -891,6 +893,10 @@ void free_host_arrays(CKZGSettings* s) {
     free(s->g1_values_monomial);
     free(s->g1_values_lagrange_brp);
     free(s->g2_values_monomial);
+    if (s->x_ext_fft_columns) {
+        for (size_t i = 0; i < 2 * CELLS_PER_BLOB; ++i) free(s->x_ext_fft_columns[i]);
+        free(s->x_ext_fft_columns);
+    }
     zero_settings(s);
 }
 
@@ -975,8 +981,29 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
         }
         CK_HIP(hipMalloc(&dev->d_brp_roots, N * sizeof(ff::Fr)));
         CK_HIP(hipMemcpy(dev->d_brp_roots, dev->brp_roots.data(), N * sizeof(ff::Fr), hipMemcpyHostToDevice));
-        // x_ext_fft_columns / tables stay NULL: FK20 state is not part of this path
-        // (blst/src/eip_4844.rs:140-142 leaves tables/wbits/scratch_size empty too)
+        // FK20 columns of the settings struct (FsKZGSettings::new, blst/src/types/kzg_settings.rs:84-101): for every
+        // offset < 64 the size-128 G1 transform of [ s^(N - 64 - 1 - offset - 64 i) ]_{i < 63}, identity, 64 x identity;
+        // x_ext_fft_columns[row][offset] = transform[row].  This library's own cell proofs do not use them (they are
+        // fixed-base MSMs), but a consumer of the struct — the reference's FK20 / recovery code — does: one batch of
+        // 64 transforms through fft_g1 on the GPU.  tables / wbits / scratch_size stay empty like the reference's
+        // (blst/src/eip_4844.rs:140-142).
+        {
+            const size_t K2 = 2 * CELLS_PER_BLOB;
+            std::vector<blst_p1> xin(CELL_SIZE * K2), xout(CELL_SIZE * K2);
+            memset(xin.data(), 0, xin.size() * sizeof(blst_p1));
+            for (size_t offset = 0; offset < CELL_SIZE; ++offset) {
+                const size_t start = N - CELL_SIZE - 1 - offset;
+                for (size_t i = 0; i + 1 < CELLS_PER_BLOB; ++i) xin[offset * K2 + i] = out->g1_values_monomial[start - i * CELL_SIZE];
+            }
+            dev->ntt = kzgamd_ntt_new(13);
+            if (!dev->ntt) throw CkErr{C_KZG_ERROR, "kzgamd_ntt_new failed"};
+            if (kzgamd_fft_g1_batch(dev->ntt, xout.data(), xin.data(), K2, CELL_SIZE, 0) != 0) throw CkErr{C_KZG_ERROR, "fft_g1"};
+            out->x_ext_fft_columns = leak_array<blst_p1*>(K2);
+            for (size_t row = 0; row < K2; ++row) {
+                out->x_ext_fft_columns[row] = leak_array<blst_p1>(CELL_SIZE);
+                for (size_t offset = 0; offset < CELL_SIZE; ++offset) out->x_ext_fft_columns[row][offset] = xout[offset * K2 + row];
+            }
+        }
         (void)hipFree(d_bytes);
         (void)hipFree(d_pts);
         (void)hipFree(d_bad);
@@ -1287,9 +1314,7 @@ void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_
     std::lock_guard<std::mutex> lk(dev->mu);
     kzgamd::DeviceGuard on_device(dev->device);
     CK_HIP(on_device.err);
-    if (!dev->ntt) {
-        dev->ntt = kzgamd_ntt_new(13);
-        if (!dev->ntt) throw CkErr{C_KZG_ERROR, "kzgamd_ntt_new failed"};
+    if (!dev->d_roots8192) {
         CK_HIP(hipMalloc(&dev->d_roots8192, (2 * N + 1) * sizeof(ff::Fr)));
         CK_HIP(hipMemcpy(dev->d_roots8192, cs->roots_of_unity, (2 * N + 1) * sizeof(ff::Fr), hipMemcpyHostToDevice));
     }

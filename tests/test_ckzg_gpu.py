@@ -312,12 +312,18 @@ def test_batch_256_blobs_commit_and_prove(kzg, settings, oracle, oracle_settings
     cms = kzg.blob_to_kzg_commitment_batch(blobs, n, settings)
     proofs = kzg.compute_blob_kzg_proof_batch(blobs, b"".join(cms), n, settings)
     assert cms[7] == b"\xc0" + bytes(47)
-    for b in (0, 7, 9, 100, 255):
+    # every one of the 256 commitments and proofs against the oracle (its C code runs without the GIL: one worker per core)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def check(b):
         bl = blobs[b * BLOB:(b + 1) * BLOB]
         ec, ep = C.create_string_buffer(48), C.create_string_buffer(48)
         assert L.oblob_to_kzg_commitment(ec, bl, C.byref(oracle_settings)) == 0
         assert L.ocompute_blob_kzg_proof(ep, bl, ec.raw, C.byref(oracle_settings)) == 0
-        assert (cms[b], proofs[b]) == (ec.raw, ep.raw), b
+        return (cms[b], proofs[b]) == (ec.raw, ep.raw)
+
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+        assert all(ex.map(check, range(n)))
     singles = hashlib.sha256()
     for b in range(0, n, 16):
         bl = blobs[b * BLOB:(b + 1) * BLOB]
@@ -507,3 +513,21 @@ def test_device_resident_blob_proofs_match_the_host_buffer_path(kzg, settings, g
     assert stat[:n] == [0] * n and stat[n] != 0 and stat[n + 1] != 0
     for i in range(n):
         assert out[48 * i:48 * i + 48] == want[i], i
+
+
+def test_settings_fk20_columns_match_oracle(kzg, settings, oracle, oracle_settings):
+    """x_ext_fft_columns of the settings struct (FsKZGSettings::new, blst/src/types/kzg_settings.rs:84-101): the
+    size-128 G1 transform of the strided monomial points, for three offsets, against the oracle's offt_g1."""
+    L = oracle.lib()
+    rows = (C.POINTER(kzg.BlstP1) * 128).from_address(settings.c.x_ext_fft_columns)
+    for offset in (0, 1, 63):
+        start = 4096 - 64 - 1 - offset
+        x = (O.G1 * 128)()
+        for i in range(63):
+            L.og1_from_affine(C.byref(x[i]), C.byref(oracle_settings.g1_monomial[start - 64 * i]))
+        want = (O.G1 * 128)()
+        assert L.offt_g1(C.byref(oracle_settings.fs), want, x, 128, 0) == 0
+        for row in (0, 1, 2, 64, 127):
+            got = O.G1()
+            C.memmove(C.byref(got), C.byref(rows[row][offset]), 144)
+            assert L.og1_equal(C.byref(got), C.byref(want[row])) == 1, (offset, row)
