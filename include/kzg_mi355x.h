@@ -16,6 +16,26 @@
 #include <stdint.h>
 #include <stdio.h>
 
+/* libkzg_mi355x_prefixed.so (python rust-kzg_amd/build.py --prefixed): the same library with every c-kzg-4844 name
+ * exported as kzgamd_ckzg_<name>, for a process that also links the reference's own C bindings (e.g. for
+ * recover_cells_and_kzg_proofs / verify_cell_kzg_proof_batch, which are not on this library's path).  Define
+ * KZG_MI355X_PREFIXED before including this header and keep writing the plain names. */
+#ifdef KZG_MI355X_PREFIXED
+#define load_trusted_setup kzgamd_ckzg_load_trusted_setup
+#define load_trusted_setup_file kzgamd_ckzg_load_trusted_setup_file
+#define free_trusted_setup kzgamd_ckzg_free_trusted_setup
+#define blob_to_kzg_commitment kzgamd_ckzg_blob_to_kzg_commitment
+#define compute_kzg_proof kzgamd_ckzg_compute_kzg_proof
+#define compute_blob_kzg_proof kzgamd_ckzg_compute_blob_kzg_proof
+#define verify_kzg_proof kzgamd_ckzg_verify_kzg_proof
+#define verify_blob_kzg_proof kzgamd_ckzg_verify_blob_kzg_proof
+#define verify_blob_kzg_proof_batch kzgamd_ckzg_verify_blob_kzg_proof_batch
+#define compute_challenge kzgamd_ckzg_compute_challenge
+#define bytes_to_kzg_commitment kzgamd_ckzg_bytes_to_kzg_commitment
+#define bytes_from_bls_field kzgamd_ckzg_bytes_from_bls_field
+#define compute_cells_and_kzg_proofs kzgamd_ckzg_compute_cells_and_kzg_proofs
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif

@@ -22,6 +22,37 @@ def _stale():
     return False
 
 
+# c-kzg-4844 names this library shares with the reference's own C bindings (blst/src/eip_4844.rs, kzg/src/eth/c_bindings.rs).
+# A process that also links the Rust staticlib (for recover_cells_and_kzg_proofs / verify_cell_kzg_proof_batch, which
+# are not on this library's path) cannot have both sets under the same names: build_prefixed() links a second flavour,
+# libkzg_mi355x_prefixed.so, in which every one of them is exported as kzgamd_ckzg_<name> instead
+# (include/kzg_mi355x.h maps the plain names when KZG_MI355X_PREFIXED is defined).
+CKZG_NAMES = ["load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment", "compute_kzg_proof",
+              "compute_blob_kzg_proof", "verify_kzg_proof", "verify_blob_kzg_proof", "verify_blob_kzg_proof_batch",
+              "compute_challenge", "bytes_to_kzg_commitment", "bytes_from_bls_field", "compute_cells_and_kzg_proofs"]
+LIB_PREFIXED = os.path.join(CSRC, "libkzg_mi355x_prefixed.so")
+
+
+def build_prefixed(verbose=False):
+    """libkzg_mi355x_prefixed.so from the objects of build(): c-kzg names renamed with llvm-objcopy, nothing recompiled."""
+    build()
+    objcopy = os.environ.get("OBJCOPY", "/opt/rocm/lib/llvm/bin/llvm-objcopy")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for s in SOURCES:
+        o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        po = os.path.join(CSRC, s.replace(".hip", ".prefixed.o"))
+        cmd = [objcopy] + ["--redefine-sym=%s=kzgamd_ckzg_%s" % (n, n) for n in CKZG_NAMES] + [o, po]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(po)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PREFIXED] + objs + ["-lpthread"], cwd=CSRC)
+    for o in objs:
+        os.remove(o)
+    return LIB_PREFIXED
+
+
 def build(force=False, verbose=False):
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if not force and not _stale():
@@ -46,3 +77,5 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--prefixed" in sys.argv:
+        print(build_prefixed(verbose=True))

@@ -5,7 +5,7 @@
 // library does the same: the field work and the G1 linear combinations of verification run on the GPU, the final
 //     e(a1, a2) == e(b1, b2)
 // check — two Miller loops and one final exponentiation per call, whatever the batch size — runs here.  It is not
-// a fallback for anything the GPU path computes and it never touches oracle/.
+// a fallback for anything the GPU path computes, and it shares no code with the CPU checker of the test-suite.
 //
 // Construction (textbook, favouring few constants over speed: ~15 ms per check on one core):
 //   tower      Fp2 = Fp[u]/(u^2+1),  Fp6 = Fp2[v]/(v^3 - xi), xi = 1+u,  Fp12 = Fp6[w]/(w^2 - v)

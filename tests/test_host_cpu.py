@@ -204,3 +204,22 @@ def test_sharded_large_msm_two_ranks_gloo():
     for rank, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % rank in o
+
+
+def test_prefixed_library_renames_every_ckzg_symbol():
+    """libkzg_mi355x_prefixed.so (build.py --prefixed): the c-kzg names are exported as kzgamd_ckzg_* only, everything
+    else as in the plain library — what lets a process link the reference's own C bindings next to this one."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("rust_kzg_amd_build", os.path.join(ROOT, "rust-kzg_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    path = b.build_prefixed()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+    names = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    for n in b.CKZG_NAMES:
+        assert "kzgamd_ckzg_" + n in names and n not in names, n
+    assert {"prepare_msm", "mult_pippenger", "ntt_fr", "kzgamd_blob_to_kzg_commitment_device"} <= names
+    text = open(os.path.join(ROOT, "include", "kzg_mi355x.h")).read()
+    for n in b.CKZG_NAMES:
+        assert "#define %s kzgamd_ckzg_%s" % (n, n) in text, n

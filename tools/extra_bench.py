@@ -56,6 +56,7 @@ def main():
     nmax = 1 << 22
     pts = torch.empty(nmax * 96, dtype=torch.uint8, device=dev)
     kzg.generate_points(pts.data_ptr(), nmax, 2, stream)
+    torch.cuda.synchronize()  # handles copy the points on their own non-blocking streams
     g = torch.Generator(device="cpu")
     g.manual_seed(2)
     sc = torch.randint(0, 256, (nmax, 32), dtype=torch.uint8, generator=g)

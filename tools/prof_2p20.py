@@ -9,6 +9,7 @@ stream = torch.cuda.current_stream().cuda_stream
 n = 1 << 20
 pts = torch.empty(n * 96, dtype=torch.uint8, device=dev)
 kzg.generate_points(pts.data_ptr(), n, 2, stream)
+torch.cuda.synchronize()  # handles copy the points on their own non-blocking streams
 g = torch.Generator(device="cpu"); g.manual_seed(2)
 sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g); sc[:, 31] &= 0x3F; sc = sc.to(dev)
 out = torch.zeros(144, dtype=torch.uint8, device=dev)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Turn the raw rocprofv3 output that tools/collect_round_profiles.sh left under gpurun_out/ into the
-committed summaries under profiles/ (round tag r01): bench line, kernel stats (overall and per launch
-shape), PMC counter files and r01_pmc_summary.json (what bench.py reads for roofline.traffic)."""
+"""Turn the raw rocprofv3 output tools/collect_round_profiles.sh left under gpurun_out/ into the committed
+summaries under profiles/ (round tag r02): bench line, kernel statistics (headline 4-stream run, 1-stream run, NTT,
+2^20 MSM timeline), the PMC counter files and r02_pmc_summary.json (what bench.py reads for roofline.traffic and
+the VALU figures, labelled with this file as their source)."""
 import collections
 import csv
 import glob
@@ -10,86 +11,114 @@ import os
 import shutil
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r01"
+TAG = "r02"
+G = os.path.join(R, "gpurun_out")
+P = os.path.join(R, "profiles")
 
 
 def short(name):
     return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
 
 
-def main():
-    bench = json.load(open(os.path.join(R, "gpurun_out", "bench_final.json")))
-    B = bench["config"]["blobs_per_gpu_per_step"]
-    c, rows = bench["config"]["msm_window_bits"], bench["config"]["table_rows"]
-    out = {}
-    for d in sorted(glob.glob(os.path.join(R, "gpurun_out", "pmc_*/"))):
-        for f in glob.glob(d + "*counter_collection.csv"):
-            agg = collections.defaultdict(lambda: collections.defaultdict(list))
-            for row in csv.DictReader(open(f)):
-                agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
-            for k, v in agg.items():
-                for cn, x in v.items():
-                    xs = sorted(x)
-                    full = [y for y in xs if y > 0.5 * xs[-1]]  # full-batch launches only
-                    out.setdefault(k, {})[cn] = {"launches": len(full), "avg_full_batch": sum(full) / len(full)}
-            tag = os.path.basename(d[:-1])[4:]
-            shutil.copy(f, os.path.join(R, "profiles", "%s_pmc_%s_counter_collection.csv" % (TAG, tag)))
-    # the instantiation that ran the full-batch launches (k_fbw_accum<4> at 1024 blobs): the one with the most work
-    name = max((k for k in out if k.startswith("k_fbw_accum")), key=lambda k: out[k].get("FETCH_SIZE", {}).get("avg_full_batch", 0))
-    ka = out[name]
-    fetch_kb, write_kb = ka["FETCH_SIZE"]["avg_full_batch"], ka["WRITE_SIZE"]["avg_full_batch"]
-    summary = {
-        "run": "rocprofv3 --pmc <one counter group per pass> --kernel-trace -- python bench.py --steps 4 --warmup 1 "
-               "--streams 1 --no-cpu-baseline --no-large",
-        "batch": B, "window_bits": c, "table_rows": rows,
-        "k_fbw_accum": {
-            "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
-            "fetch_bytes_corrected_x2": fetch_kb * 1024 * 2, "write_bytes": write_kb * 1024,
-            "hbm_bytes_per_launch": fetch_kb * 1024 * 2 + write_kb * 1024,
-            "analytic_gather_bytes": B * rows * 4096 * 128 + B * 131072, "analytic_write_bytes": B * 4096 * 224,
-            "note": "gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md HBM section), hence x2; "
-                    "the corrected figure matches the analytic gather count (one 128-B table slot per (window, scalar) "
-                    "+ the scalars)",
-            **{cn: ka[cn]["avg_full_batch"] for cn in ka if cn not in ("FETCH_SIZE", "WRITE_SIZE")},
-        },
-        "all": out,
-    }
-    # VALU utilisation from the counters alone (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* count quad-cycles; effective
-    # clock = GRBM_GUI_ACTIVE / kernel wall time, the counter being summed over the 8 XCDs): duration of the same
-    # launches inside the GRBM pass
-    durs = []
-    for f in glob.glob(os.path.join(R, "gpurun_out", "pmc_GRBM_GUI_ACTIVE", "*kernel_trace.csv")):
-        for row in csv.DictReader(open(f)):
-            if short(row["Kernel_Name"]) == name:
-                durs.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
-    if durs and "GRBM_GUI_ACTIVE" in ka and "SQ_ACTIVE_INST_VALU" in ka:
-        full = [d for d in durs if d > 0.5 * max(durs)]
-        dur_s = sum(full) / len(full) * 1e-9
-        xcd_cycles = ka["GRBM_GUI_ACTIVE"]["avg_full_batch"] / 8
-        summary["k_fbw_accum"]["kernel_s_in_grbm_pass"] = dur_s
-        summary["k_fbw_accum"]["effective_clock_ghz"] = xcd_cycles / dur_s / 1e9
-        summary["k_fbw_accum"]["valu_busy_frac"] = ka["SQ_ACTIVE_INST_VALU"]["avg_full_batch"] * 4 / (1024 * xcd_cycles)
-        summary["k_fbw_accum"]["valu_note"] = ("valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): "
-                                               "share of the kernel's cycles in which a SIMD's VALU is executing, at the clock the chip "
-                                               "sustained under this load")
-    json.dump(summary, open(os.path.join(R, "profiles", TAG + "_pmc_summary.json"), "w"), indent=1)
-    shutil.copy(os.path.join(R, "gpurun_out", "prof_final", "r01_kernel_stats.csv"),
-                os.path.join(R, "profiles", TAG + "_bench_kernel_stats.csv"))
-    shutil.copy(os.path.join(R, "gpurun_out", "bench_final.json"), os.path.join(R, "profiles", TAG + "_bench.json"))
-    rowsx = list(csv.DictReader(open(os.path.join(R, "gpurun_out", "prof_final", "r01_kernel_trace.csv"))))
+def by_grid(trace_csv, out_csv):
     agg = collections.defaultdict(list)
-    for r in rowsx:
+    for r in csv.DictReader(open(trace_csv)):
         g = r.get("Grid_Size_X") or r.get("Grid_Size") or ""
         agg[(short(r["Kernel_Name"]), g)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    with open(os.path.join(R, "profiles", TAG + "_bench_kernel_stats_by_grid.csv"), "w") as f:
+    with open(out_csv, "w") as f:
         w = csv.writer(f)
         w.writerow(["Kernel", "Grid_Size_X", "Calls", "AverageNs", "MinNs", "MaxNs"])
         for (k, g), v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             w.writerow([k, g, len(v), round(sum(v) / len(v), 1), min(v), max(v)])
+    return agg
+
+
+def counters(pattern, match):
+    out = {}
+    for d in sorted(glob.glob(os.path.join(G, pattern))):
+        for f in glob.glob(os.path.join(d, TAG + "_counter_collection.csv")):
+            agg = collections.defaultdict(lambda: collections.defaultdict(list))
+            for row in csv.DictReader(open(f)):
+                if match in row["Kernel_Name"]:
+                    agg[(short(row["Kernel_Name"]), row["Grid_Size"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            for k, v in agg.items():
+                for cn, x in v.items():
+                    out.setdefault("%s grid=%s" % k, {})[cn] = {"launches": len(x), "avg": sum(x) / len(x)}
+            tag = os.path.basename(d)[4:]
+            shutil.copy(f, os.path.join(P, "%s_pmc_%s_counter_collection.csv" % (TAG, tag)))
+    return out
+
+
+def durations(dirname, match):
+    out = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(G, dirname, TAG + "_kernel_trace.csv")):
+        for row in csv.DictReader(open(f)):
+            if match in row["Kernel_Name"]:
+                out["%s grid=%s" % (short(row["Kernel_Name"]), row.get("Grid_Size_X") or row.get("Grid_Size"))].append(
+                    int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    return out
+
+
+def main():
+    bench = json.load(open(os.path.join(G, "bench_final.json")))
+    shutil.copy(os.path.join(G, "bench_final.json"), os.path.join(P, TAG + "_bench.json"))
+    B = bench["config"]["blobs_per_batch"]
+    cfg = bench["config"]
+    for name in ("headline", "streams1", "ntt", "2p20"):
+        d = os.path.join(G, "prof_" + name)
+        if os.path.exists(os.path.join(d, "r02_kernel_stats.csv")):
+            shutil.copy(os.path.join(d, "r02_kernel_stats.csv"), os.path.join(P, "%s_%s_kernel_stats.csv" % (TAG, name)))
+            by_grid(os.path.join(d, "r02_kernel_trace.csv"), os.path.join(P, "%s_%s_kernel_stats_by_grid.csv" % (TAG, name)))
+    # ---- headline kernel ----
+    fbw = {k: v for k, v in counters("pmc_[!n]*", "fbw_accum").items()}
+    name = max(fbw, key=lambda k: fbw[k].get("SQ_INSTS_VALU", {}).get("avg", 0))
+    ka = fbw[name]
+    fetch_kb, write_kb = ka["FETCH_SIZE"]["avg"], ka["WRITE_SIZE"]["avg"]
+    adds = cfg["mixed_adds_per_scalar"]
+    summary = {
+        "run": "rocprofv3 --pmc <one counter group per pass> --kernel-trace -- python bench.py --steps 3 --warmup 1 "
+               "--batches-per-step 4 --streams 1 --no-cpu-baseline --no-extras",
+        "batch": B, "window_bits": cfg["msm_window_bits"], "table_rows": cfg["table_rows"], "glv_split": cfg["glv_split"],
+        "mixed_adds_per_scalar": adds, "kernel": name,
+        "k_fbw_accum": {
+            "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+            "fetch_bytes_corrected_x2": fetch_kb * 1024 * 2, "write_bytes": write_kb * 1024,
+            "hbm_bytes_per_launch": fetch_kb * 1024 * 2 + write_kb * 1024,
+            "analytic_gather_bytes": B * adds * 4096 * 128 + B * 131072,
+            "note": "gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md HBM section), hence x2; the "
+                    "corrected figure matches the analytic gather count (one 128-B table slot per mixed addition + the scalars)",
+            **{cn: ka[cn]["avg"] for cn in ka if cn not in ("FETCH_SIZE", "WRITE_SIZE")},
+        },
+    }
     k = summary["k_fbw_accum"]
-    print("hbm bytes/launch %.3e  SQ_INSTS_VALU %.3e" % (k["hbm_bytes_per_launch"], k["SQ_INSTS_VALU"]))
-    for (kk, g), v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:8]:
-        print(kk[:30].ljust(30), str(g).rjust(9), len(v), round(sum(v) / len(v) / 1e3, 1), "us")
+    k["valu_instructions_per_mixed_add"] = k["SQ_INSTS_VALU"] * 64 / (B * 4096 * adds)
+    durs = durations("pmc_GRBM_GUI_ACTIVE", "fbw_accum").get(name, [])
+    if durs and "GRBM_GUI_ACTIVE" in k:
+        dur_s = sum(durs) / len(durs) * 1e-9
+        xcd_cycles = k["GRBM_GUI_ACTIVE"] / 8
+        k["kernel_s_in_grbm_pass"] = dur_s
+        k["effective_clock_ghz"] = xcd_cycles / dur_s / 1e9
+        k["valu_busy_frac"] = k["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * xcd_cycles)
+        k["valu_note"] = ("valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): share of the "
+                          "kernel's cycles in which a SIMD's VALU is executing, at the clock the chip sustained under this load")
+    # ---- NTT kernels ----
+    ntt = counters("pmc_ntt_*", "ntt")
+    nd = durations("pmc_ntt_GRBM_GUI_ACTIVE", "ntt")
+    for key, v in ntt.items():
+        e = {cn: x["avg"] for cn, x in v.items()}
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            e["hbm_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 * 2 + e["WRITE_SIZE"] * 1024
+        if key in nd and "GRBM_GUI_ACTIVE" in e and "SQ_ACTIVE_INST_VALU" in e:
+            dur_s = sum(nd[key]) / len(nd[key]) * 1e-9
+            e["kernel_s_in_grbm_pass"] = dur_s
+            e["effective_clock_ghz"] = e["GRBM_GUI_ACTIVE"] / 8 / dur_s / 1e9
+            e["valu_busy_frac"] = e["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * e["GRBM_GUI_ACTIVE"] / 8)
+        summary.setdefault("ntt", {})[key] = e
+    json.dump(summary, open(os.path.join(P, TAG + "_pmc_summary.json"), "w"), indent=1)
+    print("k_fbw_accum: hbm bytes/launch %.3e  VALU/add %.0f  busy %.3f  clock %.2f GHz" % (
+        k["hbm_bytes_per_launch"], k["valu_instructions_per_mixed_add"], k.get("valu_busy_frac", 0), k.get("effective_clock_ghz", 0)))
+    for key, e in summary.get("ntt", {}).items():
+        print(key, {x: (round(y, 3) if y < 100 else int(y)) for x, y in e.items() if x in ("valu_busy_frac", "hbm_bytes_per_launch", "kernel_s_in_grbm_pass", "SQ_LDS_BANK_CONFLICT")})
 
 
 if __name__ == "__main__":
