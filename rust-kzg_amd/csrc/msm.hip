@@ -909,6 +909,7 @@ __global__ void __launch_bounds__(128) k_fbw_affine(WidePt* __restrict__ wide, c
         if (g1::is_inf(q)) {
             o.x = fp28::zero();
             o.y = fp28::zero();
+            o.pad[0] = 1;  // infinity flag
         } else {
             fp28::Fe zi = fp28::mul(inv, pref[k]);                  // 1 / (ZZ*ZZZ)
             inv = fp28::mul(inv, fp28::mul(q.zz, q.zzz));
@@ -954,6 +955,46 @@ __global__ void __launch_bounds__(64) k_bases_in_g1(const AffPt* __restrict__ pt
 // is a group endomorphism, so  sum k2_digit * psi(T) = psi(sum k2_digit * T)  — the lane that sums the k2 digits of its
 // scalars applies psi to its partial sum once (one multiplication); its neighbour sums the k1 digits.  16 additions per scalar
 // at c = 16 from a 137 GB table, against 18 at c = 15 from 154 GB without the split.
+// GLV form, step 1: one lane per scalar writes its 16 table selectors — for each half (k1, k2) and window the entry
+// (|digit| - 1) | sign << 31, or FBW_SKIP for a zero digit.  The accumulation kernel then reads 32 bytes per (scalar,
+// half) instead of redoing the split in both lanes of a pair and extracting digits from a register array with
+// select chains (≈3 % of its instructions).
+constexpr u32 FBW_SKIP = 0xffffffffu;
+__global__ void __launch_bounds__(256) k_fbw_digits(DigitParams P, const u32* __restrict__ scalars, u32* __restrict__ digits) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.n * P.nbatch) return;
+    u32 s[8], s1[8], s2[8], n1, n2;
+    load_scalar(s, scalars, t, P.mont);
+    kzgamd::glv_split(s, s1, s2, n1, n2);
+    const u32 half = 1u << (P.c - 1);
+    u32 out[16];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const u32* sv = part ? s2 : s1;
+        const u32 pneg = part ? n2 : n1;
+        u32 carry = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            u32 e = FBW_SKIP;
+            if (w < P.nwin) {
+                u32 d = window_bits(sv, w * P.c, P.c) + carry;
+                u32 neg = pneg;
+                carry = 0;
+                if (d > half) {
+                    d = (1u << P.c) - d;
+                    neg ^= 1;
+                    carry = 1;
+                }
+                if (d != 0) e = (d - 1) | (neg << 31);
+            }
+            out[part * 8 + w] = e;
+        }
+    }
+    uint4* dst = reinterpret_cast<uint4*>(digits + t * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+}
+
 template <int SPL, bool GLV>
 __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __restrict__ scalars,
                                                    const WidePt* __restrict__ wide, Xyzz* __restrict__ partial,
@@ -962,7 +1003,8 @@ __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __r
     if (t >= lanes_per_msm * P.nbatch) return;
     const size_t b = t / lanes_per_msm;
     size_t l = t % lanes_per_msm;
-    // GLV: neighbouring lanes take the two halves of the same scalars (k1 digits / k2 digits)
+    // GLV: neighbouring lanes take the two halves of the same scalars (k1 digits / k2 digits); `scalars` then holds
+    // the selectors k_fbw_digits wrote, 16 words per scalar (at most 8 windows per half)
     const u32 part = GLV ? (u32)(l & 1) : 0u;
     if (GLV) l >>= 1;
     Xyzz acc;
@@ -973,34 +1015,40 @@ __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __r
     for (int k = 0; k < SPL; ++k) {
         const size_t i = l * (size_t)SPL + k;
         if (SPL > 1 && i >= P.n) break;
-        u32 s[8];
-        load_scalar(s, scalars, b * P.n + i, P.mont);
-        u32 pneg = 0;
         if (GLV) {
-            u32 kk[8], s1[8], s2[8], n1, n2;
+            const uint4* dg = reinterpret_cast<const uint4*>(scalars + (b * P.n + i) * 16 + part * 8);
+            const uint4 lo = dg[0], hi = dg[1];
+            const u32 e8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) kk[q] = s[q];
-            kzgamd::glv_split(kk, s1, s2, n1, n2);
-            pneg = part ? n2 : n1;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) s[q] = part ? s2[q] : s1[q];
-        }
-        u32 carry = 0;
-        for (int w = 0; w < P.nwin; ++w) {
-            u32 d = window_bits(s, w * P.c, P.c) + carry;
-            u32 neg = pneg;
-            carry = 0;
-            if (d > half) {
-                d = (1u << P.c) - d;
-                neg ^= 1;
-                carry = 1;
+            for (int w = 0; w < 8; ++w) {
+                const u32 e = e8[w];
+                if (e == FBW_SKIP) continue;
+                const WidePt pk = wide[(((size_t)w * P.row_stride + i) << sh) + (e & 0x7fffffffu)];
+                if (pk.pad[0]) continue;  // multiple of a base at infinity
+                fp28::Fe x = pk.x, y = pk.y;
+                if (e >> 31) y = fp28::neg<2>(y);
+                g1::madd(acc, x, y);
             }
-            if (d == 0) continue;
-            const WidePt pk = wide[(((size_t)w * P.row_stride + i) << sh) + (d - 1)];
-            if (fp28::is_zero_limbs(pk.x) && fp28::is_zero_limbs(pk.y)) continue;  // multiple of a base at infinity
-            fp28::Fe x = pk.x, y = pk.y;
-            if (neg) y = fp28::neg<2>(y);
-            g1::madd(acc, x, y);
+        } else {
+            u32 s[8];
+            load_scalar(s, scalars, b * P.n + i, P.mont);
+            u32 carry = 0;
+            for (int w = 0; w < P.nwin; ++w) {
+                u32 d = window_bits(s, w * P.c, P.c) + carry;
+                u32 neg = 0;
+                carry = 0;
+                if (d > half) {
+                    d = (1u << P.c) - d;
+                    neg = 1;
+                    carry = 1;
+                }
+                if (d == 0) continue;
+                const WidePt pk = wide[(((size_t)w * P.row_stride + i) << sh) + (d - 1)];
+                if (pk.pad[0]) continue;  // multiple of a base at infinity
+                fp28::Fe x = pk.x, y = pk.y;
+                if (neg) y = fp28::neg<2>(y);
+                g1::madd(acc, x, y);
+            }
         }
     }
     if (GLV && part && !g1::is_inf(acc)) {
@@ -1177,7 +1225,7 @@ struct DevBuf {
 };
 
 struct Workspace {
-    DevBuf<u32> counts, offsets, sorted, scalars, ranks, tmp, bins;
+    DevBuf<u32> counts, offsets, sorted, scalars, ranks, tmp, bins, digits;
     DevBuf<Xyzz> buckets, lvlA[2], lvlM[2], top, win;
     DevBuf<unsigned char> heavy;
     DevBuf<u32> heavy_list, nheavy;
@@ -1189,6 +1237,7 @@ struct Workspace {
         if (last_done) (void)hipEventDestroy(last_done);
         last_done = nullptr;
         counts.release();
+        digits.release();
         offsets.release();
         sorted.release();
         ranks.release();
@@ -1454,6 +1503,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         ws.buckets.ensure(nbatch * lanes);
         ws.lvlM[0].ensure(nbatch);
         if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) ws.lvlA[0].ensure(nbatch * 16);
+        if (ctx->fbw_glv) ws.digits.ensure(nbatch * npoints * 16);
         if (reserve_only) return;
         WsUse ws_use(ws, stream);
         DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n, 0, 0, nwin};
@@ -1466,11 +1516,17 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             }
             pev = &ctx->ev[ctx->ev_used];
             HIP_TRY(hipEventRecord(pev[0], stream));
-            HIP_TRY(hipEventRecord(pev[1], stream));
         }
+        const u32* acc_in = (const u32*)d_scalars;
+        if (ctx->fbw_glv) {
+            hipLaunchKernelGGL(k_fbw_digits, dim3((unsigned)((npoints * nbatch + 255) / 256)), dim3(256), 0, stream, P,
+                               (const u32*)d_scalars, ws.digits.p);
+            acc_in = ws.digits.p;
+        }
+        if (pev) HIP_TRY(hipEventRecord(pev[1], stream));
         const dim3 grid((unsigned)((lanes * nbatch + 255) / 256));
 #define KZG_FBW_LAUNCH(SPL_, GLV_)                                                                           \
-    hipLaunchKernelGGL((k_fbw_accum<SPL_, GLV_>), grid, dim3(256), 0, stream, P, (const u32*)d_scalars,          \
+    hipLaunchKernelGGL((k_fbw_accum<SPL_, GLV_>), grid, dim3(256), 0, stream, P, acc_in,                         \
                        (const WidePt*)ctx->wide.p, ws.buckets.p, lanes)
         if (ctx->fbw_glv) {
             if (spl == 2) KZG_FBW_LAUNCH(2, true);
