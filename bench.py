@@ -260,6 +260,23 @@ def main():
         dist.all_gather_object(gathered, devices[0])
         devices = gathered
 
+    gather_ms = None
+    if dist is not None:
+        # the one collective a sharded batch needs: all ranks' 48-byte results of one batch, gathered as
+        # device tensors (ncclAllGather over RCCL); outside the timed region, timed on its own
+        import importlib.util as _u
+
+        _sp = _u.spec_from_file_location("kzg_sharding", os.path.join(ROOT, "rust-kzg_amd", "sharding.py"))
+        _sh = _u.module_from_spec(_sp)
+        _sp.loader.exec_module(_sh)
+        _sh.gather_results(outs[0], B * world, 48, dist)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        allc = _sh.gather_results(outs[0], B * world, 48, dist)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - t0) * 1e3
+        assert allc.numel() == B * world * 48 and torch.equal(allc[rank * B * 48:(rank + 1) * B * 48], outs[0])
+
     total_commits = B * NB * args.steps * world
     value = total_commits / wall_max
     res = {
@@ -286,6 +303,8 @@ def main():
         "streams": NS,
         "devices": devices,
     }
+    if gather_ms is not None:
+        res["result_allgather_ms"] = gather_ms
     pm, pm_src = pmc_summary()
     if prof is not None:
         accum_ms, total_ms, cnt = prof

@@ -54,3 +54,26 @@ def msm_sharded(n_points: int, msm_partial: Callable[[int, int], bytes], g1_sum:
     if any(len(p) != 144 for p in gathered):
         raise RuntimeError("sharded MSM: malformed partial")
     return g1_sum(gathered)
+
+
+def gather_results(mine, n_items: int, item_bytes: int, dist, device=None):
+    """The one collective of a sharded batch: every rank contributes its slab of fixed-size results (a uint8 tensor of
+    (hi - lo) * item_bytes bytes, on `device`) and receives all n_items * item_bytes bytes in batch order.  One
+    all_gather of equal-sized pieces — ncclAllGather over RCCL when the tensors live on the GPUs, gloo on the host
+    (256 commitments x 48 B = 12 KiB: link bandwidth is irrelevant, it is one latency).  Slabs differ by at most one item
+    (shard_range), so every piece is padded to the largest slab and trimmed after the gather."""
+    import torch
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    spans = [shard_range(n_items, world, r) for r in range(world)]
+    cap = max(hi - lo for lo, hi in spans) * item_bytes
+    lo, hi = spans[rank]
+    if mine.numel() != (hi - lo) * item_bytes or mine.dtype != torch.uint8:
+        raise ValueError("gather_results: rank %d must contribute %d bytes" % (rank, (hi - lo) * item_bytes))
+    dev = mine.device if device is None else device
+    piece = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    piece[: mine.numel()] = mine
+    out = torch.empty(world * cap, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, piece)
+    parts = [out[r * cap: r * cap + (spans[r][1] - spans[r][0]) * item_bytes] for r in range(world)]
+    return torch.cat(parts)

@@ -129,6 +129,11 @@ lo, hi = sh.shard_range(5, 2, RANK)
 assert calls == [hi - lo], calls            # each rank computed only its slab
 full = engine(blobs)
 assert got == full
+# the tensor form of the gather (what runs as ncclAllGather on GPUs): uneven slabs, batch order restored
+import torch
+mine = torch.frombuffer(bytearray(b"".join(full[lo:hi])), dtype=torch.uint8)
+allres = sh.gather_results(mine, 5, 48, dist)
+assert bytes(allres.numpy().tobytes()) == b"".join(full)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", RANK, "ok")
