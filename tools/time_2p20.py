@@ -1,26 +1,39 @@
 #!/usr/bin/env python3
-"""Time the device-resident variable-base MSM at n = 2^logn (default 20) under the current environment."""
-import os, sys
+"""2^16 .. 2^22 variable-base MSM timings (device-resident, HIP events, min of 5)."""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
-import extra_bench as eb
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
-kzg = eb.load_pkg()
+from conftest import load_package
+
+kzg = load_package()
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
-logn = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-n = 1 << logn
-pts = torch.empty(n * 96, dtype=torch.uint8, device=dev)
-kzg.generate_points(pts.data_ptr(), n, 2, stream)
-g = torch.Generator(device="cpu"); g.manual_seed(2)
-sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g); sc[:, 31] &= 0x3F; sc = sc.to(dev)
+nmax = 1 << 22
+pts = torch.empty(nmax * 96, dtype=torch.uint8, device=dev)
+kzg.generate_points(pts.data_ptr(), nmax, 2, stream)
+torch.cuda.synchronize()
+g = torch.Generator(device=dev)
+g.manual_seed(2)
+sc = torch.randint(0, 256, (nmax, 32), dtype=torch.uint8, generator=g, device=dev)
+sc[:, 31] &= 0x3F
 out = torch.zeros(144, dtype=torch.uint8, device=dev)
-h = kzg.DeviceMsm(pts.data_ptr(), n, False)
-fn = lambda: kzg.msm_prepared_batch_device(h, out.data_ptr(), sc.data_ptr(), n, 1, False, stream)
-fn(); torch.cuda.synchronize()
-ts = []
-for _ in range(5):
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record(); fn(); b.record(); torch.cuda.synchronize()
-    ts.append(a.elapsed_time(b))
-print("logn", logn, "groups", os.environ.get("KZGAMD_GROUPS", "default"), "ms", round(min(ts), 3), [round(t, 3) for t in ts], out.cpu().numpy()[:8].tolist())
+res = {}
+for logn in (14, 16, 18, 20, 22):
+    n = 1 << logn
+    h = kzg.DeviceMsm(pts.data_ptr(), n, False)
+    kzg.msm_prepared_batch_device(h, out.data_ptr(), sc.data_ptr(), n, 1, False, stream)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        kzg.msm_prepared_batch_device(h, out.data_ptr(), sc.data_ptr(), n, 1, False, stream)
+        b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    res["2^%d" % logn] = round(min(ts), 3)
+    h.close()
+print(res, out[:8].cpu().tolist())
