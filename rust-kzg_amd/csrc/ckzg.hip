@@ -1443,9 +1443,13 @@ extern "C" C_KZG_RET kzgamd_blob_to_kzg_commitment_batch(KZGCommitment* out, con
             // its chunk is staged — while this thread stages chunk k + 1 the GPU commits to chunk k, and the tails of
             // neighbouring chunks overlap (one MSM workspace per stream).  PCIe and compute run concurrently instead
             // of back to back.
-            const size_t nchunks = (n + COMMIT_CHUNK - 1) / COMMIT_CHUNK;
+            // a quarter of the call per chunk, between 256 blobs (the first copy, which nothing hides, stays short) and
+            // 1024 (where the MSM kernels run at their full rate)
+            size_t chunk = n / 4;
+            chunk = chunk < COMMIT_CHUNK ? COMMIT_CHUNK : (chunk > 4 * COMMIT_CHUNK ? 4 * COMMIT_CHUNK : chunk);
+            const size_t nchunks = (n + chunk - 1) / chunk;
             for (size_t k = 0; k < nchunks; ++k) {
-                const size_t off = k * COMMIT_CHUNK, cn = off + COMMIT_CHUNK <= n ? COMMIT_CHUNK : n - off;
+                const size_t off = k * chunk, cn = off + chunk <= n ? chunk : n - off;
                 hipStream_t cs = dev->pipe_stream(k);
                 CK_HIP(hipMemcpyAsync(dev->d_blobs + off * BYTES_PER_BLOB, blobs + off, cn * BYTES_PER_BLOB, hipMemcpyHostToDevice, cs));
                 commit_enqueue(dev, dev->d_out + off * 48, dev->d_status + off, dev->d_blobs + off * BYTES_PER_BLOB,
