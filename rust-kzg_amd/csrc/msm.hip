@@ -1037,8 +1037,8 @@ __global__ void __launch_bounds__(64) k_bases_in_g1(const AffPt* __restrict__ pt
 // is a group endomorphism, so  sum k2_digit * psi(T) = psi(sum k2_digit * T)  — the lane that sums the k2 digits of its
 // scalars applies psi to its partial sum once (one multiplication); its neighbour sums the k1 digits.  16 additions per scalar
 // at c = 16 from a 137 GB table, against 18 at c = 15 from 154 GB without the split.
-// GLV form, step 1: one lane per scalar writes its 16 table selectors — for each half (k1, k2) and window the entry
-// (|digit| - 1) | sign << 31, or FBW_SKIP for a zero digit.  The accumulation kernel then reads 32 bytes per (scalar,
+// GLV form, step 1: one lane per scalar writes its table selectors — for each half (k1, k2) and window the entry
+// (|digit| - 1) | sign << 31, or FBW_SKIP for a zero digit; DW = nwin rounded up to a multiple of 4 words per half.  The accumulation kernel then reads 32 bytes per (scalar,
 // half) instead of redoing the split in both lanes of a pair and extracting digits from a register array with
 // select chains (≈3 % of its instructions).
 constexpr u32 FBW_SKIP = 0xffffffffu;
@@ -1049,32 +1049,34 @@ __global__ void __launch_bounds__(256) k_fbw_digits(DigitParams P, const u32* __
     load_scalar(s, scalars, t, P.mont);
     kzgamd::glv_split(s, s1, s2, n1, n2);
     const u32 half = 1u << (P.c - 1);
-    u32 out[16];
-#pragma unroll
+    const int DW = (P.nwin + 3) & ~3;
     for (int part = 0; part < 2; ++part) {
         const u32* sv = part ? s2 : s1;
         const u32 pneg = part ? n2 : n1;
         u32 carry = 0;
+        uint4* dst = reinterpret_cast<uint4*>(digits + (t * 2 + part) * DW);
+        for (int w4 = 0; w4 < DW; w4 += 4) {
+            u32 e4[4];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            u32 e = FBW_SKIP;
-            if (w < P.nwin) {
-                u32 d = window_bits(sv, w * P.c, P.c) + carry;
-                u32 neg = pneg;
-                carry = 0;
-                if (d > half) {
-                    d = (1u << P.c) - d;
-                    neg ^= 1;
-                    carry = 1;
+            for (int q = 0; q < 4; ++q) {
+                const int w = w4 + q;
+                u32 e = FBW_SKIP;
+                if (w < P.nwin) {
+                    u32 d = window_bits(sv, w * P.c, P.c) + carry;
+                    u32 neg = pneg;
+                    carry = 0;
+                    if (d > half) {
+                        d = (1u << P.c) - d;
+                        neg ^= 1;
+                        carry = 1;
+                    }
+                    if (d != 0) e = (d - 1) | (neg << 31);
                 }
-                if (d != 0) e = (d - 1) | (neg << 31);
+                e4[q] = e;
             }
-            out[part * 8 + w] = e;
+            dst[w4 >> 2] = make_uint4(e4[0], e4[1], e4[2], e4[3]);
         }
     }
-    uint4* dst = reinterpret_cast<uint4*>(digits + t * 16);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
 }
 
 template <int SPL, bool GLV>
@@ -1086,7 +1088,7 @@ __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __r
     const size_t b = t / lanes_per_msm;
     size_t l = t % lanes_per_msm;
     // GLV: neighbouring lanes take the two halves of the same scalars (k1 digits / k2 digits); `scalars` then holds
-    // the selectors k_fbw_digits wrote, 16 words per scalar (at most 8 windows per half)
+    // the selectors k_fbw_digits wrote, DW words per (scalar, half)
     const u32 part = GLV ? (u32)(l & 1) : 0u;
     if (GLV) l >>= 1;
     Xyzz acc;
@@ -1098,18 +1100,21 @@ __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __r
         const size_t i = l * (size_t)SPL + k;
         if (SPL > 1 && i >= P.n) break;
         if (GLV) {
-            const uint4* dg = reinterpret_cast<const uint4*>(scalars + (b * P.n + i) * 16 + part * 8);
-            const uint4 lo = dg[0], hi = dg[1];
-            const u32 e8[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const int DW = (P.nwin + 3) & ~3;
+            const uint4* dg = reinterpret_cast<const uint4*>(scalars + ((b * P.n + i) * 2 + part) * DW);
+            for (int w4 = 0; w4 < DW; w4 += 4) {
+                const uint4 v = dg[w4 >> 2];
+                const u32 e4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const u32 e = e8[w];
-                if (e == FBW_SKIP) continue;
-                const WidePt pk = wide[(((size_t)w * P.row_stride + i) << sh) + (e & 0x7fffffffu)];
-                if (pk.pad[0]) continue;  // multiple of a base at infinity
-                fp28::Fe x = pk.x, y = pk.y;
-                if (e >> 31) y = fp28::neg<2>(y);
-                g1::madd(acc, x, y);
+                for (int q = 0; q < 4; ++q) {
+                    const u32 e = e4[q];
+                    if (e == FBW_SKIP) continue;
+                    const WidePt pk = wide[(((size_t)(w4 + q) * P.row_stride + i) << sh) + (e & 0x7fffffffu)];
+                    if (pk.pad[0]) continue;  // multiple of a base at infinity
+                    fp28::Fe x = pk.x, y = pk.y;
+                    if (e >> 31) y = fp28::neg<2>(y);
+                    g1::madd(acc, x, y);
+                }
             }
         } else {
             u32 s[8];
@@ -1586,7 +1591,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         ws.buckets.ensure(nbatch * lanes);
         ws.lvlM[0].ensure(nbatch);
         if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) ws.lvlA[0].ensure(nbatch * 16);
-        if (ctx->fbw_glv) ws.digits.ensure(nbatch * npoints * 16);
+        if (ctx->fbw_glv) ws.digits.ensure(nbatch * npoints * 2 * (size_t)((nwin + 3) & ~3));
         if (reserve_only) return;
         WsUse ws_use(ws, stream);
         DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n, 0, 0, nwin};

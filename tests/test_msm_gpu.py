@@ -353,6 +353,42 @@ def test_prepared_bucket_path_without_wide_table(oracle, kzg, monkeypatch):
     h.close()
 
 
+@pytest.mark.parametrize("env", [{"KZGAMD_FBW_MAX_GB": "2.0"}, {"KZGAMD_FBW_MAX_GB": "0.6"}, {"KZGAMD_FBW_MAX_GB": "0.3"},
+                                 {"KZGAMD_FBW_MAX_GB": "0.1"}, {"KZGAMD_FBW_MAX_GB": "2.0", "KZGAMD_FBW_GLV": "0"},
+                                 {"KZGAMD_FBW_MAX_GB": "0.3", "KZGAMD_FBW_GLV": "0"}])
+def test_wide_table_every_window_shape(oracle, kzg, monkeypatch, env):
+    """The wide table under shrinking budgets: each budget picks another (window, rows, GLV / plain) shape — among them
+    window counts that are not a multiple of four (the selector rows are padded) — and every shape gives the oracle's
+    result, single call and batch."""
+    L = oracle.lib()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rnd = random.Random(151)
+    n = 96
+    pts = gen_points(L, n, rnd)
+    pts[5] = O.G1Affine()
+    h = kzg.prepare_multi_scalar_mult(pts, n)
+    info = h.info()
+    assert info["wide_table"], info
+    # n = 96: 2.0 GB -> GLV c=15 (9 windows), 0.6 -> GLV c=13 (10), 0.3 -> GLV c=12 (11), 0.1 -> GLV c=10 (13);
+    # without the split 2.0 -> c=14 (19 windows), 0.3 -> c=10 (26)
+    want = {("2.0", None): 9, ("0.6", None): 10, ("0.3", None): 11, ("0.1", None): 13, ("2.0", "0"): 19, ("0.3", "0"): 26}
+    assert info["rows"] == want[(env["KZGAMD_FBW_MAX_GB"], env.get("KZGAMD_FBW_GLV"))], info
+    assert info["wide_glv"] == (env.get("KZGAMD_FBW_GLV") != "0")
+    vals = [rnd.randrange(O.R) for _ in range(n)]
+    vals[0], vals[1], vals[2] = 0, O.R - 1, 1
+    batches = [vals, [rnd.randrange(1 << 130) for _ in range(n)], [O.R - 1 - rnd.randrange(1 << 20) for _ in range(n)],
+               [0] * n, [rnd.randrange(O.R) for _ in range(n)]]
+    check(L, kzg, pts, O.fr_array(vals), n, prepared=h, unprepared=False)
+    flat = O.fr_array([x for v in batches for x in v])
+    got = kzg.multi_scalar_mult_prepared_batch(h, flat, n, len(batches))
+    for b, v in enumerate(batches):
+        exp = O.G1()
+        L.omsm_affine(C.byref(exp), pts, O.fr_array(v), n)
+        assert compressed(L, as_oracle_g1(got[b])) == compressed(L, exp), (b, info)
+    h.close()
+
+
 @pytest.mark.parametrize("nbatch", [3, 70])
 def test_variable_base_device_handle_batched(oracle, kzg, nbatch):
     """Several MSMs over one variable-base device handle in one launch: 3 (top-of-tree sums + limb-parallel

@@ -18,3 +18,18 @@ for name, fn in (("commit", lambda: kzg.blob_to_kzg_commitment(b, s)), ("blob pr
         fn()
     print("%-10s %.3f ms" % (name, (time.perf_counter() - t0) / 50 * 1e3), os.environ.get("KZGAMD_WSPLIT", "default"))
 s.close()
+# verification: field work / G1 combinations on the GPU, one pairing check on the host
+s = kzg.KZGSettings.from_file(eb.SETUP)
+p = kzg.compute_blob_kzg_proof(b, c, s)
+assert kzg.verify_blob_kzg_proof(b, c, p, s)
+t0 = time.perf_counter()
+for _ in range(5):
+    kzg.verify_blob_kzg_proof(b, c, p, s)
+print("%-10s %.3f ms" % ("verify_blob_kzg_proof", (time.perf_counter() - t0) / 5 * 1e3))
+n = 64
+assert kzg.verify_blob_kzg_proof_batch([b] * n, [c] * n, [p] * n, s)
+t0 = time.perf_counter()
+for _ in range(3):
+    kzg.verify_blob_kzg_proof_batch([b] * n, [c] * n, [p] * n, s)
+print("%-10s %.3f ms per call of %d blobs" % ("verify_blob_kzg_proof_batch", (time.perf_counter() - t0) / 3 * 1e3, n))
+s.close()
