@@ -1,5 +1,7 @@
-// Fp spread over the lanes of a 16-lane DPP row: limb i of the 14 x 28-bit form (fp28.hip.h) lives in lane i,
-// lanes 14 and 15 hold zero.  One element per wave (lanes 0..15 active, the rest idle).
+// Fp spread over the lanes of a 16-lane DPP row: limb i of the 14 x 28-bit form (fp28.hip.h) lives in lane i of the
+// row, lanes 14 and 15 hold zero.  A wave has four rows: values are kept replicated in all four, and a multiplication
+// step (wmul4) takes a different operand pair in each row — the independent products of a point formula run side by
+// side, so a doubling is 3 multiplication steps deep instead of 7 and an addition 4 instead of 14.
 //
 // Why: the tails of the MSM (Horner over the window sums, the short per-window chains) are single dependency
 // chains of point doublings.  A lane that owns a whole field element issues ~490 VALU instructions per
@@ -74,38 +76,61 @@ __device__ __forceinline__ u32 waddn(u32 a, u32 b, const Lane& c) { return wnorm
 __device__ __forceinline__ u32 wsub16(u32 a, u32 b, const Lane& c) { return wnorm(a + c.pad16 - b, c); }
 __device__ __forceinline__ u32 wsub32(u32 a, u32 b, const Lane& c) { return wnorm(a + c.pad32 - b, c); }
 
-// a * b * 2^-392 mod p
-__device__ __forceinline__ u32 wmul(u32 a, u32 b, const Lane& c) {
+// lane J of each row to every lane of that row
+template <int J>
+__device__ __forceinline__ u32 row_lane(u32 x) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + J, 0xF, 0xF, false);  // row_newbcast:J
+}
+// row k of the wave to all four rows (ds_bpermute: a lane permutation through the LDS crossbar, no memory)
+__device__ __forceinline__ u32 row_all(u32 x, int k, int lane) {
+    return (u32)__builtin_amdgcn_ds_bpermute(((k << 4) | (lane & 15)) << 2, (int)x);
+}
+// per-row choice: row r of the result is row r of a_r
+__device__ __forceinline__ u32 rows4(int row, u32 a0, u32 a1, u32 a2, u32 a3) {
+    return row == 0 ? a0 : row == 1 ? a1 : row == 2 ? a2 : a3;
+}
+
+// a * b * 2^-392 mod p, independently in each of the four rows.  14 steps of
+//     acc += a_i * b_j (b_j by a DPP row broadcast) ; m = acc_0 * p' ; acc += p_i * m ;
+//     acc_i <- low28(acc_{i+1}) + (acc_i >> 28)            (one DPP row shift folded into the add)
+__device__ __forceinline__ u32 wmul4(u32 a, u32 b, const Lane& c) {
     u32 acc = 0;
-#pragma unroll
-    for (int j = 0; j < fp28::L; ++j) {
-        const u32 bj = (u32)__builtin_amdgcn_readlane((int)b, j);
-        u64 t = (u64)a * bj + acc;
-        const u32 t0 = (u32)__builtin_amdgcn_readlane((int)(u32)t, 0);
-        const u32 m = (t0 * fp28::P0INV) & MASK;
-        t += (u64)c.p * m;
-        // lane 0 now holds a multiple of 2^28: drop it, everything moves one limb down
-        acc = from_next((u32)t & MASK) + (u32)(t >> 28);
+#define KZG_WSTEP(J)                                               \
+    {                                                              \
+        const u32 bj = row_lane<J>(b);                             \
+        u64 t = (u64)a * bj + acc;                                 \
+        const u32 m = (row_lane<0>((u32)t) * fp28::P0INV) & MASK;  \
+        t += (u64)c.p * m;                                         \
+        acc = from_next((u32)t & MASK) + (u32)(t >> 28);           \
     }
+    KZG_WSTEP(0) KZG_WSTEP(1) KZG_WSTEP(2) KZG_WSTEP(3) KZG_WSTEP(4) KZG_WSTEP(5) KZG_WSTEP(6)
+    KZG_WSTEP(7) KZG_WSTEP(8) KZG_WSTEP(9) KZG_WSTEP(10) KZG_WSTEP(11) KZG_WSTEP(12) KZG_WSTEP(13)
+#undef KZG_WSTEP
     return wnorm(acc, c);
 }
-__device__ __forceinline__ u32 wsqr(u32 a, const Lane& c) { return wmul(a, a, c); }
+// the same product in every row (operands replicated)
+__device__ __forceinline__ u32 wmul(u32 a, u32 b, const Lane& c) { return wmul4(a, b, c); }
+__device__ __forceinline__ u32 wsqr(u32 a, const Lane& c) { return wmul4(a, a, c); }
 
-// Jacobian doubling (dbl-2009-l with S = 4*X*YY as one product), the wide twin of the loop body of g1::dbl_k.
+// Jacobian doubling (dbl-2009-l with S = 4*X*YY as one product), the wide twin of the loop body of g1::dbl_k, in three
+// multiplication steps: [XX, YY, YZ], [YYYY, X*YY, E^2], [E*(S - X3)].
 // Bounds as there: X < 18p, Y < 17.1p, Z < 2.1p, all normalized.
-__device__ __forceinline__ void wdbl(u32& X, u32& Y, u32& Z, const Lane& c) {
-    const u32 A = wsqr(X, c), B = wsqr(Y, c), C = wsqr(B, c);
-    u32 S = wmul(X, B, c);
+__device__ __forceinline__ void wdbl(u32& X, u32& Y, u32& Z, const Lane& c, int lane) {
+    const int row = lane >> 4;
+    u32 t = wmul4(rows4(row, X, Y, Y, X), rows4(row, X, Y, Z, X), c);
+    const u32 A = row_all(t, 0, lane), B = row_all(t, 1, lane), YZ = row_all(t, 2, lane);
+    const u32 E = wnorm(A + A + A, c);        // 3*XX
+    t = wmul4(rows4(row, B, X, E, E), rows4(row, B, B, E, E), c);
+    const u32 C = row_all(t, 0, lane), EE = row_all(t, 2, lane);
+    u32 S = row_all(t, 1, lane);
     S = waddn(S, S, c);
     S = waddn(S, S, c);                       // 4*X*YY
-    const u32 E = wnorm(A + A + A, c);        // 3*XX
-    const u32 X3 = wsub16(wsqr(E, c), waddn(S, S, c), c);
+    const u32 X3 = wsub16(EE, waddn(S, S, c), c);
     u32 C8 = waddn(C, C, c);
     C8 = waddn(C8, C8, c);
     C8 = waddn(C8, C8, c);                    // 8*YYYY
-    const u32 Y3 = wsub16(wmul(E, wsub32(S, X3, c), c), C8, c);
-    const u32 Z3 = wmul(Y, Z, c);
-    Z = waddn(Z3, Z3, c);
+    const u32 Y3 = wsub16(wmul4(E, wsub32(S, X3, c), c), C8, c);
+    Z = waddn(YZ, YZ, c);
     X = X3;
     Y = Y3;
 }

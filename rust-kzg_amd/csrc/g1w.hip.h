@@ -1,5 +1,6 @@
-// G1 points with every coordinate spread over the lanes of a 16-lane row (fpw.hip.h): XYZZ coordinates as in
-// g1_28.hip.h, one point operation per wave, for the serial tails of the MSM where no other parallelism is left.
+// G1 points with every coordinate spread over the lanes of a 16-lane row (fpw.hip.h), replicated in the four rows of
+// the wave: XYZZ coordinates as in g1_28.hip.h, one point operation per wave with its independent products side by
+// side in the rows, for the serial tails of the MSM where no other parallelism is left.
 // Coordinate bounds between calls: X, Y < 18p, ZZ, ZZZ < 2p, limbs <= 2^28.
 #pragma once
 #include "fpw.hip.h"
@@ -36,7 +37,7 @@ __device__ __forceinline__ void store(g1::Xyzz* dst, const WPt& p, const Lane& c
     const int i = lane & 15;
     const u32 x = fpw::wnorm_full(p.x, c), y = fpw::wnorm_full(p.y, c), zzz = fpw::wnorm_full(p.zzz, c),
               zz = fpw::wnorm_full(p.zz, c);
-    if (i < fp28::L) {
+    if (lane < fp28::L) {  // the rows hold the same value: the first one writes
         w[i] = x;
         w[fp28::L + i] = y;
         w[2 * fp28::L + i] = zzz;
@@ -48,7 +49,7 @@ __device__ __forceinline__ void store(g1::Xyzz* dst, const WPt& p, const Lane& c
 // k*p has k = a_0 * p_0^-1 mod 2^28 < 64, which almost no other value passes; the exact comparison runs on
 // the single-lane code behind that filter
 __device__ __forceinline__ bool is_zero_mod_p(u32 a, u32* sh, int lane) {
-    const u32 a0 = (u32)__builtin_amdgcn_readlane((int)a, 0);
+    const u32 a0 = (u32)__builtin_amdgcn_readlane((int)a, 0);  // the rows hold the same value
     const u32 k = (a0 * fp28::P0INV_POS) & fp28::MASK;
     if (k >= 64) return false;
     fp28::Fe f = fpw::from_wide(a, sh, lane);
@@ -56,22 +57,27 @@ __device__ __forceinline__ bool is_zero_mod_p(u32 a, u32* sh, int lane) {
     return fp28::is_zero_mod_p(f);
 }
 
-// acc = 2 * acc (dbl-2008-s-1); acc != infinity
-__device__ __forceinline__ void dbl(WPt& acc, const Lane& c) {
+// acc = 2 * acc (dbl-2008-s-1); acc != infinity.  Three multiplication steps: [V, M], [W, S, ZZ*V, M3^2],
+// [M3*(S - X3), W*Y, ZZZ*W].
+__device__ __forceinline__ void dbl(WPt& acc, const Lane& c, int lane) {
     using namespace fpw;
+    const int row = lane >> 4;
     const u32 U = waddn(acc.y, acc.y, c);
-    const u32 V = wsqr(U, c), W = wmul(U, V, c), S = wmul(acc.x, V, c);
-    const u32 M = wsqr(acc.x, c);
+    u32 t = wmul4(rows4(row, U, acc.x, U, acc.x), rows4(row, U, acc.x, U, acc.x), c);
+    const u32 V = row_all(t, 0, lane), M = row_all(t, 1, lane);
     const u32 M3 = wnorm(M + M + M, c);
-    const u32 X3 = wsub16(wsqr(M3, c), waddn(S, S, c), c);
-    const u32 Y3 = wsub16(wmul(M3, wsub32(S, X3, c), c), wmul(W, acc.y, c), c);
+    t = wmul4(rows4(row, U, acc.x, acc.zz, M3), rows4(row, V, V, V, M3), c);
+    const u32 W = row_all(t, 0, lane), S = row_all(t, 1, lane), ZZ3 = row_all(t, 2, lane), MM = row_all(t, 3, lane);
+    const u32 X3 = wsub16(MM, waddn(S, S, c), c);
+    t = wmul4(rows4(row, M3, W, acc.zzz, W), rows4(row, wsub32(S, X3, c), acc.y, W, acc.y), c);
     acc.x = X3;
-    acc.y = Y3;
-    acc.zz = wmul(acc.zz, V, c);
-    acc.zzz = wmul(acc.zzz, W, c);
+    acc.y = wsub16(row_all(t, 0, lane), row_all(t, 1, lane), c);
+    acc.zz = ZZ3;
+    acc.zzz = row_all(t, 2, lane);
 }
 
-// acc += b (add-2008-s) with the exceptional cases of g1::dadd; sh = 16 words of LDS scratch
+// acc += b (add-2008-s) with the exceptional cases of g1::dadd; sh = 16 words of LDS scratch.  Four multiplication
+// steps: [U, S, U2, S2], [PP, RR, ZZ1*ZZ2, ZZZ1*ZZZ2], [PPP, Q, ZZ3], [R*(Q - X3), S*PPP, ZZZ3].
 __device__ __forceinline__ void dadd(WPt& acc, const WPt& b, const Lane& c, u32* sh, int lane) {
     using namespace fpw;
     if (is_inf(b)) return;
@@ -79,28 +85,35 @@ __device__ __forceinline__ void dadd(WPt& acc, const WPt& b, const Lane& c, u32*
         acc = b;
         return;
     }
-    const u32 U = wmul(acc.x, b.zz, c), S = wmul(acc.y, b.zzz, c);
-    const u32 P = wsub32(wmul(b.x, acc.zz, c), U, c), R = wsub32(wmul(b.y, acc.zzz, c), S, c);
+    const int row = lane >> 4;
+    u32 t = wmul4(rows4(row, acc.x, acc.y, b.x, b.y), rows4(row, b.zz, b.zzz, acc.zz, acc.zzz), c);
+    const u32 U = row_all(t, 0, lane), S = row_all(t, 1, lane);
+    const u32 P = wsub32(row_all(t, 2, lane), U, c), R = wsub32(row_all(t, 3, lane), S, c);
     if (is_zero_mod_p(P, sh, lane)) {
-        if (is_zero_mod_p(R, sh, lane)) dbl(acc, c);
+        if (is_zero_mod_p(R, sh, lane)) dbl(acc, c, lane);
         else set_inf(acc);
         return;
     }
-    const u32 PP = wsqr(P, c), PPP = wmul(P, PP, c), Q = wmul(U, PP, c);
-    const u32 X3 = wsub16(wsqr(R, c), wnorm(Q + Q + PPP, c), c);
-    const u32 Y3 = wsub16(wmul(R, wsub32(Q, X3, c), c), wmul(S, PPP, c), c);
+    t = wmul4(rows4(row, P, R, acc.zz, acc.zzz), rows4(row, P, R, b.zz, b.zzz), c);
+    const u32 PP = row_all(t, 0, lane), RR = row_all(t, 1, lane), ZZ12 = row_all(t, 2, lane), ZZZ12 = row_all(t, 3, lane);
+    t = wmul4(rows4(row, P, U, ZZ12, P), rows4(row, PP, PP, PP, PP), c);
+    const u32 PPP = row_all(t, 0, lane), Q = row_all(t, 1, lane), ZZ3 = row_all(t, 2, lane);
+    const u32 X3 = wsub16(RR, wnorm(Q + Q + PPP, c), c);
+    t = wmul4(rows4(row, R, S, ZZZ12, R), rows4(row, wsub32(Q, X3, c), PPP, PPP, PPP), c);
     acc.x = X3;
-    acc.y = Y3;
-    acc.zz = wmul(wmul(acc.zz, b.zz, c), PP, c);
-    acc.zzz = wmul(wmul(acc.zzz, b.zzz, c), PPP, c);
+    acc.y = wsub16(row_all(t, 0, lane), row_all(t, 1, lane), c);
+    acc.zz = ZZ3;
+    acc.zzz = row_all(t, 2, lane);
 }
 
-// acc = 2^k * acc through Jacobian doublings (7 multiplications each against 9 for the XYZZ form)
-__device__ __forceinline__ void dbl_k(WPt& acc, int k, const Lane& c) {
+// acc = 2^k * acc through Jacobian doublings (3 multiplication steps each)
+__device__ __forceinline__ void dbl_k(WPt& acc, int k, const Lane& c, int lane) {
     using namespace fpw;
     if (k <= 0 || is_inf(acc)) return;
-    u32 X = wmul(acc.x, acc.zz, c), Y = wmul(acc.y, acc.zzz, c), Z = acc.zz;
-    for (int i = 0; i < k; ++i) wdbl(X, Y, Z, c);
+    const int row = lane >> 4;
+    const u32 t = wmul4(rows4(row, acc.x, acc.y, acc.x, acc.y), rows4(row, acc.zz, acc.zzz, acc.zz, acc.zzz), c);
+    u32 X = row_all(t, 0, lane), Y = row_all(t, 1, lane), Z = acc.zz;
+    for (int i = 0; i < k; ++i) wdbl(X, Y, Z, c, lane);
     acc.x = X;
     acc.y = Y;
     acc.zz = wsqr(Z, c);

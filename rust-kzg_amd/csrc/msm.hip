@@ -673,7 +673,7 @@ __global__ void __launch_bounds__(128) k_level(const Xyzz* __restrict__ inA, con
 // bucket read J = ceil(log2(nb)/5) times),  (b) log2(nb) + 1 plain sums of <= 32 points (k_digit_bits),  (c) the
 // Horner over the log2(nb) bit sums that k_winsum_wide already does.  Depth: 4 + 8 tree steps, 5 tree steps, the
 // Horner — against ~24-addition chains per level of the (A, M) tree, which this replaces when there are few sets.
-constexpr int DIGIT_BITS = 5, DIGIT_T = 256;
+constexpr int DIGIT_BITS = 5, DIGIT_T = 128;
 // every bucket's pieces folded once into a dense array (each bucket is then read once per digit)
 __global__ void __launch_bounds__(128) k_fold_buckets(const Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
                                                       const unsigned char* __restrict__ heavy, Xyzz* __restrict__ dense,
@@ -888,23 +888,24 @@ __global__ void __launch_bounds__(64) k_final(const Xyzz* __restrict__ rootA, co
     out[3 * b + 2] = j[2];
 }
 
-// The serial tails with limb-parallel arithmetic (fpw.hip.h / g1w.hip.h): one point operation per wave, ~3x shorter
-// instruction streams than the single-lane code.  Used when there are only a few chains (one large MSM).
+// The serial tails with limb-parallel arithmetic (fpw.hip.h / g1w.hip.h): one point operation per wave, the limbs of a
+// coordinate across the 16 lanes of a row and the independent products of a formula across the four rows — a doubling
+// is 3 dependent multiplications deep (7 in the single-lane code), an addition 4 (14).  Used when there are only a few
+// chains (one large MSM).
 //
 // k_winsum_wide: one wave per set,  window sum = A + M + 2^logS * sum_q 2^q R_q
 __global__ void __launch_bounds__(64) k_winsum_wide(const Xyzz* __restrict__ top, Xyzz* __restrict__ win, int B, int logS) {
     __shared__ u32 sh[16];
     const int lane = threadIdx.x;
-    if (lane >= 16) return;
     const fpw::Lane lc = fpw::lane_consts(lane);
     const Xyzz* t = top + (size_t)blockIdx.x * (B + 2);
     g1w::WPt acc;
     g1w::set_inf(acc);
     for (int q = B - 1; q >= 0; --q) {
-        if (!g1w::is_inf(acc)) g1w::dbl(acc, lc);
+        if (!g1w::is_inf(acc)) g1w::dbl(acc, lc, lane);
         g1w::dadd(acc, g1w::load(t + q, lane), lc, sh, lane);
     }
-    g1w::dbl_k(acc, logS, lc);
+    g1w::dbl_k(acc, logS, lc, lane);
     g1w::dadd(acc, g1w::load(t + B + 1, lane), lc, sh, lane);
     g1w::dadd(acc, g1w::load(t + B, lane), lc, sh, lane);
     g1w::store(win + blockIdx.x, acc, lc, lane);
@@ -914,12 +915,11 @@ __global__ void __launch_bounds__(64) k_winsum_wide(const Xyzz* __restrict__ top
 __global__ void __launch_bounds__(64) k_final_wide(const Xyzz* __restrict__ win, void* __restrict__ out_v, int nwin, int c) {
     __shared__ u32 sh[16];
     const int lane = threadIdx.x;
-    if (lane >= 16) return;
     const size_t b = blockIdx.x;
     const fpw::Lane lc = fpw::lane_consts(lane);
     g1w::WPt wacc = g1w::load(win + b * nwin + (nwin - 1), lane);
     for (int w = nwin - 2; w >= 0; --w) {
-        g1w::dbl_k(wacc, c, lc);  // the curve has odd order: doubling never reaches infinity
+        g1w::dbl_k(wacc, c, lc, lane);  // the curve has odd order: doubling never reaches infinity
         g1w::dadd(wacc, g1w::load(win + b * nwin + w, lane), lc, sh, lane);
     }
     Xyzz acc = g1w::to_single(wacc, lc, sh, lane);
