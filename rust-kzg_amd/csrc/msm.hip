@@ -261,17 +261,20 @@ __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __rest
 // ---------------------------------------------------------------------------------------------------------
 // Two-level sort (default for one MSM up to n = 2^22).  The one-level sort above pays two global atomics' worth
 // of L2 traffic per entry (histogram with return value, then a scattered 4-byte write): 1.2 ms at n = 2^20.
-// Here a bucket id is split into a coarse bin (bucket >> 7) and a fine bucket (low 7 bits):
+// Here a bucket id is split into a coarse bin (bucket >> fb) and a fine bucket (low fb bits; fb = 7, KZGAMD_FINE_BITS
+// = 7..10 for experiments: fewer, larger bins make k_part_scatter's runs longer and the kernel faster — 169 vs 267 us at
+// n = 2^20 with fb = 10 — but k_bin_sort then has 256 workgroups of 65536 entries and loses the same time again;
+// 7, 8, 9 and 10 are within noise of each other end to end):
 //   k_part_count   : a workgroup counts its 1024 scalars' entries per coarse bin in LDS (<= 4096 bins) and adds
 //                    the non-zero counters to the global bin counts — ~8x fewer global atomics, all LDS otherwise
 //   k_part_scan    : exclusive scan of the bin counts
 //   k_part_scatter : same count again in LDS, one returning atomic per (workgroup, bin) reserves a run inside the
-//                    bin, entries are written there as  fine << 25 | sign << 24 | point index
-//   k_bin_sort     : one workgroup per coarse bin streams its run twice: LDS histogram of the 128 fine buckets ->
+//                    bin, entries are written there as  fine << (32 - fb) | sign << (31 - fb) | point index
+//   k_bin_sort     : one workgroup per coarse bin streams its run twice: LDS histogram of the 2^fb fine buckets ->
 //                    bucket offsets (+ heavy flags), then an LDS counting sort into the final order
 // Entries keep the format the accumulation expects (point index | sign << 31).
-constexpr int FINE_BITS = 7;
-constexpr u32 FINE = 1u << FINE_BITS;
+constexpr int FINE_BITS_MIN = 7, FINE_BITS_MAX = 10;
+constexpr u32 FINE_MAX = 1u << FINE_BITS_MAX;
 constexpr u32 MAX_BINS = 4096;     // coarse bins per launch (LDS counters)
 constexpr int PART_SCALARS = 4;    // scalars per lane in the partition kernels (1024 per workgroup)
 
@@ -290,12 +293,21 @@ __device__ __forceinline__ void scalar_entries(const DigitParams& P, const u32* 
         for (int q = 0; q < 8; ++q) k[q] = s[q];
         kzgamd::glv_split(k, s, s2, pneg[0], pneg[1]);
     }
-    const u32 half = 1u << (P.c - 1);
-    for (int part = 0; part <= P.glv; ++part) {
-        const u32* sv = part ? s2 : s;
+    // the digits come off the low end of a register copy that is shifted down one window at a time: every index is
+    // static (a window addressed by its bit position would index the words dynamically and push them to scratch)
+    const u32 half = 1u << (P.c - 1), cmask = (1u << P.c) - 1u;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        if (part > P.glv) break;
+        u32 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = part ? s2[q] : s[q];
         u32 carry = 0;
         for (int w = 0; w < P.w1; ++w) {
-            u32 d = window_bits(sv, w * P.c, P.c) + carry;
+            u32 d = (v[0] & cmask) + carry;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) v[q] = (v[q] >> P.c) | (v[q + 1] << (32 - P.c));
+            v[7] >>= P.c;
             u32 neg = 0;
             carry = 0;
             if (d > half) {
@@ -314,7 +326,7 @@ __device__ __forceinline__ void scalar_entries(const DigitParams& P, const u32* 
 // set0 = first set of this launch's group, cb = coarse bins per set; bins are numbered (set - set0) * cb + coarse
 __global__ void __launch_bounds__(256) k_part_count(DigitParams P, const u32* __restrict__ scalars,
                                                     const AffPt* __restrict__ pts, u32* __restrict__ bin_count, u32 set0,
-                                                    u32 cb, u32 nbins) {
+                                                    u32 cb, u32 nbins, int fb) {
     extern __shared__ u32 lds_bins[];
     for (u32 k = threadIdx.x; k < nbins; k += 256) lds_bins[k] = 0;
     __syncthreads();
@@ -324,7 +336,7 @@ __global__ void __launch_bounds__(256) k_part_count(DigitParams P, const u32* __
         const size_t t = ((size_t)blockIdx.x * PART_SCALARS + q) * 256 + threadIdx.x;
         if (t < total)
             scalar_entries(P, scalars, pts, t, [&](size_t set, u32 bucket, u32, u32) {
-                atomicAdd(&lds_bins[(u32)(set - set0) * cb + (bucket >> FINE_BITS)], 1u);
+                atomicAdd(&lds_bins[(u32)(set - set0) * cb + (bucket >> fb)], 1u);
             });
     }
     __syncthreads();
@@ -370,7 +382,7 @@ __global__ void __launch_bounds__(1024) k_part_scan(const u32* __restrict__ bin_
 __global__ void __launch_bounds__(256) k_part_scatter(DigitParams P, const u32* __restrict__ scalars,
                                                       const AffPt* __restrict__ pts, const u32* __restrict__ bin_start,
                                                       u32* __restrict__ bin_cursor, u32* __restrict__ tmp, u32 set0, u32 cb,
-                                                      u32 nbins) {
+                                                      u32 nbins, int fb) {
     extern __shared__ u32 lds_bins[];
     u32* cnt = lds_bins;
     u32* base = lds_bins + nbins;
@@ -382,7 +394,7 @@ __global__ void __launch_bounds__(256) k_part_scatter(DigitParams P, const u32* 
         const size_t t = ((size_t)blockIdx.x * PART_SCALARS + q) * 256 + threadIdx.x;
         if (t < total)
             scalar_entries(P, scalars, pts, t, [&](size_t set, u32 bucket, u32, u32) {
-                atomicAdd(&cnt[(u32)(set - set0) * cb + (bucket >> FINE_BITS)], 1u);
+                atomicAdd(&cnt[(u32)(set - set0) * cb + (bucket >> fb)], 1u);
             });
     }
     __syncthreads();
@@ -397,9 +409,9 @@ __global__ void __launch_bounds__(256) k_part_scatter(DigitParams P, const u32* 
         const size_t t = ((size_t)blockIdx.x * PART_SCALARS + q) * 256 + threadIdx.x;
         if (t < total)
             scalar_entries(P, scalars, pts, t, [&](size_t set, u32 bucket, u32 neg, u32 pidx) {
-                const u32 bin = (u32)(set - set0) * cb + (bucket >> FINE_BITS);
+                const u32 bin = (u32)(set - set0) * cb + (bucket >> fb);
                 const u32 r = atomicAdd(&cnt[bin], 1u);
-                tmp[base[bin] + r] = ((bucket & (FINE - 1)) << 25) | (neg << 24) | pidx;
+                tmp[base[bin] + r] = ((bucket & ((1u << fb) - 1)) << (32 - fb)) | (neg << (31 - fb)) | pidx;
             });
     }
 }
@@ -408,48 +420,57 @@ __global__ void __launch_bounds__(256) k_part_scatter(DigitParams P, const u32* 
 __global__ void __launch_bounds__(256) k_bin_sort(const u32* __restrict__ tmp, const u32* __restrict__ bin_start,
                                                   u32* __restrict__ offsets, u32* __restrict__ sorted,
                                                   unsigned char* __restrict__ heavy, u32* __restrict__ heavy_list,
-                                                  u32* __restrict__ nheavy, u32 heavy_cap, u32 cb, size_t nb, size_t set_cap) {
-    __shared__ u32 hist[FINE], pref[FINE], cur[FINE];
+                                                  u32* __restrict__ nheavy, u32 heavy_cap, u32 cb, size_t nb, size_t set_cap,
+                                                  int fb) {
+    __shared__ u32 hist[FINE_MAX], pref[FINE_MAX], cur[FINE_MAX];
+    __shared__ u32 wsum[4];
+    const u32 F = 1u << fb;
+    const int sh = 32 - fb;
     const u32 bin = blockIdx.x, set = bin / cb, coarse = bin % cb;
     const u32 beg = bin_start[bin], end = bin_start[bin + 1], set_start = bin_start[set * cb];
-    if (threadIdx.x < FINE) {
-        hist[threadIdx.x] = 0;
-        cur[threadIdx.x] = 0;
+    for (u32 f = threadIdx.x; f < F; f += 256) {
+        hist[f] = 0;
+        cur[f] = 0;
     }
     __syncthreads();
-    for (u32 e = beg + threadIdx.x; e < end; e += 256) atomicAdd(&hist[tmp[e] >> 25], 1u);
+    for (u32 e = beg + threadIdx.x; e < end; e += 256) atomicAdd(&hist[tmp[e] >> sh], 1u);
     __syncthreads();
-    if (threadIdx.x < FINE) {
-        // exclusive scan over the 128 fine buckets (two waves: wave scan + the first wave's total)
-        const int lane = threadIdx.x & 63;
-        const u32 v = hist[threadIdx.x];
-        u32 x = v;
+    {
+        // exclusive scan over the F fine buckets: K consecutive ones per thread, wave scan, the waves' totals
+        const u32 K = F > 256 ? F >> 8 : 1;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        u32 v[4] = {0, 0, 0, 0}, tot = 0;
+        if (threadIdx.x * K < F)
+            for (u32 k = 0; k < K; ++k) {
+                v[k] = hist[threadIdx.x * K + k];
+                tot += v[k];
+            }
+        u32 x = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             u32 y = __shfl_up(x, d, 64);
             if (lane >= d) x += y;
         }
-        if (threadIdx.x == 63) pref[0] = x;  // borrowed as a mailbox; rewritten below after the barrier
-        hist[threadIdx.x] = x - v;           // exclusive within the wave
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        u32 ex = x - tot;
+        for (int w2 = 0; w2 < wave; ++w2) ex += wsum[w2];
+        if (threadIdx.x * K < F)
+            for (u32 k = 0; k < K; ++k) {
+                pref[threadIdx.x * K + k] = ex;
+                ex += v[k];
+            }
     }
     __syncthreads();
-    const u32 first_wave_total = pref[0];
-    __syncthreads();
-    if (threadIdx.x < FINE) {
-        const u32 ex = hist[threadIdx.x] + (threadIdx.x >= 64 ? first_wave_total : 0u);
-        pref[threadIdx.x] = ex;
-        const size_t bucket = (size_t)coarse * FINE + threadIdx.x;
+    for (u32 f = threadIdx.x; f < F; f += 256) {
+        const u32 ex = pref[f];
+        const size_t bucket = (size_t)coarse * F + f;
         u32* off = offsets + (size_t)set * (nb + 1);
         off[bucket] = (beg - set_start) + ex;
-        if (coarse + 1 == cb && threadIdx.x == FINE - 1) off[nb] = bin_start[(set + 1) * cb] - set_start;
-    }
-    __syncthreads();
-    if (threadIdx.x < FINE) {
+        if (coarse + 1 == cb && f == F - 1) off[nb] = bin_start[(set + 1) * cb] - set_start;
         // bucket size = next prefix - own prefix
-        const u32 ex = pref[threadIdx.x];
-        const u32 nx = threadIdx.x + 1 < FINE ? pref[threadIdx.x + 1] : (end - beg);
+        const u32 nx = f + 1 < F ? pref[f + 1] : (end - beg);
         const u32 cntb = nx - ex;
-        const size_t bucket = (size_t)coarse * FINE + threadIdx.x;
         const bool hv = cntb > HEAVY;
         heavy[(size_t)set * nb + bucket] = hv ? 1 : 0;
         if (hv) {
@@ -461,11 +482,12 @@ __global__ void __launch_bounds__(256) k_bin_sort(const u32* __restrict__ tmp, c
         }
     }
     u32* dst = sorted + (size_t)set * set_cap + (beg - set_start);
+    const u32 pmask = (1u << (sh - 1)) - 1u;
     for (u32 e = beg + threadIdx.x; e < end; e += 256) {
         const u32 w = tmp[e];
-        const u32 f = w >> 25;
+        const u32 f = w >> sh;
         const u32 r = atomicAdd(&cur[f], 1u);
-        dst[pref[f] + r] = (w & 0xffffffu) | (((w >> 24) & 1u) << 31);
+        dst[pref[f] + r] = (w & pmask) | (((w >> (sh - 1)) & 1u) << 31);
     }
 }
 
@@ -1050,8 +1072,12 @@ __global__ void __launch_bounds__(256) k_fbw_digits(DigitParams P, const u32* __
     kzgamd::glv_split(s, s1, s2, n1, n2);
     const u32 half = 1u << (P.c - 1);
     const int DW = (P.nwin + 3) & ~3;
+    const u32 cmask = (1u << P.c) - 1u;
+#pragma unroll
     for (int part = 0; part < 2; ++part) {
-        const u32* sv = part ? s2 : s1;
+        u32 v[4];  // a half is below 2^128; shifted down one window at a time (static indices only)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = part ? s2[q] : s1[q];
         const u32 pneg = part ? n2 : n1;
         u32 carry = 0;
         uint4* dst = reinterpret_cast<uint4*>(digits + (t * 2 + part) * DW);
@@ -1062,7 +1088,10 @@ __global__ void __launch_bounds__(256) k_fbw_digits(DigitParams P, const u32* __
                 const int w = w4 + q;
                 u32 e = FBW_SKIP;
                 if (w < P.nwin) {
-                    u32 d = window_bits(sv, w * P.c, P.c) + carry;
+                    u32 d = (v[0] & cmask) + carry;
+#pragma unroll
+                    for (int x = 0; x < 3; ++x) v[x] = (v[x] >> P.c) | (v[x + 1] << (32 - P.c));
+                    v[3] >>= P.c;
                     u32 neg = pneg;
                     carry = 0;
                     if (d > half) {
@@ -1681,8 +1710,15 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     const size_t sets_per_group = (nsets + G - 1) / G;
     // two-level sort: coarse bins must fit the LDS counters and a point index 24 bits
     const size_t max_pidx = ctx->prepared ? (size_t)ctx->rows * ctx->n : (ctx->glv ? 2 * ctx->n : ctx->n);
-    const bool two_level = !getenv("KZGAMD_ONE_LEVEL_SORT") && nb >= FINE &&
-                           (nb >> FINE_BITS) * sets_per_group <= MAX_BINS && max_pidx <= ((size_t)1 << 24) &&
+    int pbits = 1;  // bits of a point index
+    while (((size_t)1 << pbits) < max_pidx) ++pbits;
+    int fb = FINE_BITS_MIN;
+    if (const char* e = getenv("KZGAMD_FINE_BITS")) {
+        const int v = atoi(e);
+        if (v >= FINE_BITS_MIN && v <= FINE_BITS_MAX && v <= 31 - pbits) fb = v;
+    }
+    const bool two_level = !getenv("KZGAMD_ONE_LEVEL_SORT") && nb >= ((size_t)1 << fb) && fb + 1 + pbits <= 32 &&
+                           (nb >> fb) * sets_per_group <= MAX_BINS &&
                            npoints * nbatch >= ((size_t)1 << 15);  // below: four more launches than they save
     if (two_level) {
         ws.tmp.ensure(nsets * set_cap);
@@ -1769,7 +1805,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         u32* nheavy = ws.nheavy.p + g;
         Xyzz* buckets = ws.buckets.p + set0 * (nb + nchunk);
         if (two_level) {
-            const u32 cb = (u32)(nb >> FINE_BITS), nbins = (u32)ns * cb;
+            const u32 cb = (u32)(nb >> fb), nbins = (u32)ns * cb;
             u32* bin_count = ws.bins.p + (size_t)g * (3 * MAX_BINS + 8);
             u32* bin_start = bin_count + MAX_BINS;
             u32* bin_cursor = bin_start + MAX_BINS + 8;
@@ -1777,14 +1813,14 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             const unsigned gpart = (unsigned)((npoints * nbatch + 256 * PART_SCALARS - 1) / (256 * PART_SCALARS));
             HIP_TRY(hipMemsetAsync(bin_count, 0, nbins * sizeof(u32), st));
             hipLaunchKernelGGL(k_part_count, dim3(gpart), dim3(256), nbins * sizeof(u32), st, P, (const u32*)d_scalars,
-                               (const AffPt*)ctx->table.p, bin_count, (u32)set0, cb, nbins);
+                               (const AffPt*)ctx->table.p, bin_count, (u32)set0, cb, nbins, fb);
             hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, st, (const u32*)bin_count, bin_start, bin_cursor, nbins);
             hipLaunchKernelGGL(k_part_scatter, dim3(gpart), dim3(256), 2 * nbins * sizeof(u32), st, P,
                                (const u32*)d_scalars, (const AffPt*)ctx->table.p, (const u32*)bin_start, bin_cursor, tmp,
-                               (u32)set0, cb, nbins);
+                               (u32)set0, cb, nbins, fb);
             HIP_TRY(hipMemsetAsync(nheavy, 0, sizeof(u32), st));
             hipLaunchKernelGGL(k_bin_sort, dim3(nbins), dim3(256), 0, st, (const u32*)tmp, (const u32*)bin_start, offsets,
-                               ws.sorted.p + set0 * set_cap, heavy, heavy_list, nheavy, (u32)heavy_cap, cb, nb, set_cap);
+                               ws.sorted.p + set0 * set_cap, heavy, heavy_list, nheavy, (u32)heavy_cap, cb, nb, set_cap, fb);
         } else {
         HIP_TRY(hipMemsetAsync(counts, 0, ns * nb * sizeof(u32), st));
         const unsigned gdig = (unsigned)((npoints * nbatch + 255) / 256);

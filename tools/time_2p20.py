@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""2^16 .. 2^22 variable-base MSM timings (device-resident, HIP events, min of 5)."""
+"""2^16 .. 2^22 variable-base MSM timings (device-resident, HIP events, min of 15)."""
 import os
 import sys
 
@@ -27,7 +27,7 @@ for logn in (14, 16, 18, 20, 22):
     kzg.msm_prepared_batch_device(h, out.data_ptr(), sc.data_ptr(), n, 1, False, stream)
     torch.cuda.synchronize()
     ts = []
-    for _ in range(5):
+    for _ in range(15):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         kzg.msm_prepared_batch_device(h, out.data_ptr(), sc.data_ptr(), n, 1, False, stream)
