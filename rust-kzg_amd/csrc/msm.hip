@@ -1684,7 +1684,14 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     }
     ws.offsets.ensure(nsets * (nb + 1));
     ws.sorted.ensure(nsets * set_cap);
-    const int lgc = npoints >= ((size_t)1 << 18) ? 5 : 4;  // 8 was tried for n <= 2^14: slower (more pieces per bucket)
+    // entries per accumulation lane, 2^lgc: longer chunks leave fewer pieces per bucket to fold, shorter ones more lanes
+    // (measured, ms at n = 2^16 / 2^18 / 2^20 / 2^22:  lgc 4: 1.07 1.60 3.96 14.29;  5: 1.24 1.56 3.89 13.64;
+    //  6: 1.58 1.61 3.82 13.43;  7: 2.17 2.18 3.81 13.23)
+    int lgc = npoints >= ((size_t)1 << 22) ? 7 : npoints >= ((size_t)1 << 20) ? 6 : npoints >= ((size_t)1 << 18) ? 5 : 4;
+    if (const char* e = getenv("KZGAMD_LGC")) {
+        const int v = atoi(e);
+        if (v >= 2 && v <= 8) lgc = v;
+    }
     const size_t nchunk = (set_cap + ((size_t)1 << lgc) - 1) >> lgc;
     ws.buckets.ensure(nsets * (nb + nchunk));
     const size_t n1 = (nb + 1) / 2, n2 = (n1 + GRP - 1) / GRP;  // level 0 folds at least 2, later levels GRP
