@@ -295,7 +295,7 @@ def test_vectors_compute_cells_and_kzg_proofs(kzg, settings, golden, blob_loader
     assert hashlib.sha256(bp[:128 * 48]).hexdigest() == golden["compute_cells_and_kzg_proofs"][-2]["output"]["proofs_sha256"]
 
 
-def test_batch_256_blobs_commit_and_prove(kzg, settings, oracle, oracle_settings):
+def test_batch_256_blobs_commit_and_prove(kzg, settings, oracle, oracle_settings, monkeypatch):
     # BASELINE configs[4] size: 256 blobs in one batched call; sampled blobs checked against the oracle,
     # all of them against the single-blob path through a digest of digests
     import hashlib
@@ -343,6 +343,23 @@ def test_batch_256_blobs_commit_and_prove(kzg, settings, oracle, oracle_settings
         with pytest.raises(kzg.KzgAmdError):
             kzg.compute_blob_kzg_proof_batch(blobs, b"".join(badc), n, settings)
     assert kzg.compute_blob_kzg_proof_batch(blobs, b"".join(cms), n, settings) == proofs  # and recovers afterwards
+    # KZGAMD_DEVICE_SHA=1: the same call with the Fiat-Shamir hashes on the GPU and no host threads
+    monkeypatch.setenv("KZGAMD_DEVICE_SHA", "1")
+    assert kzg.compute_blob_kzg_proof_batch(blobs, b"".join(cms), n, settings) == proofs
+    zs2, ys2 = kzg.compute_challenges_and_evaluate_batch(blobs, b"".join(cms), n, settings)
+    monkeypatch.delenv("KZGAMD_DEVICE_SHA")
+    zs1, ys1 = kzg.compute_challenges_and_evaluate_batch(blobs, b"".join(cms), n, settings)
+    assert (zs1, ys1) == (zs2, ys2)
+    monkeypatch.setenv("KZGAMD_DEVICE_SHA", "1")
+    bad = bytearray(blobs)
+    bad[200 * BLOB + 64:200 * BLOB + 96] = b"\xff" * 32
+    with pytest.raises(kzg.KzgAmdError):
+        kzg.compute_blob_kzg_proof_batch(bytes(bad), b"".join(cms), n, settings)
+    badc = list(cms)
+    badc[130] = b"\x9f" + b"\xff" * 47
+    with pytest.raises(kzg.KzgAmdError):
+        kzg.compute_blob_kzg_proof_batch(blobs, b"".join(badc), n, settings)
+
 
 
 def test_concurrent_callers_share_one_settings_handle(kzg, settings, oracle, oracle_settings):
