@@ -33,6 +33,11 @@ FF_HD constexpr u32 pad4_l(int i) {  // 4r with limbs 0..7 >= 2^29 - 1
     return t[i];
 }
 
+FF_HD constexpr u32 pad8_l(int i) {  // 8r, same shape
+    constexpr u32 t[L] = {0x20000008u, 0x3fffffbfu, 0x3cb7fdfeu, 0x3a402ffeu, 0x2c02a9ddu, 0x20202686u, 0x2906673au, 0x33299d7cu, 0x39f6d39u};
+    return t[i];
+}
+
 FF_HD Fe one() {
     Fe r;
 #pragma unroll
@@ -70,6 +75,16 @@ FF_HD void butterfly_lazy(Fe& x, Fe& y_out, const Fe& t) {
         const u32 xi = x.v[i];
         x.v[i] = xi + t.v[i];
         y_out.v[i] = xi + pad4_l(i) - t.v[i];
+    }
+}
+
+// x + t and x + 8r - t for a normalized t with value < 7r (a data element used as its own product by w^0 = 1)
+FF_HD void butterfly_lazy8(Fe& x, Fe& y_out, const Fe& t) {
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const u32 xi = x.v[i];
+        x.v[i] = xi + t.v[i];
+        y_out.v[i] = xi + pad8_l(i) - t.v[i];
     }
 }
 

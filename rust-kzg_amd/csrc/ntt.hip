@@ -87,6 +87,13 @@ __device__ __forceinline__ void round_regs(u32* sh, int cnt, int nelem, TwFn tw)
         const Fe y_ = e[K1];                             \
         fr29::butterfly_lazy(e[K0], e[K1], y_);          \
     }
+/* a later stage of the first round whose twiddle is w^0 = 1: the operand is a lazy sum (< 4r), normalise it first */
+#define KZG_BF1N(K0, K1)                                 \
+    {                                                    \
+        Fe y_ = e[K1];                                   \
+        fr29::norm(y_);                                  \
+        fr29::butterfly_lazy8(e[K0], e[K1], y_);         \
+    }
 #define KZG_NORM_ALL                  \
     _Pragma("unroll") for (int k_ = 0; k_ < E; ++k_) fr29::norm(e[k_]);
         if constexpr (M == 1) {
@@ -107,8 +114,12 @@ __device__ __forceinline__ void round_regs(u32* sh, int cnt, int nelem, TwFn tw)
                 KZG_BF(2, 3, w)
             }
             {
-                const Fe w0 = tw(B + 1, lo, base);
-                KZG_BF(0, 2, w0)
+                if constexpr (FIRST && B == 0) {
+                    KZG_BF1N(0, 2)  // stage 1, position 0: w^0 = 1 again
+                } else {
+                    const Fe w0 = tw(B + 1, lo, base);
+                    KZG_BF(0, 2, w0)
+                }
                 const Fe w1 = tw(B + 1, lo | (1 << B), base);
                 KZG_BF(1, 3, w1)
             }
@@ -127,17 +138,27 @@ __device__ __forceinline__ void round_regs(u32* sh, int cnt, int nelem, TwFn tw)
                 KZG_BF(6, 7, w)
             }
             {
-                const Fe w0 = tw(B + 1, lo, base);
-                KZG_BF(0, 2, w0)
-                KZG_BF(4, 6, w0)
+                // the first round of a transform: position 0 of stages 1 and 2 has the twiddle w^0 = 1 as well
+                if constexpr (FIRST && B == 0) {
+                    KZG_BF1N(0, 2)
+                    KZG_BF1N(4, 6)
+                } else {
+                    const Fe w0 = tw(B + 1, lo, base);
+                    KZG_BF(0, 2, w0)
+                    KZG_BF(4, 6, w0)
+                }
                 const Fe w1 = tw(B + 1, lo | (1 << B), base);
                 KZG_BF(1, 3, w1)
                 KZG_BF(5, 7, w1)
             }
             KZG_NORM_ALL
             {
-                const Fe w0 = tw(B + 2, lo, base);
-                KZG_BF(0, 4, w0)
+                if constexpr (FIRST && B == 0) {
+                    KZG_BF1N(0, 4)
+                } else {
+                    const Fe w0 = tw(B + 2, lo, base);
+                    KZG_BF(0, 4, w0)
+                }
                 const Fe w1 = tw(B + 2, lo | (1 << B), base);
                 KZG_BF(1, 5, w1)
                 const Fe w2 = tw(B + 2, lo | (2 << B), base);
@@ -149,6 +170,7 @@ __device__ __forceinline__ void round_regs(u32* sh, int cnt, int nelem, TwFn tw)
         }
 #undef KZG_BF
 #undef KZG_BF1
+#undef KZG_BF1N
 #undef KZG_NORM_ALL
 #pragma unroll
         for (int k = 0; k < E; ++k) lds_put(sh, cnt, sbase ^ swz(k << B), e[k]);
