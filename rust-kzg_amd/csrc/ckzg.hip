@@ -1774,15 +1774,16 @@ extern "C" C_KZG_RET kzgamd_verify_blob_kzg_proof_batch_g1(blst_p1* proof_lincom
 
 namespace {
 
-// check_proof_single (blst/src/types/kzg_settings.rs:178-196) on decoded, validated inputs:
-//     e(C - [y]G, G2) == e(proof, [tau]G2 - [z]G2)
-// One pairing-product check on the host (see host_pairing.h: the reference keeps the pairing on the CPU too).
+// check_proof_single (blst/src/types/kzg_settings.rs:178-196) on decoded, validated inputs.  The reference tests
+//     e(C - [y]G, G2) == e(proof, [tau]G2 - [z]G2);
+// with the [z] moved to the G1 side (bilinearity; the proof is a checked r-torsion point) the same statement is
+//     e(C - [y]G + [z]proof, G2) == e(proof, [tau]G2),
+// which pairs with the two fixed G2 points of the setup only: their line tables are cached (host_pairing.h), and the
+// G2 scalar multiplication becomes a G1 one.  One pairing-product check on the host (the reference keeps the pairing
+// on the CPU too).
 bool check_proof_single(const blst_p1& commitment, const blst_p1& proof, const ff::Fr& z_plain, const ff::Fr& y_plain,
                         KzgAmdSettings* dev) {
     using namespace kzgamd::pairing;
-    const G2Jac g2gen = g2_generator();
-    const G2Jac s_minus_x = g2_add(dev->g2_monomial[1], g2_neg(g2_mul(g2gen, z_plain.v)));
-    // [y]G on the host: 255 doublings of one point
     kzgamd::HostJac g;
     {
         const uint64_t GX[6] = {0x5cb38790fd530c16ull, 0x7817fc679976fff5ull, 0x154f95c7143ba1c1ull,
@@ -1797,21 +1798,26 @@ bool check_proof_single(const blst_p1& commitment, const blst_p1& proof, const f
         }
         g.z = ff::Fp::one();
     }
-    kzgamd::HostJac yg;
-    yg.x = yg.y = yg.z = ff::Fp::zero();
+    g.y = hfp::neg(g.y);  // -G
+    kzgamd::HostJac pi;
+    memcpy(&pi, &proof, sizeof pi);
+    // [z]proof - [y]G: one joint double-and-add over the 255 bits
+    kzgamd::HostJac acc;
+    acc.x = acc.y = acc.z = ff::Fp::zero();
     for (int bit = 254; bit >= 0; --bit) {
-        yg = kzgamd::host_jac_dbl(yg);
-        if ((y_plain.v[bit >> 5] >> (bit & 31)) & 1) yg = kzgamd::host_jac_add(yg, g);
+        acc = kzgamd::host_jac_dbl(acc);
+        if ((y_plain.v[bit >> 5] >> (bit & 31)) & 1) acc = kzgamd::host_jac_add(acc, g);
+        if ((z_plain.v[bit >> 5] >> (bit & 31)) & 1) acc = kzgamd::host_jac_add(acc, pi);
     }
-    yg.y = ff::neg(yg.y);
     kzgamd::HostJac c;
     memcpy(&c, &commitment, sizeof c);
-    const kzgamd::HostJac cmy = kzgamd::host_jac_add(c, yg);
+    const kzgamd::HostJac lhs = kzgamd::host_jac_add(c, acc);
     blst_p1 a1;
-    memcpy(&a1, &cmy, sizeof a1);
-    blst_p2 b2, a2;
-    memcpy(&b2, &s_minus_x, sizeof b2);
+    memcpy(&a1, &lhs, sizeof a1);
+    const G2Jac g2gen = g2_generator();
+    blst_p2 a2, b2;
     memcpy(&a2, &g2gen, sizeof a2);
+    memcpy(&b2, &dev->g2_monomial[1], sizeof b2);
     return pairings_verify(&a1, &a2, &proof, &b2);
 }
 

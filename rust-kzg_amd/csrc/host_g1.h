@@ -7,6 +7,7 @@
 
 #include "../../include/kzg_mi355x.h"
 #include "ff.hip.h"
+#include "host_fp64.h"
 
 namespace kzgamd {
 
@@ -54,8 +55,8 @@ inline void host_p1_compress(uint8_t out[48], const blst_p1* p) {
         out[0] = 0xc0;
         return;
     }
-    ff::Fp zi = ff::inverse_bgcd(P[2]), zi2 = ff::sqr(zi);
-    ff::Fp x = ff::from_mont(ff::mul(P[0], zi2)), y = ff::from_mont(ff::mul(P[1], ff::mul(zi2, zi)));
+    ff::Fp zi = ff::inverse_bgcd(P[2]), zi2 = hfp::sqr(zi);
+    ff::Fp x = hfp::from_mont(hfp::mul(P[0], zi2)), y = hfp::from_mont(hfp::mul(P[1], hfp::mul(zi2, zi)));
     host_fp_to_be48(out, x);
     out[0] |= 0x80;
     if (host_fp_lex_largest(y)) out[0] |= 0x20;
@@ -77,15 +78,15 @@ inline bool host_p1_uncompress(blst_p1* out, const uint8_t in[48]) {
         return true;
     }
     if (!lt) return false;
-    ff::Fp x = ff::to_mont(xs);
+    ff::Fp x = hfp::to_mont(xs);
     ff::Fp four = ff::Fp::zero();
     four.v[0] = 4;
-    ff::Fp y2 = ff::add(ff::mul(ff::sqr(x), x), ff::to_mont(four));
+    ff::Fp y2 = hfp::add(hfp::mul(hfp::sqr(x), x), hfp::to_mont(four));
     static const uint32_t e[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
                                    0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};
-    ff::Fp y = ff::pow_u32(y2, e, 12);
-    if (ff::sqr(y) != y2) return false;
-    if (host_fp_lex_largest(ff::from_mont(y)) != sort) y = ff::neg(y);
+    ff::Fp y = hfp::pow_u32(y2, e, 12);
+    if (hfp::sqr(y) != y2) return false;
+    if (host_fp_lex_largest(hfp::from_mont(y)) != sort) y = hfp::neg(y);
     O[0] = x;
     O[1] = y;
     O[2] = ff::Fp::one();
@@ -98,37 +99,37 @@ struct HostJac {
 };
 inline HostJac host_jac_dbl(const HostJac& p) {  // dbl-2009-l (a = 0)
     if (p.z.is_zero()) return p;
-    using namespace ff;
-    Fp A = sqr(p.x), B = sqr(p.y), C = sqr(B);
-    Fp t = sub(sub(sqr(add(p.x, B)), A), C);
-    Fp D = add(t, t), E = add(add(A, A), A), F = sqr(E);
+    using ff::Fp;
+    Fp A = hfp::sqr(p.x), B = hfp::sqr(p.y), C = hfp::sqr(B);
+    Fp t = hfp::sub(hfp::sub(hfp::sqr(hfp::add(p.x, B)), A), C);
+    Fp D = hfp::add(t, t), E = hfp::add(hfp::add(A, A), A), F = hfp::sqr(E);
     HostJac r;
-    r.x = sub(sub(F, D), D);
-    Fp C8 = dbl(dbl(dbl(C)));
-    r.y = sub(mul(E, sub(D, r.x)), C8);
-    r.z = dbl(mul(p.y, p.z));
+    r.x = hfp::sub(hfp::sub(F, D), D);
+    Fp C8 = hfp::dbl(hfp::dbl(hfp::dbl(C)));
+    r.y = hfp::sub(hfp::mul(E, hfp::sub(D, r.x)), C8);
+    r.z = hfp::dbl(hfp::mul(p.y, p.z));
     return r;
 }
 inline HostJac host_jac_add(const HostJac& a, const HostJac& b) {  // add-2007-bl with the exceptional cases
     if (a.z.is_zero()) return b;
     if (b.z.is_zero()) return a;
-    using namespace ff;
-    Fp z1z1 = sqr(a.z), z2z2 = sqr(b.z);
-    Fp u1 = mul(a.x, z2z2), u2 = mul(b.x, z1z1);
-    Fp s1 = mul(mul(a.y, b.z), z2z2), s2 = mul(mul(b.y, a.z), z1z1);
-    Fp h = sub(u2, u1), rr = sub(s2, s1);
+    using ff::Fp;
+    Fp z1z1 = hfp::sqr(a.z), z2z2 = hfp::sqr(b.z);
+    Fp u1 = hfp::mul(a.x, z2z2), u2 = hfp::mul(b.x, z1z1);
+    Fp s1 = hfp::mul(hfp::mul(a.y, b.z), z2z2), s2 = hfp::mul(hfp::mul(b.y, a.z), z1z1);
+    Fp h = hfp::sub(u2, u1), rr = hfp::sub(s2, s1);
     if (h.is_zero()) {
         if (rr.is_zero()) return host_jac_dbl(a);
         HostJac inf;
         inf.x = inf.y = inf.z = Fp::zero();
         return inf;
     }
-    rr = dbl(rr);
-    Fp i = sqr(dbl(h)), j = mul(h, i), v = mul(u1, i);
+    rr = hfp::dbl(rr);
+    Fp i = hfp::sqr(hfp::dbl(h)), j = hfp::mul(h, i), v = hfp::mul(u1, i);
     HostJac r;
-    r.x = sub(sub(sub(sqr(rr), j), v), v);
-    r.y = sub(mul(rr, sub(v, r.x)), dbl(mul(s1, j)));
-    r.z = mul(sub(sub(sqr(add(a.z, b.z)), z1z1), z2z2), h);
+    r.x = hfp::sub(hfp::sub(hfp::sub(hfp::sqr(rr), j), v), v);
+    r.y = hfp::sub(hfp::mul(rr, hfp::sub(v, r.x)), hfp::dbl(hfp::mul(s1, j)));
+    r.z = hfp::mul(hfp::sub(hfp::sub(hfp::sqr(hfp::add(a.z, b.z)), z1z1), z2z2), h);
     return r;
 }
 inline HostJac host_jac_mul_u64(const HostJac& p, uint64_t k) {
@@ -153,13 +154,13 @@ inline bool host_p1_in_g1(const blst_p1* pt) {
                                             0x6a0f77eau, 0xba69c607u, 0xdf76ce51u, 0x5f19672fu, 0x00000000u, 0x00000000u};
     ff::Fp beta;
     for (int i = 0; i < 12; ++i) beta.v[i] = beta_plain[i];
-    beta = ff::to_mont(beta);
-    HostJac e{ff::mul(p.x, beta), p.y, p.z};  // phi(P) in Jacobian form (x scales by beta, Z unchanged)
-    q.y = ff::neg(q.y);
+    beta = hfp::to_mont(beta);
+    HostJac e{hfp::mul(p.x, beta), p.y, p.z};  // phi(P) in Jacobian form (x scales by beta, Z unchanged)
+    q.y = hfp::neg(q.y);
     // projective equality
-    ff::Fp z1z1 = ff::sqr(e.z), z2z2 = ff::sqr(q.z);
-    if (ff::mul(e.x, z2z2) != ff::mul(q.x, z1z1)) return false;
-    return ff::mul(e.y, ff::mul(z2z2, q.z)) == ff::mul(q.y, ff::mul(z1z1, e.z));
+    ff::Fp z1z1 = hfp::sqr(e.z), z2z2 = hfp::sqr(q.z);
+    if (hfp::mul(e.x, z2z2) != hfp::mul(q.x, z1z1)) return false;
+    return hfp::mul(e.y, hfp::mul(z2z2, q.z)) == hfp::mul(q.y, hfp::mul(z1z1, e.z));
 }
 
 }  // namespace kzgamd

@@ -21,8 +21,13 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <memory>
+#include <mutex>
+#include <vector>
+
 #include "../../include/kzg_mi355x.h"
 #include "ff.hip.h"
+#include "host_fp64.h"
 #include "host_g1.h"
 
 namespace kzgamd {
@@ -38,25 +43,25 @@ inline Fp2 f2_zero() { return {Fp::zero(), Fp::zero()}; }
 inline Fp2 f2_one() { return {Fp::one(), Fp::zero()}; }
 inline bool f2_is_zero(const Fp2& a) { return a.c0.is_zero() && a.c1.is_zero(); }
 inline bool f2_eq(const Fp2& a, const Fp2& b) { return a.c0 == b.c0 && a.c1 == b.c1; }
-inline Fp2 f2_add(const Fp2& a, const Fp2& b) { return {ff::add(a.c0, b.c0), ff::add(a.c1, b.c1)}; }
-inline Fp2 f2_sub(const Fp2& a, const Fp2& b) { return {ff::sub(a.c0, b.c0), ff::sub(a.c1, b.c1)}; }
-inline Fp2 f2_neg(const Fp2& a) { return {ff::neg(a.c0), ff::neg(a.c1)}; }
-inline Fp2 f2_dbl(const Fp2& a) { return {ff::dbl(a.c0), ff::dbl(a.c1)}; }
-inline Fp2 f2_conj(const Fp2& a) { return {a.c0, ff::neg(a.c1)}; }
+inline Fp2 f2_add(const Fp2& a, const Fp2& b) { return {hfp::add(a.c0, b.c0), hfp::add(a.c1, b.c1)}; }
+inline Fp2 f2_sub(const Fp2& a, const Fp2& b) { return {hfp::sub(a.c0, b.c0), hfp::sub(a.c1, b.c1)}; }
+inline Fp2 f2_neg(const Fp2& a) { return {hfp::neg(a.c0), hfp::neg(a.c1)}; }
+inline Fp2 f2_dbl(const Fp2& a) { return {hfp::dbl(a.c0), hfp::dbl(a.c1)}; }
+inline Fp2 f2_conj(const Fp2& a) { return {a.c0, hfp::neg(a.c1)}; }
 inline Fp2 f2_mul(const Fp2& a, const Fp2& b) {  // Karatsuba: 3 Fp multiplications
-    const Fp t0 = ff::mul(a.c0, b.c0), t1 = ff::mul(a.c1, b.c1);
-    const Fp t2 = ff::mul(ff::add(a.c0, a.c1), ff::add(b.c0, b.c1));
-    return {ff::sub(t0, t1), ff::sub(ff::sub(t2, t0), t1)};
+    const Fp t0 = hfp::mul(a.c0, b.c0), t1 = hfp::mul(a.c1, b.c1);
+    const Fp t2 = hfp::mul(hfp::add(a.c0, a.c1), hfp::add(b.c0, b.c1));
+    return {hfp::sub(t0, t1), hfp::sub(hfp::sub(t2, t0), t1)};
 }
 inline Fp2 f2_sqr(const Fp2& a) {  // (a0+a1)(a0-a1), 2 a0 a1
-    const Fp t = ff::mul(a.c0, a.c1);
-    return {ff::mul(ff::add(a.c0, a.c1), ff::sub(a.c0, a.c1)), ff::dbl(t)};
+    const Fp t = hfp::mul(a.c0, a.c1);
+    return {hfp::mul(hfp::add(a.c0, a.c1), hfp::sub(a.c0, a.c1)), hfp::dbl(t)};
 }
-inline Fp2 f2_mul_fp(const Fp2& a, const Fp& b) { return {ff::mul(a.c0, b), ff::mul(a.c1, b)}; }
-inline Fp2 f2_mul_xi(const Fp2& a) { return {ff::sub(a.c0, a.c1), ff::add(a.c0, a.c1)}; }  // * (1 + u)
+inline Fp2 f2_mul_fp(const Fp2& a, const Fp& b) { return {hfp::mul(a.c0, b), hfp::mul(a.c1, b)}; }
+inline Fp2 f2_mul_xi(const Fp2& a) { return {hfp::sub(a.c0, a.c1), hfp::add(a.c0, a.c1)}; }  // * (1 + u)
 inline Fp2 f2_inv(const Fp2& a) {  // conj(a) / (a0^2 + a1^2)
-    const Fp n = ff::inverse_bgcd(ff::add(ff::sqr(a.c0), ff::sqr(a.c1)));
-    return {ff::mul(a.c0, n), ff::neg(ff::mul(a.c1, n))};
+    const Fp n = ff::inverse_bgcd(hfp::add(hfp::sqr(a.c0), hfp::sqr(a.c1)));
+    return {hfp::mul(a.c0, n), hfp::neg(hfp::mul(a.c1, n))};
 }
 inline Fp2 f2_pow(const Fp2& a, const uint32_t* e, int nlimbs) {
     Fp2 r = f2_one();
@@ -86,7 +91,7 @@ inline bool f2_sqrt(Fp2& out, const Fp2& a) {
     const Fp2 minus_one = f2_neg(f2_one());
     Fp2 x;
     if (f2_eq(alpha, minus_one)) {
-        x = {ff::neg(x0.c1), x0.c0};  // u * x0
+        x = {hfp::neg(x0.c1), x0.c0};  // u * x0
     } else {
         const Fp2 b = f2_pow(f2_add(f2_one(), alpha), EXP_PM1_2, 12);
         x = f2_mul(b, x0);
@@ -132,7 +137,51 @@ inline Fp12 f12_mul(const Fp12& a, const Fp12& b) {
     const Fp6 m = f6_mul(f6_add(a.c0, a.c1), f6_add(b.c0, b.c1));
     return {f6_add(t0, f6_mul_v(t1)), f6_sub(f6_sub(m, t0), t1)};
 }
-inline Fp12 f12_sqr(const Fp12& a) { return f12_mul(a, a); }
+// (a + b w)^2 = (a + b)(a + v b) - ab - v ab  +  2ab w : two Fp6 multiplications
+inline Fp12 f12_sqr(const Fp12& a) {
+    const Fp6 ab = f6_mul(a.c0, a.c1);
+    const Fp6 t = f6_mul(f6_add(a.c0, a.c1), f6_add(a.c0, f6_mul_v(a.c1)));
+    return {f6_sub(f6_sub(t, ab), f6_mul_v(ab)), f6_add(ab, ab)};
+}
+// Squaring in the cyclotomic subgroup (Granger-Scott, "Faster squaring in the cyclotomic subgroup of sixth degree
+// extensions", PKC 2010, for the tower 2-3-2): three Fp4 squarings, 18 Fp multiplications against 36.
+// Only valid for elements of norm one over Fp6, i.e. after the easy part of the final exponentiation.
+inline Fp12 f12_cyclotomic_sqr(const Fp12& f) {
+    auto fp4_sqr = [](const Fp2& a, const Fp2& b, Fp2& r0, Fp2& r1) {  // (a + b y)^2, y^2 = xi
+        const Fp2 ab = f2_mul(a, b);
+        r0 = f2_sub(f2_sub(f2_mul(f2_add(a, b), f2_add(a, f2_mul_xi(b))), ab), f2_mul_xi(ab));
+        r1 = f2_dbl(ab);
+    };
+    const Fp2 &z0 = f.c0.c0, &z4 = f.c0.c1, &z3 = f.c0.c2, &z2 = f.c1.c0, &z1 = f.c1.c1, &z5 = f.c1.c2;
+    Fp2 t0, t1, t2, t3, t4, t5;
+    fp4_sqr(z0, z1, t0, t1);
+    fp4_sqr(z2, z3, t2, t3);
+    fp4_sqr(z4, z5, t4, t5);
+    auto three_minus_two = [](const Fp2& t, const Fp2& z) { return f2_add(f2_dbl(f2_sub(t, z)), t); };  // 3t - 2z
+    auto three_plus_two = [](const Fp2& t, const Fp2& z) { return f2_add(f2_dbl(f2_add(t, z)), t); };    // 3t + 2z
+    Fp12 r;
+    r.c0.c0 = three_minus_two(t0, z0);
+    r.c1.c1 = three_plus_two(t1, z1);
+    r.c1.c0 = three_plus_two(f2_mul_xi(t5), z2);
+    r.c0.c2 = three_minus_two(t4, z3);
+    r.c0.c1 = three_minus_two(t2, z4);
+    r.c1.c2 = three_plus_two(t3, z5);
+    return r;
+}
+// f * (a + b v + c v w) for a line value: a, b in Fp2, c in Fp
+inline Fp12 f12_mul_line(const Fp12& f, const Fp2& a, const Fp2& b, const Fp& c) {
+    auto mul_ab0 = [](const Fp6& x, const Fp2& a2, const Fp2& b2) -> Fp6 {  // x * (a2 + b2 v)
+        const Fp2 t0 = f2_mul(x.c0, a2), t1 = f2_mul(x.c1, b2);
+        const Fp2 m01 = f2_sub(f2_sub(f2_mul(f2_add(x.c0, x.c1), f2_add(a2, b2)), t0), t1);  // x0 b + x1 a
+        return {f2_add(t0, f2_mul_xi(f2_mul(x.c2, b2))), m01, f2_add(t1, f2_mul(x.c2, a2))};
+    };
+    const Fp6 t0 = mul_ab0(f.c0, a, b);
+    // f1 * (c v) = (xi x2 c, x0 c, x1 c)
+    const Fp6 t1 = {f2_mul_xi(f2_mul_fp(f.c1.c2, c)), f2_mul_fp(f.c1.c0, c), f2_mul_fp(f.c1.c1, c)};
+    const Fp2 bc = {hfp::add(b.c0, c), b.c1};
+    const Fp6 m = mul_ab0(f6_add(f.c0, f.c1), a, bc);
+    return {f6_add(t0, f6_mul_v(t1)), f6_sub(f6_sub(m, t0), t1)};
+}
 inline Fp12 f12_conj(const Fp12& a) { return {a.c0, f6_neg(a.c1)}; }  // = a^(p^6)
 inline Fp12 f12_inv(const Fp12& a) {
     const Fp6 d = f6_inv(f6_sub(f6_mul(a.c0, a.c0), f6_mul_v(f6_mul(a.c1, a.c1))));
@@ -156,12 +205,12 @@ static_assert(sizeof(G2Jac) == sizeof(blst_p2), "blst_p2 layout");
 inline Fp fp_from_plain(const uint32_t v[12]) {
     Fp a;
     for (int i = 0; i < 12; ++i) a.v[i] = v[i];
-    return ff::to_mont(a);
+    return hfp::to_mont(a);
 }
 inline Fp2 b_twist() {  // 4 (1 + u)
     Fp four = Fp::zero();
     four.v[0] = 4;
-    four = ff::to_mont(four);
+    four = hfp::to_mont(four);
     return {four, four};
 }
 inline G2Jac g2_generator() {
@@ -229,9 +278,9 @@ inline bool g2_equal(const G2Jac& a, const G2Jac& b) {
 }
 // y is "lexicographically largest": compare the imaginary part first, the real part when it is zero
 inline bool f2_lex_largest(const Fp2& y) {
-    const Fp c1 = ff::from_mont(y.c1);
+    const Fp c1 = hfp::from_mont(y.c1);
     if (!c1.is_zero()) return host_fp_lex_largest(c1);
-    return host_fp_lex_largest(ff::from_mont(y.c0));
+    return host_fp_lex_largest(hfp::from_mont(y.c0));
 }
 // blst_p2_uncompress + blst_p2_from_affine (FsG2::from_bytes, blst/src/types/g2.rs:52-75): ZCash format, 96 bytes =
 // x.c1 (flags in the top three bits) | x.c0, big-endian; the point is checked to be on the curve, not in the subgroup
@@ -249,7 +298,7 @@ inline bool g2_uncompress(G2Jac& out, const uint8_t in[96]) {
         return true;
     }
     if (!lt1 || !lt0) return false;
-    const Fp2 x = {ff::to_mont(x0), ff::to_mont(x1)};
+    const Fp2 x = {hfp::to_mont(x0), hfp::to_mont(x1)};
     const Fp2 y2 = f2_add(f2_mul(f2_sqr(x), x), b_twist());
     Fp2 y;
     if (!f2_sqrt(y, y2)) return false;
@@ -264,44 +313,91 @@ inline void g2_compress(uint8_t out[96], const G2Jac& p) {
         return;
     }
     const G2Affine a = g2_to_affine(p);
-    host_fp_to_be48(out, ff::from_mont(a.x.c1));
-    host_fp_to_be48(out + 48, ff::from_mont(a.x.c0));
+    host_fp_to_be48(out, hfp::from_mont(a.x.c1));
+    host_fp_to_be48(out + 48, hfp::from_mont(a.x.c0));
     out[0] |= 0x80;
     if (f2_lex_largest(a.y)) out[0] |= 0x20;
 }
 
 // ---------------------------------------------------------------- Miller loop and final exponentiation
-// f_{|x|,Q}(P) for Q on the twist (affine), P = (xP, yP) in G1 (affine, Montgomery); infinity on either side -> 1
-inline Fp12 miller_loop(const G2Affine& Q, const Fp& xP, const Fp& yP, bool p_inf) {
-    Fp12 f = f12_one();
-    if (Q.inf || p_inf) return f;
-    const uint64_t X = 0xd201000000010000ull;
+// The G2 side of a Miller loop does not depend on the G1 point: for Q on the twist (affine) the walk T = Q, 2Q, ...
+// over the bits of |x| gives, per doubling / addition step, the slope lambda and c = lambda x_T - y_T; the line through
+// the step evaluated at P = (xP, yP) is  c + (-lambda xP) v + yP (v w).  KZG verification only ever pairs with two
+// G2 points per setup ([1]G2 and [tau]G2), so the tables are cached (prepared_lines) and a pairing check does no G2
+// arithmetic and no inversion at all.
+struct LineTable {
+    bool inf = true;
+    std::vector<Fp2> lambda, c;  // 63 doublings + 5 additions, in loop order
+};
+constexpr uint64_t BLS_X_ABS = 0xd201000000010000ull;
+inline LineTable g2_line_table(const G2Affine& Q) {
+    LineTable t;
+    t.inf = Q.inf;
+    if (Q.inf) return t;
     Fp2 tx = Q.x, ty = Q.y;
-    auto line = [&](const Fp2& lambda, const Fp2& x1, const Fp2& y1) -> Fp12 {
-        // (lambda x1 - y1) + (-lambda xP) v + yP (v w)
-        Fp12 l;
-        l.c0 = {f2_sub(f2_mul(lambda, x1), y1), f2_neg(f2_mul_fp(lambda, xP)), f2_zero()};
-        l.c1 = {f2_zero(), {yP, Fp::zero()}, f2_zero()};
-        return l;
-    };
     for (int bit = 62; bit >= 0; --bit) {
         // doubling step: lambda = 3 x^2 / (2 y)   (y != 0: the order of T is odd)
         const Fp2 x2 = f2_sqr(tx);
         const Fp2 lambda = f2_mul(f2_add(f2_dbl(x2), x2), f2_inv(f2_dbl(ty)));
-        f = f12_mul(f12_sqr(f), line(lambda, tx, ty));
+        t.lambda.push_back(lambda);
+        t.c.push_back(f2_sub(f2_mul(lambda, tx), ty));
         const Fp2 nx = f2_sub(f2_sqr(lambda), f2_dbl(tx));
         ty = f2_sub(f2_mul(lambda, f2_sub(tx, nx)), ty);
         tx = nx;
-        if ((X >> bit) & 1) {
+        if ((BLS_X_ABS >> bit) & 1) {
             // addition step T + Q (T != +-Q inside the loop: T = kQ with 1 < k < r - 1)
             const Fp2 lam = f2_mul(f2_sub(Q.y, ty), f2_inv(f2_sub(Q.x, tx)));
-            f = f12_mul(f, line(lam, tx, ty));
+            t.lambda.push_back(lam);
+            t.c.push_back(f2_sub(f2_mul(lam, tx), ty));
             const Fp2 ax = f2_sub(f2_sub(f2_sqr(lam), tx), Q.x);
             ty = f2_sub(f2_mul(lam, f2_sub(tx, ax)), ty);
             tx = ax;
         }
     }
-    return f12_conj(f);  // the BLS parameter is negative
+    return t;
+}
+// the table of a G2 point, from a small cache keyed by the point's 288 bytes (blst_p2 layout)
+inline std::shared_ptr<const LineTable> prepared_lines(const G2Jac& q) {
+    struct Entry {
+        G2Jac key;
+        std::shared_ptr<const LineTable> tab;
+    };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Entry& e : cache)
+            if (memcmp(&e.key, &q, sizeof q) == 0) return e.tab;
+    }
+    auto tab = std::make_shared<const LineTable>(g2_line_table(g2_to_affine(q)));
+    std::lock_guard<std::mutex> lk(mu);
+    if (cache.size() >= 8) cache.erase(cache.begin());
+    cache.push_back({q, tab});
+    return tab;
+}
+// prod_k f_{|x|,Q_k}(P_k), conjugated (the BLS parameter is negative): one shared squaring per bit, one sparse
+// multiplication per pair and step.  P_k = (xP[k], yP[k]) affine, Montgomery; pairs with an infinite side are skipped.
+inline Fp12 miller_loop_multi(const LineTable* const* tabs, const Fp* xP, const Fp* yP, const bool* p_inf, int n) {
+    Fp12 f = f12_one();
+    size_t idx = 0;
+    auto step = [&]() {
+        for (int k = 0; k < n; ++k) {
+            if (p_inf[k] || tabs[k]->inf) continue;
+            f = f12_mul_line(f, tabs[k]->c[idx], f2_neg(f2_mul_fp(tabs[k]->lambda[idx], xP[k])), yP[k]);
+        }
+        ++idx;
+    };
+    for (int bit = 62; bit >= 0; --bit) {
+        f = f12_sqr(f);
+        step();
+        if ((BLS_X_ABS >> bit) & 1) step();
+    }
+    return f12_conj(f);
+}
+inline Fp12 miller_loop(const G2Affine& Q, const Fp& xP, const Fp& yP, bool p_inf) {
+    const LineTable t = g2_line_table(Q);
+    const LineTable* tp = &t;
+    return miller_loop_multi(&tp, &xP, &yP, &p_inf, 1);
 }
 // Frobenius f -> f^p in the tower: conjugation on every Fp2 coefficient, times xi^(k (p-1)/6) for the coefficient of
 // w^k (v = w^2): the six constants are computed once, by exponentiation, from xi = 1 + u.
@@ -332,7 +428,7 @@ inline Fp12 f12_exp_x(const Fp12& f) {
     const uint64_t X = 0xd201000000010000ull;
     Fp12 r = f;
     for (int bit = 62; bit >= 0; --bit) {
-        r = f12_sqr(r);
+        r = f12_cyclotomic_sqr(r);
         if ((X >> bit) & 1) r = f12_mul(r, f);
     }
     return f12_conj(r);
@@ -344,9 +440,9 @@ inline Fp12 f12_exp_x(const Fp12& f) {
 inline Fp12 final_exponentiation(const Fp12& f) {
     Fp12 t2 = f12_mul(f12_conj(f), f12_inv(f));                       // f^(p^6 - 1)
     t2 = f12_mul(f12_frobenius(f12_frobenius(t2)), t2);               // ^(p^2 + 1): now in the cyclotomic subgroup
-    Fp12 t1 = f12_conj(f12_sqr(t2));
+    Fp12 t1 = f12_conj(f12_cyclotomic_sqr(t2));
     Fp12 t3 = f12_exp_x(t2);
-    Fp12 t4 = f12_sqr(t3);
+    Fp12 t4 = f12_cyclotomic_sqr(t3);
     Fp12 t5 = f12_mul(t1, t3);
     t1 = f12_exp_x(t5);
     Fp12 t0 = f12_exp_x(t1);
@@ -370,16 +466,19 @@ inline bool pairings_verify(const blst_p1* a1, const blst_p2* a2, const blst_p1*
     auto g1_affine = [](const blst_p1* p, Fp& x, Fp& y) -> bool {  // returns "is infinity"
         const Fp* P = reinterpret_cast<const Fp*>(p);
         if (P[2].is_zero()) return true;
-        const Fp zi = ff::inverse_bgcd(P[2]), zi2 = ff::sqr(zi);
-        x = ff::mul(P[0], zi2);
-        y = ff::mul(P[1], ff::mul(zi2, zi));
+        const Fp zi = ff::inverse_bgcd(P[2]), zi2 = hfp::sqr(zi);
+        x = hfp::mul(P[0], zi2);
+        y = hfp::mul(P[1], hfp::mul(zi2, zi));
         return false;
     };
     Fp ax, ay, bx, by;
     const bool ainf = g1_affine(a1, ax, ay), binf = g1_affine(b1, bx, by);
-    if (!ainf) ay = ff::neg(ay);  // e(-a1, a2) * e(b1, b2) == 1
-    const Fp12 f = f12_mul(miller_loop(g2_to_affine(A2), ax, ay, ainf), miller_loop(g2_to_affine(B2), bx, by, binf));
-    return f12_is_one(final_exponentiation(f));
+    if (!ainf) ay = hfp::neg(ay);  // e(-a1, a2) * e(b1, b2) == 1
+    const std::shared_ptr<const LineTable> ta = prepared_lines(A2), tb = prepared_lines(B2);
+    const LineTable* tabs[2] = {ta.get(), tb.get()};
+    const Fp xs[2] = {ax, bx}, ys[2] = {ay, by};
+    const bool infs[2] = {ainf, binf};
+    return f12_is_one(final_exponentiation(miller_loop_multi(tabs, xs, ys, infs, 2)));
 }
 
 }  // namespace pairing
