@@ -6,6 +6,7 @@
 // the same trick the reference uses for its precomputation tables
 // (PrecomputationTableManager, kzg/src/eip_4844.rs:64-146).
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -567,23 +568,11 @@ __global__ void __launch_bounds__(64) k_challenge_sha256(u32* __restrict__ z_be,
     for (int i = 0; i < 8; ++i) z_be[b * 8 + i] = __builtin_bswap32(red.v[7 - i]);
 }
 
-// commitment bytes -> status: 0 ok (valid encoding, and infinity or in the r-torsion subgroup), 1 bad
-// (FsG1::from_bytes + `!is_inf && !is_valid`, kzg/src/eip_4844.rs:556-558,577)
-__global__ void __launch_bounds__(64) k_check_commitments(int* __restrict__ status, const unsigned char* __restrict__ in,
-                                                          size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    unsigned char buf[48];
-    for (int k = 0; k < 48; ++k) buf[k] = in[48 * i + k];
-    AffPt p;
-    if (!g1io::uncompress(p, buf)) {
-        status[i] = 1;
-        return;
-    }
-    if (p.flags & 1) return;
-    // Subgroup membership by the endomorphism test phi(P) == -[x^2]P, phi(x,y) = (beta*x, y), x the BLS
-    // parameter (the in-tree statement of the same test: zkcrypto/bls12_381/src/g1.rs:401-435).  Two
-    // 64-bit scalar multiplications instead of one by the 255-bit group order.
+// the r-torsion test of a decoded point: phi(P) == -[x^2]P, phi(x,y) = (beta*x, y), x the BLS parameter (the in-tree
+// statement of the same test: zkcrypto/bls12_381/src/g1.rs:401-435).  Two 64-bit scalar multiplications instead of one
+// by the 255-bit group order.
+__device__ __forceinline__ bool affpt_in_g1(const AffPt& p) {
+    if (p.flags & 1) return true;
     const unsigned long long BLS_X = 0xd201000000010000ull;  // |x|; the sign cancels in x^2
     g1::Xyzz q1, q2;
     g1::set_inf(q1);
@@ -596,10 +585,7 @@ __global__ void __launch_bounds__(64) k_check_commitments(int* __restrict__ stat
         if (!g1::is_inf(q2)) g1::dbl(q2);
         if ((BLS_X >> bit) & 1) g1::dadd(q2, q1);
     }
-    if (g1::is_inf(q2)) {
-        status[i] = 1;
-        return;
-    }
+    if (g1::is_inf(q2)) return false;
     fp28::Fe beta;
     {
         constexpr u32 t[14] = {0xa75929au, 0x681b798u, 0x22a3e9du, 0xabc02bfu, 0x4e5bb45u, 0x55e6e7eu, 0x4814117u,
@@ -608,9 +594,38 @@ __global__ void __launch_bounds__(64) k_check_commitments(int* __restrict__ stat
         for (int k = 0; k < 14; ++k) beta.v[k] = t[k];  // cube root of unity, Montgomery 2^392
     }
     // phi(P) == -Q2  <=>  beta*x*ZZ == X  and  y*ZZZ == -Y
-    fp28::Fe dx = fp28::sub<16>(fp28::mul(fp28::mul(beta, p.x), q2.zz), q2.x);
-    fp28::Fe dy = fp28::addn(fp28::mul(p.y, q2.zzz), q2.y);
-    if (!fp28::is_zero_mod_p(dx) || !fp28::is_zero_mod_p(dy)) status[i] = 1;
+    const fp28::Fe dx = fp28::sub<16>(fp28::mul(fp28::mul(beta, p.x), q2.zz), q2.x);
+    const fp28::Fe dy = fp28::addn(fp28::mul(p.y, q2.zzz), q2.y);
+    return fp28::is_zero_mod_p(dx) && fp28::is_zero_mod_p(dy);
+}
+
+// compressed bytes -> table slots + status: 0 ok, 1 not a valid encoding, 2 on the curve but outside the r-torsion
+// subgroup (one square root per point: the decode and the membership test of batched verification in one kernel)
+__global__ void __launch_bounds__(64) k_decode_check_g1(AffPt* __restrict__ out, int* __restrict__ status,
+                                                        const unsigned char* __restrict__ in, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned char buf[48];
+    for (int k = 0; k < 48; ++k) buf[k] = in[48 * i + k];
+    AffPt p;
+    if (!g1io::uncompress(p, buf)) {
+        status[i] = 1;
+        return;
+    }
+    out[i] = p;
+    status[i] = affpt_in_g1(p) ? 0 : 2;
+}
+
+// commitment bytes -> status: 0 ok (valid encoding, and infinity or in the r-torsion subgroup), 1 bad
+// (FsG1::from_bytes + `!is_inf && !is_valid`, kzg/src/eip_4844.rs:556-558,577)
+__global__ void __launch_bounds__(64) k_check_commitments(int* __restrict__ status, const unsigned char* __restrict__ in,
+                                                          size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned char buf[48];
+    for (int k = 0; k < 48; ++k) buf[k] = in[48 * i + k];
+    AffPt p;
+    if (!g1io::uncompress(p, buf) || !affpt_in_g1(p)) status[i] = 1;
 }
 
 
@@ -715,6 +730,28 @@ struct KzgAmdSettings {
     hipStream_t pipe[NPIPE] = {};
     hipEvent_t pipe_ev[NPIPE] = {};
     hipEvent_t ev_commit = nullptr;  // the commitments of a proof batch are on the device (recorded on stream2)
+    // batched verification: staging for [proofs | commitments | G] and the variable-base handle over them, kept
+    // between calls (a fresh handle per call cost 1.7 ms of stream / allocation / free round trips)
+    unsigned char* d_vbytes = nullptr;
+    AffPt* d_vpts = nullptr;
+    int* d_vstat = nullptr;
+    size_t vcap = 0;
+    kzgamd::MsmContext* msm_verify = nullptr;
+    void ensure_verify(size_t np) {
+        if (np <= vcap) return;
+        if (d_vbytes) (void)hipFree(d_vbytes);
+        if (d_vpts) (void)hipFree(d_vpts);
+        if (d_vstat) (void)hipFree(d_vstat);
+        d_vbytes = nullptr;
+        d_vpts = nullptr;
+        d_vstat = nullptr;
+        vcap = 0;
+        const size_t cap = np < 257 ? 257 : np;
+        CK_HIP(hipMalloc(&d_vbytes, cap * 48));
+        CK_HIP(hipMalloc(&d_vpts, cap * sizeof(AffPt)));
+        CK_HIP(hipMalloc(&d_vstat, cap * sizeof(int)));
+        vcap = cap;
+    }
     hipStream_t pipe_stream(size_t k) {
         const int j = (int)(k % NPIPE);
         if (!pipe[j]) {
@@ -742,6 +779,10 @@ struct KzgAmdSettings {
         if (d_commit) (void)hipFree(d_commit);
         if (d_qscratch) (void)hipFree(d_qscratch);
         if (ev_commit) (void)hipEventDestroy(ev_commit);
+        if (msm_verify) kzgamd::msm_destroy(msm_verify);
+        if (d_vbytes) (void)hipFree(d_vbytes);
+        if (d_vpts) (void)hipFree(d_vpts);
+        if (d_vstat) (void)hipFree(d_vstat);
         for (int j = 0; j < NPIPE; ++j) {
             if (pipe_ev[j]) (void)hipEventDestroy(pipe_ev[j]);
             if (pipe[j]) (void)hipStreamDestroy(pipe[j]);
@@ -1646,23 +1687,7 @@ void verify_batch_g1(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commit
     kzgamd::DeviceGuard on_device(dev->device);
     CK_HIP(on_device.err);
     const size_t np = 2 * n + 1;
-    unsigned char* d_bytes = nullptr;
-    AffPt* d_pts = nullptr;
-    int *d_bad = nullptr, *d_stat = nullptr;
-    kzgamd::MsmContext* msm = nullptr;
-    struct Cleanup {
-        unsigned char*& a;
-        AffPt*& b;
-        int *&c, *&d;
-        kzgamd::MsmContext*& m;
-        ~Cleanup() {
-            if (a) (void)hipFree(a);
-            if (b) (void)hipFree(b);
-            if (c) (void)hipFree(c);
-            if (d) (void)hipFree(d);
-            if (m) kzgamd::msm_destroy(m);
-        }
-    } cleanup{d_bytes, d_pts, d_bad, d_stat, msm};
+    dev->ensure_verify(np);
     // device: [proofs | commitments | generator], decoded and checked
     std::vector<uint8_t> stage(np * 48);
     memcpy(stage.data(), proofs, n * 48);
@@ -1672,17 +1697,12 @@ void verify_batch_g1(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commit
         0xc3, 0x68, 0x8c, 0x4f, 0x97, 0x74, 0xb9, 0x05, 0xa1, 0x4e, 0x3a, 0x3f, 0x17, 0x1b, 0xac, 0x58,
         0x6c, 0x55, 0xe8, 0x3f, 0xf9, 0x7a, 0x1a, 0xef, 0xfb, 0x3a, 0xf0, 0x0a, 0xdb, 0x22, 0xc6, 0xbb};
     memcpy(stage.data() + 2 * n * 48, G1_GENERATOR_COMPRESSED, 48);
-    CK_HIP(hipMalloc(&d_bytes, stage.size()));
-    CK_HIP(hipMalloc(&d_pts, np * sizeof(AffPt)));
-    CK_HIP(hipMalloc(&d_bad, sizeof(int)));
-    CK_HIP(hipMalloc(&d_stat, np * sizeof(int)));
     hipStream_t st = dev->stream;
-    CK_HIP(hipMemcpyAsync(d_bytes, stage.data(), stage.size(), hipMemcpyHostToDevice, st));
-    CK_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), st));
-    CK_HIP(hipMemsetAsync(d_stat, 0, np * sizeof(int), st));
-    hipLaunchKernelGGL(k_uncompress, dim3((unsigned)((np + 127) / 128)), dim3(128), 0, st, d_pts, d_bad, d_bytes, np);
-    hipLaunchKernelGGL(k_check_commitments, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st, d_stat,
-                       (const unsigned char*)d_bytes, np);
+    CK_HIP(hipMemcpyAsync(dev->d_vbytes, stage.data(), stage.size(), hipMemcpyHostToDevice, st));
+    CK_HIP(hipMemsetAsync(dev->d_vstat, 0, np * sizeof(int), st));
+    CK_HIP(hipMemsetAsync(dev->d_vpts, 0, np * sizeof(AffPt), st));
+    hipLaunchKernelGGL(k_decode_check_g1, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st, dev->d_vpts, dev->d_vstat,
+                       (const unsigned char*)dev->d_vbytes, np);
     // host, meanwhile: r = hash_to_bls_field(sha256(domain | 4096 | n | (C_i | z_i | y_i | proof_i)...)), powers of r
     std::vector<ff::Fr> sc(2 * np, ff::Fr::zero());
     {
@@ -1719,17 +1739,16 @@ void verify_batch_g1(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commit
         }
         sc[np + 2 * n] = ff::neg(sy);            // row 1: generator
     }
-    int bad = 0;
     std::vector<int> stat(np);
-    CK_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
-    CK_HIP(hipMemcpyAsync(stat.data(), d_stat, np * sizeof(int), hipMemcpyDeviceToHost, st));
+    CK_HIP(hipMemcpyAsync(stat.data(), dev->d_vstat, np * sizeof(int), hipMemcpyDeviceToHost, st));
     CK_HIP(hipStreamSynchronize(st));
-    CK_REQUIRE(bad == 0, "Invalid G1 encoding");
+    for (size_t i = 0; i < np; ++i) CK_REQUIRE(stat[i] != 1, "Invalid G1 encoding");
     for (size_t i = 0; i < n; ++i) CK_REQUIRE(stat[i] == 0, "Invalid proof");
     for (size_t i = n; i < 2 * n; ++i) CK_REQUIRE(stat[i] == 0, "Invalid commitment");
-    msm = kzgamd::msm_create(d_pts, np, true, false, true);
+    if (!dev->msm_verify) dev->msm_verify = kzgamd::msm_create(dev->d_vpts, np, true, false, true);
+    else kzgamd::msm_reset_points(dev->msm_verify, dev->d_vpts, np);
     blst_p1 out[2];
-    kzgamd::msm_run_host(msm, out, sc.data(), np, 2);
+    kzgamd::msm_run_host(dev->msm_verify, out, sc.data(), np, 2);
     *proof_lincomb = out[0];
     *rhs = out[1];
 }

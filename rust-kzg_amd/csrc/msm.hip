@@ -1565,6 +1565,23 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
     return ctx;
 }
 
+void msm_reset_points(MsmContext* ctx, const void* d_affpts, size_t n) {
+    if (!ctx || ctx->prepared) throw HipErr{hipErrorInvalidValue, "msm_reset_points: not a variable-base handle"};
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard on_device(ctx->device);
+    HIP_TRY(on_device.err);
+    ctx->n = n;
+    ctx->c = choose_window(n, false, ctx->glv);
+    ctx->rows = 1;
+    ctx->nwin = ctx->glv ? (127 + ctx->c) / ctx->c : 255 / ctx->c + 1;
+    ctx->nb = (size_t)1 << (ctx->c - 1);
+    ctx->table.ensure(ctx->glv ? 2 * n : n);
+    hipLaunchKernelGGL(k_copy_affpt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->table.p,
+                       (const AffPt*)d_affpts, n, ctx->glv ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // the caller's buffer may be reused as soon as this returns
+}
+
 void msm_destroy(MsmContext* ctx) {
     if (!ctx) return;
     DeviceGuard on_device(ctx->device);

@@ -10,6 +10,9 @@ enum { OUT_JACOBIAN = 0, OUT_COMPRESSED = 1, OUT_WINDOWS = 2 };
 // points: blst_p1_affine[n] (host or device) or g1::AffPt[n] (device); prepare = build fixed-base rows
 MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare, bool points_are_affpt);
 void msm_destroy(MsmContext* ctx);
+// variable-base handle (prepare == false) over new device-resident AffPt bases: same as destroying it and creating
+// another, without the stream, the allocations and their synchronisations
+void msm_reset_points(MsmContext* ctx, const void* d_affpts, size_t n);
 // enqueue nbatch MSMs (device pointers, no sync); d_out = blst_p1[nbatch] or 48-byte compressed points
 void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npoints, size_t nbatch, int mont,
                  hipStream_t stream, int out_mode, bool reserve_only = false);

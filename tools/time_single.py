@@ -33,3 +33,18 @@ for _ in range(3):
     kzg.verify_blob_kzg_proof_batch([b] * n, [c] * n, [p] * n, s)
 print("%-10s %.3f ms per call of %d blobs" % ("verify_blob_kzg_proof_batch", (time.perf_counter() - t0) / 3 * 1e3, n))
 s.close()
+# the parts of a 64-blob batch verification, buffers joined once
+s = kzg.KZGSettings.from_file(eb.SETUP)
+blobs, cms, prs = b * n, c * n, p * n
+def tm(label, fn, reps=5):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+    print("  %-44s %.3f ms" % (label, (time.perf_counter() - t0) / reps * 1e3))
+    return r
+zs, ys = tm("challenges + evaluations (GPU)", lambda: kzg.compute_challenges_and_evaluate_batch(blobs, cms, n, s))
+pl, rhs = tm("r-powers + three lincombs (GPU)", lambda: kzg.verify_kzg_proof_batch_g1(cms, b"".join(zs), b"".join(ys), prs, n, s))
+g2 = kzg.p2_generator()
+tm("pairing check (host)", lambda: kzg.pairings_verify(pl, g2, pl, g2))
+s.close()
