@@ -2,7 +2,7 @@
 // checks, the verify_* pairing check): the same values and the same memory layout as ff::Fp (Montgomery radix 2^384,
 // canonical residues, twelve little-endian 32-bit words = six 64-bit words on the little-endian host), multiplied with
 // 64 x 64 -> 128-bit products.  ff::mul is written for the GPU's 32-bit multiplier; on a CPU core this form is ~5x
-// faster, which is the difference between a 15 ms and a 3 ms pairing check.
+// faster (75 ns per multiplication where ff::mul takes ~350).
 #pragma once
 #include <stdint.h>
 #include <string.h>
