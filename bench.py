@@ -412,6 +412,11 @@ def main():
         # ---- configs[3]: Fr NTT n = 4096 (batched) and n = 2^20, forward + DAS extension -------------------------
         fs = kzg.FFTSettings(20)
         ntt = {}
+        # HBM traffic of the NTT kernels from the committed PMC passes (tools/ntt_bench.py under rocprofv3; both bench
+        # shapes launch k_ntt_low with 256 tiles = grid 131072, the 2^20 transform adds one k_ntt_high launch)
+        npm = (pm or {}).get("ntt", {})
+        t_low = (npm.get("k_ntt_low<3> grid=131072") or {}).get("hbm_bytes_per_launch")
+        t_high = (npm.get("k_ntt_high<3> grid=131072") or {}).get("hbm_bytes_per_launch")
         for n, nb in ((4096, 256), (1 << 20, 1)):
             a = torch.randint(0, 2**31, (nb * n * 8,), dtype=torch.int32, device=dev)
             a[7::8] &= 0x3FFFFFFF  # any 256-bit pattern below r is a valid Montgomery residue
@@ -424,7 +429,11 @@ def main():
                 "ms": ms, "ms_inverse": ms_inv, "transforms_per_s": nb / (ms * 1e-3), "fr_mul_per_s": muls / (ms * 1e-3),
                 "roofline": {"bound": "hbm", "kernel": "k_ntt_low" + ("+k_ntt_high" if n > 4096 else ""),
                              "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "traffic": None,
+                             "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_bytes": alg,
+                             "traffic": (t_low if n <= 4096 else (t_low + t_high if t_low and t_high else None)),
+                             "traffic_source": pm_src + " (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, which the guide "
+                                               "calls uncalibrated for 32-byte stores; n = 2^20 crosses HBM twice: two passes)",
                              "note": "64*n algorithmic bytes (SURVEY §8d). At ~270 VALU instructions per radix-2 butterfly "
                                      "(9x29-bit Montgomery multiply + lazy add/sub) the transform needs "
                                      "%.1f M wave-instructions: VALU floor %.0f us at the nominal clock"
