@@ -742,6 +742,117 @@ __global__ void __launch_bounds__(DIGIT_T) k_digit_sums(const Xyzz* __restrict__
     if (lane == 0) S[blockIdx.x] = acc;
 }
 
+// Tiled form of the digit sums (nb a multiple of 1024).  A workgroup takes 1024 consecutive buckets as a 32 x 32
+// matrix M[g][d] (bucket = 32 g + d): the row sums are the GROUP sums G[g] — all the higher digits need, since digits
+// 1.. of a bucket are digits of its group — and the column sums are this tile's share of S[0][d].  Two additions per
+// bucket instead of J = 3, every bucket's pieces folded exactly once in the same kernel, and nsets * nb / 1024 =
+// 256 workgroups of eight waves at n = 2^20 (a chain of ~15 additions).  The (digit, value) cells that are left have
+// nb / 1024 values each: few enough additions for one wave per addition (k_digit_sums_wide, k_digit_bits_wide).
+constexpr int TILE_T = 512;  // two buckets per lane and phase: a full CU (two waves per SIMD) per tile
+__global__ void __launch_bounds__(TILE_T) k_tile_sums(const Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
+                                                      const unsigned char* __restrict__ heavy, Xyzz* __restrict__ dense,
+                                                      Xyzz* __restrict__ Gs, Xyzz* __restrict__ Cp, size_t nb, size_t nchunk,
+                                                      int lgc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ts[];
+    Xyzz* sh = (Xyzz*)smem_ts;
+    const size_t ntiles = nb >> 10;
+    const size_t set = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+    const size_t k0 = tile << 10;
+    const int t = threadIdx.x;
+    Xyzz acc;
+    {
+        // rows: lane t folds and adds buckets 32 r + 2 q, + 1 of the tile, r = t / 16, q = t % 16
+        const int r = t >> 4, q = t & 15;
+        const size_t kb = k0 + (size_t)(32 * r + 2 * q);
+        g1::set_inf(acc);
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+            Xyzz v;
+            load_bucket(v, partials + set * (nb + nchunk), offsets + set * (nb + 1), heavy + set * nb, kb + i, lgc);
+            dense[set * nb + kb + i] = v;
+            g1::dadd(acc, v);
+        }
+        sh[t] = acc;
+        __syncthreads();
+#pragma unroll 1
+        for (int stride = 8; stride > 0; stride >>= 1) {
+            if (q < stride) {
+                Xyzz v = sh[t + stride];
+                g1::dadd(acc, v);
+                sh[t] = acc;
+            }
+            __syncthreads();
+        }
+        if (q == 0) Gs[set * (nb >> 5) + (k0 >> 5) + r] = acc;
+    }
+    __threadfence();  // the folded buckets this workgroup wrote are read back below by other lanes
+    __syncthreads();
+    {
+        // columns: lane t adds rows 2 rg, 2 rg + 1 of column c, c = t % 32, rg = t / 32
+        const int c = t & 31, rg = t >> 5;
+        g1::set_inf(acc);
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+            Xyzz v = dense[set * nb + k0 + (size_t)(32 * (2 * rg + i) + c)];
+            g1::dadd(acc, v);
+        }
+        sh[t] = acc;
+        __syncthreads();
+#pragma unroll 1
+        for (int stride = 8; stride > 0; stride >>= 1) {
+            if (rg < stride) {
+                Xyzz v = sh[t + 32 * stride];
+                g1::dadd(acc, v);
+                sh[t] = acc;
+            }
+            __syncthreads();
+        }
+        if (rg == 0) Cp[(set * ntiles + tile) * 32 + c] = acc;
+    }
+}
+
+// S[set][0][d] = sum over the tiles of Cp[set][tile][d];  S[set][j][d], j >= 1, = sum of the groups whose digit j - 1
+// (base 32, of the group index) equals d.  One 64-thread workgroup per cell, nb / 1024 values each (32 at 2^15 buckets).
+__global__ void __launch_bounds__(64) k_digit_sums2(const Xyzz* __restrict__ Gs, const Xyzz* __restrict__ Cp,
+                                                    Xyzz* __restrict__ S, size_t nb, int logNb, int J) {
+    __shared__ Xyzz sh[64];
+    const int per_set = J << DIGIT_BITS;
+    const size_t set = blockIdx.x / per_set;
+    const int jd = (int)(blockIdx.x % per_set), j = jd >> DIGIT_BITS, d = jd & ((1 << DIGIT_BITS) - 1);
+    const size_t ntiles = nb >> 10, ng = nb >> 5;
+    const int lane = threadIdx.x;
+    Xyzz acc;
+    g1::set_inf(acc);
+    if (j == 0) {
+        for (size_t e = lane; e < ntiles; e += 64) {
+            Xyzz v = Cp[(set * ntiles + e) * 32 + d];
+            g1::dadd(acc, v);
+        }
+    } else {
+        const int logNg = logNb - DIGIT_BITS, lo_bits = DIGIT_BITS * (j - 1);
+        const int w = logNg - lo_bits < DIGIT_BITS ? logNg - lo_bits : DIGIT_BITS;  // width of this digit
+        if (d < (1 << w)) {
+            const size_t cnt = ng >> w;
+            for (size_t m = lane; m < cnt; m += 64) {
+                const size_t g = ((m >> lo_bits) << (lo_bits + w)) | ((size_t)d << lo_bits) | (m & (((size_t)1 << lo_bits) - 1));
+                Xyzz v = Gs[set * ng + g];
+                g1::dadd(acc, v);
+            }
+        }
+    }
+    sh[lane] = acc;
+    __syncthreads();
+    for (int stride = 32; stride > 0; stride >>= 1) {
+        if (lane < stride) {
+            Xyzz v = sh[lane + stride];
+            g1::dadd(acc, v);
+            sh[lane] = acc;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) S[blockIdx.x] = acc;
+}
+
 // top[set][q] = sum over { d : bit (q mod 5) of d } of S[set][q / 5][d]  for q < logNb;  top[set][logNb] = T = sum_d
 // S[set][0][d];  top[set][logNb + 1] = infinity  — the layout k_winsum(_wide) expects (R_q, A, M) with logS = 0
 __global__ void __launch_bounds__(64) k_digit_bits(const Xyzz* __restrict__ S, Xyzz* __restrict__ top, int logNb, int J) {
@@ -955,6 +1066,85 @@ __global__ void __launch_bounds__(64) k_final_wide(const Xyzz* __restrict__ win,
     }
 }
 
+
+// Small plain sums with one limb-parallel addition per wave.  A single-lane XYZZ addition is a ~27 us dependency
+// chain (6 700 instructions at one issue per ~8.5 cycles for a lone wave), the row-parallel one ~2.7 us, but it
+// occupies a whole wave: worth it where a stage has at most a few thousand additions per level.  A cell (one output
+// sum) is cut into WSPLIT parts; wave (cell, part) adds its elements one after the other, stores its partial sum, and
+// the last wave of a cell to finish (a counter per cell) adds the partial sums.
+constexpr int WSPLIT = 4;   // parts per cell of the bit sums (<= 32 values per cell)
+constexpr int WSPLIT_S = 2; // parts per cell of the digit sums: fewer, longer chains — the limb-parallel code is a
+                            // dependent instruction stream, and more than ~2 such waves per SIMD only queue up
+template <int NSPLIT>
+__device__ __forceinline__ void wide_cell_finish(g1w::WPt& acc, Xyzz* __restrict__ part, Xyzz* __restrict__ out,
+                                                 u32* __restrict__ counter, size_t cell, int sub, const fpw::Lane& lc, u32* sh,
+                                                 u32* last_s, int lane) {
+    g1w::store(part + cell * NSPLIT + sub, acc, lc, lane);
+    __threadfence();
+    if (lane == 0) *last_s = atomicAdd(counter + cell, 1u);
+    __syncthreads();
+    if (*last_s != (u32)(NSPLIT - 1)) return;
+    __threadfence();
+    g1w::WPt tot;
+    g1w::set_inf(tot);
+    for (int k = 0; k < NSPLIT; ++k) g1w::dadd(tot, g1w::load(part + cell * NSPLIT + k, lane), lc, sh, lane);
+    g1w::store(out + cell, tot, lc, lane);
+    if (lane == 0) counter[cell] = 0;  // ready for the next launch
+}
+
+// k_digit_sums2 with limb-parallel additions: grid = cells * WSPLIT waves
+__global__ void __launch_bounds__(64) k_digit_sums_wide(const Xyzz* __restrict__ Gs, const Xyzz* __restrict__ Cp,
+                                                        Xyzz* __restrict__ S, Xyzz* __restrict__ part,
+                                                        u32* __restrict__ counter, size_t nb, int logNb, int J) {
+    __shared__ u32 sh[16];
+    __shared__ u32 last_s;
+    const int lane = threadIdx.x;
+    const size_t cell = blockIdx.x / WSPLIT_S;
+    const int sub = (int)(blockIdx.x % WSPLIT_S);
+    const int per_set = J << DIGIT_BITS;
+    const size_t set = cell / per_set;
+    const int jd = (int)(cell % per_set), j = jd >> DIGIT_BITS, d = jd & ((1 << DIGIT_BITS) - 1);
+    const size_t ntiles = nb >> 10, ng = nb >> 5;
+    const fpw::Lane lc = fpw::lane_consts(lane);
+    g1w::WPt acc;
+    g1w::set_inf(acc);
+    if (j == 0) {
+        for (size_t e = sub; e < ntiles; e += WSPLIT_S) g1w::dadd(acc, g1w::load(Cp + (set * ntiles + e) * 32 + d, lane), lc, sh, lane);
+    } else {
+        const int logNg = logNb - DIGIT_BITS, lo_bits = DIGIT_BITS * (j - 1);
+        const int w = logNg - lo_bits < DIGIT_BITS ? logNg - lo_bits : DIGIT_BITS;  // width of this digit
+        if (d < (1 << w)) {
+            const size_t cnt = ng >> w;
+            for (size_t m = sub; m < cnt; m += WSPLIT_S) {
+                const size_t g = ((m >> lo_bits) << (lo_bits + w)) | ((size_t)d << lo_bits) | (m & (((size_t)1 << lo_bits) - 1));
+                g1w::dadd(acc, g1w::load(Gs + set * ng + g, lane), lc, sh, lane);
+            }
+        }
+    }
+    wide_cell_finish<WSPLIT_S>(acc, part, S, counter, cell, sub, lc, sh, &last_s, lane);
+}
+
+// k_digit_bits with limb-parallel additions: part `sub` of cell (set, q) takes the digit values 8 sub .. 8 sub + 7
+__global__ void __launch_bounds__(64) k_digit_bits_wide(const Xyzz* __restrict__ S, Xyzz* __restrict__ top,
+                                                        Xyzz* __restrict__ part, u32* __restrict__ counter, int logNb, int J) {
+    __shared__ u32 sh[16];
+    __shared__ u32 last_s;
+    const int lane = threadIdx.x;
+    const size_t cell = blockIdx.x / WSPLIT;
+    const int sub = (int)(blockIdx.x % WSPLIT);
+    const int per_top = logNb + 2;
+    const size_t set = cell / per_top;
+    const int q = (int)(cell % per_top);
+    const fpw::Lane lc = fpw::lane_consts(lane);
+    g1w::WPt acc;
+    g1w::set_inf(acc);
+    if (q <= logNb) {
+        const int j = q < logNb ? q / DIGIT_BITS : 0, b = q % DIGIT_BITS;
+        for (int d = sub * (32 / WSPLIT); d < (sub + 1) * (32 / WSPLIT); ++d)
+            if (q == logNb || ((d >> b) & 1)) g1w::dadd(acc, g1w::load(S + (set * J + j) * 32 + d, lane), lc, sh, lane);
+    }
+    wide_cell_finish<WSPLIT>(acc, part, top, counter, cell, sub, lc, sh, &last_s, lane);
+}
 
 // ============================ wide fixed-base table ("FBW") ============================
 // With 288 GB of HBM per GPU the 4096-point setup can afford the full signed-window table
@@ -1342,7 +1532,8 @@ struct DevBuf {
 
 struct Workspace {
     DevBuf<u32> counts, offsets, sorted, scalars, ranks, tmp, bins, digits;
-    DevBuf<Xyzz> buckets, lvlA[2], lvlM[2], top, win, dense;
+    DevBuf<Xyzz> buckets, lvlA[2], lvlM[2], top, win, dense, wpart;
+    DevBuf<u32> wcount;
     DevBuf<unsigned char> heavy;
     DevBuf<u32> heavy_list, nheavy;
     DevBuf<ff::Fp> out;
@@ -1760,6 +1951,8 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     // few sets of many buckets: the digit-decomposed reduction instead of the (A, M) tree (KZGAMD_TREE_TAIL=1: the tree)
     // measured (same box, tree vs digits): n = 2^14 (4096 buckets) 1.20 vs 1.35 ms, 2^16 1.53 vs 1.48, 2^20 4.53 vs 4.35, 2^22 14.67 vs 14.26
     const bool digit_tail = use_top && nb >= 16384 && !getenv("KZGAMD_TREE_TAIL");
+    // the tiled form of the digit sums (k_tile_sums); KZGAMD_FLAT_DIGITS=1: one pass over the buckets per digit
+    const bool tiled_digits = digit_tail && nb % 1024 == 0 && !getenv("KZGAMD_FLAT_DIGITS");
     // shape of the tree (the same for every group: level 0 folds by the group size): k_top stride B + 2
     size_t top_stride = 0;
     {
@@ -1781,6 +1974,13 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             top_stride = (size_t)logNb + 2;
             ws.lvlA[0].ensure(nsets * (size_t)(((logNb + DIGIT_BITS - 1) / DIGIT_BITS) * 32));
             ws.dense.ensure(nsets * nb);
+            if (tiled_digits) {
+                ws.lvlA[1].ensure(nsets * (nb >> 5));  // group sums
+                ws.lvlM[1].ensure(nsets * (nb >> 5));  // per-tile column sums: (nb / 1024) tiles x 32
+                const size_t cells = nsets * (size_t)(((logNb + DIGIT_BITS - 1) / DIGIT_BITS) * 32 + logNb + 2);
+                ws.wpart.ensure(cells * WSPLIT);
+                ws.wcount.ensure(cells);
+            }
         }
         if (use_top) {
             ws.top.ensure(nsets * top_stride);
@@ -1879,12 +2079,37 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             Xyzz* S = ws.lvlA[0].p + set0 * (size_t)(J * 32);
             Xyzz* top = ws.top.p + set0 * top_stride;
             Xyzz* dense = ws.dense.p + set0 * nb;
-            hipLaunchKernelGGL(k_fold_buckets, dim3((unsigned)((ns * nb + 127) / 128)), dim3(128), 0, st, (const Xyzz*)buckets,
-                               (const u32*)offsets, (const unsigned char*)heavy, dense, nb, ns, nchunk, lgc);
-            hipLaunchKernelGGL(k_digit_sums, dim3((unsigned)(ns * (size_t)(J * 32))), dim3(DIGIT_T), DIGIT_T * sizeof(Xyzz), st,
-                               (const Xyzz*)dense, S, nb, logNb, J);
-            hipLaunchKernelGGL(k_digit_bits, dim3((unsigned)(ns * (size_t)(logNb + 2))), dim3(64), 0, st, (const Xyzz*)S, top,
-                               logNb, J);
+            if (tiled_digits) {
+                Xyzz* Gs = ws.lvlA[1].p + set0 * (nb >> 5);
+                Xyzz* Cp = ws.lvlM[1].p + set0 * (nb >> 5);
+                hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)(ns * (nb >> 10))), dim3(TILE_T), TILE_T * sizeof(Xyzz), st,
+                                   (const Xyzz*)buckets, (const u32*)offsets, (const unsigned char*)heavy, dense, Gs, Cp, nb,
+                                   nchunk, lgc);
+                if (wide_tail) {
+                    // cells of this group: [0, ns * J * 32) digit sums, then ns * (logNb + 2) bit sums
+                    const size_t c1 = ns * (size_t)(J * 32), c2 = ns * (size_t)(logNb + 2);
+                    const size_t cbase = set0 * (size_t)(J * 32 + logNb + 2);
+                    u32* cnt = ws.wcount.p + cbase;
+                    Xyzz* part = ws.wpart.p + cbase * WSPLIT;  // WSPLIT >= WSPLIT_S slots per cell
+                    HIP_TRY(hipMemsetAsync(cnt, 0, (c1 + c2) * sizeof(u32), st));
+                    hipLaunchKernelGGL(k_digit_sums_wide, dim3((unsigned)(c1 * WSPLIT_S)), dim3(64), 0, st, (const Xyzz*)Gs,
+                                       (const Xyzz*)Cp, S, part, cnt, nb, logNb, J);
+                    hipLaunchKernelGGL(k_digit_bits_wide, dim3((unsigned)(c2 * WSPLIT)), dim3(64), 0, st, (const Xyzz*)S, top,
+                                       part + c1 * WSPLIT, cnt + c1, logNb, J);
+                } else {
+                    hipLaunchKernelGGL(k_digit_sums2, dim3((unsigned)(ns * (size_t)(J * 32))), dim3(64), 0, st, (const Xyzz*)Gs,
+                                       (const Xyzz*)Cp, S, nb, logNb, J);
+                }
+            } else {
+                hipLaunchKernelGGL(k_fold_buckets, dim3((unsigned)((ns * nb + 127) / 128)), dim3(128), 0, st,
+                                   (const Xyzz*)buckets, (const u32*)offsets, (const unsigned char*)heavy, dense, nb, ns, nchunk,
+                                   lgc);
+                hipLaunchKernelGGL(k_digit_sums, dim3((unsigned)(ns * (size_t)(J * 32))), dim3(DIGIT_T), DIGIT_T * sizeof(Xyzz),
+                                   st, (const Xyzz*)dense, S, nb, logNb, J);
+            }
+            if (!(tiled_digits && wide_tail))
+                hipLaunchKernelGGL(k_digit_bits, dim3((unsigned)(ns * (size_t)(logNb + 2))), dim3(64), 0, st, (const Xyzz*)S,
+                                   top, logNb, J);
             if (wide_tail)
                 hipLaunchKernelGGL(k_winsum_wide, dim3((unsigned)ns), dim3(64), 0, st, (const Xyzz*)top, ws.win.p + set0,
                                    logNb, 0);
