@@ -79,7 +79,8 @@ __device__ __forceinline__ u32 wsub32(u32 a, u32 b, const Lane& c) { return wnor
 // lane J of each row to every lane of that row
 template <int J>
 __device__ __forceinline__ u32 row_lane(u32 x) {
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + J, 0xF, 0xF, false);  // row_newbcast:J
+    // row_newbcast:J; every lane has a source, bound_ctrl only spares the compiler the "old value" move
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 + J, 0xF, 0xF, true);
 }
 // row k of the wave to all four rows (ds_bpermute: a lane permutation through the LDS crossbar, no memory)
 __device__ __forceinline__ u32 row_all(u32 x, int k, int lane) {
@@ -95,9 +96,13 @@ __device__ __forceinline__ u32 rows4(int row, u32 a0, u32 a1, u32 a2, u32 a3) {
 //     acc_i <- low28(acc_{i+1}) + (acc_i >> 28)            (one DPP row shift folded into the add)
 __device__ __forceinline__ u32 wmul4(u32 a, u32 b, const Lane& c) {
     u32 acc = 0;
+    // the 14 broadcasts of b do not depend on the accumulator chain: taken up front, they leave the chain
+    // mad -> broadcast of lane 0 -> quotient digit -> mad -> shift down
+    const u32 bb[14] = {row_lane<0>(b), row_lane<1>(b), row_lane<2>(b),  row_lane<3>(b),  row_lane<4>(b),  row_lane<5>(b),  row_lane<6>(b),
+                        row_lane<7>(b), row_lane<8>(b), row_lane<9>(b), row_lane<10>(b), row_lane<11>(b), row_lane<12>(b), row_lane<13>(b)};
 #define KZG_WSTEP(J)                                               \
     {                                                              \
-        const u32 bj = row_lane<J>(b);                             \
+        const u32 bj = bb[J];                                      \
         u64 t = (u64)a * bj + acc;                                 \
         const u32 m = (row_lane<0>((u32)t) * fp28::P0INV) & MASK;  \
         t += (u64)c.p * m;                                         \
