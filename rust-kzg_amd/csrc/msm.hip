@@ -416,6 +416,85 @@ __global__ void __launch_bounds__(256) k_part_scatter(DigitParams P, const u32* 
     }
 }
 
+// k_part_scatter with the workgroup's entries staged in LDS in bin order and written out by consecutive lanes: a wave
+// then writes ~8 runs of consecutive words per store instruction instead of 64 scattered 4-byte words.  1024 scalars
+// per workgroup of 512 lanes, at most STAGE_CAP entries (16 per scalar): 64 KB of entries + 32 KB of bin ids + the
+// three per-bin arrays.
+constexpr u32 STAGE_CAP = 16384;
+constexpr int STAGE_T = 512, STAGE_SCALARS = 2;
+__global__ void __launch_bounds__(STAGE_T) k_part_scatter_staged(DigitParams P, const u32* __restrict__ scalars,
+                                                                 const AffPt* __restrict__ pts,
+                                                                 const u32* __restrict__ bin_start, u32* __restrict__ bin_cursor,
+                                                                 u32* __restrict__ tmp, u32 set0, u32 cb, u32 nbins, int fb) {
+    extern __shared__ u32 lds_bins[];
+    u32* cnt = lds_bins;               // per bin: count, then the running rank
+    u32* gbase = lds_bins + nbins;     // per bin: start of this workgroup's run in tmp
+    u32* lstart = lds_bins + 2 * nbins;  // per bin: start of the bin's entries in the staging area
+    u32* stage = lds_bins + 3 * nbins;
+    unsigned short* binid = (unsigned short*)(stage + STAGE_CAP);
+    __shared__ u32 wsum[STAGE_T / 64];
+    for (u32 k = threadIdx.x; k < nbins; k += STAGE_T) cnt[k] = 0;
+    __syncthreads();
+    const size_t total = P.n * P.nbatch;
+#pragma unroll 1
+    for (int q = 0; q < STAGE_SCALARS; ++q) {
+        const size_t t = ((size_t)blockIdx.x * STAGE_SCALARS + q) * STAGE_T + threadIdx.x;
+        if (t < total)
+            scalar_entries(P, scalars, pts, t, [&](size_t set, u32 bucket, u32, u32) {
+                atomicAdd(&cnt[(u32)(set - set0) * cb + (bucket >> fb)], 1u);
+            });
+    }
+    __syncthreads();
+    {
+        // exclusive scan of the counts (K consecutive bins per lane), and one returning atomic per non-empty bin
+        const u32 K = (nbins + STAGE_T - 1) / STAGE_T;  // <= 8 for 4096 bins
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        u32 v[8], tot = 0;
+        for (u32 k = 0; k < K; ++k) {
+            const u32 idx = threadIdx.x * K + k;
+            v[k] = idx < nbins ? cnt[idx] : 0;
+            tot += v[k];
+        }
+        u32 x = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            u32 y = __shfl_up(x, d, 64);
+            if (lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        u32 ex = x - tot;
+        for (int w2 = 0; w2 < wave; ++w2) ex += wsum[w2];
+        for (u32 k = 0; k < K; ++k) {
+            const u32 idx = threadIdx.x * K + k;
+            if (idx < nbins) {
+                lstart[idx] = ex;
+                gbase[idx] = v[k] ? bin_start[idx] + atomicAdd(&bin_cursor[idx], v[k]) : 0u;
+                cnt[idx] = 0;
+                ex += v[k];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int q = 0; q < STAGE_SCALARS; ++q) {
+        const size_t t = ((size_t)blockIdx.x * STAGE_SCALARS + q) * STAGE_T + threadIdx.x;
+        if (t < total)
+            scalar_entries(P, scalars, pts, t, [&](size_t set, u32 bucket, u32 neg, u32 pidx) {
+                const u32 bin = (u32)(set - set0) * cb + (bucket >> fb);
+                const u32 slot = lstart[bin] + atomicAdd(&cnt[bin], 1u);
+                stage[slot] = ((bucket & ((1u << fb) - 1)) << (32 - fb)) | (neg << (31 - fb)) | pidx;
+                binid[slot] = (unsigned short)bin;
+            });
+    }
+    __syncthreads();
+    const u32 nent = lstart[nbins - 1] + cnt[nbins - 1];
+    for (u32 e = threadIdx.x; e < nent; e += STAGE_T) {
+        const u32 bin = binid[e];
+        tmp[gbase[bin] + (e - lstart[bin])] = stage[e];
+    }
+}
+
 // offsets / heavy / sorted are the group's (already shifted to its first set); heavy buckets are listed as in k_scan
 __global__ void __launch_bounds__(256) k_bin_sort(const u32* __restrict__ tmp, const u32* __restrict__ bin_start,
                                                   u32* __restrict__ offsets, u32* __restrict__ sorted,
@@ -2039,9 +2118,18 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             hipLaunchKernelGGL(k_part_count, dim3(gpart), dim3(256), nbins * sizeof(u32), st, P, (const u32*)d_scalars,
                                (const AffPt*)ctx->table.p, bin_count, (u32)set0, cb, nbins, fb);
             hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, st, (const u32*)bin_count, bin_start, bin_cursor, nbins);
-            hipLaunchKernelGGL(k_part_scatter, dim3(gpart), dim3(256), 2 * nbins * sizeof(u32), st, P,
-                               (const u32*)d_scalars, (const AffPt*)ctx->table.p, (const u32*)bin_start, bin_cursor, tmp,
-                               (u32)set0, cb, nbins, fb);
+            // entries per scalar (windows of this launch's group x halves): the staged form holds 16 per scalar
+            const size_t per_scalar = (size_t)(G > 1 ? ns : (size_t)nwin) * (ctx->glv ? 2 : 1);
+            if (per_scalar * STAGE_T * STAGE_SCALARS <= STAGE_CAP && !getenv("KZGAMD_DIRECT_SCATTER")) {
+                const unsigned gst = (unsigned)((npoints * nbatch + STAGE_T * STAGE_SCALARS - 1) / (STAGE_T * STAGE_SCALARS));
+                const size_t lds = (3 * (size_t)nbins + STAGE_CAP) * sizeof(u32) + STAGE_CAP * sizeof(unsigned short);
+                hipLaunchKernelGGL(k_part_scatter_staged, dim3(gst), dim3(STAGE_T), lds, st, P, (const u32*)d_scalars,
+                                   (const AffPt*)ctx->table.p, (const u32*)bin_start, bin_cursor, tmp, (u32)set0, cb, nbins, fb);
+            } else {
+                hipLaunchKernelGGL(k_part_scatter, dim3(gpart), dim3(256), 2 * nbins * sizeof(u32), st, P,
+                                   (const u32*)d_scalars, (const AffPt*)ctx->table.p, (const u32*)bin_start, bin_cursor, tmp,
+                                   (u32)set0, cb, nbins, fb);
+            }
             HIP_TRY(hipMemsetAsync(nheavy, 0, sizeof(u32), st));
             hipLaunchKernelGGL(k_bin_sort, dim3(nbins), dim3(256), 0, st, (const u32*)tmp, (const u32*)bin_start, offsets,
                                ws.sorted.p + set0 * set_cap, heavy, heavy_list, nheavy, (u32)heavy_cap, cb, nb, set_cap, fb);
