@@ -1637,6 +1637,8 @@ struct Workspace {
         }
         top.release();
         dense.release();
+        wpart.release();
+        wcount.release();
         win.release();
         heavy.release();
         heavy_list.release();
