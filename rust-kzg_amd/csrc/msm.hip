@@ -851,18 +851,21 @@ __global__ void __launch_bounds__(TILE_T) k_tile_sums(const Xyzz* __restrict__ p
             dense[set * nb + kb + i] = v;
             g1::dadd(acc, v);
         }
-        sh[t] = acc;
+        // the row tree runs q-major (slot 32 q + r) so that the lanes still adding at a level are the first
+        // 32 * stride of the workgroup: whole waves drop out level by level instead of all eight staying half empty
+        sh[32 * q + r] = acc;
         __syncthreads();
+        acc = sh[t];
 #pragma unroll 1
         for (int stride = 8; stride > 0; stride >>= 1) {
-            if (q < stride) {
-                Xyzz v = sh[t + stride];
+            if (t < 32 * stride) {
+                Xyzz v = sh[t + 32 * stride];
                 g1::dadd(acc, v);
                 sh[t] = acc;
             }
             __syncthreads();
         }
-        if (q == 0) Gs[set * (nb >> 5) + (k0 >> 5) + r] = acc;
+        if (t < 32) Gs[set * (nb >> 5) + (k0 >> 5) + t] = acc;
     }
     __threadfence();  // the folded buckets this workgroup wrote are read back below by other lanes
     __syncthreads();
