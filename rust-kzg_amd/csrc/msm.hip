@@ -1577,7 +1577,7 @@ int choose_window(size_t n, bool prepared, bool glv) {
         // least 2^22 — eight windows with a full top window after the balanced split; smaller n are latency-bound
         // and prefer fewer buckets
         if (n >= ((size_t)1 << 15)) return 16;
-        if (n >= ((size_t)1 << 13)) return 13;
+        if (n >= ((size_t)1 << 12)) return 13;  // 2^12: 0.81 ms against 0.91 with c = 10
         if (n >= ((size_t)1 << 10)) return 10;
     }
     int best = 2;
