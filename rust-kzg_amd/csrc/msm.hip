@@ -326,7 +326,7 @@ __device__ __forceinline__ void scalar_entries(const DigitParams& P, const u32* 
 // set0 = first set of this launch's group, cb = coarse bins per set; bins are numbered (set - set0) * cb + coarse
 __global__ void __launch_bounds__(256) k_part_count(DigitParams P, const u32* __restrict__ scalars,
                                                     const AffPt* __restrict__ pts, u32* __restrict__ bin_count, u32 set0,
-                                                    u32 cb, u32 nbins, int fb) {
+                                                    u32 cb, u32 nbins, int fb, u32* __restrict__ wg_hist) {
     extern __shared__ u32 lds_bins[];
     for (u32 k = threadIdx.x; k < nbins; k += 256) lds_bins[k] = 0;
     __syncthreads();
@@ -343,6 +343,30 @@ __global__ void __launch_bounds__(256) k_part_count(DigitParams P, const u32* __
     for (u32 k = threadIdx.x; k < nbins; k += 256) {
         const u32 v = lds_bins[k];
         if (v) atomicAdd(&bin_count[k], v);
+        if (wg_hist) wg_hist[(size_t)blockIdx.x * nbins + k] = v;  // kept for k_part_offsets / the staged scatter
+    }
+}
+
+// wg_off[wg][bin] = bin_start[bin] + sum of wg_hist[wg'][bin] over wg' < wg: where workgroup wg's run starts inside
+// the bin (the staged scatter then needs neither a second count nor a returning global atomic per (workgroup, bin)).
+// A workgroup takes 64 bins; lane (seg, bin) first sums, then rescans, its segment of the workgroups.
+constexpr int OFF_SEGS = 16;
+__global__ void __launch_bounds__(64 * OFF_SEGS) k_part_offsets(const u32* __restrict__ wg_hist, u32* __restrict__ wg_off,
+                                                              const u32* __restrict__ bin_start, u32 nwg, u32 nbins) {
+    __shared__ u32 seg_tot[OFF_SEGS][64];
+    const u32 b = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6;
+    const u32 per = (nwg + OFF_SEGS - 1) / OFF_SEGS, w0 = seg * per, w1 = w0 + per < nwg ? w0 + per : nwg;
+    u32 tot = 0;
+    if (b < nbins)
+        for (u32 w = w0; w < w1; ++w) tot += wg_hist[(size_t)w * nbins + b];
+    seg_tot[seg][threadIdx.x & 63] = tot;
+    __syncthreads();
+    if (b >= nbins) return;
+    u32 run = bin_start[b];
+    for (u32 s2 = 0; s2 < seg; ++s2) run += seg_tot[s2][threadIdx.x & 63];
+    for (u32 w = w0; w < w1; ++w) {
+        wg_off[(size_t)w * nbins + b] = run;
+        run += wg_hist[(size_t)w * nbins + b];
     }
 }
 
@@ -425,7 +449,9 @@ constexpr int STAGE_T = 512, STAGE_SCALARS = 2;
 __global__ void __launch_bounds__(STAGE_T) k_part_scatter_staged(DigitParams P, const u32* __restrict__ scalars,
                                                                  const AffPt* __restrict__ pts,
                                                                  const u32* __restrict__ bin_start, u32* __restrict__ bin_cursor,
-                                                                 u32* __restrict__ tmp, u32 set0, u32 cb, u32 nbins, int fb) {
+                                                                 u32* __restrict__ tmp, u32 set0, u32 cb, u32 nbins, int fb,
+                                                                 const u32* __restrict__ wg_hist,
+                                                                 const u32* __restrict__ wg_off) {
     extern __shared__ u32 lds_bins[];
     u32* cnt = lds_bins;               // per bin: count, then the running rank
     u32* gbase = lds_bins + nbins;     // per bin: start of this workgroup's run in tmp
@@ -433,16 +459,21 @@ __global__ void __launch_bounds__(STAGE_T) k_part_scatter_staged(DigitParams P, 
     u32* stage = lds_bins + 3 * nbins;
     unsigned short* binid = (unsigned short*)(stage + STAGE_CAP);
     __shared__ u32 wsum[STAGE_T / 64];
-    for (u32 k = threadIdx.x; k < nbins; k += STAGE_T) cnt[k] = 0;
-    __syncthreads();
     const size_t total = P.n * P.nbatch;
+    if (wg_hist) {
+        // k_part_count counted the same 1024 scalars: its histogram, and the run starts k_part_offsets derived from it
+        for (u32 k = threadIdx.x; k < nbins; k += STAGE_T) cnt[k] = wg_hist[(size_t)blockIdx.x * nbins + k];
+    } else {
+        for (u32 k = threadIdx.x; k < nbins; k += STAGE_T) cnt[k] = 0;
+        __syncthreads();
 #pragma unroll 1
-    for (int q = 0; q < STAGE_SCALARS; ++q) {
-        const size_t t = ((size_t)blockIdx.x * STAGE_SCALARS + q) * STAGE_T + threadIdx.x;
-        if (t < total)
-            scalar_entries(P, scalars, pts, t, [&](size_t set, u32 bucket, u32, u32) {
-                atomicAdd(&cnt[(u32)(set - set0) * cb + (bucket >> fb)], 1u);
-            });
+        for (int q = 0; q < STAGE_SCALARS; ++q) {
+            const size_t t = ((size_t)blockIdx.x * STAGE_SCALARS + q) * STAGE_T + threadIdx.x;
+            if (t < total)
+                scalar_entries(P, scalars, pts, t, [&](size_t set, u32 bucket, u32, u32) {
+                    atomicAdd(&cnt[(u32)(set - set0) * cb + (bucket >> fb)], 1u);
+                });
+        }
     }
     __syncthreads();
     {
@@ -469,7 +500,8 @@ __global__ void __launch_bounds__(STAGE_T) k_part_scatter_staged(DigitParams P, 
             const u32 idx = threadIdx.x * K + k;
             if (idx < nbins) {
                 lstart[idx] = ex;
-                gbase[idx] = v[k] ? bin_start[idx] + atomicAdd(&bin_cursor[idx], v[k]) : 0u;
+                if (wg_off) gbase[idx] = wg_off[(size_t)blockIdx.x * nbins + idx];
+                else gbase[idx] = v[k] ? bin_start[idx] + atomicAdd(&bin_cursor[idx], v[k]) : 0u;
                 cnt[idx] = 0;
                 ex += v[k];
             }
@@ -1613,7 +1645,7 @@ struct DevBuf {
 };
 
 struct Workspace {
-    DevBuf<u32> counts, offsets, sorted, scalars, ranks, tmp, bins, digits;
+    DevBuf<u32> counts, offsets, sorted, scalars, ranks, tmp, bins, digits, wghist;
     DevBuf<Xyzz> buckets, lvlA[2], lvlM[2], top, win, dense, wpart;
     DevBuf<u32> wcount;
     DevBuf<unsigned char> heavy;
@@ -1627,6 +1659,7 @@ struct Workspace {
         last_done = nullptr;
         counts.release();
         digits.release();
+        wghist.release();
         offsets.release();
         sorted.release();
         ranks.release();
@@ -2022,6 +2055,8 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     if (two_level) {
         ws.tmp.ensure(nsets * set_cap);
         ws.bins.ensure((size_t)G * (3 * MAX_BINS + 8));
+        if (G == 1)  // per-workgroup histograms and run starts of the partition pass (1024 scalars per workgroup)
+            ws.wghist.ensure(2 * ((npoints * nbatch + 1023) / 1024) * ((nb >> fb) * sets_per_group));
     } else {
         ws.counts.ensure(nsets * nb);
         ws.ranks.ensure((size_t)(ctx->glv ? 2 : 1) * nwin * nbatch * npoints);
@@ -2120,16 +2155,29 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             u32* tmp = ws.tmp.p + set0 * set_cap;
             const unsigned gpart = (unsigned)((npoints * nbatch + 256 * PART_SCALARS - 1) / (256 * PART_SCALARS));
             HIP_TRY(hipMemsetAsync(bin_count, 0, nbins * sizeof(u32), st));
-            hipLaunchKernelGGL(k_part_count, dim3(gpart), dim3(256), nbins * sizeof(u32), st, P, (const u32*)d_scalars,
-                               (const AffPt*)ctx->table.p, bin_count, (u32)set0, cb, nbins, fb);
-            hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, st, (const u32*)bin_count, bin_start, bin_cursor, nbins);
-            // entries per scalar (windows of this launch's group x halves): the staged form holds 16 per scalar
+            // entries per scalar (windows of this launch's group x halves): the staged scatter holds 16 per scalar
             const size_t per_scalar = (size_t)(G > 1 ? ns : (size_t)nwin) * (ctx->glv ? 2 : 1);
-            if (per_scalar * STAGE_T * STAGE_SCALARS <= STAGE_CAP && !getenv("KZGAMD_DIRECT_SCATTER")) {
+            const bool staged = per_scalar * STAGE_T * STAGE_SCALARS <= STAGE_CAP && !getenv("KZGAMD_DIRECT_SCATTER");
+            // per-workgroup histograms kept by the count pass (KZGAMD_SCATTER_ATOMICS=1: recount + one atomic per run)
+            const bool keep_hist = staged && G == 1 && !getenv("KZGAMD_SCATTER_ATOMICS");
+            u32 *wg_hist = nullptr, *wg_off = nullptr;
+            if (keep_hist) {
+                ws.wghist.ensure(2 * (size_t)gpart * nbins);
+                wg_hist = ws.wghist.p;
+                wg_off = wg_hist + (size_t)gpart * nbins;
+            }
+            hipLaunchKernelGGL(k_part_count, dim3(gpart), dim3(256), nbins * sizeof(u32), st, P, (const u32*)d_scalars,
+                               (const AffPt*)ctx->table.p, bin_count, (u32)set0, cb, nbins, fb, wg_hist);
+            hipLaunchKernelGGL(k_part_scan, dim3(1), dim3(1024), 0, st, (const u32*)bin_count, bin_start, bin_cursor, nbins);
+            if (staged) {
                 const unsigned gst = (unsigned)((npoints * nbatch + STAGE_T * STAGE_SCALARS - 1) / (STAGE_T * STAGE_SCALARS));
                 const size_t lds = (3 * (size_t)nbins + STAGE_CAP) * sizeof(u32) + STAGE_CAP * sizeof(unsigned short);
+                if (keep_hist)
+                    hipLaunchKernelGGL(k_part_offsets, dim3((nbins + 63) / 64), dim3(64 * OFF_SEGS), 0, st, (const u32*)wg_hist,
+                                       wg_off, (const u32*)bin_start, gpart, nbins);
                 hipLaunchKernelGGL(k_part_scatter_staged, dim3(gst), dim3(STAGE_T), lds, st, P, (const u32*)d_scalars,
-                                   (const AffPt*)ctx->table.p, (const u32*)bin_start, bin_cursor, tmp, (u32)set0, cb, nbins, fb);
+                                   (const AffPt*)ctx->table.p, (const u32*)bin_start, bin_cursor, tmp, (u32)set0, cb, nbins, fb,
+                                   (const u32*)wg_hist, (const u32*)wg_off);
             } else {
                 hipLaunchKernelGGL(k_part_scatter, dim3(gpart), dim3(256), 2 * nbins * sizeof(u32), st, P,
                                    (const u32*)d_scalars, (const AffPt*)ctx->table.p, (const u32*)bin_start, bin_cursor, tmp,
