@@ -2010,9 +2010,11 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     ws.offsets.ensure(nsets * (nb + 1));
     ws.sorted.ensure(nsets * set_cap);
     // entries per accumulation lane, 2^lgc: longer chunks leave fewer pieces per bucket to fold, shorter ones more lanes
-    // (measured, ms at n = 2^16 / 2^18 / 2^20 / 2^22:  lgc 4: 1.07 1.60 3.96 14.29;  5: 1.24 1.56 3.89 13.64;
-    //  6: 1.58 1.61 3.82 13.43;  7: 2.17 2.18 3.81 13.23)
-    int lgc = npoints >= ((size_t)1 << 22) ? 7 : npoints >= ((size_t)1 << 20) ? 6 : npoints >= ((size_t)1 << 18) ? 5 : 4;
+    // (A/B in one process with the tiled reduction, median ms, lgc -> time:  2^18: 5 -> 1.36, 6 -> 1.40;  2^19: 5 -> 2.13,
+    //  6 -> 2.10;  2^20: 5 -> 3.70, 6 -> 3.57, 7 -> 3.49;  2^21: 6 -> 6.50, 7 -> 6.35, 8 -> 6.52;  2^22: 6 -> 13.28,
+    //  7 -> 12.84, 8 -> 12.69)
+    int lgc = npoints >= ((size_t)1 << 22) ? 8 : npoints >= ((size_t)1 << 20) ? 7 : npoints >= ((size_t)1 << 19) ? 6
+              : npoints >= ((size_t)1 << 18) ? 5 : 4;
     if (const char* e = getenv("KZGAMD_LGC")) {
         const int v = atoi(e);
         if (v >= 2 && v <= 8) lgc = v;
