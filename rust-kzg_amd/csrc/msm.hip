@@ -650,6 +650,19 @@ __global__ void __launch_bounds__(1024) k_scan(u32* __restrict__ counts, u32* __
     if (threadIdx.x == 0) off[nb] = base_s;
 }
 
+// Entries per accumulation lane, 2^lgc, chosen per set on the device: the host's choice `hi` assumes full-length
+// uniform scalars; a set with fewer entries (short scalars leave the upper windows empty) takes smaller chunks, down to
+// `lo`, until it has `target` lanes.  Every kernel that walks the pieces derives the same value from the set's total.
+struct ChunkSel {
+    int lo, hi;
+    u32 target;
+};
+__device__ __forceinline__ int eff_lgc(u32 total, const ChunkSel& cs) {
+    int l = cs.hi;
+    while (l > cs.lo && (total >> l) < cs.target) --l;
+    return l;
+}
+
 // Bucket accumulation, load-balanced: one lane per `chunk` consecutive entries of the sorted list
 // (not per bucket), so skewed digit distributions (e.g. the < 2^248 elements of a "random blob",
 // or a blob of equal elements) cost the same as uniform ones.  A lane walks its chunk, keeps the
@@ -659,13 +672,13 @@ __global__ void __launch_bounds__(1024) k_scan(u32* __restrict__ counts, u32* __
 // unique, and bucket b's value is the sum of slots b + t for the chunks t its run touches.
 __global__ void __launch_bounds__(256) k_accum(const u32* __restrict__ offsets, const u32* __restrict__ sorted,
                                                const AffPt* __restrict__ pts, Xyzz* __restrict__ partials, size_t nb,
-                                               size_t nsets, size_t set_cap, size_t nchunk, int lgc) {
+                                               size_t nsets, size_t set_cap, size_t nchunk, ChunkSel cs) {
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= nchunk * nsets) return;
     const size_t set = tid / nchunk, t = tid % nchunk;
     const u32* off = offsets + set * (nb + 1);
     const u32 total = off[nb];
-    const u32 CHUNK = 1u << lgc;
+    const u32 CHUNK = 1u << eff_lgc(total, cs);
     const u32 base = (u32)(t * CHUNK);
     if (base >= total) return;
     const u32 end = base + CHUNK < total ? base + CHUNK : total;
@@ -707,7 +720,7 @@ __global__ void __launch_bounds__(256) k_accum(const u32* __restrict__ offsets, 
 constexpr u32 HSEG = 1024;
 __global__ void __launch_bounds__(64) k_heavy(Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
                                               const u32* __restrict__ heavy_list, const u32* __restrict__ nheavy,
-                                              u32 heavy_cap, size_t nb, size_t nchunk, u32 step, u32 span, int lgc) {
+                                              u32 heavy_cap, size_t nb, size_t nchunk, u32 step, u32 span, ChunkSel cs) {
     __shared__ Xyzz sh[64];
     u32 cnt = *nheavy;
     if (cnt > heavy_cap) cnt = heavy_cap;
@@ -716,6 +729,7 @@ __global__ void __launch_bounds__(64) k_heavy(Xyzz* __restrict__ partials, const
         const size_t set = heavy_list[2 * idx], bk = heavy_list[2 * idx + 1];
         const u32* off = offsets + set * (nb + 1);
         Xyzz* pz = partials + set * (nb + nchunk) + bk;
+        const int lgc = eff_lgc(off[nb], cs);
         const u32 t0 = off[bk] >> lgc, t1 = (off[bk + 1] - 1) >> lgc;
         const u32 nelem = (t1 - t0) / step + 1;  // elements t0 + k*step, k < nelem
         const u32 nseg = span ? (nelem + span - 1) / span : 1;
@@ -746,7 +760,9 @@ __global__ void __launch_bounds__(64) k_heavy(Xyzz* __restrict__ partials, const
 
 // value of bucket bk of a set: sum of its pieces
 __device__ __forceinline__ void load_bucket(Xyzz& v, const Xyzz* __restrict__ partials, const u32* __restrict__ off,
-                                            const unsigned char* __restrict__ heavy, size_t bk, int lgc) {
+                                            const unsigned char* __restrict__ heavy, size_t bk, size_t nb,
+                                            const ChunkSel& cs) {
+    const int lgc = eff_lgc(off[nb], cs);
     const u32 beg = off[bk], end = off[bk + 1];
     g1::set_inf(v);
     if (end == beg) return;
@@ -769,7 +785,7 @@ __global__ void __launch_bounds__(128) k_level(const Xyzz* __restrict__ inA, con
                                                Xyzz* __restrict__ outA, Xyzz* __restrict__ outM, size_t nin, size_t nsets,
                                                int logS, const u32* __restrict__ offsets,
                                                const unsigned char* __restrict__ heavy, size_t nb, size_t nchunk,
-                                               int grp, int lgc) {
+                                               int grp, ChunkSel cs) {
     const size_t nout = (nin + grp - 1) / grp;
     size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= nout * nsets) return;
@@ -782,7 +798,7 @@ __global__ void __launch_bounds__(128) k_level(const Xyzz* __restrict__ inA, con
     for (size_t k = hi; k-- > lo;) {
         Xyzz a;
         if (FIRST) {
-            load_bucket(a, inA + set * (nb + nchunk), offsets + set * (nb + 1), heavy + set * nb, k, lgc);
+            load_bucket(a, inA + set * (nb + nchunk), offsets + set * (nb + 1), heavy + set * nb, k, nb, cs);
         } else {
             a = inA[set * nin + k];
             Xyzz m = inM[set * nin + k];
@@ -810,12 +826,12 @@ constexpr int DIGIT_BITS = 5, DIGIT_T = 128;
 // every bucket's pieces folded once into a dense array (each bucket is then read once per digit)
 __global__ void __launch_bounds__(128) k_fold_buckets(const Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
                                                       const unsigned char* __restrict__ heavy, Xyzz* __restrict__ dense,
-                                                      size_t nb, size_t nsets, size_t nchunk, int lgc) {
+                                                      size_t nb, size_t nsets, size_t nchunk, ChunkSel cs) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nb * nsets) return;
     const size_t set = t / nb, k = t % nb;
     Xyzz v;
-    load_bucket(v, partials + set * (nb + nchunk), offsets + set * (nb + 1), heavy + set * nb, k, lgc);
+    load_bucket(v, partials + set * (nb + nchunk), offsets + set * (nb + 1), heavy + set * nb, k, nb, cs);
     dense[t] = v;
 }
 
@@ -863,7 +879,7 @@ constexpr int TILE_T = 512;  // two buckets per lane and phase: a full CU (two w
 __global__ void __launch_bounds__(TILE_T) k_tile_sums(const Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
                                                       const unsigned char* __restrict__ heavy, Xyzz* __restrict__ dense,
                                                       Xyzz* __restrict__ Gs, Xyzz* __restrict__ Cp, size_t nb, size_t nchunk,
-                                                      int lgc) {
+                                                      ChunkSel cs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ts[];
     Xyzz* sh = (Xyzz*)smem_ts;
     const size_t ntiles = nb >> 10;
@@ -879,7 +895,7 @@ __global__ void __launch_bounds__(TILE_T) k_tile_sums(const Xyzz* __restrict__ p
 #pragma unroll 1
         for (int i = 0; i < 2; ++i) {
             Xyzz v;
-            load_bucket(v, partials + set * (nb + nchunk), offsets + set * (nb + 1), heavy + set * nb, kb + i, lgc);
+            load_bucket(v, partials + set * (nb + nchunk), offsets + set * (nb + 1), heavy + set * nb, kb + i, nb, cs);
             dense[set * nb + kb + i] = v;
             g1::dadd(acc, v);
         }
@@ -2015,11 +2031,13 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     //  7 -> 12.84, 8 -> 12.69)
     int lgc = npoints >= ((size_t)1 << 22) ? 8 : npoints >= ((size_t)1 << 20) ? 7 : npoints >= ((size_t)1 << 19) ? 6
               : npoints >= ((size_t)1 << 18) ? 5 : 4;
+    // the device may pick chunks up to 4x smaller for sets with fewer entries (eff_lgc): the piece slots are sized for that
+    int lgc_lo = lgc > 6 ? lgc - 2 : (lgc > 4 ? 4 : lgc);
     if (const char* e = getenv("KZGAMD_LGC")) {
         const int v = atoi(e);
-        if (v >= 2 && v <= 8) lgc = v;
+        if (v >= 2 && v <= 8) lgc = lgc_lo = v;
     }
-    const size_t nchunk = (set_cap + ((size_t)1 << lgc) - 1) >> lgc;
+    const size_t nchunk = (set_cap + ((size_t)1 << lgc_lo) - 1) >> lgc_lo;
     ws.buckets.ensure(nsets * (nb + nchunk));
     const size_t n1 = (nb + 1) / 2, n2 = (n1 + GRP - 1) / GRP;  // level 0 folds at least 2, later levels GRP
     ws.lvlA[0].ensure(nsets * n1);
@@ -2042,6 +2060,8 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         }
     }
     const size_t sets_per_group = (nsets + G - 1) / G;
+    // lanes the accumulation wants per set: 90 % of two waves per SIMD over the sets of a launch
+    const ChunkSel csel{lgc_lo, lgc, (u32)(118000 / sets_per_group)};
     // two-level sort: coarse bins must fit the LDS counters and a point index 24 bits
     const size_t max_pidx = ctx->prepared ? (size_t)ctx->rows * ctx->n : (ctx->glv ? 2 * ctx->n : ctx->n);
     int pbits = 1;  // bits of a point index
@@ -2207,13 +2227,13 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         if (pev) HIP_TRY(hipEventRecord(pev[1], st));
         hipLaunchKernelGGL(k_accum, dim3((unsigned)((ns * nchunk + 255) / 256)), dim3(256), 0, st, (const u32*)offsets,
                            (const u32*)(ws.sorted.p + set0 * set_cap), (const AffPt*)ctx->table.p, buckets, nb, ns, set_cap,
-                           nchunk, lgc);
+                           nchunk, csel);
         if (pev) HIP_TRY(hipEventRecord(pev[2], st));
         if (G > 1) HIP_TRY(hipEventRecord(ctx->ev_acc[g], st));
         hipLaunchKernelGGL(k_heavy, dim3(256, 64), dim3(64), 0, st, buckets, (const u32*)offsets, (const u32*)heavy_list,
-                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, 1u, HSEG, lgc);
+                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, 1u, HSEG, csel);
         hipLaunchKernelGGL(k_heavy, dim3(1024, 1), dim3(64), 0, st, buckets, (const u32*)offsets, (const u32*)heavy_list,
-                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, HSEG, 0u, lgc);
+                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, HSEG, 0u, csel);
         if (digit_tail) {
             // few sets: digit-decomposed reduction (k_digit_sums / k_digit_bits), then the Horner over the bit sums
             int logNb = 0;
@@ -2227,7 +2247,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                 Xyzz* Cp = ws.lvlM[1].p + set0 * (nb >> 5);
                 hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)(ns * (nb >> 10))), dim3(TILE_T), TILE_T * sizeof(Xyzz), st,
                                    (const Xyzz*)buckets, (const u32*)offsets, (const unsigned char*)heavy, dense, Gs, Cp, nb,
-                                   nchunk, lgc);
+                                   nchunk, csel);
                 if (wide_tail) {
                     // cells of this group: [0, ns * J * 32) digit sums, then ns * (logNb + 2) bit sums
                     const size_t c1 = ns * (size_t)(J * 32), c2 = ns * (size_t)(logNb + 2);
@@ -2246,7 +2266,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             } else {
                 hipLaunchKernelGGL(k_fold_buckets, dim3((unsigned)((ns * nb + 127) / 128)), dim3(128), 0, st,
                                    (const Xyzz*)buckets, (const u32*)offsets, (const unsigned char*)heavy, dense, nb, ns, nchunk,
-                                   lgc);
+                                   csel);
                 hipLaunchKernelGGL(k_digit_sums, dim3((unsigned)(ns * (size_t)(J * 32))), dim3(DIGIT_T), DIGIT_T * sizeof(Xyzz),
                                    st, (const Xyzz*)dense, S, nb, logNb, J);
             }
@@ -2285,10 +2305,10 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             const unsigned grid = (unsigned)((ns * nout + 127) / 128);
             if (lvl == 0)
                 hipLaunchKernelGGL(k_level<true>, dim3(grid), dim3(128), 0, st, inA, inM, oA, oM, nin, ns, logS,
-                                   (const u32*)offsets, (const unsigned char*)heavy, nb, nchunk, grp, lgc);
+                                   (const u32*)offsets, (const unsigned char*)heavy, nb, nchunk, grp, csel);
             else
                 hipLaunchKernelGGL(k_level<false>, dim3(grid), dim3(128), 0, st, inA, inM, oA, oM, nin, ns, logS,
-                                   (const u32*)nullptr, (const unsigned char*)nullptr, nb, nchunk, grp, lgc);
+                                   (const u32*)nullptr, (const unsigned char*)nullptr, nb, nchunk, grp, csel);
             inA = oA;
             inM = oM;
             nin = nout;
