@@ -457,7 +457,7 @@ def main():
             n = 1 << logn
             h = kzg.DeviceMsm(pts.data_ptr(), n, False)
             hi = h.info()
-            ms = ev_time(lambda: kzg.msm_prepared_batch_device(h, o.data_ptr(), sc.data_ptr(), n, 1, False, stream), reps=3)
+            ms = ev_time(lambda: kzg.msm_prepared_batch_device(h, o.data_ptr(), sc.data_ptr(), n, 1, False, stream), reps=9)
             c = reference_window(n)
             w = -(-255 // c)
             adds = n * w + (1 << c) * w  # algorithmic adds with the reference's window
