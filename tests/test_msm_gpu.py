@@ -499,3 +499,35 @@ def test_horner_exceptional_additions(oracle, kzg, sign):
     assert compressed(L, got) == compressed(L, exp)
     if sign < 0:
         assert compressed(L, got) == b"\xc0" + bytes(47)
+
+
+def test_two_large_msms_in_one_launch(oracle, kzg):
+    """nbatch = 2 over a 40 000-point variable-base handle: 16 bucket sets of 32 768 buckets go through the tiled
+    digit reduction and the limb-parallel cell sums together (set indexing of every stage with more than one MSM)."""
+    import torch
+
+    L = oracle.lib()
+    n, nbatch = 40000, 2
+    stream = torch.cuda.current_stream().cuda_stream
+    d_pts = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    kzg.generate_points(d_pts.data_ptr(), n, 31, stream)
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(32)
+    sc = torch.randint(0, 256, (nbatch * n, 32), dtype=torch.uint8, generator=gen)
+    sc[:, 31] &= 0x3F
+    sc[n + 5:n + 3000, 4:] = 0  # the second MSM has a run of short scalars
+    d_sc = sc.cuda()
+    d_out = torch.zeros(144 * nbatch, dtype=torch.uint8, device="cuda")
+    h = kzg.DeviceMsm(d_pts.data_ptr(), n, False)
+    kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr(), n, nbatch, False, stream)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy().tobytes()
+    pts = (O.G1Affine * n).from_buffer_copy(d_pts.cpu().numpy().tobytes())
+    for b in range(nbatch):
+        got = O.G1()
+        C.memmove(C.byref(got), out[144 * b:144 * b + 144], 144)
+        exp = O.G1()
+        L.omsm_tiling_pippenger(C.byref(exp), pts, sc[b * n:(b + 1) * n].numpy().tobytes(), n)
+        assert compressed(L, got) == compressed(L, exp), b
+    h.close()
+
