@@ -24,6 +24,7 @@
 #include "host_g1.h"
 #include "host_pairing.h"
 #include "msm_internal.h"
+#include "ntt_internal.h"
 #include "sha256.h"
 #include <atomic>
 #include <condition_variable>
@@ -185,6 +186,7 @@ class WorkerPool {
 };
 
 constexpr int QT = 512;            // threads per blob
+constexpr size_t FK20_MIN_BLOBS = 16;  // cell proofs by FK20 from this batch size (measured crossover: 25 ms either way)
 constexpr size_t PROVE_CHUNK = 64;  // blobs per pipeline stage of a large compute_blob_kzg_proof batch
 constexpr size_t COMMIT_CHUNK = 256;  // blobs per pipeline stage of a large blob_to_kzg_commitment batch
 constexpr size_t QSPLIT_MAX = 4;   // up to this many blobs run the multi-workgroup variant (k_quotient_a/b)
@@ -704,6 +706,36 @@ struct KzgAmdSettings {
     // EIP-7594 state, built on first use
     AffPt* d_monomial = nullptr;              // g1_values_monomial as table slots
     kzgamd::MsmContext* msm_monomial = nullptr;
+    kzgamd::MsmContext* msm_xext = nullptr;  // FK20: the 128 columns of 64 points of x_ext_fft_columns, one wide table
+    ff::Fr *d_fk_a = nullptr, *d_fk_b = nullptr;  // FK20: n x 64 x 128 Toeplitz vectors / their transforms
+    g1::Xyzz *d_fk_h = nullptr, *d_fk_h2 = nullptr;  // FK20: n x 128 points, and the transform scratch
+    size_t cap_fk = 0, cap_q = 0;
+    void ensure_fk20(size_t nblobs) {
+        if (nblobs <= cap_fk) return;
+        release_fk20();
+        CK_HIP(hipMalloc(&d_fk_a, nblobs * 8192 * sizeof(ff::Fr)));
+        CK_HIP(hipMalloc(&d_fk_b, nblobs * 8192 * sizeof(ff::Fr)));
+        CK_HIP(hipMalloc(&d_fk_h, nblobs * 128 * sizeof(g1::Xyzz)));
+        CK_HIP(hipMalloc(&d_fk_h2, nblobs * 128 * sizeof(g1::Xyzz)));
+        cap_fk = nblobs;
+    }
+    void release_fk20() {
+        if (d_fk_a) (void)hipFree(d_fk_a);
+        if (d_fk_b) (void)hipFree(d_fk_b);
+        if (d_fk_h) (void)hipFree(d_fk_h);
+        if (d_fk_h2) (void)hipFree(d_fk_h2);
+        d_fk_a = d_fk_b = nullptr;
+        d_fk_h = d_fk_h2 = nullptr;
+        cap_fk = 0;
+    }
+    void ensure_q(size_t nblobs) {  // the 128 quotient vectors per blob of the direct cell-proof path (16 MB per blob)
+        if (nblobs <= cap_q) return;
+        if (d_q) (void)hipFree(d_q);
+        d_q = nullptr;
+        cap_q = 0;
+        CK_HIP(hipMalloc(&d_q, nblobs * 128 * N * 32));
+        cap_q = nblobs;
+    }
     void* ntt = nullptr;                      // kzgamd_ntt_new(13)
     ff::Fr* d_roots8192 = nullptr;            // roots_of_unity[0..=8192], Montgomery
     ff::Fr *d_fr_a = nullptr, *d_fr_b = nullptr, *d_fr_ext = nullptr;  // 4096, 4096, 8192 per blob
@@ -790,6 +822,8 @@ struct KzgAmdSettings {
         if (d_brp_roots) (void)hipFree(d_brp_roots);
         if (d_monomial) (void)hipFree(d_monomial);
         if (msm_monomial) kzgamd::msm_destroy(msm_monomial);
+        if (msm_xext) kzgamd::msm_destroy(msm_xext);
+        release_fk20();
         if (ntt) kzgamd_ntt_free(ntt);
         if (d_roots8192) (void)hipFree(d_roots8192);
         release_cells();
@@ -813,6 +847,7 @@ struct KzgAmdSettings {
         d_cells = d_q = nullptr;
         d_proofs = nullptr;
         cap_cells = 0;
+        cap_q = 0;
     }
     void ensure_cells(size_t nblobs) {
         if (nblobs <= cap_cells) return;
@@ -821,7 +856,6 @@ struct KzgAmdSettings {
         CK_HIP(hipMalloc(&d_fr_b, nblobs * N * 32));
         CK_HIP(hipMalloc(&d_fr_ext, nblobs * 2 * N * 32));
         CK_HIP(hipMalloc(&d_cells, nblobs * 2 * N * 32));
-        CK_HIP(hipMalloc(&d_q, nblobs * 128 * N * 32));
         CK_HIP(hipMalloc(&d_proofs, nblobs * 128 * 48));
         cap_cells = nblobs;
     }
@@ -1381,6 +1415,70 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
 }
 
 
+// ---------------- FK20 cell proofs (compute_fk20_proofs, kzg/src/das.rs:630-696) for batches ----------------
+// toeplitz_coeffs_stride for every (blob, offset i < 64): a 128-vector with p[4095 - i] at 0 and p[4095 - i - 64 j] at
+// 128 - j, j = 1 .. 62 (the circulant embedding of the Toeplitz matrix of every 64th coefficient)
+__global__ void __launch_bounds__(256) k_fk20_toeplitz(ff::Fr* __restrict__ out, const ff::Fr* __restrict__ mono, size_t nblobs) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblobs * 64 * 128) return;
+    const size_t b = t >> 13;
+    const u32 i = (u32)(t >> 7) & 63, idx = (u32)t & 127;
+    const ff::Fr* p = mono + b * N;
+    ff::Fr v = ff::Fr::zero();
+    if (idx == 0) v = p[N - 1 - i];
+    else if (idx >= 66) v = p[N - 1 - i - 64 * (128 - idx)];
+    out[t] = v;
+}
+// coeffs[blob][j][i] = transform_i[j]: the scalars of column j next to each other (the MSM's layout)
+__global__ void __launch_bounds__(256) k_fk20_transpose(ff::Fr* __restrict__ out, const ff::Fr* __restrict__ in, size_t nblobs) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblobs * 128 * 64) return;
+    const size_t b = t >> 13;
+    const u32 j = (u32)(t >> 6) & 127, i = (u32)t & 63;
+    out[t] = in[(b * 64 + i) * 128 + j];
+}
+// h[64 .. 128) = identity (das.rs:688-691)
+__global__ void __launch_bounds__(256) k_fk20_zero_upper(g1::Xyzz* __restrict__ h, size_t nblobs) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblobs * 64) return;
+    g1::set_inf(h[(t >> 6) * 128 + 64 + (t & 63)]);
+}
+// reverse_bit_order of the 128 proofs of a blob (das.rs:288)
+__global__ void __launch_bounds__(256) k_fk20_brp(g1::Xyzz* __restrict__ out, const g1::Xyzz* __restrict__ in, size_t nblobs) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblobs * 128) return;
+    out[t] = in[(t & ~(size_t)127) | (__builtin_bitreverse32((u32)t & 127u) >> 25)];
+}
+
+// the fixed-base handle over the 128 x 64 points of x_ext_fft_columns (column-major: base j * 64 + i)
+void fk20_prepare(KzgAmdSettings* dev, const CKZGSettings* cs) {
+    if (dev->msm_xext) return;
+    const size_t K2 = 2 * CELLS_PER_BLOB, total = K2 * CELL_SIZE;
+    std::vector<ff::Fp> aff(2 * total);  // blst_p1_affine: x, y
+    std::vector<ff::Fp> pre(total);
+    // Montgomery's trick over the Z coordinates (the columns hold no point at infinity for a valid setup; a zero Z
+    // is skipped and its point written as (0, 0), blst's affine infinity)
+    ff::Fp run = ff::Fp::one();
+    for (size_t k = 0; k < total; ++k) {
+        const ff::Fp* P = reinterpret_cast<const ff::Fp*>(&cs->x_ext_fft_columns[k / CELL_SIZE][k % CELL_SIZE]);
+        pre[k] = run;
+        if (!P[2].is_zero()) run = hfp::mul(run, P[2]);
+    }
+    ff::Fp inv = ff::inverse_bgcd(run);
+    for (size_t k = total; k-- > 0;) {
+        const ff::Fp* P = reinterpret_cast<const ff::Fp*>(&cs->x_ext_fft_columns[k / CELL_SIZE][k % CELL_SIZE]);
+        if (P[2].is_zero()) {
+            aff[2 * k] = aff[2 * k + 1] = ff::Fp::zero();
+            continue;
+        }
+        const ff::Fp zi = hfp::mul(inv, pre[k]), zi2 = hfp::sqr(zi);
+        inv = hfp::mul(inv, P[2]);
+        aff[2 * k] = hfp::mul(P[0], zi2);
+        aff[2 * k + 1] = hfp::mul(P[1], hfp::mul(zi2, zi));
+    }
+    dev->msm_xext = kzgamd::msm_create(aff.data(), total, false, true, false);
+}
+
 // compute_cells_and_kzg_proofs (kzg/src/das.rs:244-292) for n blobs; cells / proofs may be null (not both)
 void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_t n, const CKZGSettings* cs,
                       KzgAmdSettings* dev) {
@@ -1391,9 +1489,20 @@ void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_
         CK_HIP(hipMalloc(&dev->d_roots8192, (2 * N + 1) * sizeof(ff::Fr)));
         CK_HIP(hipMemcpy(dev->d_roots8192, cs->roots_of_unity, (2 * N + 1) * sizeof(ff::Fr), hipMemcpyHostToDevice));
     }
-    if (proofs && !dev->msm_monomial) dev->msm_monomial = kzgamd::msm_create(dev->d_monomial, N, true, true, true);
+    // Cell proofs: FK20 for batches (the reference's algorithm: 64 transforms of 128 scalars, 128 MSMs of 64 points
+    // over x_ext_fft_columns, two G1 transforms of 128 points — ~25x fewer point additions than 128 MSMs of 4096, but
+    // the G1 transforms are 14 serial stages of a 128-bit scalar multiplication each: tens of ms of latency whatever
+    // the batch).  A few blobs: the direct form, one more fixed-base MSM per cell over the monomial table.
+    // KZGAMD_FK20 = 0 / 1 forces one or the other.
+    bool fk20 = proofs && n >= FK20_MIN_BLOBS;
+    if (const char* e = getenv("KZGAMD_FK20")) fk20 = proofs && atoi(e) != 0;
+    if (proofs && fk20) fk20_prepare(dev, cs);
+    if (proofs && fk20 && !kzgamd::msm_has_wide_table(dev->msm_xext)) fk20 = false;  // no HBM left for its table
+    if (proofs && !fk20 && !dev->msm_monomial) dev->msm_monomial = kzgamd::msm_create(dev->d_monomial, N, true, true, true);
     dev->ensure(n);
     dev->ensure_cells(n);
+    if (proofs && fk20) dev->ensure_fk20(n);
+    if (proofs && !fk20) dev->ensure_q(n);
     hipStream_t st = dev->stream;
     CK_HIP(hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, st));
     CK_HIP(hipMemsetAsync(dev->d_status, 0, n * sizeof(int), st));
@@ -1412,7 +1521,33 @@ void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_
                            reinterpret_cast<u32*>(dev->d_fr_ext), (const ff::Fr*)ev, n);
         // fetched below, after the proof kernels are enqueued: a copy into pageable memory blocks this thread
     }
-    if (proofs) {
+    if (proofs && fk20) {
+        const size_t nv = n * 64 * 128;
+        hipLaunchKernelGGL(k_fk20_toeplitz, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, dev->d_fk_a,
+                           (const ff::Fr*)dev->d_fr_b, n);
+        if (kzgamd_ntt_fr_device(dev->ntt, dev->d_fk_b, dev->d_fk_a, 128, 64 * n, 0, st) != 0) throw CkErr{C_KZG_ERROR, "ntt"};
+        hipLaunchKernelGGL(k_fk20_transpose, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, dev->d_fk_a,
+                           (const ff::Fr*)dev->d_fk_b, n);
+        // h_ext_fft[blob][j] = sum_i coeffs[j][i] * x_ext_fft_columns[j][i]: 128 n MSMs of 64 points, column j of the table
+        kzgamd::msm_lock(dev->msm_xext);
+        try {
+            kzgamd::msm_enqueue(dev->msm_xext, dev->d_fk_h, dev->d_fk_a, CELL_SIZE, n * 128, 1, st, kzgamd::OUT_XYZZ, false, 128);
+        } catch (...) {
+            kzgamd::msm_unlock(dev->msm_xext);
+            throw;
+        }
+        kzgamd::msm_unlock(dev->msm_xext);
+        // h = ifft_g1(h_ext_fft), upper half cleared, proofs = fft_g1(h), bit-reversed, compressed
+        g1::Xyzz* h = (g1::Xyzz*)kzgamd::fftg1_device((NttCtx*)dev->ntt, dev->d_fk_h, dev->d_fk_h2, 128, n, 1, st);
+        if (!h) throw CkErr{C_KZG_ERROR, "fft_g1"};
+        g1::Xyzz* other = h == dev->d_fk_h ? dev->d_fk_h2 : dev->d_fk_h;
+        hipLaunchKernelGGL(k_fk20_zero_upper, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, h, n);
+        g1::Xyzz* pr = (g1::Xyzz*)kzgamd::fftg1_device((NttCtx*)dev->ntt, h, other, 128, n, 0, st);
+        if (!pr) throw CkErr{C_KZG_ERROR, "fft_g1"};
+        g1::Xyzz* fin = pr == h ? other : h;
+        hipLaunchKernelGGL(k_fk20_brp, dim3((unsigned)((n * 128 + 255) / 256)), dim3(256), 0, st, fin, (const g1::Xyzz*)pr, n);
+        kzgamd::g1_compress_xyzz(dev->d_proofs, fin, n * 128, st);
+    } else if (proofs) {
         hipLaunchKernelGGL(k_cell_quotients, dim3((unsigned)(n * 128)), dim3(64), 0, st, dev->d_q, (const ff::Fr*)dev->d_fr_b,
                            (const ff::Fr*)dev->d_roots8192, n);
         kzgamd::msm_lock(dev->msm_monomial);

@@ -168,6 +168,25 @@ __global__ void __launch_bounds__(NTHREADS) k_g1_store(ff::Fp* __restrict__ out,
     if (half == 0) g1::to_blst_jacobian(out + (t >> 1) * 3, p);
 }
 
+// device-resident form: XYZZ in natural order -> bit-reversed order of each transform
+__global__ void __launch_bounds__(256) k_g1_brp_xyzz(Xyzz* __restrict__ out, const Xyzz* __restrict__ in, u32 n, int logn,
+                                                     size_t total) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const size_t xf = t / n;
+    out[t] = in[xf * n + brev((u32)(t % n), logn)];
+}
+// data[p] *= n^-1 (two lanes per point, both in one wave: the loads of a pair precede its store)
+__global__ void __launch_bounds__(NTHREADS) k_g1_scale_xyzz(Xyzz* __restrict__ data, Xyzz* __restrict__ tab, RootSplit inv_n,
+                                                            size_t total) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // total = 2 * points
+    if (t >= total) return;
+    const int half = (int)(t & 1);
+    Xyzz p = data[t >> 1];
+    glv_mul_pair(p, inv_n, half, tab + t, total);
+    if (half == 0) data[t >> 1] = p;
+}
+
 int ilog2(size_t n) {
     int l = 0;
     while (((size_t)1 << l) < n) ++l;
@@ -211,7 +230,57 @@ void ensure_g1(NttCtx* ctx, size_t total, size_t tab_lanes) {
     }
 }
 
+void ensure_g1_tab(NttCtx* ctx, size_t tab_lanes) {
+    if (!ctx->d_kroots) {
+        std::vector<RootSplit> split(ctx->W + 1);
+        for (size_t i = 0; i <= ctx->W; ++i) split[i] = split_scalar(ff::from_mont(ctx->roots[i]));
+        NTT_TRY(hipMalloc(&ctx->d_kroots, (ctx->W + 1) * sizeof(RootSplit)));
+        NTT_TRY(hipMemcpy(ctx->d_kroots, split.data(), (ctx->W + 1) * sizeof(RootSplit), hipMemcpyHostToDevice));
+    }
+    if (tab_lanes > ctx->cap_tab) {
+        if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+        ctx->d_tab = nullptr;
+        ctx->cap_tab = 0;
+        NTT_TRY(hipMalloc(&ctx->d_tab, tab_lanes * NTAB * sizeof(Xyzz)));
+        ctx->cap_tab = tab_lanes;
+    }
+}
+
 }  // namespace
+
+// G1 transforms of device-resident XYZZ data (natural order in `data`, nbatch transforms of n points each); `scratch`
+// has the same size.  Enqueued on `st`, nothing synchronised; returns the buffer (data or scratch) that holds the
+// result in natural order, or nullptr on an allocation failure.  The per-lane tables are shared by the handle: one
+// stream at a time (the c-kzg layer calls this under its settings lock and synchronises before it returns).
+void* kzgamd::fftg1_device(NttCtx* ctx, void* data_v, void* scratch_v, size_t n, size_t nbatch, int inverse, hipStream_t st) {
+    if (!ctx || n == 0 || (n & (n - 1)) || n > ctx->W) return nullptr;
+    try {
+        const size_t total = n * nbatch, bf = total / 2;
+        const int logn = ilog2(n);
+        ensure_g1_tab(ctx, 2 * total);
+        Xyzz* bufs[2] = {(Xyzz*)scratch_v, (Xyzz*)data_v};
+        Xyzz* tab = (Xyzz*)ctx->d_tab;
+        hipLaunchKernelGGL(k_g1_brp_xyzz, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bufs[0],
+                           (const Xyzz*)data_v, (u32)n, logn, total);
+        for (int s = 0; s < logn; ++s)
+            hipLaunchKernelGGL(k_g1_stage, dim3((unsigned)((2 * bf + NTHREADS - 1) / NTHREADS)), dim3(NTHREADS), 0, st,
+                               bufs[(s + 1) & 1], (const Xyzz*)bufs[s & 1], tab, (const RootSplit*)ctx->d_kroots, (u32)n, s,
+                               (u32)ctx->W, inverse ? 1 : 0, 2 * bf);
+        Xyzz* res = bufs[logn & 1];
+        if (inverse && n > 1) {
+            Fr v = Fr::zero();
+            v.v[0] = (u32)n;
+            v.v[1] = (u32)((u64)n >> 32);
+            const RootSplit inv_n = split_scalar(ff::from_mont(ff::inverse_bgcd(ff::to_mont(v))));
+            hipLaunchKernelGGL(k_g1_scale_xyzz, dim3((unsigned)((2 * total + NTHREADS - 1) / NTHREADS)), dim3(NTHREADS), 0, st, res,
+                               tab, inv_n, 2 * total);
+        }
+        NTT_TRY(hipGetLastError());
+        return res;
+    } catch (const NttErr&) {
+        return nullptr;
+    }
+}
 
 extern "C" int kzgamd_fft_g1_batch(void* vctx, blst_p1* out, const blst_p1* in, size_t n, size_t nbatch, int inverse) {
     NttCtx* ctx = (NttCtx*)vctx;

@@ -156,6 +156,7 @@ struct DigitParams {
     size_t row_stride;  // prepared: points per table row; glv: offset of the [x^2]P half of the table
     int glv;         // 1: scalars are split k = k1 + k2*x^2 (two 128-bit halves, nwin windows each)
     int w0, w1;      // windows [w0, w1) are emitted by this launch (the others only feed the digit carry)
+    u32 nseg;        // wide-table path: MSM b runs over table bases (b % nseg) * n .. + n (0: every MSM over bases 0 .. n)
 };
 
 // canonical 256-bit scalar (8 x u32) -> signed digit of window w, carrying from below
@@ -1444,6 +1445,7 @@ __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __r
     g1::set_inf(acc);
     const u32 half = 1u << (P.c - 1);
     const int sh = P.c - 1;
+    const size_t seg0 = P.nseg ? (b % P.nseg) * P.n : 0;  // first table base of this MSM
 #pragma unroll
     for (int k = 0; k < SPL; ++k) {
         const size_t i = l * (size_t)SPL + k;
@@ -1458,7 +1460,7 @@ __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __r
                 for (int q = 0; q < 4; ++q) {
                     const u32 e = e4[q];
                     if (e == FBW_SKIP) continue;
-                    const WidePt pk = wide[(((size_t)(w4 + q) * P.row_stride + i) << sh) + (e & 0x7fffffffu)];
+                    const WidePt pk = wide[(((size_t)(w4 + q) * P.row_stride + seg0 + i) << sh) + (e & 0x7fffffffu)];
                     if (pk.pad[0]) continue;  // multiple of a base at infinity
                     fp28::Fe x = pk.x, y = pk.y;
                     if (e >> 31) y = fp28::neg<2>(y);
@@ -1479,7 +1481,7 @@ __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __r
                     carry = 1;
                 }
                 if (d == 0) continue;
-                const WidePt pk = wide[(((size_t)w * P.row_stride + i) << sh) + (d - 1)];
+                const WidePt pk = wide[(((size_t)w * P.row_stride + seg0 + i) << sh) + (d - 1)];
                 if (pk.pad[0]) continue;  // multiple of a base at infinity
                 fp28::Fe x = pk.x, y = pk.y;
                 if (neg) y = fp28::neg<2>(y);
@@ -1517,6 +1519,18 @@ __global__ void __launch_bounds__(256) k_blocksum(const Xyzz* __restrict__ in_al
         __syncthreads();
     }
     if (threadIdx.x == 0) out[set] = acc;
+}
+
+// out[m] = sum of the n (<= 64) consecutive partial sums of MSM m: one lane per MSM
+__global__ void __launch_bounds__(64) k_lane_sum(const Xyzz* __restrict__ in, Xyzz* __restrict__ out, size_t n, size_t count) {
+    const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= count) return;
+    Xyzz acc = in[m * n];
+    for (size_t k = 1; k < n; ++k) {
+        Xyzz b = in[m * n + k];
+        g1::dadd(acc, b);
+    }
+    out[m] = acc;
 }
 
 // device copy of already-converted table slots (row 0)
@@ -1912,13 +1926,24 @@ void msm_destroy(MsmContext* ctx) {
     delete ctx;
 }
 int msm_device(MsmContext* ctx) { return ctx->device; }
+bool msm_has_wide_table(MsmContext* ctx) { return ctx->fbw; }
+
+// 48-byte compressed form of `count` XYZZ points (device pointers), batched inversion per 64 points
+void g1_compress_xyzz(void* d_out48, const void* d_xyzz, size_t count, hipStream_t stream) {
+    if (!count) return;
+    hipLaunchKernelGGL(k_final, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)nullptr,
+                       (const Xyzz*)d_xyzz, d_out48, count, 1, 1, 1, OUT_COMPRESSED);
+    HIP_TRY(hipGetLastError());
+}
 
 // enqueue nbatch MSMs over the first npoints bases; d_scalars / d_out device pointers
 // reserve_only: size and allocate the workspace `stream` will use for this shape, launch nothing (hipMalloc
 // synchronises the device, so callers that must not stall a running pipeline reserve during set-up)
 void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npoints, size_t nbatch, int mont,
-                 hipStream_t stream, int out_mode, bool reserve_only) {
-    if (npoints > ctx->n) throw HipErr{hipErrorInvalidValue, "npoints exceeds the prepared size"};
+                 hipStream_t stream, int out_mode, bool reserve_only, size_t nseg) {
+    if (npoints * (nseg ? nseg : 1) > ctx->n) throw HipErr{hipErrorInvalidValue, "npoints exceeds the prepared size"};
+    if ((nseg || out_mode == OUT_XYZZ) && !ctx->fbw)
+        throw HipErr{hipErrorInvalidValue, "segmented / XYZZ-output MSMs need the wide-table path"};
     if (nbatch == 0) return;
     const int c = ctx->c;
     const int nwin = ctx->nwin;
@@ -1964,7 +1989,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         if (ctx->fbw_glv) ws.digits.ensure(nbatch * npoints * 2 * (size_t)((nwin + 3) & ~3));
         if (reserve_only) return;
         WsUse ws_use(ws, stream);
-        DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n, 0, 0, nwin};
+        DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n, 0, 0, nwin, (u32)nseg};
         hipEvent_t* pev = nullptr;
         if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
             while (ctx->ev.size() < ctx->ev_used + 4) {
@@ -1997,14 +2022,19 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         }
 #undef KZG_FBW_LAUNCH
         if (pev) HIP_TRY(hipEventRecord(pev[2], stream));
-        if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) {
+        Xyzz* sums = out_mode == OUT_XYZZ ? (Xyzz*)d_out : ws.lvlM[0].p;
+        if (lanes <= 64) {
+            // many small MSMs (segments of a table): one lane adds the few partial sums of an MSM
+            hipLaunchKernelGGL(k_lane_sum, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)ws.buckets.p,
+                               sums, lanes, nbatch);
+        } else if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) {
             // a few MSMs: the one-workgroup-per-MSM fold is a latency chain (16 strided additions + 8 tree rounds);
             // 16 workgroups per MSM and a second small fold take 9 + 6 rounds instead (single commitment call
             // 0.83 -> 0.71 ms).  Splitting the windows of a scalar over 3 lanes as well was measured: no gain.
             hipLaunchKernelGGL(k_blocksum, dim3((unsigned)(nbatch * 16)), dim3(256), 256 * sizeof(Xyzz), stream,
                                (const Xyzz*)ws.buckets.p, ws.lvlA[0].p, lanes / 16);
             hipLaunchKernelGGL(k_blocksum, dim3((unsigned)nbatch), dim3(64), 64 * sizeof(Xyzz), stream,
-                               (const Xyzz*)ws.lvlA[0].p, ws.lvlM[0].p, (size_t)16);
+                               (const Xyzz*)ws.lvlA[0].p, sums, (size_t)16);
         } else {
             // many MSMs: two waves per MSM instead of four — fewer mostly-idle tree rounds per partial sum
             // (256 / 128 / 64 threads: 87.7 k / 88.9 k / 87.6 k commitments/s at 1024 blobs, same box)
@@ -2012,10 +2042,11 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             if (nbatch >= 256) bs = 128;
             if (const char* e = getenv("KZGAMD_BLOCKSUM_THREADS")) bs = atoi(e) == 64 || atoi(e) == 128 || atoi(e) == 256 ? atoi(e) : bs;
             hipLaunchKernelGGL(k_blocksum, dim3((unsigned)nbatch), dim3(bs), bs * sizeof(Xyzz), stream,
-                               (const Xyzz*)ws.buckets.p, ws.lvlM[0].p, lanes);
+                               (const Xyzz*)ws.buckets.p, sums, lanes);
         }
-        hipLaunchKernelGGL(k_final, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)nullptr,
-                           (const Xyzz*)ws.lvlM[0].p, d_out, nbatch, nwin, c, 1, out_mode);
+        if (out_mode != OUT_XYZZ)
+            hipLaunchKernelGGL(k_final, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)nullptr,
+                               (const Xyzz*)ws.lvlM[0].p, d_out, nbatch, nwin, c, 1, out_mode);
         if (pev) {
             HIP_TRY(hipEventRecord(pev[3], stream));
             ctx->ev_used += 4;
@@ -2162,7 +2193,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         }
         // with groups, sets are windows (nbatch == 1): group g emits windows [set0, set0 + ns)
         DigitParams P{npoints, nbatch, c, nwin, ctx->prepared ? 1 : 0, mont, nb, ctx->n, ctx->glv ? 1 : 0,
-                      G > 1 ? (int)set0 : 0, G > 1 ? (int)(set0 + ns) : nwin};
+                      G > 1 ? (int)set0 : 0, G > 1 ? (int)(set0 + ns) : nwin, 0u};
         u32* counts = two_level ? nullptr : ws.counts.p + set0 * nb;
         u32* offsets = ws.offsets.p + set0 * (nb + 1);
         unsigned char* heavy = ws.heavy.p + set0 * nb;

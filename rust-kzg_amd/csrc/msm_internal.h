@@ -6,7 +6,8 @@
 namespace kzgamd {
 struct MsmContext;
 // OUT_WINDOWS (unprepared handles): one Jacobian point per (MSM, window); the caller does the Horner steps
-enum { OUT_JACOBIAN = 0, OUT_COMPRESSED = 1, OUT_WINDOWS = 2 };
+// OUT_XYZZ (wide-table handles): g1::Xyzz sums, for consumers on the device (the G1 transforms of FK20)
+enum { OUT_JACOBIAN = 0, OUT_COMPRESSED = 1, OUT_WINDOWS = 2, OUT_XYZZ = 3 };
 // points: blst_p1_affine[n] (host or device) or g1::AffPt[n] (device); prepare = build fixed-base rows
 MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare, bool points_are_affpt);
 void msm_destroy(MsmContext* ctx);
@@ -14,8 +15,13 @@ void msm_destroy(MsmContext* ctx);
 // another, without the stream, the allocations and their synchronisations
 void msm_reset_points(MsmContext* ctx, const void* d_affpts, size_t n);
 // enqueue nbatch MSMs (device pointers, no sync); d_out = blst_p1[nbatch] or 48-byte compressed points
+// nseg != 0 (wide-table handles): MSM b runs over the table bases (b % nseg) * npoints .. + npoints — nseg different
+// small base sets in one handle (the 128 columns of 64 points of FK20)
 void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npoints, size_t nbatch, int mont,
-                 hipStream_t stream, int out_mode, bool reserve_only = false);
+                 hipStream_t stream, int out_mode, bool reserve_only = false, size_t nseg = 0);
+bool msm_has_wide_table(MsmContext* ctx);
+// 48-byte compressed form of `count` g1::Xyzz points (device pointers)
+void g1_compress_xyzz(void* d_out48, const void* d_xyzz, size_t count, hipStream_t stream);
 int msm_device(MsmContext* ctx);
 void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoints, size_t nbatch);
 void msm_lock(MsmContext* ctx);

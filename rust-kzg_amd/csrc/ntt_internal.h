@@ -55,3 +55,8 @@ struct NttCtx {
         cap = n;
     }
 };
+
+namespace kzgamd {
+// fftg1.hip: G1 transforms of device-resident g1::Xyzz data, see there
+void* fftg1_device(NttCtx* ctx, void* data_xyzz, void* scratch_xyzz, size_t n, size_t nbatch, int inverse, hipStream_t st);
+}  // namespace kzgamd
