@@ -495,6 +495,19 @@ def main():
             kzg.compute_blob_kzg_proof_batch(hb, cmb, nb, settings)
         res["pcie_inclusive_proofs_per_s"] = 2 * nb / (time.perf_counter() - t0)
 
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- EIP-7594 cell proofs, 256 blobs per call (FK20 on the GPU), host buffers in and out
+        ncell = min(256, B * NB)
+        hbc = blobs[:ncell].cpu().numpy().tobytes()
+        kzg.compute_cells_and_kzg_proofs_batch(hbc, ncell, settings)
+        t0 = time.perf_counter()
+        kzg.compute_cells_and_kzg_proofs_batch(hbc, ncell, settings)
+        dtc = time.perf_counter() - t0
+        res["cells_and_proofs_256"] = {"ms_per_call": dtc * 1e3, "cell_proofs_per_s": ncell * 128 / dtc, "blobs_per_s": ncell / dtc,
+                                       "path": "kzgamd_compute_cells_and_kzg_proofs_batch: 128 cells + 128 cell proofs per blob, "
+                                               "FK20 (64 NTTs of 128, 128 MSMs of 64 points, two G1 transforms of 128)"}
+        del hbc
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ns = min(B, 64)
         host = blobs[:ns].cpu().numpy()
