@@ -499,10 +499,20 @@ def main():
         # ---- EIP-7594 cell proofs, 256 blobs per call (FK20 on the GPU), host buffers in and out
         ncell = min(256, B * NB)
         hbc = blobs[:ncell].cpu().numpy().tobytes()
-        kzg.compute_cells_and_kzg_proofs_batch(hbc, ncell, settings)
+        import ctypes as C_
+
+        cbuf, pbuf = C_.create_string_buffer(ncell * 128 * 2048), C_.create_string_buffer(ncell * 128 * 48)
+
+        def cells_call():
+            rc = kzg.lib().kzgamd_compute_cells_and_kzg_proofs_batch(cbuf, pbuf, hbc, ncell, C_.byref(settings.c))
+            if rc != 0:
+                raise RuntimeError("kzgamd_compute_cells_and_kzg_proofs_batch: %d" % rc)
+
+        cells_call()
         t0 = time.perf_counter()
-        kzg.compute_cells_and_kzg_proofs_batch(hbc, ncell, settings)
-        dtc = time.perf_counter() - t0
+        cells_call()
+        cells_call()
+        dtc = (time.perf_counter() - t0) / 2
         res["cells_and_proofs_256"] = {"ms_per_call": dtc * 1e3, "cell_proofs_per_s": ncell * 128 / dtc, "blobs_per_s": ncell / dtc,
                                        "path": "kzgamd_compute_cells_and_kzg_proofs_batch: 128 cells + 128 cell proofs per blob, "
                                                "FK20 (64 NTTs of 128, 128 MSMs of 64 points, two G1 transforms of 128)"}
