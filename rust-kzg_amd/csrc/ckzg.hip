@@ -1429,13 +1429,16 @@ __global__ void __launch_bounds__(256) k_fk20_toeplitz(ff::Fr* __restrict__ out,
     else if (idx >= 66) v = p[N - 1 - i - 64 * (128 - idx)];
     out[t] = v;
 }
-// coeffs[blob][j][i] = transform_i[j]: the scalars of column j next to each other (the MSM's layout)
-__global__ void __launch_bounds__(256) k_fk20_transpose(ff::Fr* __restrict__ out, const ff::Fr* __restrict__ in, size_t nblobs) {
+// coeffs[blob][j][i] = transform_i[j] / 128: the scalars of column j next to each other (the MSM's layout), with the
+// 1/128 of the inverse G1 transform that follows folded in (a field multiplication here instead of a scalar
+// multiplication per point there)
+__global__ void __launch_bounds__(256) k_fk20_transpose(ff::Fr* __restrict__ out, const ff::Fr* __restrict__ in, size_t nblobs,
+                                                        ff::Fr inv128) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nblobs * 128 * 64) return;
     const size_t b = t >> 13;
     const u32 j = (u32)(t >> 6) & 127, i = (u32)t & 63;
-    out[t] = in[(b * 64 + i) * 128 + j];
+    out[t] = ff::mul(in[(b * 64 + i) * 128 + j], inv128);
 }
 // h[64 .. 128) = identity (das.rs:688-691)
 __global__ void __launch_bounds__(256) k_fk20_zero_upper(g1::Xyzz* __restrict__ h, size_t nblobs) {
@@ -1526,8 +1529,11 @@ void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_
         hipLaunchKernelGGL(k_fk20_toeplitz, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, dev->d_fk_a,
                            (const ff::Fr*)dev->d_fr_b, n);
         if (kzgamd_ntt_fr_device(dev->ntt, dev->d_fk_b, dev->d_fk_a, 128, 64 * n, 0, st) != 0) throw CkErr{C_KZG_ERROR, "ntt"};
+        ff::Fr k128 = ff::Fr::zero();
+        k128.v[0] = 128;
+        const ff::Fr inv128 = ff::inverse_bgcd(ff::to_mont(k128));  // Montgomery form of 1/128
         hipLaunchKernelGGL(k_fk20_transpose, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, dev->d_fk_a,
-                           (const ff::Fr*)dev->d_fk_b, n);
+                           (const ff::Fr*)dev->d_fk_b, n, inv128);
         // h_ext_fft[blob][j] = sum_i coeffs[j][i] * x_ext_fft_columns[j][i]: 128 n MSMs of 64 points, column j of the table
         kzgamd::msm_lock(dev->msm_xext);
         try {
@@ -1538,7 +1544,7 @@ void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_
         }
         kzgamd::msm_unlock(dev->msm_xext);
         // h = ifft_g1(h_ext_fft), upper half cleared, proofs = fft_g1(h), bit-reversed, compressed
-        g1::Xyzz* h = (g1::Xyzz*)kzgamd::fftg1_device((NttCtx*)dev->ntt, dev->d_fk_h, dev->d_fk_h2, 128, n, 1, st);
+        g1::Xyzz* h = (g1::Xyzz*)kzgamd::fftg1_device((NttCtx*)dev->ntt, dev->d_fk_h, dev->d_fk_h2, 128, n, 1, st, false);
         if (!h) throw CkErr{C_KZG_ERROR, "fft_g1"};
         g1::Xyzz* other = h == dev->d_fk_h ? dev->d_fk_h2 : dev->d_fk_h;
         hipLaunchKernelGGL(k_fk20_zero_upper, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, h, n);

@@ -250,9 +250,11 @@ void ensure_g1_tab(NttCtx* ctx, size_t tab_lanes) {
 
 // G1 transforms of device-resident XYZZ data (natural order in `data`, nbatch transforms of n points each); `scratch`
 // has the same size.  Enqueued on `st`, nothing synchronised; returns the buffer (data or scratch) that holds the
-// result in natural order, or nullptr on an allocation failure.  The per-lane tables are shared by the handle: one
+// result in natural order, or nullptr on an allocation failure.  scale_inverse = false leaves out the n^-1 of an inverse
+// transform (a caller that can fold it into its scalars saves one scalar multiplication per point).  The per-lane tables are shared by the handle: one
 // stream at a time (the c-kzg layer calls this under its settings lock and synchronises before it returns).
-void* kzgamd::fftg1_device(NttCtx* ctx, void* data_v, void* scratch_v, size_t n, size_t nbatch, int inverse, hipStream_t st) {
+void* kzgamd::fftg1_device(NttCtx* ctx, void* data_v, void* scratch_v, size_t n, size_t nbatch, int inverse, hipStream_t st,
+                           bool scale_inverse) {
     if (!ctx || n == 0 || (n & (n - 1)) || n > ctx->W) return nullptr;
     try {
         const size_t total = n * nbatch, bf = total / 2;
@@ -267,7 +269,7 @@ void* kzgamd::fftg1_device(NttCtx* ctx, void* data_v, void* scratch_v, size_t n,
                                bufs[(s + 1) & 1], (const Xyzz*)bufs[s & 1], tab, (const RootSplit*)ctx->d_kroots, (u32)n, s,
                                (u32)ctx->W, inverse ? 1 : 0, 2 * bf);
         Xyzz* res = bufs[logn & 1];
-        if (inverse && n > 1) {
+        if (inverse && n > 1 && scale_inverse) {
             Fr v = Fr::zero();
             v.v[0] = (u32)n;
             v.v[1] = (u32)((u64)n >> 32);

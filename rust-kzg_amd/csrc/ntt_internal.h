@@ -58,5 +58,6 @@ struct NttCtx {
 
 namespace kzgamd {
 // fftg1.hip: G1 transforms of device-resident g1::Xyzz data, see there
-void* fftg1_device(NttCtx* ctx, void* data_xyzz, void* scratch_xyzz, size_t n, size_t nbatch, int inverse, hipStream_t st);
+void* fftg1_device(NttCtx* ctx, void* data_xyzz, void* scratch_xyzz, size_t n, size_t nbatch, int inverse, hipStream_t st,
+                   bool scale_inverse = true);
 }  // namespace kzgamd
