@@ -23,3 +23,5 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_2p20 -o r02 -- python $R/tools/prof_2p20.py > $R/gpurun_out/prof_2p20.log 2>&1
 ls $R/gpurun_out | head -40
+# 5. kernel trace of the FK20 cell-proof batches (tools/time_cells.py)
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cells -o r02 -- python $R/tools/time_cells.py 256 > $R/gpurun_out/prof_cells.log 2>&1
