@@ -1896,6 +1896,13 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         staging.release();
         if (prepare) build_wide_table(ctx);
         if (ctx->fbw_glv && !ctx->fbw) throw HipErr{hipErrorOutOfMemory, "wide GLV table did not fit the HBM budget it was sized for"};
+        if (prepare && getenv("KZGAMD_VERBOSE")) {
+            // the shape a handle ended up with depends on the HBM that was free: say so when asked
+            const double gb = ctx->fbw ? (double)ctx->rows * (double)n * (double)ctx->nb * sizeof(WidePt) / 1e9 : 0.0;
+            fprintf(stderr, "kzg_mi355x: prepared handle over %zu points on GPU %d: %s, %d-bit windows, %d rows, %s, %.1f GB, %d additions per scalar\n",
+                    n, ctx->device, ctx->fbw ? "wide table" : "bucket engine (no room for a wide table)", ctx->c, ctx->rows,
+                    ctx->fbw_glv ? "GLV split" : "no split", gb, ctx->fbw ? (ctx->fbw_glv ? 2 * ctx->rows : ctx->rows) : 0);
+        }
     } catch (...) {
         delete ctx;
         throw;
