@@ -20,7 +20,7 @@ blobs = bytearray(rnd.randbytes(nmax * BLOB))
 for i in range(0, nmax * BLOB, 32):
     blobs[i] = 0
 blobs = bytes(blobs)
-for n in (1, 16, 64, 256, nmax):
+for n in sorted({m for m in (1, 16, 64, 256, nmax) if m <= nmax}):
     row = {}
     for mode in ("1", "0"):
         if mode == "0" and n > 256:
