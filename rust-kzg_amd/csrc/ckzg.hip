@@ -265,7 +265,9 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
         invs[k] = ff::mul(inv, pre[k]);
         inv = ff::mul(inv, d);
         bool ok;
-        ff::Fr p = ff::to_mont(fr_load_be(bw + (size_t)i * 8, &ok));
+        // the blob element stays canonical: a Montgomery product with one canonical operand is the canonical product,
+        // so neither the elements nor the results below need a conversion multiplication
+        const ff::Fr p = fr_load_be(bw + (size_t)i * 8, &ok);
         bad |= !ok;
         acc = ff::add(acc, ff::mul(ff::mul(invs[k], w), p));
     }
@@ -277,10 +279,10 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
         __syncthreads();
     }
     if (t == 0) {
-        ff::Fr y;
+        ff::Fr y;  // canonical
         if (m >= 0) {
             bool ok;
-            y = ff::to_mont(fr_load_be(bw + (size_t)m * 8, &ok));
+            y = fr_load_be(bw + (size_t)m * 8, &ok);
             sh_misc[2] = fr_inverse(z);
         } else {
             // out = sum / N * (z^N - 1)
@@ -289,9 +291,8 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
             y = ff::mul(ff::mul(sh_a[0], ninv), ff::sub(zn, ff::Fr::one()));  // ninv = 1/N, computed once on the host
         }
         sh_misc[1] = y;
-        ff::Fr yc = ff::from_mont(y);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) y_out[blob * 8 + k] = yc.v[k];
+        for (int k = 0; k < 8; ++k) y_out[blob * 8 + k] = y.v[k];
         if (sh_bad) status[blob] = 1;
     }
     __syncthreads();
@@ -304,11 +305,10 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
         const int i = k * QT + t;
         if (i == m) continue;
         bool ok;
-        ff::Fr p = ff::to_mont(fr_load_be(bw + (size_t)i * 8, &ok));
-        ff::Fr ymp = ff::sub(y, p);
-        ff::Fr q = ff::mul(ymp, invs[k]);
+        const ff::Fr p = fr_load_be(bw + (size_t)i * 8, &ok);
+        const ff::Fr ymp = ff::sub(y, p);            // canonical
+        const ff::Fr qc = ff::mul(ymp, invs[k]);     // canonical x Montgomery -> canonical
         if (m >= 0) col = ff::add(col, ff::mul(ff::mul(ff::neg(ymp), roots_brp[i]), invs[k]));
-        ff::Fr qc = ff::from_mont(q);
 #pragma unroll
         for (int l = 0; l < 8; ++l) q_out[(blob * N + i) * 8 + l] = qc.v[l];
     }
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
             __syncthreads();
         }
         if (t == 0) {
-            ff::Fr qc = ff::from_mont(ff::mul(sh_a[0], sh_misc[2]));
+            const ff::Fr qc = ff::mul(sh_a[0], sh_misc[2]);  // canonical column sum x z^-1 (Montgomery)
 #pragma unroll
             for (int l = 0; l < 8; ++l) q_out[(blob * N + m) * 8 + l] = qc.v[l];
         }
