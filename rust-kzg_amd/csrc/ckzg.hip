@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(QT) k_quotient_a(unsigned char* __restrict__ s
     if (t + 1 < QT) inv = ff::mul(inv, sh_b[t + 1]);  // 1 / d_i
     __syncthreads();
     bool ok;
-    const ff::Fr p = ff::to_mont(fr_load_be(blobs + (blob * N + (size_t)i) * 8, &ok));
+    const ff::Fr p = fr_load_be(blobs + (blob * N + (size_t)i) * 8, &ok);  // canonical, as in k_quotient
     if (!ok || !zok) status[blob] = 1;
     sc_fr[i] = inv;
     sh_a[t] = ff::mul(ff::mul(inv, w), p);
@@ -409,9 +409,9 @@ __global__ void __launch_bounds__(QT) k_quotient_b(u32* __restrict__ q_out, u32*
     bool ok;
     const ff::Fr z = ff::to_mont(fr_load_be(z_be + blob * 8, &ok));
     if (t == 0) {
-        ff::Fr y;
+        ff::Fr y;  // canonical
         if (m >= 0) {
-            y = ff::to_mont(fr_load_be(bw + (size_t)m * 8, &ok));
+            y = fr_load_be(bw + (size_t)m * 8, &ok);
         } else {
             ff::Fr sum = sc_fr[N];
             for (int k = 1; k < QS; ++k) sum = ff::add(sum, sc_fr[N + k]);
@@ -421,18 +421,17 @@ __global__ void __launch_bounds__(QT) k_quotient_b(u32* __restrict__ q_out, u32*
         }
         sh_y = y;
         if (blk == 0) {
-            const ff::Fr yc = ff::from_mont(y);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) y_out[blob * 8 + k] = yc.v[k];
+            for (int k = 0; k < 8; ++k) y_out[blob * 8 + k] = y.v[k];
         }
     }
     __syncthreads();
     const ff::Fr y = sh_y;
     const ff::Fr inv = sc_fr[i];
-    const ff::Fr p = ff::to_mont(fr_load_be(bw + (size_t)i * 8, &ok));
+    const ff::Fr p = fr_load_be(bw + (size_t)i * 8, &ok);
     const ff::Fr ymp = ff::sub(y, p);
     if (i != m) {
-        const ff::Fr qc = ff::from_mont(ff::mul(ymp, inv));
+        const ff::Fr qc = ff::mul(ymp, inv);  // canonical x Montgomery
 #pragma unroll
         for (int l = 0; l < 8; ++l) q_out[(blob * N + i) * 8 + l] = qc.v[l];
     }
@@ -454,7 +453,7 @@ __global__ void __launch_bounds__(QT) k_quotient_b(u32* __restrict__ q_out, u32*
     __threadfence();
     ff::Fr col = sc_fr[N + QS];
     for (int k = 1; k < QS; ++k) col = ff::add(col, sc_fr[N + QS + k]);
-    const ff::Fr qc = ff::from_mont(ff::mul(col, fr_inverse(z)));
+    const ff::Fr qc = ff::mul(col, fr_inverse(z));
 #pragma unroll
     for (int l = 0; l < 8; ++l) q_out[(blob * N + m) * 8 + l] = qc.v[l];
 }
