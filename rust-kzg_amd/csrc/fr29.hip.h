@@ -141,6 +141,27 @@ FF_HD ff::Fr pack(const Fe& a) {  // normalized, value < 2^256
     }
     return r;
 }
+// a * 32 as 9 x 29-bit limbs (bit re-slicing with the 5-bit shift folded in; value < 2^261)
+FF_HD Fe unpack_shl5(const ff::Fr& a) {
+    Fe r;
+    r.v[0] = (a.v[0] << 5) & MASK;
+#pragma unroll
+    for (int i = 1; i < L; ++i) {
+        const int bit = 29 * i - 5, w = bit >> 5, s = bit & 31;
+        u64 two = (u64)a.v[w] | ((w + 1 < 8) ? ((u64)a.v[w + 1] << 32) : 0);
+        r.v[i] = (u32)(two >> s) & MASK;
+    }
+    return r;
+}
+// ff::mul for blst_fr operands (a * b * 2^-256 mod r, result in [0, r)) through the 29-bit multiplier:
+// (32 a) * b * 2^-261.  Same value as ff::mul bit for bit, in about half the instructions (the 8 x 32-bit CIOS form
+// pays a 64-bit add and a pile of moves per multiply-add).  Operands below 2^256 with a * b < 2^256 * r.
+FF_HD ff::Fr mul_blst(const ff::Fr& a, const ff::Fr& b) {
+    ff::Fr r = pack(mul(unpack_shl5(a), unpack(b)));
+    ff::reduce_once(r);
+    return r;
+}
+
 // lazy value (< 64r) times a normalized canonical multiplier (W = w*2^261), fully reduced to [0, r)
 FF_HD ff::Fr finish(const Fe& a, const Fe& mult) {
     ff::Fr r = pack(mul(a, mult));
