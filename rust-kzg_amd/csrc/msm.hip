@@ -1277,6 +1277,25 @@ __global__ void __launch_bounds__(64) k_digit_bits_wide(const Xyzz* __restrict__
     wide_cell_finish<WSPLIT>(acc, part, top, counter, cell, sub, lc, sh, &last_s, lane);
 }
 
+// out[c] = sum of in[64 c .. 64 c + 63]: eight waves per cell add eight points each, the last one to finish adds the
+// eight partial sums (the fold of a single commitment's 4096 partial sums: two launches, ~50 us each, instead of the
+// 13 single-lane tree levels of k_blocksum)
+constexpr int WFOLD = 8;
+__global__ void __launch_bounds__(64) k_wide_fold64(const Xyzz* __restrict__ in, Xyzz* __restrict__ out, Xyzz* __restrict__ part,
+                                                    u32* __restrict__ counter) {
+    __shared__ u32 sh[16];
+    __shared__ u32 last_s;
+    const int lane = threadIdx.x;
+    const size_t cell = blockIdx.x / WFOLD;
+    const int sub = (int)(blockIdx.x % WFOLD);
+    const fpw::Lane lc = fpw::lane_consts(lane);
+    g1w::WPt acc;
+    g1w::set_inf(acc);
+    const Xyzz* src = in + cell * 64 + (size_t)sub * 8;
+    for (int e = 0; e < 8; ++e) g1w::dadd(acc, g1w::load(src + e, lane), lc, sh, lane);
+    wide_cell_finish<WFOLD>(acc, part, out, counter, cell, sub, lc, sh, &last_s, lane);
+}
+
 // ============================ wide fixed-base table ("FBW") ============================
 // With 288 GB of HBM per GPU the 4096-point setup can afford the full signed-window table
 //     W[w][i][m-1] = m * 2^(c*w) * P_i ,   m = 1 .. 2^(c-1)
@@ -1992,7 +2011,11 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         const size_t lanes = (npoints + spl - 1) / spl * (ctx->fbw_glv ? 2 : 1);
         ws.buckets.ensure(nbatch * lanes);
         ws.lvlM[0].ensure(nbatch);
-        if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) ws.lvlA[0].ensure(nbatch * 16);
+        if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) ws.lvlA[0].ensure(nbatch * 64);
+        if (nbatch <= 4 && lanes == 4096) {
+            ws.wpart.ensure((nbatch * 64 + nbatch) * (size_t)8);
+            ws.wcount.ensure(nbatch * 64 + nbatch);
+        }
         if (ctx->fbw_glv) ws.digits.ensure(nbatch * npoints * 2 * (size_t)((nwin + 3) & ~3));
         if (reserve_only) return;
         WsUse ws_use(ws, stream);
@@ -2034,6 +2057,14 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             // many small MSMs (segments of a table): one lane adds the few partial sums of an MSM
             hipLaunchKernelGGL(k_lane_sum, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)ws.buckets.p,
                                sums, lanes, nbatch);
+        } else if (nbatch <= 4 && lanes == 4096 && !getenv("KZGAMD_NO_WIDE_TAIL")) {
+            // one or a few commitments: the 4096 partial sums folded 64 : 1 twice with limb-parallel additions
+            const size_t c1 = nbatch * 64, c2 = nbatch;
+            HIP_TRY(hipMemsetAsync(ws.wcount.p, 0, (c1 + c2) * sizeof(u32), stream));
+            hipLaunchKernelGGL(k_wide_fold64, dim3((unsigned)(c1 * WFOLD)), dim3(64), 0, stream, (const Xyzz*)ws.buckets.p,
+                               ws.lvlA[0].p, ws.wpart.p, ws.wcount.p);
+            hipLaunchKernelGGL(k_wide_fold64, dim3((unsigned)(c2 * WFOLD)), dim3(64), 0, stream, (const Xyzz*)ws.lvlA[0].p, sums,
+                               ws.wpart.p + c1 * WFOLD, ws.wcount.p + c1);
         } else if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) {
             // a few MSMs: the one-workgroup-per-MSM fold is a latency chain (16 strided additions + 8 tree rounds);
             // 16 workgroups per MSM and a second small fold take 9 + 6 rounds instead (single commitment call
