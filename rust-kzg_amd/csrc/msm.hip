@@ -1277,12 +1277,12 @@ __global__ void __launch_bounds__(64) k_digit_bits_wide(const Xyzz* __restrict__
     wide_cell_finish<WSPLIT>(acc, part, top, counter, cell, sub, lc, sh, &last_s, lane);
 }
 
-// out[c] = sum of in[64 c .. 64 c + 63]: eight waves per cell add eight points each, the last one to finish adds the
-// eight partial sums (the fold of a single commitment's 4096 partial sums: two launches, ~50 us each, instead of the
-// 13 single-lane tree levels of k_blocksum)
+// out[c] = sum of the 8 * per_wave consecutive points of cell c: eight waves per cell add per_wave points each, the last
+// one to finish adds the eight partial sums (the fold of a single commitment's partial sums: two launches instead of
+// the 13 single-lane tree levels of k_blocksum)
 constexpr int WFOLD = 8;
 __global__ void __launch_bounds__(64) k_wide_fold64(const Xyzz* __restrict__ in, Xyzz* __restrict__ out, Xyzz* __restrict__ part,
-                                                    u32* __restrict__ counter) {
+                                                    u32* __restrict__ counter, int per_wave) {
     __shared__ u32 sh[16];
     __shared__ u32 last_s;
     const int lane = threadIdx.x;
@@ -1291,8 +1291,8 @@ __global__ void __launch_bounds__(64) k_wide_fold64(const Xyzz* __restrict__ in,
     const fpw::Lane lc = fpw::lane_consts(lane);
     g1w::WPt acc;
     g1w::set_inf(acc);
-    const Xyzz* src = in + cell * 64 + (size_t)sub * 8;
-    for (int e = 0; e < 8; ++e) g1w::dadd(acc, g1w::load(src + e, lane), lc, sh, lane);
+    const Xyzz* src = in + (cell * WFOLD + (size_t)sub) * per_wave;  // a cell = WFOLD * per_wave consecutive points
+    for (int e = 0; e < per_wave; ++e) g1w::dadd(acc, g1w::load(src + e, lane), lc, sh, lane);
     wide_cell_finish<WFOLD>(acc, part, out, counter, cell, sub, lc, sh, &last_s, lane);
 }
 
@@ -2008,13 +2008,17 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         if (const char* e = getenv("KZGAMD_SPL")) spl = atoi(e) > 0 ? atoi(e) : spl;
         if (spl == 3 || spl > 4) spl = 4;
         if (ctx->fbw_glv) spl *= 2;  // two lanes (k1 / k2 digits) per scalar group: the same number of partial sums
+        // one or two MSMs over the 4096-point setup: a lane per (scalar, half) — 8 additions per lane instead of 16,
+        // twice the partial sums for the limb-parallel fold
+        if (ctx->fbw_glv && nbatch <= 2 && npoints == 4096 && !getenv("KZGAMD_SPL") && !getenv("KZGAMD_NO_WIDE_TAIL")) spl = 1;
         const size_t lanes = (npoints + spl - 1) / spl * (ctx->fbw_glv ? 2 : 1);
         ws.buckets.ensure(nbatch * lanes);
         ws.lvlM[0].ensure(nbatch);
-        if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) ws.lvlA[0].ensure(nbatch * 64);
-        if (nbatch <= 4 && lanes == 4096) {
-            ws.wpart.ensure((nbatch * 64 + nbatch) * (size_t)8);
-            ws.wcount.ensure(nbatch * 64 + nbatch);
+        if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) ws.lvlA[0].ensure(nbatch * 128);
+        const bool wide_fold = nbatch <= 2 && (lanes == 4096 || lanes == 8192) && !getenv("KZGAMD_NO_WIDE_TAIL");
+        if (wide_fold) {
+            ws.wpart.ensure((nbatch * 128 + nbatch) * (size_t)WFOLD);
+            ws.wcount.ensure(nbatch * 128 + nbatch);
         }
         if (ctx->fbw_glv) ws.digits.ensure(nbatch * npoints * 2 * (size_t)((nwin + 3) & ~3));
         if (reserve_only) return;
@@ -2042,7 +2046,8 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     hipLaunchKernelGGL((k_fbw_accum<SPL_, GLV_>), grid, dim3(256), 0, stream, P, acc_in,                         \
                        (const WidePt*)ctx->wide.p, ws.buckets.p, lanes)
         if (ctx->fbw_glv) {
-            if (spl == 2) KZG_FBW_LAUNCH(2, true);
+            if (spl == 1) KZG_FBW_LAUNCH(1, true);
+            else if (spl == 2) KZG_FBW_LAUNCH(2, true);
             else if (spl == 4) KZG_FBW_LAUNCH(4, true);
             else KZG_FBW_LAUNCH(8, true);
         } else {
@@ -2057,14 +2062,15 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             // many small MSMs (segments of a table): one lane adds the few partial sums of an MSM
             hipLaunchKernelGGL(k_lane_sum, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)ws.buckets.p,
                                sums, lanes, nbatch);
-        } else if (nbatch <= 4 && lanes == 4096 && !getenv("KZGAMD_NO_WIDE_TAIL")) {
-            // one or a few commitments: the 4096 partial sums folded 64 : 1 twice with limb-parallel additions
-            const size_t c1 = nbatch * 64, c2 = nbatch;
+        } else if (wide_fold) {
+            // one or two commitments: the partial sums folded 64 : 1, then 64 : 1 or 128 : 1, with limb-parallel additions
+            const int pw2 = (int)(lanes / 64 / WFOLD);  // 8 or 16 points per wave in the second launch
+            const size_t c1 = nbatch * (lanes / 64), c2 = nbatch;
             HIP_TRY(hipMemsetAsync(ws.wcount.p, 0, (c1 + c2) * sizeof(u32), stream));
             hipLaunchKernelGGL(k_wide_fold64, dim3((unsigned)(c1 * WFOLD)), dim3(64), 0, stream, (const Xyzz*)ws.buckets.p,
-                               ws.lvlA[0].p, ws.wpart.p, ws.wcount.p);
+                               ws.lvlA[0].p, ws.wpart.p, ws.wcount.p, 8);
             hipLaunchKernelGGL(k_wide_fold64, dim3((unsigned)(c2 * WFOLD)), dim3(64), 0, stream, (const Xyzz*)ws.lvlA[0].p, sums,
-                               ws.wpart.p + c1 * WFOLD, ws.wcount.p + c1);
+                               ws.wpart.p + c1 * WFOLD, ws.wcount.p + c1, pw2);
         } else if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) {
             // a few MSMs: the one-workgroup-per-MSM fold is a latency chain (16 strided additions + 8 tree rounds);
             // 16 workgroups per MSM and a second small fold take 9 + 6 rounds instead (single commitment call
