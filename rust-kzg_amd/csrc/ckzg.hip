@@ -1106,6 +1106,7 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
 // handful of results the host-buffer entry points fetch Jacobian points instead and compress them on the host
 // (~20 us each): a single blob_to_kzg_commitment call 0.71 -> 0.5 ms.
 constexpr size_t HOST_COMPRESS_MAX = 4;
+constexpr size_t HOST_CHECK_MAX = 64;  // commitments of a proof batch validated on the host's cores up to this many
 
 void compress_on_host(uint8_t* out48, const blst_p1* jac, size_t n) {
     for (size_t i = 0; i < n; ++i) kzgamd::host_p1_compress(out48 + 48 * i, &jac[i]);
@@ -1244,7 +1245,9 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
     // Commitment validity (decode + subgroup) only decides BadArgs at the end; nothing downstream depends
     // on it.  A few commitments: on the host while the GPU proves (a serial 381-bit chain is ~7x faster on
     // a CPU core than in one GPU lane); a batch: one lane each on a second stream.
-    const bool host_check = derive && n <= 4;
+    // (the device check is a 1.7 ms latency chain whatever the count; a host core takes ~0.2 ms per commitment with
+    // 64-bit limbs, and the hashing pool does them in parallel while the GPU proves: up to 64 blobs the host wins)
+    const bool host_check = derive && n <= HOST_CHECK_MAX;
     // KZGAMD_DEVICE_SHA=1: the Fiat-Shamir hashes of a host-buffer batch on the GPU too (k_challenge_sha256, one lane per
     // blob: 2050 serial compressions, ~8 ms however many blobs) and no host threads at all.  Measured against the host
     // pool: 256 blobs 22 k vs 50 k proofs/s, 1024 blobs 47 k vs 66 k, 4096 blobs 72 k vs 78 k — the kernel only pays when
@@ -1397,11 +1400,20 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
         prove_enqueue(dev, 0, n, dev->stream, proofs == nullptr, out_mode);
     }
     // commitment check on the host, while the GPU works (the copies below block until it is done)
-    if (host_check)
-        for (size_t i = 0; i < n; ++i) {
+    if (host_check) {
+        auto check = [&](size_t i) {
             blst_p1 c;
             if (!kzgamd::host_p1_uncompress(&c, commitments[i].bytes) || !kzgamd::host_p1_in_g1(&c)) cstat[i] = 1;
+        };
+        if (n > 1 && nth > 1) {
+            if (!dev->pool) dev->pool.reset(new WorkerPool(16));
+            dev->pool->run(nth, [&, nth](unsigned w) {
+                for (size_t i = w; i < n; i += nth) check(i);
+            });
+        } else {
+            for (size_t i = 0; i < n; ++i) check(i);
         }
+    }
     std::vector<int> status(n);
     std::vector<u32> ylimbs(n * 8);
     blst_p1 jac[HOST_COMPRESS_MAX];

@@ -1281,6 +1281,7 @@ __global__ void __launch_bounds__(64) k_digit_bits_wide(const Xyzz* __restrict__
 // one to finish adds the eight partial sums (the fold of a single commitment's partial sums: two launches instead of
 // the 13 single-lane tree levels of k_blocksum)
 constexpr int WFOLD = 8;
+constexpr size_t WIDE_FOLD_MAX = 4;  // MSMs per launch folded this way (8 and 16 measured slower than k_blocksum, whose levels are then busy)
 __global__ void __launch_bounds__(64) k_wide_fold64(const Xyzz* __restrict__ in, Xyzz* __restrict__ out, Xyzz* __restrict__ part,
                                                     u32* __restrict__ counter, int per_wave) {
     __shared__ u32 sh[16];
@@ -2010,12 +2011,12 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         if (ctx->fbw_glv) spl *= 2;  // two lanes (k1 / k2 digits) per scalar group: the same number of partial sums
         // one or two MSMs over the 4096-point setup: a lane per (scalar, half) — 8 additions per lane instead of 16,
         // twice the partial sums for the limb-parallel fold
-        if (ctx->fbw_glv && nbatch <= 2 && npoints == 4096 && !getenv("KZGAMD_SPL") && !getenv("KZGAMD_NO_WIDE_TAIL")) spl = 1;
+        if (ctx->fbw_glv && nbatch <= WIDE_FOLD_MAX && npoints == 4096 && !getenv("KZGAMD_SPL") && !getenv("KZGAMD_NO_WIDE_TAIL")) spl = 1;
         const size_t lanes = (npoints + spl - 1) / spl * (ctx->fbw_glv ? 2 : 1);
         ws.buckets.ensure(nbatch * lanes);
         ws.lvlM[0].ensure(nbatch);
         if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) ws.lvlA[0].ensure(nbatch * 128);
-        const bool wide_fold = nbatch <= 2 && (lanes == 4096 || lanes == 8192) && !getenv("KZGAMD_NO_WIDE_TAIL");
+        const bool wide_fold = nbatch <= WIDE_FOLD_MAX && (lanes == 4096 || lanes == 8192) && !getenv("KZGAMD_NO_WIDE_TAIL");
         if (wide_fold) {
             ws.wpart.ensure((nbatch * 128 + nbatch) * (size_t)WFOLD);
             ws.wcount.ensure(nbatch * 128 + nbatch);
