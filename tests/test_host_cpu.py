@@ -228,3 +228,48 @@ def test_prefixed_library_renames_every_ckzg_symbol():
     text = open(os.path.join(ROOT, "include", "kzg_mi355x.h")).read()
     for n in b.CKZG_NAMES:
         assert "#define %s kzgamd_ckzg_%s" % (n, n) in text, n
+
+
+def test_fast_field_multipliers_equal_the_generic_ones(tmp_path):
+    """hfp::mul (6 x 64-bit limbs, host pairing) and fr29::mul_blst (9 x 29-bit limbs, quotient kernels) are drop-in
+    replacements of ff::mul: compiled for the host and compared on random and edge operands."""
+    import shutil
+    import subprocess
+
+    cxx = shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        cxx = shutil.which("g++")
+    src = tmp_path / "fieldcheck.cpp"
+    csrc = os.path.join(ROOT, "rust-kzg_amd", "csrc")
+    src.write_text('''
+#include <cstdio>
+#include <cstdint>
+#include "%s/host_fp64.h"
+#include "%s/fr29.hip.h"
+static uint64_t st = 0x9e3779b97f4a7c15ull;
+static uint32_t rnd() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 16); }
+int main() {
+    int bad = 0;
+    for (int it = 0; it < 20000; ++it) {
+        ff::Fp a, b;
+        for (int k = 0; k < 12; ++k) { a.v[k] = rnd(); b.v[k] = rnd(); }
+        a.v[11] &= 0x0fffffffu; b.v[11] &= 0x0fffffffu;  // below p
+        if (it == 0) a = ff::Fp::zero();
+        if (it == 1) { a = ff::Fp::modulus(); a.v[0] -= 1; b = a; }
+        if (!(hfp::mul(a, b) == ff::mul(a, b))) ++bad;
+        if (!(hfp::add(a, b) == ff::add(a, b))) ++bad;
+        if (!(hfp::sub(a, b) == ff::sub(a, b))) ++bad;
+        ff::Fr x, y;
+        for (int k = 0; k < 8; ++k) { x.v[k] = rnd(); y.v[k] = rnd(); }
+        x.v[7] &= 0x3fffffffu; y.v[7] &= 0x3fffffffu;  // below r
+        if (it == 2) x = ff::Fr::zero();
+        if (it == 3) { x = ff::Fr::modulus(); x.v[0] -= 1; y = x; }
+        if (!(fr29::mul_blst(x, y) == ff::mul(x, y))) ++bad;
+    }
+    printf("%%d\\n", bad);
+    return bad != 0;
+}
+''' % (csrc, csrc))
+    exe = tmp_path / "fieldcheck"
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-x", "c++", str(src), "-o", str(exe)])
+    assert subprocess.check_output([str(exe)]).strip() == b"0"
