@@ -767,6 +767,8 @@ struct KzgAmdSettings {
     hipEvent_t ev_commit = nullptr;  // the commitments of a proof batch are on the device (recorded on stream2)
     // batched verification: staging for [proofs | commitments | G] and the variable-base handle over them, kept
     // between calls (a fresh handle per call cost 1.7 ms of stream / allocation / free round trips)
+    std::mutex vmu;                 // one batched verification at a time per settings object (its staging buffers)
+    std::vector<uint8_t> vstage;    // host staging of the 2n + 1 compressed points (must outlive the async copy)
     unsigned char* d_vbytes = nullptr;
     AffPt* d_vpts = nullptr;
     int* d_vstat = nullptr;
@@ -1231,7 +1233,7 @@ bool host_blob_valid(const uint8_t* blob) {
 // from the commitments (compute_blob_kzg_proof)
 // proofs == nullptr: evaluation only (zs_out receives the derived challenges)
 void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32* zs, const Bytes48* commitments, size_t n,
-                 KzgAmdSettings* dev, Bytes32* zs_out = nullptr) {
+                 KzgAmdSettings* dev, Bytes32* zs_out = nullptr, bool commitments_checked_elsewhere = false) {
     std::lock_guard<std::mutex> lk(dev->mu);
     kzgamd::DeviceGuard on_device(dev->device);
     CK_HIP(on_device.err);
@@ -1247,16 +1249,16 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
     // a CPU core than in one GPU lane); a batch: one lane each on a second stream.
     // (the device check is a 1.7 ms latency chain whatever the count; a host core takes ~0.2 ms per commitment with
     // 64-bit limbs, and the hashing pool does them in parallel while the GPU proves: up to 64 blobs the host wins)
-    const bool host_check = derive && n <= HOST_CHECK_MAX;
+    const bool host_check = derive && n <= HOST_CHECK_MAX && !commitments_checked_elsewhere;
     // KZGAMD_DEVICE_SHA=1: the Fiat-Shamir hashes of a host-buffer batch on the GPU too (k_challenge_sha256, one lane per
     // blob: 2050 serial compressions, ~8 ms however many blobs) and no host threads at all.  Measured against the host
     // pool: 256 blobs 22 k vs 50 k proofs/s, 1024 blobs 47 k vs 66 k, 4096 blobs 72 k vs 78 k — the kernel only pays when
     // other batches hide it (the device-resident pipeline), so the host pool stays the default.
     const char* dsha = getenv("KZGAMD_DEVICE_SHA");
-    const bool device_sha = derive && n >= 2 * PROVE_CHUNK && dsha && atoi(dsha) != 0;
+    const bool device_sha = derive && n >= 2 * PROVE_CHUNK && dsha && atoi(dsha) != 0 && !commitments_checked_elsewhere;
     if (derive) {
         cstat.assign(n, 0);
-        if (!host_check) {
+        if (!host_check && !commitments_checked_elsewhere) {
             CK_HIP(hipMemcpyAsync(dev->d_commit, commitments, n * 48, hipMemcpyHostToDevice, dev->stream2));
             if (device_sha) {
                 if (!dev->ev_commit) CK_HIP(hipEventCreateWithFlags(&dev->ev_commit, hipEventDisableTiming));
@@ -1424,7 +1426,7 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
     CK_HIP(hipStreamSynchronize(dev->stream));
     if (zs_out) memcpy(zs_out, zs, n * 32);
     if (derive) {
-        if (!host_check) {
+        if (!host_check && !commitments_checked_elsewhere) {
             CK_HIP(hipMemcpyAsync(cstat.data(), dev->d_cstatus, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream2));
             CK_HIP(hipStreamSynchronize(dev->stream2));
         }
@@ -1837,12 +1839,39 @@ bool fr_from_be32_checked(ff::Fr& out, const uint8_t* in) {  // FsFr::from_bytes
 // (validate_batched_input, :721-734) and the linear combinations — as ONE two-row MSM over [proofs | commitments | G]:
 //     row 0:  r^i           0      0                 -> proof_lincomb
 //     row 1:  r^i z_i       r^i    -sum r^i y_i      -> rhs  ( = sum r^i (C_i - [y_i]G) + sum r^i z_i proof_i )
-void verify_batch_g1(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commitments, const Bytes32* zs, const Bytes32* ys,
-                     const Bytes48* proofs, size_t n, KzgAmdSettings* dev) {
+// Batched verification, G1 half, in two steps so that the decode + subgroup check of the 2n points (a 1.7 ms latency
+// chain on its own stream) runs under whatever the caller does in between — the challenges and evaluations of
+// verify_blob_kzg_proof_batch.  The caller holds dev->vmu from begin to finish.
+void verify_g1_begin(const Bytes48* commitments, const Bytes48* proofs, size_t n, KzgAmdSettings* dev) {
+    std::lock_guard<std::mutex> lk(dev->mu);
+    kzgamd::DeviceGuard on_device(dev->device);
+    CK_HIP(on_device.err);
+    const size_t np = 2 * n + 1;
+    dev->ensure_verify(np);
+    // device: [proofs | commitments | generator], decoded and checked
+    dev->vstage.resize(np * 48);
+    memcpy(dev->vstage.data(), proofs, n * 48);
+    memcpy(dev->vstage.data() + n * 48, commitments, n * 48);
+    static const uint8_t G1_GENERATOR_COMPRESSED[48] = {
+        0x97, 0xf1, 0xd3, 0xa7, 0x31, 0x97, 0xd7, 0x94, 0x26, 0x95, 0x63, 0x8c, 0x4f, 0xa9, 0xac, 0x0f,
+        0xc3, 0x68, 0x8c, 0x4f, 0x97, 0x74, 0xb9, 0x05, 0xa1, 0x4e, 0x3a, 0x3f, 0x17, 0x1b, 0xac, 0x58,
+        0x6c, 0x55, 0xe8, 0x3f, 0xf9, 0x7a, 0x1a, 0xef, 0xfb, 0x3a, 0xf0, 0x0a, 0xdb, 0x22, 0xc6, 0xbb};
+    memcpy(dev->vstage.data() + 2 * n * 48, G1_GENERATOR_COMPRESSED, 48);
+    hipStream_t st = dev->stream2;
+    CK_HIP(hipMemcpyAsync(dev->d_vbytes, dev->vstage.data(), dev->vstage.size(), hipMemcpyHostToDevice, st));
+    CK_HIP(hipMemsetAsync(dev->d_vstat, 0, np * sizeof(int), st));
+    CK_HIP(hipMemsetAsync(dev->d_vpts, 0, np * sizeof(AffPt), st));
+    hipLaunchKernelGGL(k_decode_check_g1, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st, dev->d_vpts, dev->d_vstat,
+                       (const unsigned char*)dev->d_vbytes, np);
+    CK_HIP(hipGetLastError());
+}
+
+void verify_g1_finish(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commitments, const Bytes32* zs, const Bytes32* ys,
+                      const Bytes48* proofs, size_t n, KzgAmdSettings* dev) {
     std::vector<ff::Fr> z(n), y(n);
+    bool scalars_ok = true;
     for (size_t i = 0; i < n; ++i) {
-        CK_REQUIRE(fr_from_be32_checked(z[i], zs[i].bytes), "Invalid scalar");
-        CK_REQUIRE(fr_from_be32_checked(y[i], ys[i].bytes), "Invalid scalar");
+        scalars_ok = scalars_ok && fr_from_be32_checked(z[i], zs[i].bytes) && fr_from_be32_checked(y[i], ys[i].bytes);
         z[i] = ff::to_mont(z[i]);
         y[i] = ff::to_mont(y[i]);
     }
@@ -1850,22 +1879,7 @@ void verify_batch_g1(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commit
     kzgamd::DeviceGuard on_device(dev->device);
     CK_HIP(on_device.err);
     const size_t np = 2 * n + 1;
-    dev->ensure_verify(np);
-    // device: [proofs | commitments | generator], decoded and checked
-    std::vector<uint8_t> stage(np * 48);
-    memcpy(stage.data(), proofs, n * 48);
-    memcpy(stage.data() + n * 48, commitments, n * 48);
-    static const uint8_t G1_GENERATOR_COMPRESSED[48] = {
-        0x97, 0xf1, 0xd3, 0xa7, 0x31, 0x97, 0xd7, 0x94, 0x26, 0x95, 0x63, 0x8c, 0x4f, 0xa9, 0xac, 0x0f,
-        0xc3, 0x68, 0x8c, 0x4f, 0x97, 0x74, 0xb9, 0x05, 0xa1, 0x4e, 0x3a, 0x3f, 0x17, 0x1b, 0xac, 0x58,
-        0x6c, 0x55, 0xe8, 0x3f, 0xf9, 0x7a, 0x1a, 0xef, 0xfb, 0x3a, 0xf0, 0x0a, 0xdb, 0x22, 0xc6, 0xbb};
-    memcpy(stage.data() + 2 * n * 48, G1_GENERATOR_COMPRESSED, 48);
-    hipStream_t st = dev->stream;
-    CK_HIP(hipMemcpyAsync(dev->d_vbytes, stage.data(), stage.size(), hipMemcpyHostToDevice, st));
-    CK_HIP(hipMemsetAsync(dev->d_vstat, 0, np * sizeof(int), st));
-    CK_HIP(hipMemsetAsync(dev->d_vpts, 0, np * sizeof(AffPt), st));
-    hipLaunchKernelGGL(k_decode_check_g1, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st, dev->d_vpts, dev->d_vstat,
-                       (const unsigned char*)dev->d_vbytes, np);
+    hipStream_t st = dev->stream2;
     // host, meanwhile: r = hash_to_bls_field(sha256(domain | 4096 | n | (C_i | z_i | y_i | proof_i)...)), powers of r
     std::vector<ff::Fr> sc(2 * np, ff::Fr::zero());
     {
@@ -1905,6 +1919,7 @@ void verify_batch_g1(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commit
     std::vector<int> stat(np);
     CK_HIP(hipMemcpyAsync(stat.data(), dev->d_vstat, np * sizeof(int), hipMemcpyDeviceToHost, st));
     CK_HIP(hipStreamSynchronize(st));
+    CK_REQUIRE(scalars_ok, "Invalid scalar");
     for (size_t i = 0; i < np; ++i) CK_REQUIRE(stat[i] != 1, "Invalid G1 encoding");
     for (size_t i = 0; i < n; ++i) CK_REQUIRE(stat[i] == 0, "Invalid proof");
     for (size_t i = n; i < 2 * n; ++i) CK_REQUIRE(stat[i] == 0, "Invalid commitment");
@@ -1914,6 +1929,18 @@ void verify_batch_g1(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commit
     kzgamd::msm_run_host(dev->msm_verify, out, sc.data(), np, 2);
     *proof_lincomb = out[0];
     *rhs = out[1];
+}
+
+void verify_batch_g1(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commitments, const Bytes32* zs, const Bytes32* ys,
+                     const Bytes48* proofs, size_t n, KzgAmdSettings* dev) {
+    std::lock_guard<std::mutex> vlk(dev->vmu);
+    // (the scalars are validated before anything is launched, as before)
+    for (size_t i = 0; i < n; ++i) {
+        ff::Fr t;
+        CK_REQUIRE(fr_from_be32_checked(t, zs[i].bytes) && fr_from_be32_checked(t, ys[i].bytes), "Invalid scalar");
+    }
+    verify_g1_begin(commitments, proofs, n, dev);
+    verify_g1_finish(proof_lincomb, rhs, commitments, zs, ys, proofs, n, dev);
 }
 
 }  // namespace
@@ -1949,8 +1976,10 @@ extern "C" C_KZG_RET kzgamd_verify_blob_kzg_proof_batch_g1(blst_p1* proof_lincom
     if (!blobs || !commitments || !proofs) return C_KZG_BADARGS;
     return guarded([&] {
         std::vector<Bytes32> zs(n), ys(n);
-        prove_batch(nullptr, ys.data(), blobs, nullptr, commitments, n, dev, zs.data());
-        verify_batch_g1(proof_lincomb_out, rhs_out, commitments, zs.data(), ys.data(), proofs, n, dev);
+        std::lock_guard<std::mutex> vlk(dev->vmu);
+        verify_g1_begin(commitments, proofs, n, dev);  // decode + subgroup check run under the evaluations
+        prove_batch(nullptr, ys.data(), blobs, nullptr, commitments, n, dev, zs.data(), true);
+        verify_g1_finish(proof_lincomb_out, rhs_out, commitments, zs.data(), ys.data(), proofs, n, dev);
     });
 }
 
@@ -2069,8 +2098,12 @@ extern "C" C_KZG_RET verify_blob_kzg_proof_batch(bool* ok, const Blob* blobs, co
     return guarded([&] {
         blst_p1 pl, rhs;
         std::vector<Bytes32> zs(n), ys(n);
-        prove_batch(nullptr, ys.data(), blobs, nullptr, commitments_bytes, n, dev, zs.data());
-        verify_batch_g1(&pl, &rhs, commitments_bytes, zs.data(), ys.data(), proofs_bytes, n, dev);
+        {
+            std::lock_guard<std::mutex> vlk(dev->vmu);
+            verify_g1_begin(commitments_bytes, proofs_bytes, n, dev);  // decode + subgroup check run under the evaluations
+            prove_batch(nullptr, ys.data(), blobs, nullptr, commitments_bytes, n, dev, zs.data(), true);
+            verify_g1_finish(&pl, &rhs, commitments_bytes, zs.data(), ys.data(), proofs_bytes, n, dev);
+        }
         blst_p2 g2gen, g2tau;
         const kzgamd::pairing::G2Jac gen = kzgamd::pairing::g2_generator();
         memcpy(&g2gen, &gen, sizeof g2gen);
