@@ -394,7 +394,8 @@ def blob_to_kzg_commitment_batch(blobs: bytes, n: int, settings: KZGSettings):
     rc = lib().kzgamd_blob_to_kzg_commitment_batch(out, blobs, n, C.byref(settings.c))
     if rc != C_KZG_OK:
         raise KzgAmdError("kzgamd_blob_to_kzg_commitment_batch: C_KZG_RET %d" % rc)
-    return [out.raw[48 * i:48 * i + 48] for i in range(n)]
+    raw = out.raw  # one copy (out.raw copies the whole buffer at every access)
+    return [raw[48 * i:48 * i + 48] for i in range(n)]
 
 
 def blob_to_kzg_commitment_device(d_out, d_status, d_scratch, d_blobs, n, settings, stream=0):
@@ -561,7 +562,8 @@ def compute_blob_kzg_proof_batch(blobs: bytes, commitments: bytes, n: int, setti
     rc = lib().kzgamd_compute_blob_kzg_proof_batch(out, blobs, commitments, n, C.byref(settings.c))
     if rc != C_KZG_OK:
         raise KzgAmdError("kzgamd_compute_blob_kzg_proof_batch: C_KZG_RET %d" % rc)
-    return [out.raw[48 * i:48 * i + 48] for i in range(n)]
+    raw = out.raw  # one copy (out.raw copies the whole buffer at every access)
+    return [raw[48 * i:48 * i + 48] for i in range(n)]
 
 
 def compute_challenges_and_evaluate_batch(blobs: bytes, commitments: bytes, n: int, settings: KZGSettings):
@@ -571,7 +573,8 @@ def compute_challenges_and_evaluate_batch(blobs: bytes, commitments: bytes, n: i
     rc = lib().kzgamd_compute_challenges_and_evaluate_batch(zs, ys, blobs, commitments, n, C.byref(settings.c))
     if rc != C_KZG_OK:
         raise KzgAmdError("kzgamd_compute_challenges_and_evaluate_batch: C_KZG_RET %d" % rc)
-    return ([zs.raw[32 * i:32 * i + 32] for i in range(n)], [ys.raw[32 * i:32 * i + 32] for i in range(n)])
+    zr, yr = zs.raw, ys.raw
+    return ([zr[32 * i:32 * i + 32] for i in range(n)], [yr[32 * i:32 * i + 32] for i in range(n)])
 
 
 def verify_kzg_proof_batch_g1(commitments: bytes, zs: bytes, ys: bytes, proofs: bytes, n: int, settings: KZGSettings):
