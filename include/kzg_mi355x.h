@@ -125,6 +125,11 @@ int kzgamd_fft_g1_batch(void *ctx, blst_p1 *out, const blst_p1 *in, size_t n, si
 int kzgamd_ntt_fr_device(void *ctx, void *d_out, const void *d_in, size_t n, size_t nbatch, int inverse, void *stream);
 /* host copies of the settings arrays (FFTSettings getters, kzg/src/lib.rs:465-481); counts in elements */
 int kzgamd_ntt_roots(void *ctx, blst_fr *roots /*W+1*/, blst_fr *reverse_roots /*W+1*/, blst_fr *brp_roots /*W*/);
+/* The tile plan the NTT kernel runs for (kind, T) — host-only, no GPU needed (rust-kzg_amd/csrc/ntt_plan.h):
+ * kind 0 = whole transform of 2^T <= 4096 points, 1 = first pass of a longer one, 2 = later pass; rounds[4*r..] =
+ * {first stage, stages, barrier after, element bit}; tab[(r*1024 + thread)*4..] = {idxA, idxB, lds(idxA), lds(idxB)}.
+ * Returns the number of rounds (<= 6), -1 on bad arguments. */
+int kzgamd_ntt_plan_dump(int kind, int T, int *rounds /* 6 x 4 */, uint16_t *tab /* 6 x 1024 x 4 */);
 
 /* ------------------------------------------------------------------------------------------
  * B3 — c-kzg-4844 surface for the proving path (blst/src/eip_4844.rs:160-530).

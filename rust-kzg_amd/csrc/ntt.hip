@@ -4,13 +4,15 @@
 // Contract identical to the reference: natural order in, natural order out, Montgomery blst_fr,
 // roots taken with stride max_width/n from roots_of_unity (forward) or reverse_roots_of_unity
 // (inverse), inverse scaled by n^-1.  The reference recurses (out-of-place DIT, even/odd split);
-// here the same butterfly network is run iteratively:
-//   n <= 4096 : one workgroup per transform, all log2(n) stages in LDS (4096 x 32 B = 128 KiB of the
-//               160 KiB CDNA4 LDS), bit-reversal folded into the load;
-//   n  > 4096 : pass 1 = the 12 low stages on contiguous 4096-blocks (same kernel), then up to 12 further
-//               stages per pass on strided tiles (C positions x R rows = 4096 elements per workgroup): two
-//               passes up to 2^24, three up to the 2^31 the roots table allows; every element crosses HBM
-//               once per pass (64*n algorithmic bytes each).
+// here the same butterfly network is run iteratively on tiles of 4096 elements (ntt_plan.h):
+//   n <= 4096 : one pass, a workgroup takes 4096 / n transforms, bit reversal folded into the load;
+//   n  > 4096 : log2(n) stages split evenly over ceil(log2(n) / 10) passes (2^20 = 10 + 10): the first takes, per tile,
+//               4096 >> T blocks of the bit-reversed sequence whose pieces are neighbours in memory, the later ones
+//               2^T rows x (4096 >> T) >= 4 consecutive columns in place — every global access is a run of >= 128
+//               bytes and every element crosses HBM once per pass (64*n algorithmic bytes each).
+// Inside a tile: 1024 threads x 4 elements, radix-4 rounds at <= 128 VGPRs (4 waves per SIMD); the first round
+// loads from global memory into registers and the last stores from them; a wave keeps the same 256 elements for up
+// to 6 stages, so its exchanges need no workgroup barrier (one barrier per 4096-point transform).
 // Field arithmetic: 9 x 29-bit Montgomery with lazy butterflies (fr29.hip.h); integer VALU only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,6 +27,7 @@
 #include "fr29.hip.h"
 #include "device_guard.h"
 #include "ntt_internal.h"
+#include "ntt_plan.h"
 
 using ff::Fr;
 using fr29::Fe;
@@ -33,286 +36,200 @@ using ff::u64;
 
 namespace {
 
-constexpr int LOG_TILE = 12;
-constexpr int TILE = 1 << LOG_TILE;  // elements per workgroup
-// threads per workgroup = TILE >> MAXM: 2^MAXM elements per thread in a round of MAXM stages
-//   MAXM = 3 (radix-8 rounds, 512 threads, 2 waves per SIMD: the 144 KiB tile allows one workgroup per CU)
-//   MAXM = 2 (radix-4 rounds, 1024 threads, 4 waves per SIMD, half the registers, 1.5x the LDS traffic) was measured
-//            7 % slower (98.8 vs 92.4 us for 256 transforms of 4096) and is not instantiated
+using nttplan::KIND_A1;
+using nttplan::KIND_A2;
+using nttplan::KIND_B;
+constexpr int LOGT = nttplan::LOGT;
+constexpr int TILE = nttplan::TILE;  // elements per workgroup
+constexpr int NT = nttplan::NT;      // threads per workgroup: 4 elements each, 16 waves = 4 per SIMD at <= 128 VGPRs
 
-__device__ __forceinline__ u32 brev(u32 v, int bits) { return bits == 0 ? 0u : __builtin_bitreverse32(v) >> (32 - bits); }
-
-// LDS holds a tile in the 9 x 29-bit form, limb-major: sh[limb * cnt + swz(idx)].  The XOR swizzle folds
-// index bits 5..11 into the bank bits, so that every access pattern of the kernels below — unit stride, the
-// strides 8 / 64 / 512 of the radix-8 rounds, and the bit-reversed scatter of the loads — puts the 32 lanes of a
-// ds_read_b32 / ds_write_b32 group on 32 distinct banks (4096 x 36 B = 144 KiB of the 160 KiB LDS).
-__host__ __device__ constexpr int swz(int i) { return i ^ (((i >> 5) & 7) ^ (((i >> 6) & 3) << 3) ^ ((i >> 7) & 31)); }
-
-__device__ __forceinline__ Fe lds_get(const u32* sh, int cnt, int sidx) {  // sidx already swizzled
+// LDS holds the tile in the 9 x 29-bit form, limb-major: sh[limb * TILE + swz(idx)] (144 KiB of the 160 KiB).
+__device__ __forceinline__ Fe lds_get(const u32* sh, u32 sidx) {  // sidx already swizzled
     Fe r;
 #pragma unroll
-    for (int k = 0; k < fr29::L; ++k) r.v[k] = sh[k * cnt + sidx];
+    for (int k = 0; k < fr29::L; ++k) r.v[k] = sh[k * TILE + sidx];
     return r;
 }
-__device__ __forceinline__ void lds_put(u32* sh, int cnt, int sidx, const Fe& a) {
+__device__ __forceinline__ void lds_put(u32* sh, u32 sidx, const Fe& a) {
 #pragma unroll
-    for (int k = 0; k < fr29::L; ++k) sh[k * cnt + sidx] = a.v[k];
+    for (int k = 0; k < fr29::L; ++k) sh[k * TILE + sidx] = a.v[k];
 }
 
-// One round = M consecutive butterfly stages (B .. B+M-1 of the tile's DIT network) on 2^M elements held in
-// registers: one LDS round trip and one barrier per M stages instead of per stage.  Virtual thread v owns the
-// tile indices  base | (k << B),  k < 2^M,  base = v with M zero bits inserted at position B.  Stage B+q pairs
-// k and k | 2^q; its twiddle depends on the low B+q bits of the index, so the round loads 2^M - 1 twiddles for
-// its M * 2^(M-1) butterflies.  FIRST: stage 0 of a transform multiplies by w^0 = 1 — no multiplication.
-template <int NT, int M, int B, bool FIRST, class TwFn>
-__device__ __forceinline__ void round_regs(u32* sh, int cnt, int nelem, TwFn tw) {
-    constexpr int E = 1 << M;
-    for (int v = threadIdx.x; v < (nelem >> M); v += NT) {
-        const int lo = v & ((1 << B) - 1);
-        const int base = ((v >> B) << (B + M)) | lo;
-        const int sbase = swz(base);  // swz is XOR-linear: swz(base | k << B) = swz(base) ^ swz(k << B)
-        Fe e[E];
-#pragma unroll
-        for (int k = 0; k < E; ++k) e[k] = lds_get(sh, cnt, sbase ^ swz(k << B));
-        // butterflies written out per stage (no loop nests for the compiler to leave rolled: a rolled loop would
-        // index e[] dynamically and push it to scratch)
-        // limbs are renormalised after the second stage of a round and at its end, not after every stage
+struct RoundDev {
+    u32 bit;      // a thread's elements are idxA, idxA | bit, idxB, idxB | bit
+    u32 sbit;     // swz(bit): the swizzle is XOR-linear
+    u32 pos;      // first stage of the round (tile-local)
+    u32 M;        // stages in the round: 2, 1, or 0 (n = 1)
+    u32 barrier;  // the next round belongs to another phase: workgroup barrier instead of the wave-local exchange
+};
+
+struct PassParams {
+    RoundDev rd[nttplan::MAXR];
+    const uint2* tab;  // [round][thread] = {idxA | idxB << 16, swz(idxA) | swz(idxB) << 16}   (ntt_plan.h)
+    const Fe* tw;      // stage-major twiddles of this direction: entry (2^s - 1) + j = w_{2^(s+1)}^(+-j), times 2^261
+    size_t total;      // elements in the batch
+    u32 n;             // transform length
+    int kind, T, nrounds;
+    int s0;            // global stage of the tile's stage 0 (KIND_B; 0 otherwise)
+    int Lh;            // KIND_A2: log2(n) - T
+    u32 tiles_per_xform;
+    int last;          // last pass of the transform
+    int inverse;
+    Fr scale;          // inverse transforms: n^-1 * 2^261 (applied by the last pass)
+};
+
+// One pass: T stages (1..12) of the DIT network on a tile of 4096 elements (ntt_plan.h has the geometry).
+//   round 0 loads its elements straight from global memory, the last round stores straight to it; in between the
+//   tile lives in LDS.  Rounds of one phase exchange data between the lanes of a wave only — LDS operations of a wave
+//   execute in order, no barrier — so a wave that has its data starts computing while others still wait for theirs,
+//   and a 4096-point transform synchronises the workgroup once (between stages 5 and 6).
+//   Butterflies are lazy (fr29.hip.h): a round's inputs have normalised limbs, its outputs are renormalised once.
+__global__ void __launch_bounds__(NT) k_ntt_pass(Fr* __restrict__ out, const Fr* __restrict__ in, const PassParams P) {
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    const u32 tid = threadIdx.x;
+    const int T = P.T, kind = P.kind;
+    const u32 mT = (1u << T) - 1u;
+    size_t xbase = 0, tile0 = 0, origin = 0;
+    u32 o_base = 0, lo0 = 0;
+    if (kind == KIND_A1) {
+        tile0 = (size_t)blockIdx.x * TILE;
+    } else {
+        const u32 xf = blockIdx.x / P.tiles_per_xform, g = blockIdx.x % P.tiles_per_xform;
+        xbase = (size_t)xf * P.n;
+        if (kind == KIND_A2) {
+            o_base = g << (LOGT - T);
+        } else {
+            const int logC = LOGT - T;
+            const u32 lo_tiles = (1u << P.s0) >> logC;  // tiles per block of 2^(s0 + T) positions
+            const u32 hi = g / lo_tiles;
+            lo0 = (g % lo_tiles) << logC;
+            origin = ((size_t)hi << (P.s0 + T)) + lo0;
+        }
+    }
+    auto brev_t = [&](u32 p) -> u32 { return T ? (__builtin_bitreverse32(p) >> (32 - T)) : 0u; };
+    // where tile element idx comes from / goes to
+    auto src_index = [&](u32 idx) -> size_t {
+        const u32 p = idx & mT, c = idx >> T;
+        if (kind == KIND_A1) return tile0 + ((size_t)c << T) + brev_t(p);
+        if (kind == KIND_A2) return xbase + o_base + c + ((size_t)brev_t(p) << P.Lh);
+        return xbase + origin + ((size_t)p << P.s0) + c;
+    };
+    auto dst_index = [&](u32 idx) -> size_t {
+        const u32 p = idx & mT, c = idx >> T;
+        if (kind == KIND_A1) return tile0 + idx;
+        if (kind == KIND_A2) return xbase + ((size_t)(__builtin_bitreverse32(o_base + c) >> (32 - P.Lh)) << T) + p;
+        return xbase + origin + ((size_t)p << P.s0) + c;
+    };
+    // twiddle of tile stage s for the pair whose lower element is i: global stage s0 + s, position
+    // (i mod 2^s) * 2^s0 + column  ->  entry (2^(s0+s) - 1) + that
+    auto tw_ent = [&](u32 s, u32 i) -> u32 {
+        u32 ent = ((1u << (P.s0 + s)) - 1u) + ((i & ((1u << s) - 1u)) << P.s0);
+        if (kind == KIND_B) ent += lo0 + (i >> T);
+        return ent;
+    };
+
 #define KZG_BF(K0, K1, W)                                \
     {                                                    \
         const Fe tt_ = fr29::mul(e[K1], W);              \
         fr29::butterfly_lazy(e[K0], e[K1], tt_);         \
     }
+/* twiddle w^0 = 1 on a normalised operand */
 #define KZG_BF1(K0, K1)                                  \
     {                                                    \
         const Fe y_ = e[K1];                             \
         fr29::butterfly_lazy(e[K0], e[K1], y_);          \
     }
-/* a later stage of the first round whose twiddle is w^0 = 1: the operand is a lazy sum (< 4r), normalise it first */
+/* twiddle w^0 = 1 on a lazy sum (< 4r): normalise it first, pad with 8r */
 #define KZG_BF1N(K0, K1)                                 \
     {                                                    \
         Fe y_ = e[K1];                                   \
         fr29::norm(y_);                                  \
         fr29::butterfly_lazy8(e[K0], e[K1], y_);         \
     }
-#define KZG_NORM_ALL                  \
-    _Pragma("unroll") for (int k_ = 0; k_ < E; ++k_) fr29::norm(e[k_]);
-        if constexpr (M == 1) {
-            if constexpr (FIRST && B == 0) {
-                KZG_BF1(0, 1)
-            } else {
-                const Fe w = tw(B, lo, base);
-                KZG_BF(0, 1, w)
+    for (int r = 0; r < P.nrounds; ++r) {
+        const RoundDev rd = P.rd[r];
+        const uint2 te = P.tab[r * NT + tid];
+        const u32 iA = te.x & 0xffffu, iB = te.x >> 16, sA = te.y & 0xffffu, sB = te.y >> 16;
+        Fe e[4];
+        if (r == 0) {
+            const u32 idx[4] = {iA, iA | rd.bit, iB, iB | rd.bit};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t gi = src_index(idx[k]);
+                e[k] = fr29::unpack(gi < P.total ? in[gi] : Fr::zero());
             }
-            KZG_NORM_ALL
-        } else if constexpr (M == 2) {
-            if constexpr (FIRST && B == 0) {
-                KZG_BF1(0, 1)
-                KZG_BF1(2, 3)
-            } else {
-                const Fe w = tw(B, lo, base);
-                KZG_BF(0, 1, w)
-                KZG_BF(2, 3, w)
-            }
-            {
-                if constexpr (FIRST && B == 0) {
-                    KZG_BF1N(0, 2)  // stage 1, position 0: w^0 = 1 again
-                } else {
-                    const Fe w0 = tw(B + 1, lo, base);
-                    KZG_BF(0, 2, w0)
-                }
-                const Fe w1 = tw(B + 1, lo | (1 << B), base);
-                KZG_BF(1, 3, w1)
-            }
-            KZG_NORM_ALL
         } else {
-            if constexpr (FIRST && B == 0) {
+            e[0] = lds_get(sh, sA);
+            e[1] = lds_get(sh, sA ^ rd.sbit);
+            e[2] = lds_get(sh, sB);
+            e[3] = lds_get(sh, sB ^ rd.sbit);
+        }
+        if (rd.M) {
+            // stages 0 (and 1 at position 0) of a transform multiply by w^0 = 1: no multiplication
+            const bool unit = r == 0 && kind != KIND_B;
+            if (unit) {
                 KZG_BF1(0, 1)
                 KZG_BF1(2, 3)
-                KZG_BF1(4, 5)
-                KZG_BF1(6, 7)
             } else {
-                const Fe w = tw(B, lo, base);
+                const Fe w = P.tw[tw_ent(rd.pos, iA)];
                 KZG_BF(0, 1, w)
-                KZG_BF(2, 3, w)
-                KZG_BF(4, 5, w)
-                KZG_BF(6, 7, w)
+                if (rd.M == 2) {
+                    KZG_BF(2, 3, w)
+                } else {
+                    const Fe w2 = P.tw[tw_ent(rd.pos, iB)];
+                    KZG_BF(2, 3, w2)
+                }
             }
-            {
-                // the first round of a transform: position 0 of stages 1 and 2 has the twiddle w^0 = 1 as well
-                if constexpr (FIRST && B == 0) {
+            if (rd.M == 2) {
+                if (unit) {
                     KZG_BF1N(0, 2)
-                    KZG_BF1N(4, 6)
                 } else {
-                    const Fe w0 = tw(B + 1, lo, base);
+                    const Fe w0 = P.tw[tw_ent(rd.pos + 1, iA)];
                     KZG_BF(0, 2, w0)
-                    KZG_BF(4, 6, w0)
                 }
-                const Fe w1 = tw(B + 1, lo | (1 << B), base);
+                const Fe w1 = P.tw[tw_ent(rd.pos + 1, iA | rd.bit)];
                 KZG_BF(1, 3, w1)
-                KZG_BF(5, 7, w1)
             }
-            KZG_NORM_ALL
-            {
-                if constexpr (FIRST && B == 0) {
-                    KZG_BF1N(0, 4)
-                } else {
-                    const Fe w0 = tw(B + 2, lo, base);
-                    KZG_BF(0, 4, w0)
-                }
-                const Fe w1 = tw(B + 2, lo | (1 << B), base);
-                KZG_BF(1, 5, w1)
-                const Fe w2 = tw(B + 2, lo | (2 << B), base);
-                KZG_BF(2, 6, w2)
-                const Fe w3 = tw(B + 2, lo | (3 << B), base);
-                KZG_BF(3, 7, w3)
-            }
-            KZG_NORM_ALL
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fr29::norm(e[k]);
         }
+        if (r == P.nrounds - 1) {
+            const u32 idx[4] = {iA, iA | rd.bit, iB, iB | rd.bit};
+            // an inverse transform multiplies by n^-1 at the end of its last pass; everything else only needs the
+            // lazy value (< 64r) brought back to [0, r)
+            if (P.last && P.inverse) {
+                const Fe fin = fr29::unpack(P.scale);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const size_t gi = dst_index(idx[k]);
+                    if (gi < P.total) out[gi] = fr29::finish(e[k], fin);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const size_t gi = dst_index(idx[k]);
+                    if (gi < P.total) out[gi] = fr29::reduce_lazy(e[k]);
+                }
+            }
+        } else {
+            lds_put(sh, sA, e[0]);
+            lds_put(sh, sA ^ rd.sbit, e[1]);
+            lds_put(sh, sB, e[2]);
+            lds_put(sh, sB ^ rd.sbit, e[3]);
+            if (rd.barrier) {
+                __syncthreads();
+            } else {
+                // the next round reads what other lanes of this wave have just written: LDS operations of one wave
+                // execute in issue order; the fences only keep the compiler from reordering across this point
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
 #undef KZG_BF
 #undef KZG_BF1
 #undef KZG_BF1N
-#undef KZG_NORM_ALL
-#pragma unroll
-        for (int k = 0; k < E; ++k) lds_put(sh, cnt, sbase ^ swz(k << B), e[k]);
-    }
-    __syncthreads();
-}
-
-// `stages` butterfly stages (1..12) of a DIT network on the tile in LDS: stage s pairs tile indices i and i + 2^s.
-// tw(s, j, base): twiddle of stage s for pair position j = i mod 2^s (base = any index of the thread's group: the
-// caller derives the tile column from its high bits).
-template <bool FIRST, int MAXM, class TwFn>
-__device__ __forceinline__ void tile_stages(u32* sh, int cnt, int nelem, int stages, TwFn tw) {
-    constexpr int NT = TILE >> MAXM;
-    if constexpr (MAXM == 3) {
-#define KZG_ROUNDS(B_)                                                                  \
-    if (stages >= (B_) + 3) round_regs<NT, 3, B_, FIRST>(sh, cnt, nelem, tw);           \
-    else if (stages == (B_) + 2) round_regs<NT, 2, B_, FIRST>(sh, cnt, nelem, tw);      \
-    else if (stages == (B_) + 1) round_regs<NT, 1, B_, FIRST>(sh, cnt, nelem, tw);
-        KZG_ROUNDS(0)
-        KZG_ROUNDS(3)
-        KZG_ROUNDS(6)
-        KZG_ROUNDS(9)
-#undef KZG_ROUNDS
-    } else {
-#define KZG_ROUNDS(B_)                                                                  \
-    if (stages >= (B_) + 2) round_regs<NT, 2, B_, FIRST>(sh, cnt, nelem, tw);           \
-    else if (stages == (B_) + 1) round_regs<NT, 1, B_, FIRST>(sh, cnt, nelem, tw);
-        KZG_ROUNDS(0)
-        KZG_ROUNDS(2)
-        KZG_ROUNDS(4)
-        KZG_ROUNDS(6)
-        KZG_ROUNDS(8)
-        KZG_ROUNDS(10)
-#undef KZG_ROUNDS
-    }
-}
-
-struct NttParams {
-    u32 n;          // transform length
-    int logn;
-    u32 W;          // roots table width (max_width)
-    int inverse;
-    Fr scale;       // final multiplier in the 2^261 domain: 2^261 mod r, times n^-1 on the last pass of an inverse
-    int dbg;        // timing experiments only (KZGAMD_NTT_DBG): 1 = skip the butterfly stages, 2 = every twiddle = roots[0]
-};
-
-// Pass 1 (the whole transform when n <= TILE): stages 0 .. min(logn,12)-1.
-//   n <= TILE: a workgroup takes C = cnt / n whole transforms (cnt = min(TILE, n * nbatch) elements): coalesced
-//              natural-order loads, scattered into LDS at the bit-reversed index, coalesced natural-order stores.
-//   n  > TILE: a workgroup takes TILE consecutive positions of the bit-reversed sequence (block `blk`), i.e. the
-//              natural indices  o + (t << L),  o = brev_L(blk), L = logn - 12: 32-byte pieces 2^L elements apart.
-//              The four blocks whose pieces share 128-byte lines (o, o^1, o^2, o^3) are given to workgroups
-//              8 apart in launch order — same XCD, dispatched together — so the line is fetched from HBM once.
-template <int MAXM>
-__global__ void __launch_bounds__(TILE >> MAXM) k_ntt_low(Fr* __restrict__ out, const Fr* __restrict__ in,
-                                                const Fe* __restrict__ roots, NttParams P, u32 blocks_per_xform, int nelem,
-                                                size_t total) {
-    extern __shared__ __attribute__((aligned(16))) u32 sh[];
-    constexpr int NT = TILE >> MAXM;
-    const int cnt = (nelem + 31) & ~31;  // limb stride: the swizzle permutes within aligned groups of 32
-    const int stages = P.logn < LOG_TILE ? P.logn : LOG_TILE;
-    const bool last_pass = P.logn <= LOG_TILE;
-    size_t src0, dst0;
-    int L = 0;
-    if (P.n <= (u32)TILE) {
-        src0 = dst0 = (size_t)blockIdx.x * (size_t)nelem;
-    } else {
-        const u32 xf = blockIdx.x / blocks_per_xform, g = blockIdx.x % blocks_per_xform;
-        L = P.logn - LOG_TILE;
-        u32 o = g;
-        if (L >= 5) {
-            const u32 xcd = g & 7, slot = g >> 3;
-            o = (((slot >> 2) << 3 | xcd) << 2) | (slot & 3);
-        }
-        src0 = (size_t)xf * P.n + o;
-        dst0 = (size_t)xf * P.n + (size_t)brev(o, L) * TILE;
-    }
-    const int mask = (1 << stages) - 1;
-    for (int t = threadIdx.x; t < nelem; t += NT) {
-        const size_t gi = src0 + ((size_t)t << L);
-        Fe v;
-        if (gi < total) v = fr29::unpack(in[gi]);
-        else v = fr29::unpack(Fr::zero());
-        lds_put(sh, cnt, swz((t & ~mask) | (int)brev((u32)(t & mask), stages)), v);
-    }
-    __syncthreads();
-    // stage s: half = 2^s, twiddle w_n^(j * n / 2^(s+1)) = roots[j * (W / 2^(s+1))]
-    // `roots` is the stage-major table of this direction: entry (2^s - 1) + j = w_{2^(s+1)}^(+-j), so the twiddles a
-    // wave asks for are neighbours in memory whatever the ratio between the table width and n
-    tile_stages<true, MAXM>(sh, cnt, nelem, (P.dbg & 1) ? 0 : stages, [&](int s, int j, int) -> Fe {
-        return roots[(P.dbg & 2) ? 0u : ((1u << s) - 1u) + (u32)j];
-    });
-    // an inverse transform multiplies by n^-1 at the end of its last pass; everything else only needs the lazy value
-    // (< 64r) brought back to [0, r)
-    if (last_pass && P.inverse) {
-        const Fe fin = fr29::unpack(P.scale);
-        for (int t = threadIdx.x; t < nelem; t += NT)
-            if (dst0 + t < total) out[dst0 + t] = fr29::finish(lds_get(sh, cnt, swz(t)), fin);
-    } else {
-        for (int t = threadIdx.x; t < nelem; t += NT)
-            if (dst0 + t < total) out[dst0 + t] = fr29::reduce_lazy(lds_get(sh, cnt, swz(t)));
-    }
-}
-
-// Passes 2, 3: `logR` stages starting at global stage `stage0` (a multiple of 12), in place.
-// View the bit-reversed-order array as [hi][r][lo] with lo < 2^stage0, r < R = 2^logR: stage stage0+s pairs
-// rows r and r + 2^s.  A workgroup takes C = 4096 / R consecutive lo positions of one hi block
-// (C * 32 B contiguous per row), runs the logR stages on the tile, writes back.  Tile index = c * R + r.
-template <int MAXM>
-__global__ void __launch_bounds__(TILE >> MAXM) k_ntt_high(Fr* __restrict__ data, const Fe* __restrict__ roots, NttParams P,
-                                                 u32 tiles_per_xform, int stage0, int logR, int last) {
-    extern __shared__ __attribute__((aligned(16))) u32 sh[];
-    constexpr int NT = TILE >> MAXM;
-    const u32 xf = blockIdx.x / tiles_per_xform, tile = blockIdx.x % tiles_per_xform;
-    const int C = TILE >> logR, logC = LOG_TILE - logR;
-    Fr* base = data + (size_t)xf * P.n;
-    const u32 lo_tiles = (1u << stage0) >> logC;  // tiles per hi block
-    const u32 hi = tile / lo_tiles, lo0 = (tile % lo_tiles) << logC;
-    const size_t origin = ((size_t)hi << (stage0 + logR)) + lo0;
-    for (int e = threadIdx.x; e < TILE; e += NT) {
-        const int c = e & (C - 1), r = e >> logC;  // consecutive lanes -> consecutive positions
-        lds_put(sh, TILE, swz((c << logR) | r), fr29::unpack(base[origin + ((size_t)r << stage0) + c]));
-    }
-    __syncthreads();
-    tile_stages<false, MAXM>(sh, TILE, TILE, (P.dbg & 1) ? 0 : logR, [&](int s, int j, int tidx) -> Fe {
-        // global stage stage0+s: half = 2^(stage0+s); position mod half = (r mod 2^s) * 2^stage0 + lo
-        const u32 lo = lo0 + (u32)(tidx >> logR);
-        const u32 jg = ((u32)j << stage0) + lo;
-        return roots[(P.dbg & 2) ? 0u : ((1u << (stage0 + s)) - 1u) + jg];
-    });
-    if (last && P.inverse) {
-        const Fe fin = fr29::unpack(P.scale);
-        for (int e = threadIdx.x; e < TILE; e += NT) {
-            const int c = e & (C - 1), r = e >> logC;
-            base[origin + ((size_t)r << stage0) + c] = fr29::finish(lds_get(sh, TILE, swz((c << logR) | r)), fin);
-        }
-    } else {
-        for (int e = threadIdx.x; e < TILE; e += NT) {
-            const int c = e & (C - 1), r = e >> logC;
-            base[origin + ((size_t)r << stage0) + c] = fr29::reduce_lazy(lds_get(sh, TILE, swz((c << logR) | r)));
-        }
-    }
 }
 
 // DAS helper: data[i] *= roots[i * stride]  (the shift by the 2n-th root between the two NTTs)
@@ -350,39 +267,71 @@ Fr inv_len(size_t n) {
     return ff::inverse_bgcd(ff::to_mont(v));
 }
 
-// enqueue nbatch transforms of length n (device pointers; out may equal in only when n > TILE is false... so never alias)
-void ntt_enqueue(NttCtx* ctx, Fr* d_out, const Fr* d_in, size_t n, size_t nbatch, bool inverse, hipStream_t stream) {
-    NttParams P;
-    P.n = (u32)n;
-    P.logn = ilog2(n);
-    P.W = (u32)ctx->W;
-    P.inverse = inverse ? 1 : 0;
-    static const int dbg = getenv("KZGAMD_NTT_DBG") ? atoi(getenv("KZGAMD_NTT_DBG")) : 0;
-    P.dbg = dbg;
-    // 2^261 mod r as a plain residue (= "one" of the 2^261 domain); an inverse transform folds n^-1 in:
-    // data is d*2^256, so the multiplier n^-1*2^261 is (n^-1 in blst Montgomery form) * 2^5
-    P.scale = inverse ? times32(inv_len(n)) : one261();
-    const size_t total = n * nbatch;
-    const Fe* tw = (const Fe*)(inverse ? ctx->d_tw_inv : ctx->d_tw_fwd);
-    if (n <= (size_t)TILE) {
-        // whole transforms per workgroup: TILE / n of them (all of them when the batch is smaller than a tile)
-        const size_t cnt = total < (size_t)TILE ? total : (size_t)TILE;
-        const size_t wgs = (total + cnt - 1) / cnt;
-        const size_t lds = ((cnt + 31) & ~(size_t)31) * sizeof(u32) * fr29::L;
-        hipLaunchKernelGGL(k_ntt_low<3>, dim3((unsigned)wgs), dim3(TILE >> 3), lds, stream, d_out, d_in,
-                               tw, P, 1u, (int)cnt, total);
-    } else {
-        const u32 blocks = (u32)(n >> LOG_TILE);
-        hipLaunchKernelGGL(k_ntt_low<3>, dim3((unsigned)(blocks * nbatch)), dim3(TILE >> 3), (size_t)TILE * sizeof(u32) * fr29::L,
-                               stream, d_out, d_in, tw, P, blocks, TILE, total);
+// the device copy of one plan: the round table and the per-round constants
+void upload_plan(NttCtx* ctx, int kind, int T) {
+    const nttplan::Plan pl = nttplan::make_plan(kind, T);
+    NttPlanDev pd;
+    pd.nrounds = pl.nrounds;
+    for (int r = 0; r < pl.nrounds; ++r) {
+        const u32 bit = 1u << pl.elem_bit(r);
+        pd.rd[r][0] = bit;
+        pd.rd[r][1] = nttplan::swz(bit);
+        pd.rd[r][2] = (u32)pl.rounds[r].pos;
+        pd.rd[r][3] = (u32)pl.rounds[r].M;
+        pd.rd[r][4] = (u32)pl.rounds[r].barrier_after;
     }
-    // remaining stages, up to 12 per pass: 12..23, then 24..30
-    for (int stage0 = LOG_TILE; stage0 < P.logn; stage0 += LOG_TILE) {
-        const int logR = P.logn - stage0 < LOG_TILE ? P.logn - stage0 : LOG_TILE;
-        const int last = stage0 + logR == P.logn;
-        const u32 tiles = (u32)(n >> LOG_TILE);
-        hipLaunchKernelGGL(k_ntt_high<3>, dim3((unsigned)(tiles * nbatch)), dim3(TILE >> 3), (size_t)TILE * sizeof(u32) * fr29::L,
-                               stream, d_out, tw, P, tiles, stage0, logR, last);
+    // tab[..][4] of u16 = {idxA, idxB, swz(idxA), swz(idxB)} is read as uint2 {idxA | idxB << 16, swzA | swzB << 16}
+    NTT_TRY(hipMalloc(&pd.d_tab, pl.tab.size() * sizeof(uint16_t)));
+    NTT_TRY(hipMemcpy(pd.d_tab, pl.tab.data(), pl.tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    ctx->plans[kind * 16 + T] = pd;
+}
+
+void launch_pass(NttCtx* ctx, int kind, int T, Fr* d_out, const Fr* d_in, PassParams& P, unsigned grid, hipStream_t stream) {
+    const NttPlanDev& pd = ctx->plans.at(kind * 16 + T);
+    P.kind = kind;
+    P.T = T;
+    P.nrounds = pd.nrounds;
+    for (int r = 0; r < pd.nrounds; ++r) {
+        P.rd[r].bit = pd.rd[r][0];
+        P.rd[r].sbit = pd.rd[r][1];
+        P.rd[r].pos = pd.rd[r][2];
+        P.rd[r].M = pd.rd[r][3];
+        P.rd[r].barrier = pd.rd[r][4];
+    }
+    P.tab = (const uint2*)pd.d_tab;
+    hipLaunchKernelGGL(k_ntt_pass, dim3(grid), dim3(NT), (size_t)TILE * sizeof(u32) * fr29::L, stream, d_out, d_in, P);
+}
+
+// enqueue nbatch transforms of length n (device pointers; d_out must not alias d_in)
+void ntt_enqueue(NttCtx* ctx, Fr* d_out, const Fr* d_in, size_t n, size_t nbatch, bool inverse, hipStream_t stream) {
+    PassParams P;
+    memset(&P, 0, sizeof(P));
+    const int logn = ilog2(n);
+    P.n = (u32)n;
+    P.inverse = inverse ? 1 : 0;
+    // an inverse transform folds n^-1 into its last pass: data is d*2^256, so the multiplier n^-1*2^261 is
+    // (n^-1 in blst Montgomery form) * 2^5
+    P.scale = inverse ? times32(inv_len(n)) : one261();
+    P.total = n * nbatch;
+    P.tw = (const Fe*)(inverse ? ctx->d_tw_inv : ctx->d_tw_fwd);
+    if (logn <= LOGT) {
+        // the whole transform in one pass; a tile takes 4096 / n consecutive transforms
+        P.last = 1;
+        launch_pass(ctx, KIND_A1, logn, d_out, d_in, P, (unsigned)((P.total + TILE - 1) / TILE), stream);
+    } else {
+        const std::vector<int> Ts = nttplan::split_passes(logn);
+        const u32 tiles = (u32)(n >> LOGT);
+        P.tiles_per_xform = tiles;
+        P.Lh = logn - Ts[0];
+        P.last = 0;
+        launch_pass(ctx, KIND_A2, Ts[0], d_out, d_in, P, (unsigned)(tiles * nbatch), stream);
+        int s0 = Ts[0];
+        for (size_t i = 1; i < Ts.size(); ++i) {
+            P.s0 = s0;
+            P.last = i + 1 == Ts.size();
+            launch_pass(ctx, KIND_B, Ts[i], d_out, d_out, P, (unsigned)(tiles * nbatch), stream);
+            s0 += Ts[i];
+        }
     }
     NTT_TRY(hipGetLastError());
 }
@@ -423,6 +372,12 @@ extern "C" void* kzgamd_ntt_new(unsigned scale) {
             NTT_TRY(hipMalloc(&ctx->d_tw_inv, ctx->W * sizeof(Fe)));
             NTT_TRY(hipMemcpy(ctx->d_tw_fwd, sm.data(), ctx->W * sizeof(Fe), hipMemcpyHostToDevice));
             NTT_TRY(hipMemcpy(ctx->d_tw_inv, smi.data(), ctx->W * sizeof(Fe), hipMemcpyHostToDevice));
+        }
+        // every plan the passes can ask for (35 tables of <= 48 KiB), built once: launches never allocate
+        for (int T = 0; T <= nttplan::LOGT; ++T) upload_plan(ctx, KIND_A1, T);
+        for (int T = 0; T <= 10; ++T) {
+            upload_plan(ctx, KIND_A2, T);
+            upload_plan(ctx, KIND_B, T);
         }
     } catch (...) {
         delete ctx;
@@ -501,6 +456,23 @@ extern "C" int das_fft_extension(void* vctx, blst_fr* odds, const blst_fr* evens
         return -(int)e.e - 100;
     }
     return 0;
+}
+
+// The tile plan of (kind, T) as the kernel receives it — no GPU needed: rounds[r] = {pos, M, barrier_after, element bit},
+// tab[(r * 1024 + thread) * 4 ..] = {idxA, idxB, swz(idxA), swz(idxB)}.  Returns the number of rounds, -1 on bad arguments.
+extern "C" int kzgamd_ntt_plan_dump(int kind, int T, int* rounds /* 6 x 4 */, uint16_t* tab /* 6 x 1024 x 4 */) {
+    if (kind < 0 || kind > 2 || T < 0 || T > (kind == nttplan::KIND_A1 ? nttplan::LOGT : 10)) return -1;
+    const nttplan::Plan pl = nttplan::make_plan(kind, T);
+    for (int r = 0; r < pl.nrounds; ++r) {
+        if (rounds) {
+            rounds[4 * r + 0] = pl.rounds[r].pos;
+            rounds[4 * r + 1] = pl.rounds[r].M;
+            rounds[4 * r + 2] = pl.rounds[r].barrier_after;
+            rounds[4 * r + 3] = pl.elem_bit(r);
+        }
+    }
+    if (tab) memcpy(tab, pl.tab.data(), pl.tab.size() * sizeof(uint16_t));
+    return pl.nrounds;
 }
 
 extern "C" int kzgamd_ntt_roots(void* vctx, blst_fr* roots, blst_fr* reverse_roots, blst_fr* brp_roots) {

@@ -2,6 +2,7 @@
 // behind the opaque handle of kzgamd_ntt_new().
 #pragma once
 #include <hip/hip_runtime.h>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -16,8 +17,16 @@ struct NttErr {
         if (_e != hipSuccess) throw NttErr{_e}; \
     } while (0)
 
+// device copy of one tile plan (ntt_plan.h): the per-thread element table of every round + per-round constants
+struct NttPlanDev {
+    void* d_tab = nullptr;
+    int nrounds = 0;
+    unsigned rd[6][5];  // bit, swz(bit), pos, M, barrier_after
+};
+
 struct NttCtx {
     using Fr = ff::Fr;
+    std::map<int, NttPlanDev> plans;  // key = kind * 16 + T; filled by kzgamd_ntt_new, read-only afterwards
     int device = 0;
     unsigned scale = 0;
     size_t W = 0;
@@ -43,6 +52,8 @@ struct NttCtx {
         if (d_pts) (void)hipFree(d_pts);
         if (d_tab) (void)hipFree(d_tab);
         if (stream) (void)hipStreamDestroy(stream);
+        for (auto& kv : plans)
+            if (kv.second.d_tab) (void)hipFree(kv.second.d_tab);
     }
     void ensure(size_t n) {
         if (n <= cap) return;

@@ -140,6 +140,53 @@ def main():
                           "sha256": hashlib.sha256(data).hexdigest()}
     out["setup_fixtures"] = {"cite": "kzg-bench/src/tests/c_bindings.rs:344-489", "files": fixtures}
 
+    # ---- EIP-7594 cell functions (c_bindings.rs:202-355, blst/src/eip_7594.rs:35-97): cells are 2048-byte strings, most
+    # of them shared between cases; stored once each in cells_7594.bin.gz, the cases refer to them by position
+    cell_pos = {}
+    cell_list = []
+
+    def cell_ref(hexstr):
+        b = unhex(hexstr)
+        if len(b) != 2048:
+            return {"hex": hexstr}  # wrong-length input: kept inline
+        k = hashlib.sha256(b).digest()
+        if k not in cell_pos:
+            cell_pos[k] = len(cell_list)
+            cell_list.append(b)
+        return cell_pos[k]
+
+    out7 = {"source": out["source"], "cells_file": "cells_7594.bin.gz"}
+    v = []
+    for name, y in cases("verify_cell_kzg_proof_batch"):
+        i = y["input"]
+        v.append({"name": name, "commitments": i["commitments"], "cell_indices": i["cell_indices"],
+                  "cells": [cell_ref(c) for c in i["cells"]], "proofs": i["proofs"], "output": y["output"]})
+    out7["verify_cell_kzg_proof_batch"] = v
+    v = []
+    for name, y in cases("recover_cells_and_kzg_proofs"):
+        i, o = y["input"], y["output"]
+        e = {"name": name, "cell_indices": i["cell_indices"], "cells": [cell_ref(c) for c in i["cells"]], "output": None}
+        if o is not None:
+            cells = b"".join(unhex(c) for c in o[0])
+            proofs = b"".join(unhex(c) for c in o[1])
+            assert len(cells) == 128 * 2048 and len(proofs) == 128 * 48
+            e["output"] = {"cells_sha256": hashlib.sha256(cells).hexdigest(), "proofs_sha256": hashlib.sha256(proofs).hexdigest(),
+                           "cells": [cell_ref(c) for c in o[0]], "proof0": o[1][0], "proof1": o[1][1], "proof127": o[1][127]}
+        v.append(e)
+    out7["recover_cells_and_kzg_proofs"] = v
+    v = []
+    for name, y in cases("compute_verify_cell_kzg_proof_batch_challenge"):
+        i = y["input"]
+        v.append({"name": name, "commitments": i["commitments"], "commitment_indices": i["commitment_indices"],
+                  "cell_indices": i["cell_indices"], "cells": [cell_ref(c) for c in i["cosets_evals"]], "proofs": i["proofs"],
+                  "output": y["output"]})
+    out7["compute_verify_cell_kzg_proof_batch_challenge"] = v
+    with gzip.GzipFile(os.path.join(OUT, "cells_7594.bin.gz"), "wb", mtime=0) as f:
+        f.write(b"".join(cell_list))
+    with open(os.path.join(OUT, "kzg_mainnet_7594.json"), "w") as f:
+        json.dump(out7, f, indent=1)
+    print("eip-7594 cells:", len(cell_list))
+
     for h, b in blobs.items():
         with gzip.GzipFile(os.path.join(OUT, "blobs", h + ".bin.gz"), "wb", mtime=0) as f:
             f.write(b)

@@ -42,7 +42,7 @@ def test_inverse_fft_kat_and_das_kat(kzg, oracle, kats):
     fs.close()
 
 
-@pytest.mark.parametrize("logn", [0, 1, 2, 5, 9, 12, 13, 15])
+@pytest.mark.parametrize("logn", list(range(0, 17)))
 def test_fft_matches_oracle(kzg, oracle, logn):
     L = oracle.lib()
     scale = max(logn, 1) + 1
@@ -63,6 +63,36 @@ def test_fft_matches_oracle(kzg, oracle, logn):
         assert rc == 0
         got = fs.das_fft_extension(data, n)
         assert bytes(got)[: 32 * n] == bytes(exp)
+    L.offt_settings_free(C.byref(ofs))
+    fs.close()
+
+
+@pytest.mark.parametrize("logn,nbatch", [(0, 5), (1, 3), (3, 1000), (7, 3), (7, 64), (8, 17), (10, 5), (11, 3), (12, 3), (13, 3), (14, 2)])
+def test_device_batches_match_oracle(kzg, oracle, logn, nbatch):
+    # kzgamd_ntt_fr_device: nbatch contiguous transforms in one call, partial tiles included (4096 does not divide
+    # n * nbatch), every transform against the oracle
+    import torch
+
+    L = oracle.lib()
+    n = 1 << logn
+    fs = kzg.FFTSettings(max(logn, 1))
+    ofs = O.FFTSettings()
+    assert L.offt_settings_new(C.byref(ofs), max(logn, 1)) == 0
+    rnd = random.Random(1000 * logn + nbatch)
+    vals = [rnd.randrange(O.R) for _ in range(n * nbatch)]
+    raw = b"".join(v.to_bytes(32, "little") for v in vals)
+    d_in = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+    d_out = torch.zeros_like(d_in)
+    stream = torch.cuda.current_stream().cuda_stream
+    for inv in (False, True):
+        fs.fft_fr_device(d_out.data_ptr(), d_in.data_ptr(), n, nbatch, inv, stream)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy().tobytes()
+        for b in range(nbatch):
+            one = (O.Fr * n).from_buffer_copy(raw[32 * n * b: 32 * n * (b + 1)])
+            exp = (O.Fr * n)()
+            assert L.offt_fr(C.byref(ofs), exp, one, n, 1 if inv else 0) == 0
+            assert got[32 * n * b: 32 * n * (b + 1)] == bytes(exp), (logn, nbatch, inv, b)
     L.offt_settings_free(C.byref(ofs))
     fs.close()
 
