@@ -120,6 +120,84 @@ FF_HD Fe mul(const Fe& a, const Fe& b) {
     return r;
 }
 
+// ---- the butterfly multiplier of the NTT: subtractive Montgomery steps, one accumulator chain ----
+// With r = 1 mod 2^29 the quotient digit of a column is the column's low 29 bits themselves (m = acc mod 2^29) if
+// m*r is SUBTRACTED instead of added: (acc - m) >> 29 is a plain arithmetic shift, no negation and no carry fix-up
+// (two instructions per column instead of four).  The products m_i * (-r_j) are signed multiply-adds
+// (v_mad_i64_i32) on the same 64-bit accumulator as the unsigned a_i * b_j.  CHAIN keeps every column on one
+// accumulator: left to itself the compiler splits a column into several chains and pays a 64-bit addition per merge
+// (~40 per multiplication inside the NTT kernel).
+//   The result is congruent to a*b*2^-261 and lies in (-r, r) for a < 64r, b < r: limbs 0..7 normalised, the top limb
+//   SIGNED (two's complement in the u32).  Limbs 0..7 of a <= 1.5 * 2^30, of b < 2^29: every column stays below 2^63
+//   in absolute value.  a's top limb is taken as signed too (a lazy sum x + t + r can have top limb -1 with the
+//   carries of the lower limbs still pending): its nine products are signed multiply-adds.
+// `acc += a * b` as ONE accumulator chain: the empty asm makes the compiler treat every step's result as opaque, so
+// it cannot re-associate the column into several chains (each merge costs a 64-bit addition); the multiply-add is
+// still pattern-matched to a single v_mad_u64_u32 / v_mad_i64_i32.
+template <bool CHAIN>
+FF_HD void chain_step(u64& acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (CHAIN) asm("" : "+v"(acc));
+#endif
+}
+template <bool CHAIN>
+FF_HD void mad_uu(u64& acc, u32 a, u32 b) {  // unsigned x unsigned
+    acc += (u64)a * b;
+    chain_step<CHAIN>(acc);
+}
+template <bool CHAIN>
+FF_HD void mad_ii(u64& acc, u32 a, int b) {  // signed x signed
+    acc += (u64)((long long)(int)a * (long long)b);
+    chain_step<CHAIN>(acc);
+}
+template <bool CHAIN = true>
+FF_HD Fe mul_signed(const Fe& a, const Fe& b) {
+    u32 m[L];
+    Fe r;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) {
+            if (i == L - 1) mad_ii<CHAIN>(acc, a.v[i], (int)b.v[k - i]);
+            else mad_uu<CHAIN>(acc, a.v[i], b.v[k - i]);
+        }
+#pragma unroll
+        for (int i = 0; i < k; ++i) mad_ii<CHAIN>(acc, m[i], -(int)rl(k - i));
+        m[k] = (u32)acc & MASK;
+        acc = (u64)((long long)acc >> 29);  // (acc - m[k] * r_0) / 2^29, r_0 = 1
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; ++k) {
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) {
+            if (i == L - 1) mad_ii<CHAIN>(acc, a.v[i], (int)b.v[k - i]);
+            else mad_uu<CHAIN>(acc, a.v[i], b.v[k - i]);
+        }
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) mad_ii<CHAIN>(acc, m[i], -(int)rl(k - i));
+        r.v[k - L] = (u32)acc & MASK;
+        acc = (u64)((long long)acc >> 29);
+    }
+    r.v[L - 1] = (u32)acc;
+    return r;
+}
+
+// x + t + r  and  x + 4r - t  for t = mul_signed(..) in (-r, 2r): the +r that makes the first one positive rides in a
+// three-operand addition, the second is |4r_i - t_i| + x_i in one instruction for the normalised limbs (4r's limbs
+// 0..7 are >= 2^29 - 1 >= t_i) and an ordinary add/sub for the signed top limb.  Limbs grow by < 2^30 per call, the
+// value by < 5r.
+FF_HD void butterfly_signed(Fe& x, Fe& y_out, const Fe& t) {
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const u32 xi = x.v[i], ti = t.v[i];
+        x.v[i] = xi + ti + rl(i);
+        // |4r_i - t_i| + x_i with 4r_i >= t_i: written so that it is selected as one v_sad_u32
+        if (i < L - 1) y_out.v[i] = (pad4_l(i) > ti ? pad4_l(i) - ti : ti - pad4_l(i)) + xi;
+        else y_out.v[i] = xi + pad4_l(i) - ti;
+    }
+}
+
 // bit re-slicing 8 x 32 <-> 9 x 29
 FF_HD Fe unpack(const ff::Fr& a) {
     Fe r;

@@ -78,60 +78,72 @@ struct PassParams {
     Fr scale;          // inverse transforms: n^-1 * 2^261 (applied by the last pass)
 };
 
-// One pass: T stages (1..12) of the DIT network on a tile of 4096 elements (ntt_plan.h has the geometry).
-//   round 0 loads its elements straight from global memory, the last round stores straight to it; in between the
-//   tile lives in LDS.  Rounds of one phase exchange data between the lanes of a wave only — LDS operations of a wave
-//   execute in order, no barrier — so a wave that has its data starts computing while others still wait for theirs,
-//   and a 4096-point transform synchronises the workgroup once (between stages 5 and 6).
-//   Butterflies are lazy (fr29.hip.h): a round's inputs have normalised limbs, its outputs are renormalised once.
-__global__ void __launch_bounds__(NT) k_ntt_pass(Fr* __restrict__ out, const Fr* __restrict__ in, const PassParams P) {
-    extern __shared__ __attribute__((aligned(16))) u32 sh[];
-    const u32 tid = threadIdx.x;
-    const int T = P.T, kind = P.kind;
-    const u32 mT = (1u << T) - 1u;
+// Uniform per-workgroup state of a pass: where the tile sits in the batch.
+template <int KIND>
+struct TileGeo {
     size_t xbase = 0, tile0 = 0, origin = 0;
-    u32 o_base = 0, lo0 = 0;
-    if (kind == KIND_A1) {
-        tile0 = (size_t)blockIdx.x * TILE;
-    } else {
-        const u32 xf = blockIdx.x / P.tiles_per_xform, g = blockIdx.x % P.tiles_per_xform;
-        xbase = (size_t)xf * P.n;
-        if (kind == KIND_A2) {
-            o_base = g << (LOGT - T);
+    u32 o_base = 0, lo0 = 0, mT = 0;
+    int T = 0, s0 = 0, Lh = 0;
+    __device__ __forceinline__ TileGeo(const PassParams& P) {
+        T = P.T;
+        s0 = P.s0;
+        Lh = P.Lh;
+        mT = (1u << T) - 1u;
+        if (KIND == KIND_A1) {
+            tile0 = (size_t)blockIdx.x * TILE;
         } else {
-            const int logC = LOGT - T;
-            const u32 lo_tiles = (1u << P.s0) >> logC;  // tiles per block of 2^(s0 + T) positions
-            const u32 hi = g / lo_tiles;
-            lo0 = (g % lo_tiles) << logC;
-            origin = ((size_t)hi << (P.s0 + T)) + lo0;
+            const u32 xf = blockIdx.x / P.tiles_per_xform, g = blockIdx.x % P.tiles_per_xform;
+            xbase = (size_t)xf * P.n;
+            if (KIND == KIND_A2) {
+                o_base = g << (LOGT - T);
+            } else {
+                const int logC = LOGT - T;
+                const u32 lo_tiles = (1u << s0) >> logC;  // tiles per block of 2^(s0 + T) positions
+                const u32 hi = g / lo_tiles;
+                lo0 = (g % lo_tiles) << logC;
+                origin = ((size_t)hi << (s0 + T)) + lo0;
+            }
         }
     }
-    auto brev_t = [&](u32 p) -> u32 { return T ? (__builtin_bitreverse32(p) >> (32 - T)) : 0u; };
+    __device__ __forceinline__ u32 brev_t(u32 p) const { return T ? (__builtin_bitreverse32(p) >> (32 - T)) : 0u; }
     // where tile element idx comes from / goes to
-    auto src_index = [&](u32 idx) -> size_t {
+    __device__ __forceinline__ size_t src_index(u32 idx) const {
         const u32 p = idx & mT, c = idx >> T;
-        if (kind == KIND_A1) return tile0 + ((size_t)c << T) + brev_t(p);
-        if (kind == KIND_A2) return xbase + o_base + c + ((size_t)brev_t(p) << P.Lh);
-        return xbase + origin + ((size_t)p << P.s0) + c;
-    };
-    auto dst_index = [&](u32 idx) -> size_t {
+        if (KIND == KIND_A1) return tile0 + ((size_t)c << T) + brev_t(p);
+        if (KIND == KIND_A2) return xbase + o_base + c + ((size_t)brev_t(p) << Lh);
+        return xbase + origin + ((size_t)p << s0) + c;
+    }
+    __device__ __forceinline__ size_t dst_index(u32 idx) const {
         const u32 p = idx & mT, c = idx >> T;
-        if (kind == KIND_A1) return tile0 + idx;
-        if (kind == KIND_A2) return xbase + ((size_t)(__builtin_bitreverse32(o_base + c) >> (32 - P.Lh)) << T) + p;
-        return xbase + origin + ((size_t)p << P.s0) + c;
-    };
+        if (KIND == KIND_A1) return tile0 + idx;
+        if (KIND == KIND_A2) return xbase + ((size_t)(__builtin_bitreverse32(o_base + c) >> (32 - Lh)) << T) + p;
+        return xbase + origin + ((size_t)p << s0) + c;
+    }
     // twiddle of tile stage s for the pair whose lower element is i: global stage s0 + s, position
     // (i mod 2^s) * 2^s0 + column  ->  entry (2^(s0+s) - 1) + that
-    auto tw_ent = [&](u32 s, u32 i) -> u32 {
-        u32 ent = ((1u << (P.s0 + s)) - 1u) + ((i & ((1u << s) - 1u)) << P.s0);
-        if (kind == KIND_B) ent += lo0 + (i >> T);
-        return ent;
-    };
+    __device__ __forceinline__ u32 tw_ent(u32 s, u32 i) const {
+        if (KIND != KIND_B) return ((1u << s) - 1u) + (i & ((1u << s) - 1u));
+        return ((1u << (s0 + s)) - 1u) + ((i & ((1u << s) - 1u)) << s0) + lo0 + (i >> T);
+    }
+};
 
-#define KZG_BF(K0, K1, W)                                \
-    {                                                    \
-        const Fe tt_ = fr29::mul(e[K1], W);              \
-        fr29::butterfly_lazy(e[K0], e[K1], tt_);         \
+// One round of a pass on the four elements of a thread.  FIRST: the elements come from global memory (and, for a
+// transform's first pass, stages 0 and 1 multiply by w^0 = 1 at position 0: no multiplication); LAST: they go back
+// to it.  V: how a butterfly multiplies — 1 = subtractive Montgomery steps on one accumulator chain
+// (fr29::mul_signed), 2 = the same left to the compiler's re-association, 0 = round 2's additive multiplier
+// (measurement variants, KZGAMD_NTT_VARIANT at kzgamd_ntt_new; all three give the same bits).
+template <int KIND, int V, bool FIRST, bool LAST>
+__device__ __forceinline__ void ntt_round(u32* sh, Fr* __restrict__ out, const Fr* __restrict__ in, const PassParams& P,
+                                          const TileGeo<KIND>& G, int r, u32 tid) {
+#define KZG_BF(K0, K1, W)                                      \
+    {                                                          \
+        if constexpr (V == 0) {                                \
+            const Fe tt_ = fr29::mul(e[K1], W);                \
+            fr29::butterfly_lazy(e[K0], e[K1], tt_);           \
+        } else {                                               \
+            const Fe tt_ = fr29::mul_signed<V == 1>(e[K1], W); \
+            fr29::butterfly_signed(e[K0], e[K1], tt_);         \
+        }                                                      \
     }
 /* twiddle w^0 = 1 on a normalised operand */
 #define KZG_BF1(K0, K1)                                  \
@@ -146,90 +158,102 @@ __global__ void __launch_bounds__(NT) k_ntt_pass(Fr* __restrict__ out, const Fr*
         fr29::norm(y_);                                  \
         fr29::butterfly_lazy8(e[K0], e[K1], y_);         \
     }
-    for (int r = 0; r < P.nrounds; ++r) {
-        const RoundDev rd = P.rd[r];
-        const uint2 te = P.tab[r * NT + tid];
-        const u32 iA = te.x & 0xffffu, iB = te.x >> 16, sA = te.y & 0xffffu, sB = te.y >> 16;
-        Fe e[4];
-        if (r == 0) {
-            const u32 idx[4] = {iA, iA | rd.bit, iB, iB | rd.bit};
+    const RoundDev rd = P.rd[r];
+    const uint2 te = P.tab[r * NT + tid];
+    const u32 iA = te.x & 0xffffu, iB = te.x >> 16, sA = te.y & 0xffffu, sB = te.y >> 16;
+    Fe e[4];
+    if constexpr (FIRST) {
+        const u32 idx[4] = {iA, iA | rd.bit, iB, iB | rd.bit};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t gi = G.src_index(idx[k]);
+            e[k] = fr29::unpack((KIND != KIND_A1 || gi < P.total) ? in[gi] : Fr::zero());
+        }
+    } else {
+        e[0] = lds_get(sh, sA);
+        e[1] = lds_get(sh, sA ^ rd.sbit);
+        e[2] = lds_get(sh, sB);
+        e[3] = lds_get(sh, sB ^ rd.sbit);
+    }
+    if (rd.M) {
+        constexpr bool unit = FIRST && KIND != KIND_B;
+        if constexpr (unit) {
+            KZG_BF1(0, 1)
+            KZG_BF1(2, 3)
+        } else {
+            // M = 2: both pairs share the twiddle (idxB = idxA | 2 << pos); M = 1: two unrelated pairs
+            const Fe w = P.tw[G.tw_ent(rd.pos, iA)];
+            const Fe w2 = P.tw[G.tw_ent(rd.pos, iB)];
+            KZG_BF(0, 1, w)
+            KZG_BF(2, 3, w2)
+        }
+        if (rd.M == 2) {
+            if constexpr (unit) {
+                KZG_BF1N(0, 2)
+            } else {
+                const Fe w0 = P.tw[G.tw_ent(rd.pos + 1, iA)];
+                KZG_BF(0, 2, w0)
+            }
+            const Fe w1 = P.tw[G.tw_ent(rd.pos + 1, iA | rd.bit)];
+            KZG_BF(1, 3, w1)
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fr29::norm(e[k]);
+    }
+    if constexpr (LAST) {
+        const u32 idx[4] = {iA, iA | rd.bit, iB, iB | rd.bit};
+        // an inverse transform multiplies by n^-1 at the end of its last pass; everything else only needs the lazy
+        // value (< 64r) brought back to [0, r)
+        if (P.last && P.inverse) {
+            const Fe fin = fr29::unpack(P.scale);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const size_t gi = src_index(idx[k]);
-                e[k] = fr29::unpack(gi < P.total ? in[gi] : Fr::zero());
+                const size_t gi = G.dst_index(idx[k]);
+                if (KIND != KIND_A1 || gi < P.total) out[gi] = fr29::finish(e[k], fin);
             }
         } else {
-            e[0] = lds_get(sh, sA);
-            e[1] = lds_get(sh, sA ^ rd.sbit);
-            e[2] = lds_get(sh, sB);
-            e[3] = lds_get(sh, sB ^ rd.sbit);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t gi = G.dst_index(idx[k]);
+                if (KIND != KIND_A1 || gi < P.total) out[gi] = fr29::reduce_lazy(e[k]);
+            }
         }
-        if (rd.M) {
-            // stages 0 (and 1 at position 0) of a transform multiply by w^0 = 1: no multiplication
-            const bool unit = r == 0 && kind != KIND_B;
-            if (unit) {
-                KZG_BF1(0, 1)
-                KZG_BF1(2, 3)
-            } else {
-                const Fe w = P.tw[tw_ent(rd.pos, iA)];
-                KZG_BF(0, 1, w)
-                if (rd.M == 2) {
-                    KZG_BF(2, 3, w)
-                } else {
-                    const Fe w2 = P.tw[tw_ent(rd.pos, iB)];
-                    KZG_BF(2, 3, w2)
-                }
-            }
-            if (rd.M == 2) {
-                if (unit) {
-                    KZG_BF1N(0, 2)
-                } else {
-                    const Fe w0 = P.tw[tw_ent(rd.pos + 1, iA)];
-                    KZG_BF(0, 2, w0)
-                }
-                const Fe w1 = P.tw[tw_ent(rd.pos + 1, iA | rd.bit)];
-                KZG_BF(1, 3, w1)
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) fr29::norm(e[k]);
-        }
-        if (r == P.nrounds - 1) {
-            const u32 idx[4] = {iA, iA | rd.bit, iB, iB | rd.bit};
-            // an inverse transform multiplies by n^-1 at the end of its last pass; everything else only needs the
-            // lazy value (< 64r) brought back to [0, r)
-            if (P.last && P.inverse) {
-                const Fe fin = fr29::unpack(P.scale);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const size_t gi = dst_index(idx[k]);
-                    if (gi < P.total) out[gi] = fr29::finish(e[k], fin);
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const size_t gi = dst_index(idx[k]);
-                    if (gi < P.total) out[gi] = fr29::reduce_lazy(e[k]);
-                }
-            }
+    } else {
+        lds_put(sh, sA, e[0]);
+        lds_put(sh, sA ^ rd.sbit, e[1]);
+        lds_put(sh, sB, e[2]);
+        lds_put(sh, sB ^ rd.sbit, e[3]);
+        if (rd.barrier) {
+            __syncthreads();
         } else {
-            lds_put(sh, sA, e[0]);
-            lds_put(sh, sA ^ rd.sbit, e[1]);
-            lds_put(sh, sB, e[2]);
-            lds_put(sh, sB ^ rd.sbit, e[3]);
-            if (rd.barrier) {
-                __syncthreads();
-            } else {
-                // the next round reads what other lanes of this wave have just written: LDS operations of one wave
-                // execute in issue order; the fences only keep the compiler from reordering across this point
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
+            // the next round reads what other lanes of this wave have just written: LDS operations of one wave
+            // execute in issue order; the fences only keep the compiler from reordering across this point
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
 #undef KZG_BF
 #undef KZG_BF1
 #undef KZG_BF1N
+}
+
+// One pass: T stages (0..12) of the DIT network on a tile of 4096 elements (ntt_plan.h has the geometry).
+//   Round 0 loads its elements straight from global memory, the last round stores straight to it; in between the
+//   tile lives in LDS.  Rounds of one phase exchange data between the lanes of a wave only — LDS operations of a wave
+//   execute in order, no barrier — so a wave that has its data starts computing while others still wait for theirs,
+//   and a 4096-point transform synchronises the workgroup once (between stages 5 and 6).
+//   Butterflies are lazy (fr29.hip.h): a round's inputs have normalised limbs, its outputs are renormalised once;
+//   values grow by < 5r per stage (8r for the multiplication-free stage 1 of a transform): < 61r after 12 stages.
+template <int KIND, int V>
+__global__ void __launch_bounds__(NT) k_ntt_pass(Fr* __restrict__ out, const Fr* __restrict__ in, const PassParams P) {
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    const u32 tid = threadIdx.x;
+    const TileGeo<KIND> G(P);
+    const int n = P.nrounds;  // >= 2 (ntt_plan.h)
+    ntt_round<KIND, V, true, false>(sh, out, in, P, G, 0, tid);
+    for (int r = 1; r < n - 1; ++r) ntt_round<KIND, V, false, false>(sh, out, in, P, G, r, tid);
+    ntt_round<KIND, V, false, true>(sh, out, in, P, G, n - 1, tid);
 }
 
 // DAS helper: data[i] *= roots[i * stride]  (the shift by the 2n-th root between the two NTTs)
@@ -299,7 +323,21 @@ void launch_pass(NttCtx* ctx, int kind, int T, Fr* d_out, const Fr* d_in, PassPa
         P.rd[r].barrier = pd.rd[r][4];
     }
     P.tab = (const uint2*)pd.d_tab;
-    hipLaunchKernelGGL(k_ntt_pass, dim3(grid), dim3(NT), (size_t)TILE * sizeof(u32) * fr29::L, stream, d_out, d_in, P);
+    const size_t lds = (size_t)TILE * sizeof(u32) * fr29::L;
+#define KZG_LAUNCH(K, V) hipLaunchKernelGGL((k_ntt_pass<K, V>), dim3(grid), dim3(NT), lds, stream, d_out, d_in, P)
+#define KZG_LAUNCH_V(K)                      \
+    if (ctx->variant == 0) KZG_LAUNCH(K, 0); \
+    else if (ctx->variant == 1) KZG_LAUNCH(K, 1); \
+    else KZG_LAUNCH(K, 2)
+    if (kind == KIND_A1) {
+        KZG_LAUNCH_V(KIND_A1);
+    } else if (kind == KIND_A2) {
+        KZG_LAUNCH_V(KIND_A2);
+    } else {
+        KZG_LAUNCH_V(KIND_B);
+    }
+#undef KZG_LAUNCH_V
+#undef KZG_LAUNCH
 }
 
 // enqueue nbatch transforms of length n (device pointers; d_out must not alias d_in)
@@ -351,6 +389,7 @@ extern "C" void* kzgamd_ntt_new(unsigned scale) {
         NTT_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->scale = scale;
         ctx->W = (size_t)1 << scale;
+        if (const char* v = getenv("KZGAMD_NTT_VARIANT")) ctx->variant = atoi(v);
         kzgamd::expand_roots(ctx->roots, scale);
         // device twiddles in the 2^261 domain, w*2^261 = (w*2^256) * 2^5, already sliced into the 9 x 29-bit limbs
         // the butterflies multiply with (36 bytes per root instead of 32, ~27 instructions less per butterfly)

@@ -28,6 +28,7 @@ struct NttCtx {
     using Fr = ff::Fr;
     std::map<int, NttPlanDev> plans;  // key = kind * 16 + T; filled by kzgamd_ntt_new, read-only afterwards
     int device = 0;
+    int variant = 1;  // butterfly multiplier of the Fr kernels (ntt.hip), read from KZGAMD_NTT_VARIANT at creation
     unsigned scale = 0;
     size_t W = 0;
     void* d_roots = nullptr;  // W + 1 twiddles in the 2^261 domain as 9 x 29-bit limbs (Fr transforms), natural order

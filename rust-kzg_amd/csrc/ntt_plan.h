@@ -7,9 +7,9 @@
 // on tiles of 4096 elements.  Tile-local element index idx (12 bits): bits [0, T) are the stage bits (stage s pairs
 // idx and idx ^ (1 << s)), bits [T, 12) are column bits (independent sub-problems).  1024 threads = 16 waves x 64
 // lanes hold 4 elements each per round.  A round runs two stages (M = 2: idxA, idxA | 1 << pos, idxB = idxA | 2 << pos,
-// idxB | 1 << pos) or one (M = 1: two unrelated pairs; M = 0 only for n = 1).  A phase = consecutive rounds in which
-// every wave keeps the same 256 elements, so that its exchanges go through LDS without a workgroup barrier: a
-// 4096-point transform is 6 + 6 stages with ONE barrier.  Per round the planner decides which idx bit every thread-id
+// idxB | 1 << pos) or one (M = 1: two unrelated pairs) or none (M = 0: a copy; T <= 2 is padded to two rounds).
+// A phase = consecutive rounds in which every wave keeps the same 256 elements, so that its exchanges go through LDS
+// without a workgroup barrier: a 4096-point transform is 6 + 6 stages with ONE barrier.  Per round the planner decides which idx bit every thread-id
 // bit stands for: the wave bits are fixed per phase; the lane bits follow the low address bits in the round that
 // loads from / stores to global memory (coalescing) and are otherwise chosen so that the 32 lanes of a ds_read_b32
 // group hit 32 distinct banks under the XOR swizzle swz().
@@ -150,12 +150,13 @@ inline Plan make_plan(int kind, int T) {
             ++n;
         }
     }
-    if (n == 0) {  // T == 0: one round without stages
-        pl.rounds[0].pos = 0;
-        pl.rounds[0].M = 0;
-        of_round[0] = &ph[0];
-        last_of_phase[0] = true;
-        n = 1;
+    while (n < 2) {  // the kernel peels a loading and a storing round: T <= 2 gets rounds without stages (copies)
+        if (n) last_of_phase[n - 1] = false;
+        pl.rounds[n].pos = 0;
+        pl.rounds[n].M = 0;
+        of_round[n] = &ph.back();
+        last_of_phase[n] = true;
+        ++n;
     }
     pl.nrounds = n;
     for (int r = 0; r < n; ++r) {

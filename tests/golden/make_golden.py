@@ -178,7 +178,7 @@ def main():
     for name, y in cases("compute_verify_cell_kzg_proof_batch_challenge"):
         i = y["input"]
         v.append({"name": name, "commitments": i["commitments"], "commitment_indices": i["commitment_indices"],
-                  "cell_indices": i["cell_indices"], "cells": [cell_ref(c) for c in i["cosets_evals"]], "proofs": i["proofs"],
+                  "cell_indices": i["cell_indices"], "cells": [cell_ref("0x" + "".join(fe[2:] for fe in c)) for c in i["cosets_evals"]], "proofs": i["proofs"],
                   "output": y["output"]})
     out7["compute_verify_cell_kzg_proof_batch_challenge"] = v
     with gzip.GzipFile(os.path.join(OUT, "cells_7594.bin.gz"), "wb", mtime=0) as f:

@@ -17,7 +17,10 @@ stream = torch.cuda.current_stream().cuda_stream
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 fs = kzg.FFTSettings(scale)
 res = {}
-for n, nb in ((4096, 256), (4096, 1024), (1 << 20, 1), (8192, 128), (1 << 16, 16)):
+shapes = ((4096, 256), (4096, 1024), (1 << 20, 1), (8192, 128), (1 << 16, 16), (2048, 512), (1 << 19, 2))
+if len(sys.argv) > 2:  # "n x batch" pairs: 4096x1024,1048576x1
+    shapes = tuple(tuple(int(v) for v in p.split("x")) for p in sys.argv[2].split(","))
+for n, nb in shapes:
     if n > (1 << scale):
         continue
     a = torch.randint(0, 2**31, (nb * n * 8,), dtype=torch.int32, device=dev)

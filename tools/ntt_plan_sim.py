@@ -108,8 +108,10 @@ def plan_pass(kind, T):
         rs = rounds_of_phase(lo, hi)
         for ri, (pos, M) in enumerate(rs):
             rounds.append(dict(pos=pos, M=M, F=F, W=W, last_of_phase=(ri == len(rs) - 1)))
-    if not rounds:  # T == 0: one round without stages (copy / scale only)
-        lo, hi, F, W = ph[0]
+    while len(rounds) < 2:  # the kernel peels a loading and a storing round: T <= 2 gets rounds without stages (copies)
+        lo, hi, F, W = ph[-1]
+        if rounds:
+            rounds[-1]["last_of_phase"] = False
         rounds.append(dict(pos=0, M=0, F=F, W=W, last_of_phase=True))
     n = len(rounds)
     for r, R in enumerate(rounds):
