@@ -123,6 +123,11 @@ int fft_g1(void *ctx, blst_p1 *out, const blst_p1 *in, size_t n, int inverse);
 int kzgamd_fft_g1_batch(void *ctx, blst_p1 *out, const blst_p1 *in, size_t n, size_t nbatch, int inverse);
 /* device-resident, batched (nbatch independent transforms of length n, contiguous), on `stream` */
 int kzgamd_ntt_fr_device(void *ctx, void *d_out, const void *d_in, size_t n, size_t nbatch, int inverse, void *stream);
+/* das_fft_extension on device-resident data: nbatch contiguous lists of half_n elements; d_scratch (half_n * nbatch
+ * elements) must differ from d_odds and d_evens, which must not alias each other (-3).  Two half-size transforms:
+ * the twist by the 2n-th roots and the n^-1 ride in their last-pass multiplications. */
+int kzgamd_das_fft_extension_device(void *ctx, void *d_odds, const void *d_evens, void *d_scratch, size_t half_n,
+                                    size_t nbatch, void *stream);
 /* host copies of the settings arrays (FFTSettings getters, kzg/src/lib.rs:465-481); counts in elements */
 int kzgamd_ntt_roots(void *ctx, blst_fr *roots /*W+1*/, blst_fr *reverse_roots /*W+1*/, blst_fr *brp_roots /*W*/);
 /* The tile plan the NTT kernel runs for (kind, T) — host-only, no GPU needed (rust-kzg_amd/csrc/ntt_plan.h):

@@ -60,7 +60,7 @@ EXPORTS = [
     "prepare_msm", "mult_pippenger_prepared", "mult_pippenger", "free_msm", "mult_pippenger_prepared_batch",
     "kzgamd_msm_prepared_batch_device", "kzgamd_msm_info", "kzgamd_msm_uses_wide_table", "kzgamd_msm_set_profile", "kzgamd_msm_get_profile",
     "kzgamd_device_count", "kzgamd_version", "kzgamd_msm_create_device", "kzgamd_generate_points",
-    "kzgamd_ntt_new", "kzgamd_ntt_free", "ntt_fr", "das_fft_extension", "kzgamd_ntt_fr_device", "kzgamd_ntt_roots", "kzgamd_ntt_plan_dump",
+    "kzgamd_ntt_new", "kzgamd_ntt_free", "ntt_fr", "das_fft_extension", "kzgamd_ntt_fr_device", "kzgamd_ntt_roots", "kzgamd_ntt_plan_dump", "kzgamd_das_fft_extension_device",
     "fft_g1", "kzgamd_fft_g1_batch", "kzgamd_g1_sum",
     "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
     "compute_kzg_proof", "compute_blob_kzg_proof", "kzgamd_compute_blob_kzg_proof_batch", "compute_challenge",
@@ -133,6 +133,8 @@ def lib():
     L.das_fft_extension.argtypes = [vp, vp, vp, sz]
     L.kzgamd_ntt_fr_device.restype = C.c_int
     L.kzgamd_ntt_fr_device.argtypes = [vp, vp, vp, sz, sz, C.c_int, vp]
+    L.kzgamd_das_fft_extension_device.restype = C.c_int
+    L.kzgamd_das_fft_extension_device.argtypes = [vp, vp, vp, vp, sz, sz, vp]
     L.kzgamd_g1_sum.restype = None
     L.kzgamd_g1_sum.argtypes = [vp, vp, sz]
     L.fft_g1.restype = C.c_int
@@ -515,6 +517,12 @@ class FFTSettings:
                                         C.c_void_p(stream))
         if rc != 0:
             raise KzgAmdError("kzgamd_ntt_fr_device: %d" % rc)
+
+    def das_fft_extension_device(self, d_odds, d_evens, d_scratch, half_n, nbatch=1, stream=0):
+        rc = lib().kzgamd_das_fft_extension_device(self.handle, C.c_void_p(d_odds), C.c_void_p(d_evens), C.c_void_p(d_scratch),
+                                                   half_n, nbatch, C.c_void_p(stream))
+        if rc != 0:
+            raise KzgAmdError("kzgamd_das_fft_extension_device: %d" % rc)
 
     def roots(self):
         W = self.max_width

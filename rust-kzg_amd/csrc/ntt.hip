@@ -42,6 +42,10 @@ using nttplan::KIND_B;
 constexpr int LOGT = nttplan::LOGT;
 constexpr int TILE = nttplan::TILE;  // elements per workgroup
 constexpr int NT = nttplan::NT;      // threads per workgroup: 4 elements each, 16 waves = 4 per SIMD at <= 128 VGPRs
+#ifndef KZGAMD_NTT_NT_STORES
+#define KZGAMD_NTT_NT_STORES 1
+#endif
+constexpr bool nt_stores = KZGAMD_NTT_NT_STORES != 0;
 
 // LDS holds the tile in the 9 x 29-bit form, limb-major: sh[limb * TILE + swz(idx)] (144 KiB of the 160 KiB).
 __device__ __forceinline__ Fe lds_get(const u32* sh, u32 sidx) {  // sidx already swizzled
@@ -53,6 +57,21 @@ __device__ __forceinline__ Fe lds_get(const u32* sh, u32 sidx) {  // sidx alread
 __device__ __forceinline__ void lds_put(u32* sh, u32 sidx, const Fe& a) {
 #pragma unroll
     for (int k = 0; k < fr29::L; ++k) sh[k * TILE + sidx] = a.v[k];
+}
+
+// A pass's results are streamed (non-temporal stores): they drain towards HBM while other waves still compute
+// instead of sitting dirty in L2 until the kernel's end.
+__device__ __forceinline__ void store_fr(Fr* p, const Fr& v) {
+    typedef u32 v4u __attribute__((ext_vector_type(4)));
+    const v4u lo = {v.v[0], v.v[1], v.v[2], v.v[3]}, hi = {v.v[4], v.v[5], v.v[6], v.v[7]};
+    v4u* q = reinterpret_cast<v4u*>(p);
+    if (nt_stores) {
+        __builtin_nontemporal_store(lo, q);
+        __builtin_nontemporal_store(hi, q + 1);
+    } else {
+        q[0] = lo;
+        q[1] = hi;
+    }
 }
 
 struct RoundDev {
@@ -74,8 +93,11 @@ struct PassParams {
     int Lh;            // KIND_A2: log2(n) - T
     u32 tiles_per_xform;
     int last;          // last pass of the transform
-    int inverse;
-    Fr scale;          // inverse transforms: n^-1 * 2^261 (applied by the last pass)
+    int epilogue;      // what the last pass does to a result x (< 64r, lazy): 0 = bring it to [0, r),
+                       // 1 = x * scale, 2 = x * post[j * post_stride] for output position j of its transform
+    Fr scale;          // epilogue 1: multiplier * 2^261 (an inverse transform's n^-1)
+    const Fe* post;    // epilogue 2: multipliers * 2^261 as 9 x 29-bit limbs (the DAS extension's twist by the 2n-th roots)
+    u32 post_stride;
 };
 
 // Uniform per-workgroup state of a pass: where the tile sits in the batch.
@@ -202,20 +224,27 @@ __device__ __forceinline__ void ntt_round(u32* sh, Fr* __restrict__ out, const F
     }
     if constexpr (LAST) {
         const u32 idx[4] = {iA, iA | rd.bit, iB, iB | rd.bit};
-        // an inverse transform multiplies by n^-1 at the end of its last pass; everything else only needs the lazy
-        // value (< 64r) brought back to [0, r)
-        if (P.last && P.inverse) {
+        // an inverse transform multiplies by n^-1 at the end of its last pass (the DAS extension by a per-position
+        // factor); everything else only needs the lazy value (< 64r) brought back to [0, r)
+        if (P.last && P.epilogue == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const size_t gi = G.dst_index(idx[k]);
+                if (KIND != KIND_A1 || gi < P.total)
+                    store_fr(out + gi, fr29::finish(e[k], P.post[(size_t)((u32)gi & (P.n - 1u)) * P.post_stride]));
+            }
+        } else if (P.last && P.epilogue == 1) {
             const Fe fin = fr29::unpack(P.scale);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const size_t gi = G.dst_index(idx[k]);
-                if (KIND != KIND_A1 || gi < P.total) out[gi] = fr29::finish(e[k], fin);
+                if (KIND != KIND_A1 || gi < P.total) store_fr(out + gi, fr29::finish(e[k], fin));
             }
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const size_t gi = G.dst_index(idx[k]);
-                if (KIND != KIND_A1 || gi < P.total) out[gi] = fr29::reduce_lazy(e[k]);
+                if (KIND != KIND_A1 || gi < P.total) store_fr(out + gi, fr29::reduce_lazy(e[k]));
             }
         }
     } else {
@@ -254,15 +283,6 @@ __global__ void __launch_bounds__(NT) k_ntt_pass(Fr* __restrict__ out, const Fr*
     ntt_round<KIND, V, true, false>(sh, out, in, P, G, 0, tid);
     for (int r = 1; r < n - 1; ++r) ntt_round<KIND, V, false, false>(sh, out, in, P, G, r, tid);
     ntt_round<KIND, V, false, true>(sh, out, in, P, G, n - 1, tid);
-}
-
-// DAS helper: data[i] *= roots[i * stride]  (the shift by the 2n-th root between the two NTTs)
-__global__ void __launch_bounds__(256) k_twist(Fr* __restrict__ data, const Fe* __restrict__ roots, u32 n, u32 stride,
-                                               size_t total) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    u32 i = (u32)(t % n);
-    data[t] = fr29::finish(fr29::unpack(data[t]), roots[(size_t)i * stride]);
 }
 
 }  // namespace
@@ -340,16 +360,30 @@ void launch_pass(NttCtx* ctx, int kind, int T, Fr* d_out, const Fr* d_in, PassPa
 #undef KZG_LAUNCH
 }
 
+// what the last pass multiplies the results by
+enum NttScale {
+    SCALE_PLAIN = 0,    // forward transform: nothing; inverse transform: n^-1
+    SCALE_FWD_NINV = 1, // forward transform times n^-1 (second half of the DAS extension)
+    SCALE_INV_TWIST = 2 // inverse transform WITHOUT n^-1, result j times the 2n-th root w^j (first half of it)
+};
+
 // enqueue nbatch transforms of length n (device pointers; d_out must not alias d_in)
-void ntt_enqueue(NttCtx* ctx, Fr* d_out, const Fr* d_in, size_t n, size_t nbatch, bool inverse, hipStream_t stream) {
+void ntt_enqueue(NttCtx* ctx, Fr* d_out, const Fr* d_in, size_t n, size_t nbatch, bool inverse, hipStream_t stream,
+                 NttScale mode = SCALE_PLAIN) {
     PassParams P;
     memset(&P, 0, sizeof(P));
     const int logn = ilog2(n);
     P.n = (u32)n;
-    P.inverse = inverse ? 1 : 0;
     // an inverse transform folds n^-1 into its last pass: data is d*2^256, so the multiplier n^-1*2^261 is
     // (n^-1 in blst Montgomery form) * 2^5
-    P.scale = inverse ? times32(inv_len(n)) : one261();
+    if (mode == SCALE_INV_TWIST) {
+        P.epilogue = 2;
+        P.post = (const Fe*)ctx->d_roots;  // roots_of_unity[i] * 2^261, natural order, W + 1 entries
+        P.post_stride = (u32)(ctx->W / (2 * n));
+    } else if (inverse || mode == SCALE_FWD_NINV) {
+        P.epilogue = 1;
+        P.scale = times32(inv_len(n));
+    }
     P.total = n * nbatch;
     P.tw = (const Fe*)(inverse ? ctx->d_tw_inv : ctx->d_tw_fwd);
     if (logn <= LOGT) {
@@ -471,8 +505,16 @@ extern "C" int ntt_fr(void* vctx, blst_fr* out, const blst_fr* in, size_t n, int
 
 // odds = FFT_n( w^j * IFFT_n(evens)_j ), w the 2n-th root: the values of the degree < n interpolant of
 // `evens` at the odd positions of the size-2n domain — what das_fft_extension_stride computes with its
-// fused butterfly network (data_availability_sampling.rs:14-72), including the final n^-1 (:95-97,
-// absorbed here by the inverse transform).
+// fused butterfly network (data_availability_sampling.rs:14-72), including the final n^-1 (:95-97).  Like the
+// reference's network this costs two half-size transforms and nothing else: the twist by w^j rides in the inverse
+// transform's last-pass multiplication (instead of its n^-1), the n^-1 in the forward transform's.
+namespace {
+void das_enqueue(NttCtx* ctx, Fr* d_odds, const Fr* d_evens, Fr* d_tmp, size_t n, size_t nbatch, hipStream_t stream) {
+    ntt_enqueue(ctx, d_tmp, d_evens, n, nbatch, true, stream, SCALE_INV_TWIST);
+    ntt_enqueue(ctx, d_odds, d_tmp, n, nbatch, false, stream, SCALE_FWD_NINV);
+}
+}  // namespace
+
 extern "C" int das_fft_extension(void* vctx, blst_fr* odds, const blst_fr* evens, size_t n) {
     NttCtx* ctx = (NttCtx*)vctx;
     if (!ctx || !odds || !evens) return -1;
@@ -483,14 +525,31 @@ extern "C" int das_fft_extension(void* vctx, blst_fr* odds, const blst_fr* evens
     try {
         kzgamd::DeviceGuard on_device(ctx->device);
         NTT_TRY(on_device.err);
-        ctx->ensure(n);
+        ctx->ensure(2 * n);
         NTT_TRY(hipMemcpyAsync(ctx->d_a, evens, n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-        ntt_enqueue(ctx, ctx->d_b, ctx->d_a, n, 1, true, ctx->stream);
-        hipLaunchKernelGGL(k_twist, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_b,
-                           (const Fe*)ctx->d_roots, (u32)n, (u32)(ctx->W / (2 * n)), n);
-        ntt_enqueue(ctx, ctx->d_a, ctx->d_b, n, 1, false, ctx->stream);
-        NTT_TRY(hipMemcpyAsync(odds, ctx->d_a, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+        das_enqueue(ctx, ctx->d_a + n, ctx->d_a, ctx->d_b, n, 1, ctx->stream);
+        NTT_TRY(hipMemcpyAsync(odds, ctx->d_a + n, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
         NTT_TRY(hipStreamSynchronize(ctx->stream));
+    } catch (const NttErr& e) {
+        return -(int)e.e - 100;
+    }
+    return 0;
+}
+
+// Device-resident form: nbatch contiguous half-size lists in d_evens -> d_odds; d_scratch holds n * nbatch elements
+// and must differ from both (d_odds may not alias d_evens either).  Same error codes as das_fft_extension.
+extern "C" int kzgamd_das_fft_extension_device(void* vctx, void* d_odds, const void* d_evens, void* d_scratch, size_t n,
+                                               size_t nbatch, void* stream) {
+    NttCtx* ctx = (NttCtx*)vctx;
+    if (!ctx || !d_odds || !d_evens || !d_scratch) return -1;
+    if (n == 0) return 1;
+    if (n & (n - 1)) return 2;
+    if (n * 2 > ctx->W) return 3;
+    if (d_odds == d_evens || d_scratch == d_evens || d_scratch == d_odds) return -3;
+    try {
+        kzgamd::DeviceGuard on_device(ctx->device);
+        NTT_TRY(on_device.err);
+        das_enqueue(ctx, (Fr*)d_odds, (const Fr*)d_evens, (Fr*)d_scratch, n, nbatch, (hipStream_t)stream);
     } catch (const NttErr& e) {
         return -(int)e.e - 100;
     }

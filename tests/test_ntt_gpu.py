@@ -97,6 +97,52 @@ def test_device_batches_match_oracle(kzg, oracle, logn, nbatch):
     fs.close()
 
 
+@pytest.mark.parametrize("logh,nbatch", [(0, 3), (3, 9), (6, 64), (10, 3), (11, 5), (12, 2), (14, 1)])
+def test_das_extension_device_batches(kzg, oracle, logh, nbatch):
+    # kzgamd_das_fft_extension_device: batches of half-size lists, each against the oracle's restatement of the
+    # reference's fused network (data_availability_sampling.rs:14-100)
+    import torch
+
+    L = oracle.lib()
+    n = 1 << logh
+    fs = kzg.FFTSettings(logh + 1)
+    ofs = O.FFTSettings()
+    assert L.offt_settings_new(C.byref(ofs), logh + 1) == 0
+    rnd = random.Random(77 * logh + nbatch)
+    raw = b"".join(rnd.randrange(O.R).to_bytes(32, "little") for _ in range(n * nbatch))
+    d_in = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+    d_out, d_tmp = torch.zeros_like(d_in), torch.zeros_like(d_in)
+    fs.das_fft_extension_device(d_out.data_ptr(), d_in.data_ptr(), d_tmp.data_ptr(), n, nbatch, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().tobytes()
+    for b in range(nbatch):
+        one = (O.Fr * n).from_buffer_copy(raw[32 * n * b: 32 * n * (b + 1)])
+        exp = (O.Fr * n)()
+        assert L.odas_fft_extension(C.byref(ofs), exp, one, n) == 0
+        assert got[32 * n * b: 32 * n * (b + 1)] == bytes(exp), (logh, nbatch, b)
+    with pytest.raises(kzg.KzgAmdError):
+        fs.das_fft_extension_device(d_in.data_ptr(), d_in.data_ptr(), d_tmp.data_ptr(), n, nbatch, 0)
+    L.offt_settings_free(C.byref(ofs))
+    fs.close()
+
+
+def test_das_extension_half_of_2p20_digest(kzg, oracle):
+    # BASELINE configs[3]: the DAS extension of 2^19 evens (the odd half of a 2^20 domain) against the oracle, by digest
+    L = oracle.lib()
+    logh = 19
+    n = 1 << logh
+    fs = kzg.FFTSettings(logh + 1)
+    ofs = O.FFTSettings()
+    assert L.offt_settings_new(C.byref(ofs), logh + 1) == 0
+    data = fr_bulk(list(range(n)))
+    got = fs.das_fft_extension(data, n)
+    exp = (O.Fr * n)()
+    assert L.odas_fft_extension(C.byref(ofs), exp, data, n) == 0
+    assert hashlib.sha256(bytes(got)[: 32 * n]).digest() == hashlib.sha256(bytes(exp)).digest()
+    L.offt_settings_free(C.byref(ofs))
+    fs.close()
+
+
 def test_roots_and_errors(kzg, oracle):
     L = oracle.lib()
     fs = kzg.FFTSettings(8)

@@ -39,4 +39,19 @@ for n, nb in shapes:
     ms = min(ts)
     res["%d x %d" % (n, nb)] = {"us": ms * 1e3, "alg_GBps": 64 * n * nb / (ms * 1e-3) / 1e9,
                                 "G_fr_mul_per_s": nb * (n / 2) * math.log2(n) / (ms * 1e-3) / 1e9}
+for n, nb in ((2048, 256), (1 << 19, 1)):
+    if 2 * n > (1 << scale) or len(sys.argv) > 2:
+        continue
+    a = torch.randint(0, 2**31, (nb * n * 8,), dtype=torch.int32, device=dev)
+    a[7::8] &= 0x3FFFFFFF
+    b, t = torch.empty_like(a), torch.empty_like(a)
+    ts = []
+    for _ in range(11):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fs.das_fft_extension_device(b.data_ptr(), a.data_ptr(), t.data_ptr(), n, nb, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    res["das %d x %d" % (n, nb)] = {"us": min(ts[1:]) * 1e3}
 print(json.dumps(res, indent=1))
