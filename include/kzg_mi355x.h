@@ -17,8 +17,8 @@
 #include <stdio.h>
 
 /* libkzg_mi355x_prefixed.so (python rust-kzg_amd/build.py --prefixed): the same library with every c-kzg-4844 name
- * exported as kzgamd_ckzg_<name>, for a process that also links the reference's own C bindings (e.g. for
- * recover_cells_and_kzg_proofs / verify_cell_kzg_proof_batch, which are not on this library's path).  Define
+ * exported as kzgamd_ckzg_<name>, for a process that also links the reference's own C bindings (e.g. to compare the
+ * two backends in one test binary).  Define
  * KZG_MI355X_PREFIXED before including this header and keep writing the plain names. */
 #ifdef KZG_MI355X_PREFIXED
 #define load_trusted_setup kzgamd_ckzg_load_trusted_setup
@@ -34,6 +34,9 @@
 #define bytes_to_kzg_commitment kzgamd_ckzg_bytes_to_kzg_commitment
 #define bytes_from_bls_field kzgamd_ckzg_bytes_from_bls_field
 #define compute_cells_and_kzg_proofs kzgamd_ckzg_compute_cells_and_kzg_proofs
+#define recover_cells_and_kzg_proofs kzgamd_ckzg_recover_cells_and_kzg_proofs
+#define verify_cell_kzg_proof_batch kzgamd_ckzg_verify_cell_kzg_proof_batch
+#define compute_verify_cell_kzg_proof_batch_challenge kzgamd_ckzg_compute_verify_cell_kzg_proof_batch_challenge
 #endif
 
 #ifdef __cplusplus
@@ -255,6 +258,23 @@ typedef struct { uint8_t bytes[2048]; } Cell;
 C_KZG_RET compute_cells_and_kzg_proofs(Cell *cells, KZGProof *proofs, const Blob *blob, const CKZGSettings *s);
 C_KZG_RET kzgamd_compute_cells_and_kzg_proofs_batch(Cell *cells, KZGProof *proofs, const Blob *blobs, size_t n,
                                                     const CKZGSettings *s);
+/* EIP-7594 recovery and cell verification (kzg/src/eth/c_bindings.rs:202-355 -> kzg/src/das.rs:101-243, 294-389).
+ * recover: num_cells in [64, 128] cells with strictly ascending cell_indices < 128 -> all 128 cells and (unless
+ * recovered_proofs is NULL) their 128 proofs; the five 8192-point transforms, coset shifts and inversions run on the GPU.
+ * verify: ok = every (commitment, cell index, cell, proof) tuple is consistent; num_cells = 0 is true; decoding,
+ * subgroup checks and the linear combinations (one two-row MSM) on the GPU, one pairing check on the host.
+ * Every failure of the reference (bad encoding, element >= r, index >= 128, point outside G1, too few / unordered
+ * cells) is C_KZG_BADARGS, as there. */
+C_KZG_RET recover_cells_and_kzg_proofs(Cell *recovered_cells, KZGProof *recovered_proofs, const uint64_t *cell_indices,
+                                       const Cell *cells, uint64_t num_cells, const CKZGSettings *s);
+C_KZG_RET verify_cell_kzg_proof_batch(bool *ok, const Bytes48 *commitments_bytes, const uint64_t *cell_indices,
+                                      const Cell *cells, const Bytes48 *proofs_bytes, uint64_t num_cells,
+                                      const CKZGSettings *s);
+/* blst/src/eip_7594.rs:35-97: the Fiat-Shamir scalar of a cell batch over DEDUPLICATED commitments (Montgomery blst_fr) */
+C_KZG_RET compute_verify_cell_kzg_proof_batch_challenge(blst_fr *challenge_out, const Bytes48 *commitment_bytes,
+                                                        uint64_t num_commitments, const uint64_t *commitment_indices,
+                                                        const uint64_t *cell_indices, const Cell *cells,
+                                                        const Bytes48 *proofs_bytes, uint64_t num_cells);
 /* the prepared-MSM handle behind a settings object (for kzgamd_msm_* calls) */
 void *kzgamd_settings_msm_handle(const CKZGSettings *s);
 /* the GPU a settings object lives on (-1 if unknown) */

@@ -65,6 +65,7 @@ EXPORTS = [
     "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
     "compute_kzg_proof", "compute_blob_kzg_proof", "kzgamd_compute_blob_kzg_proof_batch", "compute_challenge",
     "bytes_to_kzg_commitment", "bytes_from_bls_field", "compute_cells_and_kzg_proofs",
+    "recover_cells_and_kzg_proofs", "verify_cell_kzg_proof_batch", "compute_verify_cell_kzg_proof_batch_challenge",
     "kzgamd_compute_cells_and_kzg_proofs_batch", "kzgamd_compute_challenges_and_evaluate_batch",
     "kzgamd_blob_to_kzg_commitment_batch", "kzgamd_blob_to_kzg_commitment_device", "kzgamd_settings_msm_handle",
     "kzgamd_msm_reserve", "kzgamd_msm_device", "kzgamd_set_device", "kzgamd_get_device", "kzgamd_settings_device",
@@ -706,6 +707,49 @@ def compute_cells_and_kzg_proofs(blob: bytes, settings: KZGSettings, want_cells=
     if rc != C_KZG_OK:
         raise KzgAmdError("compute_cells_and_kzg_proofs: C_KZG_RET %d" % rc)
     return (cells.raw if cells else None), (proofs.raw if proofs else None)
+
+
+def recover_cells_and_kzg_proofs(cell_indices, cells: bytes, settings: KZGSettings, want_proofs=True):
+    """kzg/src/eth/c_bindings.rs:202-289 -> (cells bytes 128*2048, proofs bytes 128*48 | None)"""
+    n = len(cell_indices)
+    idx = (C.c_uint64 * max(n, 1))(*cell_indices)
+    out_cells = C.create_string_buffer(128 * 2048)
+    out_proofs = C.create_string_buffer(128 * 48) if want_proofs else None
+    f = lib().recover_cells_and_kzg_proofs
+    f.restype = C.c_int
+    rc = f(out_cells, out_proofs, idx, cells, C.c_uint64(n), C.byref(settings.c))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("recover_cells_and_kzg_proofs: C_KZG_RET %d" % rc)
+    return out_cells.raw, (out_proofs.raw if out_proofs else None)
+
+
+def verify_cell_kzg_proof_batch(commitments: bytes, cell_indices, cells: bytes, proofs: bytes, settings: KZGSettings):
+    """kzg/src/eth/c_bindings.rs:290-355 -> bool; len(cell_indices) tuples of 48 + 2048 + 48 bytes"""
+    n = len(cell_indices)
+    idx = (C.c_uint64 * max(n, 1))(*cell_indices)
+    ok = C.c_bool(False)
+    f = lib().verify_cell_kzg_proof_batch
+    f.restype = C.c_int
+    rc = f(C.byref(ok), commitments, idx, cells, proofs, C.c_uint64(n), C.byref(settings.c))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("verify_cell_kzg_proof_batch: C_KZG_RET %d" % rc)
+    return bool(ok.value)
+
+
+def compute_verify_cell_kzg_proof_batch_challenge(commitments: bytes, commitment_indices, cell_indices, cells: bytes, proofs: bytes):
+    """blst/src/eip_7594.rs:35-97 -> the challenge as 32 big-endian bytes (canonical)"""
+    n = len(cell_indices)
+    ci = (C.c_uint64 * max(n, 1))(*commitment_indices)
+    idx = (C.c_uint64 * max(n, 1))(*cell_indices)
+    out = BlstFr()
+    f = lib().compute_verify_cell_kzg_proof_batch_challenge
+    f.restype = C.c_int
+    rc = f(C.byref(out), commitments, C.c_uint64(len(commitments) // 48), ci, idx, cells, proofs, C.c_uint64(n))
+    if rc != C_KZG_OK:
+        raise KzgAmdError("compute_verify_cell_kzg_proof_batch_challenge: C_KZG_RET %d" % rc)
+    b = C.create_string_buffer(32)
+    lib().bytes_from_bls_field(b, C.byref(out))
+    return b.raw
 
 
 def compute_cells_and_kzg_proofs_batch(blobs: bytes, n: int, settings: KZGSettings):

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libkzg_mi355x.so")
 SOURCES = ["msm.hip", "ckzg.hip", "ntt.hip", "fftg1.hip"]
-HEADERS = ["ff.hip.h", "fp28.hip.h", "g1_28.hip.h", "g1_io.hip.h", "msm_internal.h", "ckzg_internal.h", "sha256.h", "host_g1.h", "host_pairing.h", "host_fp64.h", "ff28.hip.h", "fr29.hip.h", "ntt_internal.h", "device_guard.h", "fpw.hip.h", "g1w.hip.h", "glv.hip.h",
+HEADERS = ["ff.hip.h", "fp28.hip.h", "g1_28.hip.h", "g1_io.hip.h", "msm_internal.h", "ckzg_internal.h", "sha256.h", "host_g1.h", "host_pairing.h", "host_fp64.h", "ff28.hip.h", "fr29.hip.h", "ntt_internal.h", "device_guard.h", "fpw.hip.h", "g1w.hip.h", "glv.hip.h", "ntt_plan.h",
            os.path.join("..", "..", "include", "kzg_mi355x.h")]
 
 
@@ -23,13 +23,14 @@ def _stale():
 
 
 # c-kzg-4844 names this library shares with the reference's own C bindings (blst/src/eip_4844.rs, kzg/src/eth/c_bindings.rs).
-# A process that also links the Rust staticlib (for recover_cells_and_kzg_proofs / verify_cell_kzg_proof_batch, which
-# are not on this library's path) cannot have both sets under the same names: build_prefixed() links a second flavour,
+# A process that also links the Rust staticlib (e.g. a test binary comparing the two backends) cannot have both sets
+# under the same names: build_prefixed() links a second flavour,
 # libkzg_mi355x_prefixed.so, in which every one of them is exported as kzgamd_ckzg_<name> instead
 # (include/kzg_mi355x.h maps the plain names when KZG_MI355X_PREFIXED is defined).
 CKZG_NAMES = ["load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment", "compute_kzg_proof",
               "compute_blob_kzg_proof", "verify_kzg_proof", "verify_blob_kzg_proof", "verify_blob_kzg_proof_batch",
-              "compute_challenge", "bytes_to_kzg_commitment", "bytes_from_bls_field", "compute_cells_and_kzg_proofs"]
+              "compute_challenge", "bytes_to_kzg_commitment", "bytes_from_bls_field", "compute_cells_and_kzg_proofs",
+              "recover_cells_and_kzg_proofs", "verify_cell_kzg_proof_batch", "compute_verify_cell_kzg_proof_batch_challenge"]
 LIB_PREFIXED = os.path.join(CSRC, "libkzg_mi355x_prefixed.so")
 
 

@@ -807,6 +807,34 @@ struct KzgAmdSettings {
                 (void)hipStreamWaitEvent(stream, pipe_ev[j], 0);
             }
     }
+    // EIP-7594 cell verification / recovery state, built on first use
+    std::vector<uint8_t> mono64_bytes;  // g1_values_monomial[0..64) compressed (the interpolation-polynomial commitment)
+    ff::Fr* d_rec[4] = {nullptr, nullptr, nullptr, nullptr};  // recovery: four vectors of 8192 field elements
+    u32* d_rec_in = nullptr;         // up to 128 cells as canonical limbs
+    u32* d_rec_idx = nullptr;        // their cell indices
+    ff::Fr* d_pow7 = nullptr;        // 7^i and 7^-i, i < 8192 (coset shifts, das.rs:463-491)
+    ff::Fr* d_pow7inv = nullptr;
+    bool fk20_unavailable = false;   // the FK20 table could not be built (no HBM left): batches use the direct form
+    void ensure_recover() {
+        if (d_rec[0]) return;
+        for (int k = 0; k < 4; ++k) CK_HIP(hipMalloc(&d_rec[k], 2 * N * sizeof(ff::Fr)));
+        CK_HIP(hipMalloc(&d_rec_in, 2 * N * 32));
+        CK_HIP(hipMalloc(&d_rec_idx, 128 * sizeof(u32)));
+        CK_HIP(hipMalloc(&d_pow7, 2 * N * sizeof(ff::Fr)));
+        CK_HIP(hipMalloc(&d_pow7inv, 2 * N * sizeof(ff::Fr)));
+        std::vector<ff::Fr> p(2 * N), q(2 * N);
+        ff::Fr seven = ff::Fr::zero();
+        seven.v[0] = 7;
+        seven = ff::to_mont(seven);
+        const ff::Fr inv7 = ff::inverse_bgcd(seven);
+        p[0] = q[0] = ff::Fr::one();
+        for (size_t i = 1; i < 2 * N; ++i) {
+            p[i] = ff::mul(p[i - 1], seven);
+            q[i] = ff::mul(q[i - 1], inv7);
+        }
+        CK_HIP(hipMemcpy(d_pow7, p.data(), p.size() * sizeof(ff::Fr), hipMemcpyHostToDevice));
+        CK_HIP(hipMemcpy(d_pow7inv, q.data(), q.size() * sizeof(ff::Fr), hipMemcpyHostToDevice));
+    }
     std::vector<kzgamd::pairing::G2Jac> g2_monomial;  // [tau^i]G2, i < 65 (host; the pairing checks use [1])
     std::vector<ff::Fr> brp_roots;  // brp_roots_of_unity[0..8192) (host copy, Montgomery)
     ff::Fr* d_brp_roots = nullptr;  // first 4096 = the blob evaluation domain
@@ -825,6 +853,12 @@ struct KzgAmdSettings {
             if (pipe[j]) (void)hipStreamDestroy(pipe[j]);
         }
         if (d_brp_roots) (void)hipFree(d_brp_roots);
+        for (int k = 0; k < 4; ++k)
+            if (d_rec[k]) (void)hipFree(d_rec[k]);
+        if (d_rec_in) (void)hipFree(d_rec_in);
+        if (d_rec_idx) (void)hipFree(d_rec_idx);
+        if (d_pow7) (void)hipFree(d_pow7);
+        if (d_pow7inv) (void)hipFree(d_pow7inv);
         if (d_monomial) (void)hipFree(d_monomial);
         if (msm_monomial) kzgamd::msm_destroy(msm_monomial);
         if (msm_xext) kzgamd::msm_destroy(msm_xext);
@@ -1506,49 +1540,11 @@ void fk20_prepare(KzgAmdSettings* dev, const CKZGSettings* cs) {
     dev->msm_xext = kzgamd::msm_create(aff.data(), total, false, true, false);
 }
 
-// compute_cells_and_kzg_proofs (kzg/src/das.rs:244-292) for n blobs; cells / proofs may be null (not both)
-void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_t n, const CKZGSettings* cs,
-                      KzgAmdSettings* dev) {
-    std::lock_guard<std::mutex> lk(dev->mu);
-    kzgamd::DeviceGuard on_device(dev->device);
-    CK_HIP(on_device.err);
-    if (!dev->d_roots8192) {
-        CK_HIP(hipMalloc(&dev->d_roots8192, (2 * N + 1) * sizeof(ff::Fr)));
-        CK_HIP(hipMemcpy(dev->d_roots8192, cs->roots_of_unity, (2 * N + 1) * sizeof(ff::Fr), hipMemcpyHostToDevice));
-    }
-    // Cell proofs: FK20 for batches (the reference's algorithm: 64 transforms of 128 scalars, 128 MSMs of 64 points
-    // over x_ext_fft_columns, two G1 transforms of 128 points — ~25x fewer point additions than 128 MSMs of 4096, but
-    // the G1 transforms are 14 serial stages of a 128-bit scalar multiplication each: tens of ms of latency whatever
-    // the batch).  A few blobs: the direct form, one more fixed-base MSM per cell over the monomial table.
-    // KZGAMD_FK20 = 0 / 1 forces one or the other.
-    bool fk20 = proofs && n >= FK20_MIN_BLOBS;
-    if (const char* e = getenv("KZGAMD_FK20")) fk20 = proofs && atoi(e) != 0;
-    if (proofs && fk20) fk20_prepare(dev, cs);
-    if (proofs && fk20 && !kzgamd::msm_has_wide_table(dev->msm_xext)) fk20 = false;  // no HBM left for its table
-    if (proofs && !fk20 && !dev->msm_monomial) dev->msm_monomial = kzgamd::msm_create(dev->d_monomial, N, true, true, true);
-    dev->ensure(n);
-    dev->ensure_cells(n);
-    if (proofs && fk20) dev->ensure_fk20(n);
-    if (proofs && !fk20) dev->ensure_q(n);
-    hipStream_t st = dev->stream;
-    CK_HIP(hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, st));
-    CK_HIP(hipMemsetAsync(dev->d_status, 0, n * sizeof(int), st));
-    hipLaunchKernelGGL(k_blob_to_fr_brp, dim3((unsigned)((n * N + 255) / 256)), dim3(256), 0, st, dev->d_fr_a, dev->d_status,
-                       (const u32*)dev->d_blobs, n);
-    // poly_lagrange_to_monomial: inverse NTT of the bit-reversed evaluations
-    if (kzgamd_ntt_fr_device(dev->ntt, dev->d_fr_b, dev->d_fr_a, N, n, 1, st) != 0) throw CkErr{C_KZG_ERROR, "ntt"};
-    if (cells) {
-        hipLaunchKernelGGL(k_zero_extend, dim3((unsigned)((n * 2 * N + 255) / 256)), dim3(256), 0, st, dev->d_fr_ext,
-                           (const ff::Fr*)dev->d_fr_b, n);
-        // d_fr_a is free again only for n*N elements; the 8192-point result needs its own buffer: reuse d_cells
-        // as scratch for the transform output, then convert in place through d_fr_ext
-        ff::Fr* ev = reinterpret_cast<ff::Fr*>(dev->d_cells);
-        if (kzgamd_ntt_fr_device(dev->ntt, ev, dev->d_fr_ext, 2 * N, n, 0, st) != 0) throw CkErr{C_KZG_ERROR, "ntt"};
-        hipLaunchKernelGGL(k_cells_out, dim3((unsigned)((n * 2 * N + 255) / 256)), dim3(256), 0, st,
-                           reinterpret_cast<u32*>(dev->d_fr_ext), (const ff::Fr*)ev, n);
-        // fetched below, after the proof kernels are enqueued: a copy into pageable memory blocks this thread
-    }
-    if (proofs && fk20) {
+// The 128 cell proofs of n polynomials whose 4096 monomial coefficients are in dev->d_fr_b, compressed into
+// dev->d_proofs (compute_fk20_proofs + reverse_bit_order, kzg/src/das.rs:280-288, 630-696): enqueue only.
+// The caller has prepared the handle its `fk20` choice needs and the buffers (ensure_fk20 / ensure_q).
+void enqueue_cell_proofs(KzgAmdSettings* dev, size_t n, hipStream_t st, bool fk20) {
+    if (fk20) {
         const size_t nv = n * 64 * 128;
         hipLaunchKernelGGL(k_fk20_toeplitz, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, dev->d_fk_a,
                            (const ff::Fr*)dev->d_fr_b, n);
@@ -1577,7 +1573,7 @@ void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_
         g1::Xyzz* fin = pr == h ? other : h;
         hipLaunchKernelGGL(k_fk20_brp, dim3((unsigned)((n * 128 + 255) / 256)), dim3(256), 0, st, fin, (const g1::Xyzz*)pr, n);
         kzgamd::g1_compress_xyzz(dev->d_proofs, fin, n * 128, st);
-    } else if (proofs) {
+    } else {
         hipLaunchKernelGGL(k_cell_quotients, dim3((unsigned)(n * 128)), dim3(64), 0, st, dev->d_q, (const ff::Fr*)dev->d_fr_b,
                            (const ff::Fr*)dev->d_roots8192, n);
         kzgamd::msm_lock(dev->msm_monomial);
@@ -1589,12 +1585,104 @@ void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_
         }
         kzgamd::msm_unlock(dev->msm_monomial);
     }
+}
+
+// compute_cells_and_kzg_proofs (kzg/src/das.rs:244-292) for n blobs; cells / proofs may be null (not both)
+void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_t n, const CKZGSettings* cs,
+                      KzgAmdSettings* dev) {
+    std::lock_guard<std::mutex> lk(dev->mu);
+    kzgamd::DeviceGuard on_device(dev->device);
+    CK_HIP(on_device.err);
+    if (!dev->d_roots8192) {
+        CK_HIP(hipMalloc(&dev->d_roots8192, (2 * N + 1) * sizeof(ff::Fr)));
+        CK_HIP(hipMemcpy(dev->d_roots8192, cs->roots_of_unity, (2 * N + 1) * sizeof(ff::Fr), hipMemcpyHostToDevice));
+    }
+    // Cell proofs: FK20 for batches (the reference's algorithm: 64 transforms of 128 scalars, 128 MSMs of 64 points
+    // over x_ext_fft_columns, two G1 transforms of 128 points — ~25x fewer point additions than 128 MSMs of 4096, but
+    // the G1 transforms are 14 serial stages of a 128-bit scalar multiplication each: tens of ms of latency whatever
+    // the batch).  A few blobs: the direct form, one more fixed-base MSM per cell over the monomial table.
+    // KZGAMD_FK20 = 0 / 1 forces one or the other.
+    bool fk20 = proofs && n >= FK20_MIN_BLOBS;
+    if (const char* e = getenv("KZGAMD_FK20")) fk20 = proofs && atoi(e) != 0;
+    if (dev->fk20_unavailable) fk20 = false;
+    if (proofs && fk20) {
+        // no HBM left for the FK20 table (creation throws, or succeeds without a wide table): the direct form computes
+        // the same proofs; the useless handle is dropped and the choice remembered
+        try {
+            fk20_prepare(dev, cs);
+        } catch (...) {
+            dev->fk20_unavailable = true;
+        }
+        if (!dev->fk20_unavailable && !kzgamd::msm_has_wide_table(dev->msm_xext)) dev->fk20_unavailable = true;
+        if (dev->fk20_unavailable) {
+            if (dev->msm_xext) kzgamd::msm_destroy(dev->msm_xext);
+            dev->msm_xext = nullptr;
+            fk20 = false;
+        }
+    }
+    if (proofs && !fk20 && !dev->msm_monomial) dev->msm_monomial = kzgamd::msm_create(dev->d_monomial, N, true, true, true);
+    dev->ensure(n);
+    dev->ensure_cells(n);
+    if (proofs && fk20) dev->ensure_fk20(n);
+    if (proofs && !fk20) dev->ensure_q(n);
+    hipStream_t st = dev->stream;
+    CK_HIP(hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, st));
+    CK_HIP(hipMemsetAsync(dev->d_status, 0, n * sizeof(int), st));
+    hipLaunchKernelGGL(k_blob_to_fr_brp, dim3((unsigned)((n * N + 255) / 256)), dim3(256), 0, st, dev->d_fr_a, dev->d_status,
+                       (const u32*)dev->d_blobs, n);
+    // poly_lagrange_to_monomial: inverse NTT of the bit-reversed evaluations
+    if (kzgamd_ntt_fr_device(dev->ntt, dev->d_fr_b, dev->d_fr_a, N, n, 1, st) != 0) throw CkErr{C_KZG_ERROR, "ntt"};
+    if (cells) {
+        hipLaunchKernelGGL(k_zero_extend, dim3((unsigned)((n * 2 * N + 255) / 256)), dim3(256), 0, st, dev->d_fr_ext,
+                           (const ff::Fr*)dev->d_fr_b, n);
+        // d_fr_a is free again only for n*N elements; the 8192-point result needs its own buffer: reuse d_cells
+        // as scratch for the transform output, then convert in place through d_fr_ext
+        ff::Fr* ev = reinterpret_cast<ff::Fr*>(dev->d_cells);
+        if (kzgamd_ntt_fr_device(dev->ntt, ev, dev->d_fr_ext, 2 * N, n, 0, st) != 0) throw CkErr{C_KZG_ERROR, "ntt"};
+        hipLaunchKernelGGL(k_cells_out, dim3((unsigned)((n * 2 * N + 255) / 256)), dim3(256), 0, st,
+                           reinterpret_cast<u32*>(dev->d_fr_ext), (const ff::Fr*)ev, n);
+        // fetched below, after the proof kernels are enqueued: a copy into pageable memory blocks this thread
+    }
+    if (proofs) enqueue_cell_proofs(dev, n, st, fk20);
     if (cells) CK_HIP(hipMemcpyAsync(cells, dev->d_fr_ext, n * 2 * N * 32, hipMemcpyDeviceToHost, st));
     if (proofs) CK_HIP(hipMemcpyAsync(proofs, dev->d_proofs, n * 128 * 48, hipMemcpyDeviceToHost, st));
     std::vector<int> status(n);
     CK_HIP(hipMemcpyAsync(status.data(), dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, st));
     CK_HIP(hipStreamSynchronize(st));
     for (size_t i = 0; i < n; ++i) CK_REQUIRE(status[i] == 0, "Invalid scalar");
+}
+
+
+// ---------------- EIP-7594 recovery (kzg/src/das.rs:101-243, 566-657) ----------------
+// provided cells (canonical little-endian limbs, already checked < r on the host) -> the 8192 evaluations in
+// bit-reversed order, Montgomery form, missing positions and the reference's "null" sentinel as zero
+// (recover_cells: `if cells_brp[i].is_null() { zero }`, das.rs:611-617; Fr::null() = from_u64_arr([u64::MAX; 4]),
+// blst/src/types/fr.rs:36-38 — a provided element equal to it is dropped by the reference too)
+__global__ void __launch_bounds__(256) k_rec_scatter(ff::Fr* __restrict__ ev_brp, const u32* __restrict__ limbs,
+                                                     const u32* __restrict__ cell_idx, size_t ncells) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ncells * CELL_SIZE) return;
+    const u32 c = cell_idx[t >> 6], j = (u32)t & 63;
+    ff::Fr v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v.v[k] = limbs[t * 8 + k];
+    v = ff::to_mont(v);
+    ff::Fr nul;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) nul.v[k] = 0xffffffffu;
+    nul = ff::to_mont(nul);  // from_u64_arr reduces: (2^256 - 1) mod r in Montgomery form
+    if (v == nul) v = ff::Fr::zero();
+    ev_brp[brev32(c * (u32)CELL_SIZE + j, 13)] = v;
+}
+__global__ void __launch_bounds__(256) k_fr_mul(ff::Fr* __restrict__ out, const ff::Fr* __restrict__ a, const ff::Fr* __restrict__ b,
+                                                size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = fr29::mul_blst(a[t], b[t]);
+}
+// 1 / x per element (batch_inverse of the vanishing polynomial over the coset, das.rs:628-630: never zero there)
+__global__ void __launch_bounds__(64) k_fr_inverse(ff::Fr* __restrict__ data, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) data[t] = ff::inverse_bgcd(data[t]);
 }
 
 template <class F>
@@ -2109,6 +2197,361 @@ extern "C" C_KZG_RET verify_blob_kzg_proof_batch(bool* ok, const Blob* blobs, co
         memcpy(&g2gen, &gen, sizeof g2gen);
         memcpy(&g2tau, &dev->g2_monomial[1], sizeof g2tau);
         *ok = kzgamd::pairing::pairings_verify(&pl, &g2tau, &rhs, &g2gen);
+    });
+}
+
+
+// ================================================================ EIP-7594: cell verification and recovery
+namespace {
+
+constexpr size_t CELLS_PER_EXT_BLOB = 2 * CELLS_PER_BLOB;  // 128
+constexpr size_t BYTES_PER_CELL = CELL_SIZE * 32;
+
+inline u32 rbl7(u32 i) {  // CELL_INDICES_RBL (das.rs:87-96): reverse_bits_limited(128, i)
+    u32 r = 0;
+    for (int b = 0; b < 7; ++b)
+        if (i & (1u << b)) r |= 1u << (6 - b);
+    return r;
+}
+
+inline void put_u64_be(uint8_t* p, uint64_t v) {
+    for (int i = 0; i < 8; ++i) p[7 - i] = (uint8_t)(v >> (8 * i));
+}
+
+// hash_to_bls_field (kzg/src/eip_4844.rs:916-918): 32 big-endian bytes reduced mod r, Montgomery form
+inline ff::Fr hash_to_fr(const uint8_t digest[32]) {
+    ff::Fr v;
+    for (int i = 0; i < 8; ++i) {
+        const uint8_t* q = digest + (7 - i) * 4;
+        v.v[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
+    }
+    return ff::mul(v, ff::Fr::r2());
+}
+
+// compute_verify_cell_kzg_proof_batch_challenge (kzg/src/das.rs:391-452) on the caller's bytes: FsG1::to_bytes /
+// FsFr::to_bytes of a decoded, valid input are the input bytes themselves
+ff::Fr cell_batch_challenge(const Bytes48* commitments, size_t ncommit, const uint64_t* commitment_indices,
+                            const uint64_t* cell_indices, const Cell* cells, const Bytes48* proofs, size_t ncells) {
+    kzgamd::Sha256 h;
+    uint8_t head[48];
+    memcpy(head, "RCKZGCBATCH__V1_", 16);
+    put_u64_be(head + 16, N);
+    put_u64_be(head + 24, CELL_SIZE);
+    put_u64_be(head + 32, ncommit);
+    put_u64_be(head + 40, ncells);
+    h.update(head, 48);
+    for (size_t i = 0; i < ncommit; ++i) h.update(commitments[i].bytes, 48);
+    for (size_t i = 0; i < ncells; ++i) {
+        uint8_t ix[16];
+        put_u64_be(ix, commitment_indices[i]);
+        put_u64_be(ix + 8, cell_indices[i]);
+        h.update(ix, 16);
+        h.update(cells[i].bytes, BYTES_PER_CELL);
+        h.update(proofs[i].bytes, 48);
+    }
+    uint8_t digest[32];
+    h.finish(digest);
+    return hash_to_fr(digest);
+}
+
+// cells -> field elements (FsFr::from_bytes per element, c_bindings.rs:225-233): canonical limbs, false if any >= r
+bool cells_to_limbs(std::vector<ff::Fr>& out, const Cell* cells, size_t ncells) {
+    out.resize(ncells * CELL_SIZE);
+    bool ok = true;
+    for (size_t i = 0; i < ncells; ++i)
+        for (size_t j = 0; j < CELL_SIZE; ++j) ok = fr_from_be32_checked(out[i * CELL_SIZE + j], cells[i].bytes + 32 * j) && ok;
+    return ok;
+}
+
+// decode `np` compressed G1 points on the GPU (stream2): AffPt slots in dev->d_vpts, per-point status in dev->d_vstat
+// (0 ok, 1 not an encoding of a curve point, 2 on the curve but outside G1).  Caller holds dev->vmu.
+void decode_points_begin(KzgAmdSettings* dev, const std::vector<uint8_t>& bytes, size_t np) {
+    std::lock_guard<std::mutex> lk(dev->mu);
+    kzgamd::DeviceGuard on_device(dev->device);
+    CK_HIP(on_device.err);
+    dev->ensure_verify(np);
+    dev->vstage = bytes;
+    hipStream_t st = dev->stream2;
+    CK_HIP(hipMemcpyAsync(dev->d_vbytes, dev->vstage.data(), np * 48, hipMemcpyHostToDevice, st));
+    CK_HIP(hipMemsetAsync(dev->d_vstat, 0, np * sizeof(int), st));
+    CK_HIP(hipMemsetAsync(dev->d_vpts, 0, np * sizeof(AffPt), st));
+    hipLaunchKernelGGL(k_decode_check_g1, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st, dev->d_vpts, dev->d_vstat,
+                       (const unsigned char*)dev->d_vbytes, np);
+    CK_HIP(hipGetLastError());
+}
+std::vector<int> decode_points_status(KzgAmdSettings* dev, size_t np) {
+    std::lock_guard<std::mutex> lk(dev->mu);
+    kzgamd::DeviceGuard on_device(dev->device);
+    CK_HIP(on_device.err);
+    std::vector<int> stat(np);
+    CK_HIP(hipMemcpyAsync(stat.data(), dev->d_vstat, np * sizeof(int), hipMemcpyDeviceToHost, dev->stream2));
+    CK_HIP(hipStreamSynchronize(dev->stream2));
+    return stat;
+}
+
+// inverse transform of 64 values on the host (fft_fr(.., inverse = true) of a column, das.rs:818-819): exact field
+// arithmetic, so any butterfly order gives the reference's values.  roots = roots_of_unity[0..=8192].
+void host_ifft64(ff::Fr* a, const ff::Fr* roots) {
+    for (u32 i = 0; i < 64; ++i) {
+        u32 j = 0;
+        for (int b = 0; b < 6; ++b)
+            if (i & (1u << b)) j |= 1u << (5 - b);
+        if (j > i) std::swap(a[i], a[j]);
+    }
+    for (u32 len = 2; len <= 64; len <<= 1) {
+        const u32 half = len >> 1, step = (u32)(2 * N) / len;
+        for (u32 i = 0; i < 64; i += len)
+            for (u32 j = 0; j < half; ++j) {
+                const ff::Fr w = roots[2 * N - j * step];  // w^-j
+                const ff::Fr u = a[i + j], v = ff::mul(a[i + j + half], w);
+                a[i + j] = ff::add(u, v);
+                a[i + j + half] = ff::sub(u, v);
+            }
+    }
+    ff::Fr k64 = ff::Fr::zero();
+    k64.v[0] = 64;
+    const ff::Fr inv64 = ff::inverse_bgcd(ff::to_mont(k64));
+    for (u32 i = 0; i < 64; ++i) a[i] = ff::mul(a[i], inv64);
+}
+
+// verify_cell_kzg_proof_batch (kzg/src/das.rs:294-389).  Host: parsing, the Fiat-Shamir scalar, the powers of r,
+// the aggregated interpolation polynomial (<= 128 inverse transforms of 64 values; compute_commitment_to_aggregated_
+// interpolation_poly, :778-835).  GPU: decoding + subgroup checks of proofs and commitments, and every linear
+// combination as ONE two-row MSM over [proofs | unique commitments | g1_monomial[0..64)]:
+//     row 0:  r^i             0          0        -> proof_lincomb
+//     row 1:  r^i h_k(i)^64   weight_j   -I_k     -> sum_j w_j C_j - [I(s)] + sum_i r^i h^64 proof_i
+// then one pairing check e(row 1, G2) == e(row 0, [s^64]G2) on the host.
+void verify_cells(bool* ok, const Bytes48* commitments_bytes, const uint64_t* cell_indices, const Cell* cells,
+                  const Bytes48* proofs_bytes, size_t n, const CKZGSettings* cs, KzgAmdSettings* dev) {
+    std::vector<ff::Fr> cf;
+    CK_REQUIRE(cells_to_limbs(cf, cells, n), "Invalid scalar");
+    for (size_t i = 0; i < n; ++i) CK_REQUIRE(cell_indices[i] < CELLS_PER_EXT_BLOB, "Invalid cell index");
+    // deduplicate_with_indices (das.rs:57-76): first occurrences, in order
+    std::vector<Bytes48> uniq;
+    std::vector<uint64_t> cidx(n);
+    for (size_t i = 0; i < n; ++i) {
+        size_t j = 0;
+        while (j < uniq.size() && memcmp(uniq[j].bytes, commitments_bytes[i].bytes, 48) != 0) ++j;
+        if (j == uniq.size()) uniq.push_back(commitments_bytes[i]);
+        cidx[i] = j;
+    }
+    const size_t m = uniq.size(), np = n + m + CELL_SIZE;
+    std::lock_guard<std::mutex> vlk(dev->vmu);
+    if (dev->mono64_bytes.empty()) {
+        dev->mono64_bytes.resize(CELL_SIZE * 48);
+        compress_on_host(dev->mono64_bytes.data(), cs->g1_values_monomial, CELL_SIZE);
+    }
+    std::vector<uint8_t> stage(np * 48);
+    memcpy(stage.data(), proofs_bytes, n * 48);
+    memcpy(stage.data() + n * 48, uniq.data(), m * 48);
+    memcpy(stage.data() + (n + m) * 48, dev->mono64_bytes.data(), CELL_SIZE * 48);
+    decode_points_begin(dev, stage, np);
+    // host, meanwhile
+    const ff::Fr* roots = reinterpret_cast<const ff::Fr*>(cs->roots_of_unity);
+    const ff::Fr r = cell_batch_challenge(uniq.data(), m, cidx.data(), cell_indices, cells, proofs_bytes, n);
+    std::vector<ff::Fr> sc(2 * np, ff::Fr::zero());
+    std::vector<ff::Fr> agg(CELLS_PER_EXT_BLOB * CELL_SIZE, ff::Fr::zero());
+    std::vector<char> used(CELLS_PER_EXT_BLOB, 0);
+    ff::Fr pw = ff::Fr::one();
+    for (size_t i = 0; i < n; ++i) {
+        const size_t col = (size_t)cell_indices[i];
+        sc[i] = pw;                                                                     // row 0: proofs
+        sc[np + i] = ff::mul(pw, roots[rbl7((u32)col) * CELL_SIZE]);                    // row 1: r^i * h_k^64 (:837-884)
+        sc[np + n + cidx[i]] = ff::add(sc[np + n + cidx[i]], pw);                       // row 1: commitment weights (:698-743)
+        for (size_t f = 0; f < CELL_SIZE; ++f)
+            agg[col * CELL_SIZE + f] = ff::add(agg[col * CELL_SIZE + f], ff::mul(ff::to_mont(cf[i * CELL_SIZE + f]), pw));
+        used[col] = 1;
+        pw = ff::mul(pw, r);
+    }
+    std::vector<ff::Fr> interp(CELL_SIZE, ff::Fr::zero());
+    for (size_t col = 0; col < CELLS_PER_EXT_BLOB; ++col) {
+        if (!used[col]) continue;
+        ff::Fr colv[CELL_SIZE];
+        for (u32 f = 0; f < CELL_SIZE; ++f) {  // reverse_bit_order of the column
+            u32 j = 0;
+            for (int b = 0; b < 6; ++b)
+                if (f & (1u << b)) j |= 1u << (5 - b);
+            colv[j] = agg[col * CELL_SIZE + f];
+        }
+        host_ifft64(colv, roots);
+        const ff::Fr inv_shift = roots[2 * N - rbl7((u32)col)];  // h_k^-1 (:746-776)
+        ff::Fr fp = ff::Fr::one();
+        for (size_t k = 0; k < CELL_SIZE; ++k) {  // shift_poly + accumulate
+            interp[k] = ff::add(interp[k], k == 0 ? colv[0] : ff::mul(colv[k], fp));
+            fp = ff::mul(fp, inv_shift);
+        }
+    }
+    for (size_t k = 0; k < CELL_SIZE; ++k) sc[np + n + m + k] = ff::neg(interp[k]);
+    const std::vector<int> stat = decode_points_status(dev, np);
+    for (size_t i = 0; i < np; ++i) CK_REQUIRE(stat[i] != 1, "Invalid G1 encoding");
+    for (size_t i = 0; i < n; ++i) CK_REQUIRE(stat[i] == 0, "Proof is not valid");
+    for (size_t i = n; i < n + m; ++i) CK_REQUIRE(stat[i] == 0, "Commitment is not valid");
+    blst_p1 out[2];
+    {
+        std::lock_guard<std::mutex> lk(dev->mu);
+        kzgamd::DeviceGuard on_device(dev->device);
+        CK_HIP(on_device.err);
+        if (!dev->msm_verify) dev->msm_verify = kzgamd::msm_create(dev->d_vpts, np, true, false, true);
+        else kzgamd::msm_reset_points(dev->msm_verify, dev->d_vpts, np);
+        kzgamd::msm_run_host(dev->msm_verify, out, sc.data(), np, 2);
+    }
+    blst_p2 g2gen, g2s64;
+    const kzgamd::pairing::G2Jac gen = kzgamd::pairing::g2_generator();
+    memcpy(&g2gen, &gen, sizeof g2gen);
+    memcpy(&g2s64, &dev->g2_monomial[CELL_SIZE], sizeof g2s64);
+    *ok = kzgamd::pairing::pairings_verify(&out[1], &g2gen, &out[0], &g2s64);
+}
+
+// compute_vanishing_polynomial_from_roots (das.rs:493-518)
+std::vector<ff::Fr> vanishing_from_roots(const std::vector<ff::Fr>& rts) {
+    std::vector<ff::Fr> poly;
+    poly.push_back(ff::neg(rts[0]));
+    for (size_t i = 1; i < rts.size(); ++i) {
+        const ff::Fr nr = ff::neg(rts[i]);
+        poly.push_back(ff::add(nr, poly[i - 1]));
+        for (size_t j = i - 1; j >= 1; --j) poly[j] = ff::add(ff::mul(poly[j], nr), poly[j - 1]);
+        poly[0] = ff::mul(poly[0], nr);
+    }
+    poly.push_back(ff::Fr::one());
+    return poly;
+}
+
+// recover_cells_and_kzg_proofs (kzg/src/das.rs:101-205; recover_cells :566-657): the five 8192-point transforms, the
+// pointwise products, the coset shifts and the inversions on the GPU; the vanishing polynomial of the <= 64 missing
+// cells (65 coefficients) on the host.
+void recover_cells(Cell* recovered_cells, KZGProof* recovered_proofs, const uint64_t* cell_indices, const Cell* cells,
+                   size_t ncells, const CKZGSettings* cs, KzgAmdSettings* dev) {
+    std::vector<ff::Fr> cf;
+    CK_REQUIRE(cells_to_limbs(cf, cells, ncells), "Invalid scalar");
+    CK_REQUIRE(ncells <= CELLS_PER_EXT_BLOB, "Cell length cannot be larger than CELLS_PER_EXT_BLOB");
+    CK_REQUIRE(ncells >= CELLS_PER_EXT_BLOB / 2, "Impossible to recover");
+    std::vector<char> have(CELLS_PER_EXT_BLOB, 0);
+    std::vector<u32> idx32(ncells);
+    for (size_t i = 0; i < ncells; ++i) {
+        CK_REQUIRE(cell_indices[i] < CELLS_PER_EXT_BLOB, "Invalid cell index");
+        if (i + 1 < ncells) CK_REQUIRE(cell_indices[i + 1] > cell_indices[i], "Indices must be in strictly ascending order");
+        have[cell_indices[i]] = 1;
+        idx32[i] = (u32)cell_indices[i];
+    }
+    const ff::Fr* roots = reinterpret_cast<const ff::Fr*>(cs->roots_of_unity);
+    std::lock_guard<std::mutex> lk(dev->mu);
+    kzgamd::DeviceGuard on_device(dev->device);
+    CK_HIP(on_device.err);
+    dev->ensure(1);
+    dev->ensure_cells(1);
+    dev->ensure_recover();
+    hipStream_t st = dev->stream;
+    const size_t E = 2 * N;
+    ff::Fr *A = dev->d_rec[0], *B = dev->d_rec[1], *C = dev->d_rec[2], *D = dev->d_rec[3];
+    auto ntt = [&](ff::Fr* out, const ff::Fr* in, int inverse) {
+        if (kzgamd_ntt_fr_device(dev->ntt, out, in, E, 1, inverse, st) != 0) throw CkErr{C_KZG_ERROR, "ntt"};
+    };
+    auto mul = [&](ff::Fr* out, const ff::Fr* a, const ff::Fr* b) {
+        hipLaunchKernelGGL(k_fr_mul, dim3((unsigned)(E / 256)), dim3(256), 0, st, out, a, b, E);
+    };
+    // the provided evaluations in bit-reversed order, missing ones zero
+    CK_HIP(hipMemsetAsync(A, 0, E * sizeof(ff::Fr), st));
+    CK_HIP(hipMemcpyAsync(dev->d_rec_in, cf.data(), ncells * CELL_SIZE * 32, hipMemcpyHostToDevice, st));
+    CK_HIP(hipMemcpyAsync(dev->d_rec_idx, idx32.data(), ncells * sizeof(u32), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_rec_scatter, dim3((unsigned)((ncells * CELL_SIZE + 255) / 256)), dim3(256), 0, st, A,
+                       (const u32*)dev->d_rec_in, (const u32*)dev->d_rec_idx, ncells);
+    std::vector<ff::Fr> vanishing;  // must outlive the copy below
+    if (ncells != CELLS_PER_EXT_BLOB) {
+        // vanishing_polynomial_for_missing_cells (:520-551): roots w^(64 * brp7(i)) for the missing cells i, short
+        // polynomial stretched by 64
+        std::vector<ff::Fr> rts;
+        for (u32 i = 0; i < CELLS_PER_EXT_BLOB; ++i)
+            if (!have[i]) rts.push_back(roots[(size_t)rbl7(i) * CELL_SIZE]);
+        const std::vector<ff::Fr> shortp = vanishing_from_roots(rts);
+        vanishing.assign(E, ff::Fr::zero());
+        for (size_t i = 0; i < shortp.size(); ++i) vanishing[i * CELL_SIZE] = shortp[i];
+        CK_HIP(hipMemcpyAsync(B, vanishing.data(), E * sizeof(ff::Fr), hipMemcpyHostToDevice, st));
+        ntt(C, B, 0);                      // vanishing_poly_eval
+        mul(A, A, C);                      // extended_evaluation_times_zero
+        ntt(D, A, 1);                      // ..._coeffs
+        mul(D, D, dev->d_pow7);            // coset_fft: shift_poly by 7, then the transform
+        ntt(A, D, 0);                      // extended_evaluations_over_coset
+        mul(B, B, dev->d_pow7);
+        ntt(C, B, 0);                      // vanishing_poly_over_coset
+        hipLaunchKernelGGL(k_fr_inverse, dim3((unsigned)(E / 64)), dim3(64), 0, st, C, E);
+        mul(A, A, C);
+        ntt(D, A, 1);                      // coset_ifft: the transform, then shift_poly by 1/7
+        mul(D, D, dev->d_pow7inv);         // reconstructed_poly_coeff
+        ntt(A, D, 0);                      // its 8192 evaluations, natural order
+        hipLaunchKernelGGL(k_cells_out, dim3((unsigned)(E / 256)), dim3(256), 0, st, reinterpret_cast<u32*>(dev->d_fr_ext),
+                           (const ff::Fr*)A, (size_t)1);
+        CK_HIP(hipMemcpyAsync(recovered_cells, dev->d_fr_ext, E * 32, hipMemcpyDeviceToHost, st));
+    } else {
+        memcpy(recovered_cells, cells, E * 32);
+        if (recovered_proofs) ntt(D, A, 1);  // poly_lagrange_to_monomial of the given cells (:186-188)
+    }
+    if (recovered_proofs) {
+        // compute_fk20_proofs reads the first 4096 coefficients (:190-200, toeplitz_coeffs_stride :659-688)
+        if (!dev->d_roots8192) {
+            CK_HIP(hipMalloc(&dev->d_roots8192, (2 * N + 1) * sizeof(ff::Fr)));
+            CK_HIP(hipMemcpy(dev->d_roots8192, cs->roots_of_unity, (2 * N + 1) * sizeof(ff::Fr), hipMemcpyHostToDevice));
+        }
+        if (!dev->msm_monomial) dev->msm_monomial = kzgamd::msm_create(dev->d_monomial, N, true, true, true);
+        dev->ensure_q(1);
+        CK_HIP(hipMemcpyAsync(dev->d_fr_b, D, N * sizeof(ff::Fr), hipMemcpyDeviceToDevice, st));
+        enqueue_cell_proofs(dev, 1, st, false);
+        CK_HIP(hipMemcpyAsync(recovered_proofs, dev->d_proofs, CELLS_PER_EXT_BLOB * 48, hipMemcpyDeviceToHost, st));
+    }
+    CK_HIP(hipStreamSynchronize(st));
+}
+
+}  // namespace
+
+// c_bindings.rs:290-355 -> DAS::verify_cell_kzg_proof_batch (kzg/src/das.rs:294-389)
+extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool* ok, const Bytes48* commitments_bytes, const uint64_t* cell_indices,
+                                                 const Cell* cells, const Bytes48* proofs_bytes, uint64_t num_cells,
+                                                 const CKZGSettings* s) {
+    if (!ok) return C_KZG_BADARGS;
+    *ok = false;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    if (num_cells == 0) {
+        *ok = true;
+        return C_KZG_OK;
+    }
+    if (!commitments_bytes || !cell_indices || !cells || !proofs_bytes) return C_KZG_BADARGS;
+    return guarded([&] { verify_cells(ok, commitments_bytes, cell_indices, cells, proofs_bytes, (size_t)num_cells, s, dev); });
+}
+
+// c_bindings.rs:202-289 -> DAS::recover_cells_and_kzg_proofs (kzg/src/das.rs:101-205); recovered_proofs may be NULL
+extern "C" C_KZG_RET recover_cells_and_kzg_proofs(Cell* recovered_cells, KZGProof* recovered_proofs, const uint64_t* cell_indices,
+                                                  const Cell* cells, uint64_t num_cells, const CKZGSettings* s) {
+    if (!recovered_cells) return C_KZG_BADARGS;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    if (num_cells && (!cell_indices || !cells)) return C_KZG_BADARGS;
+    return guarded([&] { recover_cells(recovered_cells, recovered_proofs, cell_indices, cells, (size_t)num_cells, s, dev); });
+}
+
+// blst/src/eip_7594.rs:35-97: the Fiat-Shamir scalar of a cell batch (no settings: the inputs are only parsed —
+// FsG1::from_bytes accepts any curve point, blst/src/types/g1.rs:65-87 — and hashed)
+extern "C" C_KZG_RET compute_verify_cell_kzg_proof_batch_challenge(blst_fr* challenge_out, const Bytes48* commitment_bytes,
+                                                                   uint64_t num_commitments, const uint64_t* commitment_indices,
+                                                                   const uint64_t* cell_indices, const Cell* cells,
+                                                                   const Bytes48* proofs_bytes, uint64_t num_cells) {
+    if (!challenge_out) return C_KZG_BADARGS;
+    memset(challenge_out, 0, sizeof *challenge_out);
+    if ((num_commitments && !commitment_bytes) || (num_cells && (!commitment_indices || !cell_indices || !cells || !proofs_bytes)))
+        return C_KZG_BADARGS;
+    return guarded([&] {
+        for (size_t i = 0; i < num_commitments; ++i) {
+            blst_p1 t;
+            CK_REQUIRE(kzgamd::host_p1_uncompress(&t, commitment_bytes[i].bytes), "Invalid commitment");
+        }
+        std::vector<ff::Fr> cf;
+        CK_REQUIRE(cells_to_limbs(cf, cells, (size_t)num_cells), "Invalid scalar");
+        for (size_t i = 0; i < num_cells; ++i) {
+            blst_p1 t;
+            CK_REQUIRE(kzgamd::host_p1_uncompress(&t, proofs_bytes[i].bytes), "Invalid proof");
+        }
+        const ff::Fr r = cell_batch_challenge(commitment_bytes, (size_t)num_commitments, commitment_indices, cell_indices, cells,
+                                              proofs_bytes, (size_t)num_cells);
+        memcpy(challenge_out, &r, sizeof r);
     });
 }
 
