@@ -29,6 +29,7 @@
 #include "sha256.h"
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <thread>
@@ -739,6 +740,40 @@ struct KzgAmdSettings {
         CK_HIP(hipMalloc(&d_q, nblobs * 128 * N * 32));
         cap_q = nblobs;
     }
+    // Lanes: the reference's callers share one settings object between rayon workers (kzg/src/eip_4844.rs:781-805).
+    // A host-buffer call of a few blobs takes the first idle lane — a settings object of its own for everything a call
+    // mutates (streams, staging buffers, mutex) that BORROWS the tables and engine handles of its parent — so that up to
+    // MAX_LANES + 1 small calls are in flight on the GPU at once (their kernels are a few hundred waves each) instead
+    // of queueing on one mutex.  Lane objects are created on demand and live as long as the parent.
+    static constexpr size_t LANE_MAX_BLOBS = 16;
+    static constexpr int MAX_LANES = 15;
+    // Coalescing of concurrent single-blob calls (one queue per entry point): callers push a request; up to
+    // MAX_LEADERS of them at a time take everything queued (up to LANE_MAX_BLOBS requests) and run it as ONE batch on a
+    // lane, so that the ~10 runtime operations of a pipeline invocation (each of them takes a device-wide lock inside
+    // the HIP runtime: ~100 us of serialised host time per invocation) are paid per batch, not per call.
+    struct CoalesceQueue {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<void*> pending;
+        int leaders = 0;
+    };
+    static inline int MAX_LEADERS = getenv("KZGAMD_LEADERS") ? atoi(getenv("KZGAMD_LEADERS")) : 3;  // read once, at load
+    CoalesceQueue q_commit, q_blob_proof, q_proof;
+    bool is_lane = false;
+    std::atomic<bool> busy{false};
+    // page-locked staging for calls of up to LANE_MAX_BLOBS blobs: copies to and from it are truly asynchronous (a
+    // copy from / to the caller's pageable memory goes through the runtime's own staging path, which serialises
+    // concurrent callers)
+    unsigned char* h_in = nullptr;   // LANE_MAX_BLOBS blobs
+    unsigned char* h_res = nullptr;  // per blob: 144 B result + 32 B y + 4 B status + 4 B commitment status
+    void ensure_pinned() {
+        if (h_in) return;
+        CK_HIP(hipHostMalloc((void**)&h_in, LANE_MAX_BLOBS * BYTES_PER_BLOB, hipHostMallocDefault));
+        CK_HIP(hipHostMalloc((void**)&h_res, LANE_MAX_BLOBS * 256, hipHostMallocDefault));
+    }
+    std::mutex lanes_mu;
+    std::vector<std::unique_ptr<KzgAmdSettings>> lanes;
+    std::atomic<unsigned> lane_rr{0};
     void* ntt = nullptr;                      // kzgamd_ntt_new(13)
     ff::Fr* d_roots8192 = nullptr;            // roots_of_unity[0..=8192], Montgomery
     ff::Fr *d_fr_a = nullptr, *d_fr_b = nullptr, *d_fr_ext = nullptr;  // 4096, 4096, 8192 per blob
@@ -839,6 +874,17 @@ struct KzgAmdSettings {
     std::vector<ff::Fr> brp_roots;  // brp_roots_of_unity[0..8192) (host copy, Montgomery)
     ff::Fr* d_brp_roots = nullptr;  // first 4096 = the blob evaluation domain
     ~KzgAmdSettings() {
+        lanes.clear();  // before the handles they borrow go away
+        if (h_in) (void)hipHostFree(h_in);
+        if (h_res) (void)hipHostFree(h_res);
+        if (is_lane) {
+            msm = nullptr;
+            msm_monomial = msm_xext = nullptr;
+            d_monomial = nullptr;
+            d_brp_roots = nullptr;
+            ntt = nullptr;
+            d_roots8192 = nullptr;
+        }
         if (d_z) (void)hipFree(d_z);
         if (d_y) (void)hipFree(d_y);
         if (d_commit) (void)hipFree(d_commit);
@@ -867,7 +913,7 @@ struct KzgAmdSettings {
         if (d_roots8192) (void)hipFree(d_roots8192);
         release_cells();
         if (d_cstatus) (void)hipFree(d_cstatus);
-        if (stream2) (void)hipStreamDestroy(stream2);
+        if (stream2 && stream2 != stream) (void)hipStreamDestroy(stream2);
         if (msm) kzgamd::msm_destroy(msm);
         if (d_blobs) (void)hipFree(d_blobs);
         if (d_scalars) (void)hipFree(d_scalars);
@@ -940,6 +986,66 @@ KzgAmdSettings* lookup(const CKZGSettings* s) {
     auto it = g_registry.find(s->g1_values_lagrange_brp);
     return it == g_registry.end() ? nullptr : it->second;
 }
+
+// A lane of `parent`: own streams, staging and mutex; tables and engine handles borrowed (see KzgAmdSettings::lanes)
+KzgAmdSettings* make_lane(KzgAmdSettings* parent) {
+    std::unique_ptr<KzgAmdSettings> ln(new KzgAmdSettings());
+    ln->is_lane = true;
+    ln->device = parent->device;
+    kzgamd::DeviceGuard on_device(parent->device);
+    CK_HIP(on_device.err);
+    // ONE stream per lane: the runtime deals streams round-robin onto its (by default four) hardware queues, and a
+    // second, idle stream per lane would put every lane's working stream on the same two queues
+    CK_HIP(hipStreamCreateWithFlags(&ln->stream, hipStreamNonBlocking));
+    ln->stream2 = ln->stream;
+    ln->msm = parent->msm;
+    ln->d_brp_roots = parent->d_brp_roots;
+    ln->brp_roots = parent->brp_roots;
+    ln->busy.store(true);
+    parent->lanes.push_back(std::move(ln));
+    return parent->lanes.back().get();
+}
+
+// The settings object a small host-buffer call runs on: the parent if idle, else an idle lane, else a new lane, else
+// (all MAX_LANES busy) one of them in turn — its mutex queues the call.  Released by the destructor.
+struct LaneRef {
+    KzgAmdSettings* use = nullptr;
+    bool flagged = false;
+    LaneRef(KzgAmdSettings* dev, size_t nblobs) {
+        use = dev;
+        if (nblobs > KzgAmdSettings::LANE_MAX_BLOBS) {
+            // large batches: the parent's own pipeline, one at a time (its mutex); marked busy so that small calls go
+            // to the lanes meanwhile
+            flagged = !dev->busy.exchange(true);
+            return;
+        }
+        bool expect = false;
+        if (dev->busy.compare_exchange_strong(expect, true)) {
+            flagged = true;
+            return;
+        }
+        std::lock_guard<std::mutex> lk(dev->lanes_mu);
+        for (auto& ln : dev->lanes) {
+            expect = false;
+            if (ln->busy.compare_exchange_strong(expect, true)) {
+                use = ln.get();
+                flagged = true;
+                return;
+            }
+        }
+        if ((int)dev->lanes.size() < KzgAmdSettings::MAX_LANES) {
+            use = make_lane(dev);  // created busy
+            flagged = true;
+            return;
+        }
+        use = dev->lanes[dev->lane_rr.fetch_add(1) % dev->lanes.size()].get();
+    }
+    ~LaneRef() {
+        if (flagged) use->busy.store(false);
+    }
+    LaneRef(const LaneRef&) = delete;
+    LaneRef& operator=(const LaneRef&) = delete;
+};
 
 size_t reverse_bits(size_t v, unsigned bits) {
     size_t r = 0;
@@ -1752,13 +1858,112 @@ extern "C" void free_trusted_setup(CKZGSettings* s) {
     free_host_arrays(s);
 }
 
+namespace {
+// See KzgAmdSettings::CoalesceQueue.  Req has `bool done` and `C_KZG_RET rc`; run(batch) serves every request of the
+// batch (sets rc).  A caller returns as soon as its own request is served; leadership passes to whoever is waiting.
+template <class Req, class Run>
+C_KZG_RET coalesced_call(KzgAmdSettings::CoalesceQueue& q, Req& me, Run&& run) {
+    static const size_t gather_min = getenv("KZGAMD_GATHER_MIN") ? (size_t)atoi(getenv("KZGAMD_GATHER_MIN")) : 6;
+    static const int gather_us = getenv("KZGAMD_GATHER_US") ? atoi(getenv("KZGAMD_GATHER_US")) : 60;
+    std::unique_lock<std::mutex> lk(q.mu);
+    q.pending.push_back(&me);
+    while (!me.done) {
+        if (q.leaders < KzgAmdSettings::MAX_LEADERS && !q.pending.empty()) {
+            ++q.leaders;
+            while (!q.pending.empty() && !me.done) {
+                // under load (other batches in flight) a short wait lets the callers that have just been served come
+                // back with their next request: larger batches, fewer pipeline invocations
+                if (q.leaders > 1 && q.pending.size() < gather_min) {
+                    q.cv.wait_for(lk, std::chrono::microseconds(gather_us));
+                    if (me.done) break;
+                    if (q.pending.empty()) continue;
+                }
+                std::vector<Req*> batch;
+                while (!q.pending.empty() && batch.size() < KzgAmdSettings::LANE_MAX_BLOBS) {
+                    batch.push_back(static_cast<Req*>(q.pending.front()));
+                    q.pending.pop_front();
+                }
+                lk.unlock();
+                try {
+                    run(batch);
+                } catch (...) {
+                    for (Req* r : batch) r->rc = C_KZG_ERROR;
+                }
+                lk.lock();
+                for (Req* r : batch) r->done = true;
+                q.cv.notify_all();
+            }
+            --q.leaders;
+            q.cv.notify_all();
+        } else {
+            q.cv.wait(lk);
+        }
+    }
+    return me.rc;
+}
+
+struct CommitReq {
+    const Blob* blob;
+    KZGCommitment* out;
+    bool done = false;
+    C_KZG_RET rc = C_KZG_ERROR;
+};
+
+// up to LANE_MAX_BLOBS commitments on one lane, through its page-locked staging: every copy asynchronous, one wait at
+// the end; a blob with an element >= r fails its own request only (per-blob status of k_blob_to_scalars)
+void commit_lane_batch(KzgAmdSettings* dev, const std::vector<CommitReq*>& reqs) {
+    const size_t n = reqs.size();
+    std::lock_guard<std::mutex> lk(dev->mu);
+    kzgamd::DeviceGuard on_device(dev->device);
+    CK_HIP(on_device.err);
+    dev->ensure(n < 4 ? 4 : KzgAmdSettings::LANE_MAX_BLOBS);
+    dev->ensure_pinned();
+    const bool host_compress = n <= HOST_COMPRESS_MAX;
+    for (size_t i = 0; i < n; ++i) memcpy(dev->h_in + i * BYTES_PER_BLOB, reqs[i]->blob, BYTES_PER_BLOB);
+    CK_HIP(hipMemcpyAsync(dev->d_blobs, dev->h_in, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream));
+    commit_enqueue(dev, dev->d_out, dev->d_status, dev->d_blobs, dev->d_scalars, n, dev->stream,
+                   host_compress ? kzgamd::OUT_JACOBIAN : kzgamd::OUT_COMPRESSED);
+    int* hs = reinterpret_cast<int*>(dev->h_res);
+    unsigned char* ho = dev->h_res + KzgAmdSettings::LANE_MAX_BLOBS * sizeof(int);
+    CK_HIP(hipMemcpyAsync(hs, dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
+    CK_HIP(hipMemcpyAsync(ho, dev->d_out, n * (host_compress ? 144 : 48), hipMemcpyDeviceToHost, dev->stream));
+    CK_HIP(hipStreamSynchronize(dev->stream));
+    for (size_t i = 0; i < n; ++i) {
+        if (hs[i] != 0) {
+            reqs[i]->rc = C_KZG_BADARGS;  // "Invalid scalar"
+            continue;
+        }
+        if (host_compress) compress_on_host(reqs[i]->out->bytes, reinterpret_cast<const blst_p1*>(ho) + i, 1);
+        else memcpy(reqs[i]->out->bytes, ho + 48 * i, 48);
+        reqs[i]->rc = C_KZG_OK;
+    }
+}
+
+}  // namespace
+
 extern "C" C_KZG_RET kzgamd_blob_to_kzg_commitment_batch(KZGCommitment* out, const Blob* blobs, size_t n,
                                                          const CKZGSettings* s) {
     if (!out || !blobs) return C_KZG_BADARGS;
     KzgAmdSettings* dev = lookup(s);
     if (!dev) return C_KZG_BADARGS;
     if (n == 0) return C_KZG_OK;
-    return guarded([&] {
+    if (n <= KzgAmdSettings::LANE_MAX_BLOBS)
+        return guarded([&] {
+            // a few blobs: an idle lane of the settings object (concurrent callers overlap on the GPU)
+            std::vector<CommitReq> reqs(n);
+            std::vector<CommitReq*> ptrs(n);
+            for (size_t i = 0; i < n; ++i) {
+                reqs[i].blob = blobs + i;
+                reqs[i].out = out + i;
+                ptrs[i] = &reqs[i];
+            }
+            LaneRef lane(dev, n);
+            commit_lane_batch(lane.use, ptrs);
+            for (size_t i = 0; i < n; ++i) CK_REQUIRE(reqs[i].rc == C_KZG_OK, "Invalid scalar");
+        });
+    return guarded([&, root = dev] {
+        LaneRef lane(root, n);
+        KzgAmdSettings* dev = lane.use;
         std::lock_guard<std::mutex> lk(dev->mu);
         kzgamd::DeviceGuard on_device(dev->device);
         CK_HIP(on_device.err);
@@ -1798,8 +2003,18 @@ extern "C" C_KZG_RET kzgamd_blob_to_kzg_commitment_batch(KZGCommitment* out, con
     });
 }
 
+// blst/src/eip_4844.rs:163-175.  Concurrent callers on one settings object are merged into batches (coalesced_call).
 extern "C" C_KZG_RET blob_to_kzg_commitment(KZGCommitment* out, const Blob* blob, const CKZGSettings* s) {
-    return kzgamd_blob_to_kzg_commitment_batch(out, blob, 1, s);
+    if (!out || !blob) return C_KZG_BADARGS;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    CommitReq me;
+    me.blob = blob;
+    me.out = out;
+    return coalesced_call(dev->q_commit, me, [&](const std::vector<CommitReq*>& batch) {
+        LaneRef lane(dev, batch.size());
+        commit_lane_batch(lane.use, batch);
+    });
 }
 
 extern "C" C_KZG_RET kzgamd_blob_to_kzg_commitment_device(void* d_out, void* d_status, void* d_scratch, const void* d_blobs,
@@ -1877,12 +2092,60 @@ extern "C" C_KZG_RET kzgamd_compute_blob_kzg_proof_device(void* d_proofs, void* 
     });
 }
 
+namespace {
+struct ProofReq {
+    const Blob* blob;
+    const Bytes48* commitment;  // compute_blob_kzg_proof
+    const Bytes32* z;           // compute_kzg_proof
+    KZGProof* proof;
+    Bytes32* y;
+    bool done = false;
+    C_KZG_RET rc = C_KZG_ERROR;
+};
+
+// a batch of merged single-proof calls on one lane; prove_batch rejects the whole batch when one request is invalid:
+// then every request is served on its own, so that only the offender fails
+void proof_lane_batch(KzgAmdSettings* root, const std::vector<ProofReq*>& reqs, bool with_z) {
+    const size_t n = reqs.size();
+    LaneRef lane(root, n);
+    if (n == 1) {
+        ProofReq* r = reqs[0];
+        r->rc = guarded([&] { prove_batch(r->proof, r->y, r->blob, with_z ? r->z : nullptr, with_z ? nullptr : r->commitment, 1, lane.use); });
+        return;
+    }
+    std::vector<Blob> blobs(n);
+    std::vector<Bytes48> cms(with_z ? 0 : n);
+    std::vector<Bytes32> zs(with_z ? n : 0), ys(n);
+    std::vector<KZGProof> proofs(n);
+    for (size_t i = 0; i < n; ++i) {
+        memcpy(&blobs[i], reqs[i]->blob, sizeof(Blob));
+        if (with_z) zs[i] = *reqs[i]->z;
+        else cms[i] = *reqs[i]->commitment;
+    }
+    const C_KZG_RET rc = guarded([&] {
+        prove_batch(proofs.data(), with_z ? ys.data() : nullptr, blobs.data(), with_z ? zs.data() : nullptr,
+                    with_z ? nullptr : cms.data(), n, lane.use);
+    });
+    if (rc == C_KZG_OK) {
+        for (size_t i = 0; i < n; ++i) {
+            *reqs[i]->proof = proofs[i];
+            if (with_z) *reqs[i]->y = ys[i];
+            reqs[i]->rc = C_KZG_OK;
+        }
+        return;
+    }
+    for (ProofReq* r : reqs)
+        r->rc = guarded([&] { prove_batch(r->proof, r->y, r->blob, with_z ? r->z : nullptr, with_z ? nullptr : r->commitment, 1, lane.use); });
+}
+}  // namespace
+
 extern "C" C_KZG_RET compute_kzg_proof(KZGProof* proof_out, Bytes32* y_out, const Blob* blob, const Bytes32* z_bytes,
                                        const CKZGSettings* s) {
     if (!proof_out || !y_out || !blob || !z_bytes) return C_KZG_BADARGS;
     KzgAmdSettings* dev = lookup(s);
     if (!dev) return C_KZG_BADARGS;
-    return guarded([&] { prove_batch(proof_out, y_out, blob, z_bytes, nullptr, 1, dev); });
+    ProofReq me{blob, nullptr, z_bytes, proof_out, y_out};
+    return coalesced_call(dev->q_proof, me, [&](const std::vector<ProofReq*>& batch) { proof_lane_batch(dev, batch, true); });
 }
 
 extern "C" C_KZG_RET kzgamd_compute_blob_kzg_proof_batch(KZGProof* out, const Blob* blobs, const Bytes48* commitments,
@@ -1891,7 +2154,10 @@ extern "C" C_KZG_RET kzgamd_compute_blob_kzg_proof_batch(KZGProof* out, const Bl
     KzgAmdSettings* dev = lookup(s);
     if (!dev) return C_KZG_BADARGS;
     if (n == 0) return C_KZG_OK;
-    return guarded([&] { prove_batch(out, nullptr, blobs, nullptr, commitments, n, dev); });
+    return guarded([&] {
+        LaneRef lane(dev, n);
+        prove_batch(out, nullptr, blobs, nullptr, commitments, n, lane.use);
+    });
 }
 
 // compute_challenges_and_evaluate_polynomial (kzg/src/eip_4844.rs:690-719): the per-blob field work of
@@ -1904,7 +2170,10 @@ extern "C" C_KZG_RET kzgamd_compute_challenges_and_evaluate_batch(Bytes32* zs_ou
     KzgAmdSettings* dev = lookup(s);
     if (!dev) return C_KZG_BADARGS;
     if (n == 0) return C_KZG_OK;
-    return guarded([&] { prove_batch(nullptr, ys_out, blobs, nullptr, commitments, n, dev, zs_out); });
+    return guarded([&] {
+        LaneRef lane(dev, n);
+        prove_batch(nullptr, ys_out, blobs, nullptr, commitments, n, lane.use, zs_out);
+    });
 }
 
 namespace {
@@ -2160,7 +2429,10 @@ extern "C" C_KZG_RET verify_blob_kzg_proof(bool* ok, const Blob* blob, const Byt
         CK_REQUIRE(kzgamd::host_p1_uncompress(&c, commitment_bytes->bytes), "Invalid commitment");
         CK_REQUIRE(kzgamd::host_p1_uncompress(&pr, proof_bytes->bytes), "Invalid proof");
         Bytes32 zb, yb;
-        prove_batch(nullptr, &yb, blob, nullptr, commitment_bytes, 1, dev, &zb);  // also validates the commitment
+        {
+            LaneRef lane(dev, 1);
+            prove_batch(nullptr, &yb, blob, nullptr, commitment_bytes, 1, lane.use, &zb);  // also validates the commitment
+        }
         CK_REQUIRE(kzgamd::host_p1_in_g1(&pr), "Invalid proof");
         ff::Fr z, y;
         CK_REQUIRE(fr_from_be32_checked(z, zb.bytes) && fr_from_be32_checked(y, yb.bytes), "Invalid scalar");
@@ -2593,9 +2865,15 @@ extern "C" void kzgamd_p2_add(blst_p2* out, const blst_p2* a, const blst_p2* b) 
     memcpy(out, &r, sizeof r);
 }
 
+// blst/src/eip_4844.rs:498-517.  Concurrent callers on one settings object are merged into batches (coalesced_call).
 extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof* out, const Blob* blob, const Bytes48* commitment_bytes,
                                             const CKZGSettings* s) {
-    return kzgamd_compute_blob_kzg_proof_batch(out, blob, commitment_bytes, 1, s);
+    if (!out || !blob || !commitment_bytes) return C_KZG_BADARGS;
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev) return C_KZG_BADARGS;
+    ProofReq me{blob, commitment_bytes, nullptr, out, nullptr};
+    return coalesced_call(dev->q_blob_proof, me,
+                          [&](const std::vector<ProofReq*>& batch) { proof_lane_batch(dev, batch, false); });
 }
 
 // The reference exports this helper with raw blst types (blst/src/eip_4844.rs:501-514): the commitment

@@ -1748,7 +1748,7 @@ struct kzgamd::MsmContext {
     bool fbw = false;
     bool fbw_glv = false;  // the wide table covers 128-bit half-scalars (rows = ceil(128 / c)); scalars are GLV-split
     Workspace ws;
-    // One workspace per stream the handle is used on (up to 8): independent batches enqueued on different streams
+    // One workspace per stream the handle is used on (up to 24): independent batches enqueued on different streams
     // may overlap on the GPU — the low-occupancy tail of one batch under the accumulation of the next.  `ws` serves
     // the handle's own stream and the first caller stream; further streams get their own.
     hipStream_t ws_owner = nullptr;
@@ -1763,7 +1763,7 @@ struct kzgamd::MsmContext {
         if (st == ws_owner) return ws;
         for (auto& e : ws_extra)
             if (e.first == st) return *e.second;
-        if (ws_extra.size() >= 7) return ws;  // more streams than workspaces: shared, see WsUse in msm_enqueue
+        if (ws_extra.size() >= 23) return ws;  // more streams than workspaces: shared, see WsUse in msm_enqueue
         ws_extra.emplace_back(st, new Workspace());
         return *ws_extra.back().second;
     }

@@ -446,6 +446,69 @@ def test_concurrent_callers_share_one_settings_handle(kzg, settings, oracle, ora
     assert not errors, errors
 
 
+def test_sixteen_concurrent_callers_every_result_against_the_oracle(kzg, settings, oracle, oracle_settings):
+    """16 threads on ONE CKZGSettings, as the reference's rayon workers use it (kzg/src/eip_4844.rs:781-805): single
+    commitments, single proofs, proofs at explicit points and small batches interleaved (the calls overlap on the
+    lanes of the settings object, see ckzg.hip), a large batch on the parent's own pipeline in the middle; every
+    result is compared with the oracle's, and an invalid blob in one thread fails only that call."""
+    import threading
+
+    L = oracle.lib()
+    rnd = random.Random(16)
+    nthreads = 16
+    blobs = []
+    for _ in range(nthreads):
+        b = bytearray(rnd.randbytes(BLOB))
+        for i in range(0, BLOB, 32):
+            b[i] = 0
+        blobs.append(bytes(b))
+    want_c, want_p, want_zp = [], [], []
+    zs = [rnd.randrange(O.R).to_bytes(32, "big") for _ in range(nthreads)]
+    for b, z in zip(blobs, zs):
+        c = C.create_string_buffer(48)
+        assert L.oblob_to_kzg_commitment(c, b, C.byref(oracle_settings)) == 0
+        pr = C.create_string_buffer(48)
+        assert L.ocompute_blob_kzg_proof(pr, b, c.raw, C.byref(oracle_settings)) == 0
+        pz, y = C.create_string_buffer(48), C.create_string_buffer(32)
+        assert L.ocompute_kzg_proof(pz, y, b, z, C.byref(oracle_settings)) == 0
+        want_c.append(c.raw)
+        want_p.append(pr.raw)
+        want_zp.append((pz.raw, y.raw))
+    bad = bytearray(blobs[0])
+    bad[:32] = O.R.to_bytes(32, "big")  # element == r
+    errors = []
+    start = threading.Barrier(nthreads)
+
+    def worker(i):
+        try:
+            start.wait()
+            for rep in range(4):
+                assert kzg.blob_to_kzg_commitment(blobs[i], settings) == want_c[i]
+                assert kzg.compute_blob_kzg_proof(blobs[i], want_c[i], settings) == want_p[i]
+                assert kzg.compute_kzg_proof(blobs[i], zs[i], settings) == want_zp[i]
+                j = (i + 1) % nthreads
+                assert kzg.blob_to_kzg_commitment_batch(blobs[i] + blobs[j], 2, settings) == [want_c[i], want_c[j]]
+                assert kzg.compute_blob_kzg_proof_batch(blobs[i] + blobs[j], want_c[i] + want_c[j], 2, settings) == \
+                    [want_p[i], want_p[j]]
+                if i == 3 and rep == 1:  # beyond the lane size: the parent's pipeline, while the others keep calling
+                    big = kzg.blob_to_kzg_commitment_batch(b"".join(blobs) * 2, 2 * nthreads, settings)
+                    assert big == want_c * 2
+                if i == 5:
+                    with pytest.raises(kzg.KzgAmdError):
+                        kzg.blob_to_kzg_commitment(bytes(bad), settings)
+                    with pytest.raises(kzg.KzgAmdError):
+                        kzg.compute_blob_kzg_proof(bytes(bad), want_c[0], settings)
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(nthreads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+
+
 def test_challenges_and_evaluations_for_batched_verification(kzg, settings, oracle, oracle_settings, golden, blob_loader):
     """compute_challenges_and_evaluate_polynomial (kzg/src/eip_4844.rs:690-719), the field half of
     verify_blob_kzg_proof_batch: z from the oracle's Fiat-Shamir restatement, y from the oracle's evaluation; the

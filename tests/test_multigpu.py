@@ -149,6 +149,97 @@ print("rank", RANK, "ok")
 '''
 
 
+ONE_GPU_WORKER = r'''
+import ctypes as C, os, sys, random, importlib.util
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, torch.distributed as dist
+from importlib import util
+spec = util.spec_from_file_location("sharding", os.path.join(ROOT, "rust-kzg_amd", "sharding.py"))
+sh = util.module_from_spec(spec); spec.loader.exec_module(sh)
+torch.cuda.set_device(0)
+path = os.path.join(ROOT, "rust-kzg_amd", "__init__.py")
+spec = importlib.util.spec_from_file_location("rust_kzg_amd", path, submodule_search_locations=[os.path.dirname(path)])
+kzg = importlib.util.module_from_spec(spec); sys.modules["rust_kzg_amd"] = kzg; spec.loader.exec_module(kzg)
+import oracle_ffi as O
+L = O.lib()
+# two ranks, ONE GPU: RCCL refuses two ranks on one device, so the result gather runs over gloo on host tensors;
+# everything that computes is this rank's own libkzg_mi355x.so context on GPU 0
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % PORT, rank=RANK, world_size=2)
+kzg.set_device(0)
+s = kzg.KZGSettings.from_file(os.path.join(ROOT, "tests", "golden", "trusted_setup.txt"))
+assert s.device() == 0
+with open(os.path.join(ROOT, "tests", "golden", "trusted_setup.txt"), "rb") as f:
+    rc, os_ = O.load_settings(f.read())
+assert rc == 0
+rnd = random.Random(3)
+blobs = []
+for _ in range(9):
+    b = bytearray(rnd.randbytes(131072))
+    for i in range(0, 131072, 32):
+        b[i] = 0
+    blobs.append(bytes(b))
+want = []
+for b in blobs:
+    o = C.create_string_buffer(48)
+    assert L.oblob_to_kzg_commitment(o, b, C.byref(os_)) == 0
+    want.append(o.raw)
+# 1. commit_sharded: each rank commits to its slab with the GPU engine, results all-gathered as objects
+calls = []
+def engine(bs):
+    calls.append(len(bs))
+    return kzg.blob_to_kzg_commitment_batch(b"".join(bs), len(bs), s)
+got = sh.commit_sharded(blobs, engine, dist)
+lo, hi = sh.shard_range(9, 2, RANK)
+assert calls == [hi - lo], calls
+assert got == want
+# 2. gather_results: the tensor form of the same gather (ncclAllGather on a multi-GPU node), device-resident proofs
+proofs = kzg.compute_blob_kzg_proof_batch(b"".join(blobs[lo:hi]), b"".join(want[lo:hi]), hi - lo, s)
+allp = sh.gather_results(torch.frombuffer(bytearray(b"".join(proofs)), dtype=torch.uint8), 9, 48, dist)
+allp = bytes(allp.numpy().tobytes())
+for i, b in enumerate(blobs):
+    o = C.create_string_buffer(48)
+    assert L.ocompute_blob_kzg_proof(o, b, want[i], C.byref(os_)) == 0
+    assert allp[48 * i: 48 * i + 48] == o.raw, i
+# 3. msm_sharded: one MSM split by index range, partial sums by the GPU engine, combined with kzgamd_g1_sum
+n = 5000
+g = O.G1(); L.og1_generator(C.byref(g))
+pts = (O.G1Affine * n)()
+base = O.G1(); k0 = O.fr_from_int(rnd.randrange(1, O.R)); L.og1_mul(C.byref(base), C.byref(g), C.byref(k0))
+acc = O.G1(); C.memmove(C.byref(acc), C.byref(base), 144)
+for i in range(n):   # P_i = base + i * G: cheap to generate, all distinct
+    L.og1_to_affine(C.byref(pts[i]), C.byref(acc)); L.og1_add_or_dbl(C.byref(acc), C.byref(acc), C.byref(g))
+sc = O.fr_array([rnd.randrange(O.R) for _ in range(n)])
+def partial(lo, hi):
+    out = kzg.multi_scalar_mult(C.cast(C.byref(pts, lo * 96), C.POINTER(kzg.BlstP1Affine)),
+                                C.cast(C.byref(sc, lo * 32), C.POINTER(kzg.BlstFr)), hi - lo)
+    return bytes(out)
+total = sh.msm_sharded(n, partial, kzg.g1_sum, dist)
+full = O.G1(); L.omsm_affine(C.byref(full), pts, sc, n)
+a = O.G1(); C.memmove(C.byref(a), total, 144)
+assert L.og1_equal(C.byref(a), C.byref(full)) == 1
+dist.barrier()
+dist.destroy_process_group()
+s.close()
+print("rank", RANK, "ok")
+'''
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_with_the_gpu_engine(kzg):
+    # SURVEY 8(e) on the hardware there is: both ranks open their own settings on GPU 0 (table budget capped so that
+    # two fit), shard a commit batch, a proof batch and one MSM, gather over gloo, and every result equals the oracle's
+    port = 31200 + (os.getpid() % 500)
+    procs = []
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", KZGAMD_FBW_MAX_GB="40")
+    for rank in range(2):
+        code = "ROOT=%r\nPORT=%d\nRANK=%d\n" % (ROOT, port, rank) + ONE_GPU_WORKER
+        procs.append(subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env))
+    outs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    for rank, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o[-3000:]
+        assert "rank %d ok" % rank in o
+
+
 @pytest.mark.gpu
 def test_sharded_commit_gpu_engine_two_ranks(kzg):
     if kzg.device_count() < 2:

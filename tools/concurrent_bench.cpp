@@ -1,0 +1,78 @@
+// Throughput of single-blob host-buffer calls from T native threads sharing one CKZGSettings — the reference's rayon
+// pattern (kzg/src/eip_4844.rs:781-805) without an interpreter lock in the way.
+// Build: g++ -O2 -std=c++17 tools/concurrent_bench.cpp -Iinclude -Lrust-kzg_amd/csrc -lkzg_mi355x -lpthread -o tools/concurrent_bench
+// Run:   LD_LIBRARY_PATH=rust-kzg_amd/csrc tools/concurrent_bench tests/golden/trusted_setup.txt [seconds]
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "kzg_mi355x.h"
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    const double secs = argc > 2 ? atof(argv[2]) : 1.5;
+    FILE* f = fopen(argv[1], "r");
+    if (!f) return 2;
+    CKZGSettings s;
+    if (load_trusted_setup_file(&s, f) != C_KZG_OK) return 3;
+    fclose(f);
+    const int NB = 16;
+    std::vector<Blob> blobs(NB);
+    std::mt19937_64 rng(4);
+    for (auto& b : blobs) {
+        for (size_t i = 0; i < sizeof b.bytes; i += 8) {
+            uint64_t v = rng();
+            memcpy(b.bytes + i, &v, 8);
+        }
+        for (size_t i = 0; i < sizeof b.bytes; i += 32) b.bytes[i] = 0;
+    }
+    std::vector<KZGCommitment> cm(NB);
+    for (int i = 0; i < NB; ++i)
+        if (blob_to_kzg_commitment(&cm[i], &blobs[i], &s) != C_KZG_OK) return 4;
+    printf("{");
+    bool first = true;
+    std::vector<int> Ts = {1, 2, 4, 8, 16, 32};
+    if (argc > 3) Ts = {atoi(argv[3])};
+    const int only = argc > 4 ? atoi(argv[4]) : -1;  // 0 = commitments only, 1 = proofs only
+    for (int T : Ts) {
+        for (int what = 0; what < 2; ++what) {
+            if (only >= 0 && what != only) continue;
+            std::atomic<bool> stop{false};
+            std::atomic<long> total{0};
+            std::atomic<int> bad{0};
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t)
+                th.emplace_back([&, t] {
+                    long n = 0;
+                    KZGCommitment c;
+                    KZGProof p;
+                    const int i = t % NB;
+                    while (!stop.load(std::memory_order_relaxed)) {
+                        C_KZG_RET rc = what == 0 ? blob_to_kzg_commitment(&c, &blobs[i], &s)
+                                                 : compute_blob_kzg_proof(&p, &blobs[i], &cm[i], &s);
+                        if (rc != C_KZG_OK || (what == 0 && memcmp(c.bytes, cm[i].bytes, 48) != 0)) bad.fetch_add(1);
+                        ++n;
+                    }
+                    total.fetch_add(n);
+                });
+            auto t0 = std::chrono::steady_clock::now();
+            std::this_thread::sleep_for(std::chrono::duration<double>(secs));
+            stop.store(true);
+            for (auto& x : th) x.join();
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            printf("%s\"%s_threads_%d\": %.0f", first ? "" : ", ", what == 0 ? "commit" : "proof", T, total.load() / dt);
+            first = false;
+            if (bad.load()) {
+                printf(", \"errors\": %d", bad.load());
+            }
+        }
+    }
+    printf("}\n");
+    free_trusted_setup(&s);
+    return 0;
+}
