@@ -57,6 +57,10 @@ typedef struct { int code; char *message; } RustError;
  * (blst-sppark/src/lib.rs:8-62, defined today by blst-sppark/cuda/pippenger.cu:23-38).
  * Scalars are blst_fr IN MONTGOMERY FORM (blst/src/kzg_proofs.rs:47-48); out is Jacobian.
  * Thread-safe: calls on one handle serialise on an internal mutex.
+ * Bases may be ANY points of the curve, as in the reference (FsG1::from_bytes does not test the subgroup,
+ * blst/src/types/g1.rs:65-87): the result is the plain sum of k_i P_i.  The engines' endomorphism (GLV) split is an
+ * identity of the r-torsion subgroup G1 only, so every handle tests its bases once at creation and runs unsplit if one
+ * fails; mult_pippenger, whose handle lives for one call, tests up to 2^15 bases and runs unsplit beyond.
  * ------------------------------------------------------------------------------------------ */
 void *prepare_msm(const blst_p1_affine points[], size_t npoints);
 RustError mult_pippenger_prepared(void *msm, blst_p1 *out, size_t npoints, const blst_fr scalars[]);

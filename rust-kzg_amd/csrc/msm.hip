@@ -1840,7 +1840,7 @@ static void build_wide_table(MsmContext* ctx) {
 }
 
 // uploads points (host or device pointer), builds the fixed-base rows when `prepare`
-MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare, bool points_are_affpt) {
+MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare, bool points_are_affpt, int g1_policy) {
     require_device();
     auto* ctx = new MsmContext();
     try {
@@ -1848,26 +1848,46 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->n = n;
         ctx->prepared = prepare;
-        ctx->glv = !prepare;
+        // The variable-base engine's GLV split (k = k1 + k2 x^2, second base psi(P) = [x^2]P) is an identity of the
+        // r-torsion subgroup only, and the reference's G1::from_bytes accepts any curve point
+        // (blst/src/types/g1.rs:65-87): the split is used when the caller vouches for the bases (internal callers
+        // that have just subgroup-checked them), or after every base has passed the membership test here; otherwise
+        // the engine runs on the 255-bit scalars.
+        ctx->glv = !prepare && g1_policy != G1_NO_SPLIT;
         if (const char* e = getenv("KZGAMD_GLV")) ctx->glv = ctx->glv && atoi(e) != 0;
         // the bases first (row 0 of the table; the variable-base engine appends the [x^2]P images)
         DevBuf<AffPt> row0;
         row0.ensure(ctx->glv ? 2 * n : n);
         DevBuf<ff::Fp> staging;
         const ff::Fp* src = (const ff::Fp*)points;
-        if (points_are_affpt) {
-            if (!points_on_device) throw HipErr{hipErrorInvalidValue, "AffPt input must be device-resident"};
-            hipLaunchKernelGGL(k_copy_affpt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, row0.p,
-                               (const AffPt*)points, n, ctx->glv ? 1 : 0);
-        } else {
-            if (!points_on_device) {
-                staging.ensure(2 * n);
-                HIP_TRY(hipMemcpyAsync(staging.p, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
-                src = staging.p;
-            }
-            hipLaunchKernelGGL(k_points_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, row0.p, src, n,
-                               ctx->glv ? 1 : 0);
+        if (!points_are_affpt && !points_on_device) {
+            staging.ensure(2 * n);
+            HIP_TRY(hipMemcpyAsync(staging.p, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
+            src = staging.p;
         }
+        if (points_are_affpt && !points_on_device) throw HipErr{hipErrorInvalidValue, "AffPt input must be device-resident"};
+        auto bases_in = [&](int with_images) {
+            if (points_are_affpt)
+                hipLaunchKernelGGL(k_copy_affpt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, row0.p,
+                                   (const AffPt*)points, n, with_images);
+            else
+                hipLaunchKernelGGL(k_points_in, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, row0.p, src, n,
+                                   with_images);
+        };
+        if (ctx->glv && g1_policy == G1_CHECK) {
+            bases_in(0);
+            DevBuf<int> bad;
+            bad.ensure(1);
+            HIP_TRY(hipMemsetAsync(bad.p, 0, sizeof(int), ctx->stream));
+            hipLaunchKernelGGL(k_bases_in_g1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, (const AffPt*)row0.p, n,
+                               bad.p);
+            int nbad = 1;
+            HIP_TRY(hipMemcpyAsync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            bad.release();
+            if (nbad != 0) ctx->glv = false;  // a base outside G1: no split (row0 keeps its 2n slots, n are used)
+        }
+        bases_in(ctx->glv ? 1 : 0);
         // shape of the engine
         bool wide_glv = false;
         int cw = 0;
@@ -2514,7 +2534,7 @@ static RustError guarded(F&& f) {
 extern "C" void* prepare_msm(const blst_p1_affine points[], size_t npoints) {
     try {
         if (!points || npoints == 0) return nullptr;
-        return kzgamd::msm_create(points, npoints, false, true, false);
+        return kzgamd::msm_create(points, npoints, false, true, false, kzgamd::G1_CHECK);
     } catch (const HipErr& e) {
         fprintf(stderr, "kzg_mi355x: prepare_msm failed: %s: %s\n", e.what, hipGetErrorString(e.e));
         return nullptr;
@@ -2545,7 +2565,10 @@ extern "C" RustError mult_pippenger(blst_p1* out, const blst_p1_affine points[],
             memset(out, 0, sizeof *out);
             return;
         }
-        MsmContext* ctx = kzgamd::msm_create(points, npoints, false, false, false);
+        // bases outside G1 are legal input here: the membership test where it costs less than the split saves
+        // (a 1.8 ms latency chain up to ~2^16 points, 14 ms at 2^20), the unsplit engine beyond
+        MsmContext* ctx = kzgamd::msm_create(points, npoints, false, false, false,
+                                             npoints <= ((size_t)1 << 15) ? kzgamd::G1_CHECK : kzgamd::G1_NO_SPLIT);
         try {
             kzgamd::msm_run_host(ctx, out, scalars, npoints, 1);
         } catch (...) {
@@ -2633,7 +2656,7 @@ extern "C" RustError kzgamd_generate_points(void* d_out_affine, size_t n, uint64
 extern "C" void* kzgamd_msm_create_device(const void* d_points_affine, size_t npoints, int prepare) {
     try {
         if (!d_points_affine || npoints == 0) return nullptr;
-        return kzgamd::msm_create(d_points_affine, npoints, true, prepare != 0, false);
+        return kzgamd::msm_create(d_points_affine, npoints, true, prepare != 0, false, kzgamd::G1_CHECK);
     } catch (const HipErr& e) {
         fprintf(stderr, "kzg_mi355x: kzgamd_msm_create_device failed: %s: %s\n", e.what, hipGetErrorString(e.e));
         return nullptr;

@@ -8,8 +8,13 @@ struct MsmContext;
 // OUT_WINDOWS (unprepared handles): one Jacobian point per (MSM, window); the caller does the Horner steps
 // OUT_XYZZ (wide-table handles): g1::Xyzz sums, for consumers on the device (the G1 transforms of FK20)
 enum { OUT_JACOBIAN = 0, OUT_COMPRESSED = 1, OUT_WINDOWS = 2, OUT_XYZZ = 3 };
+// What the caller knows about the bases' membership in the r-torsion subgroup G1 (the GLV split of the engines is an
+// identity of G1 only): G1_TRUSTED = all in G1 (just decoded and checked, or a validated setup), G1_CHECK = test them
+// at creation and fall back to the unsplit engine if one fails, G1_NO_SPLIT = never split.
+enum { G1_TRUSTED = 0, G1_CHECK = 1, G1_NO_SPLIT = 2 };
 // points: blst_p1_affine[n] (host or device) or g1::AffPt[n] (device); prepare = build fixed-base rows
-MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare, bool points_are_affpt);
+MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare, bool points_are_affpt,
+                       int g1_policy = G1_TRUSTED);
 void msm_destroy(MsmContext* ctx);
 // variable-base handle (prepare == false) over new device-resident AffPt bases: same as destroying it and creating
 // another, without the stream, the allocations and their synchronisations

@@ -94,6 +94,63 @@ def test_edge_scalars_and_points(oracle, kzg):
     hs.close()
 
 
+def curve_points_outside_g1(count, seed):
+    """(x, y) with y^2 = x^3 + 4 for small x: on the curve, and (the cofactor is ~2^126) outside the r-torsion subgroup"""
+    out, x = [], seed
+    while len(out) < count:
+        x += 1
+        rhs = (pow(x, 3, O.P) + 4) % O.P
+        y = pow(rhs, (O.P + 1) // 4, O.P)
+        if y * y % O.P == rhs:
+            out.append((x, y))
+    return out
+
+
+def test_bases_outside_the_subgroup(oracle, kzg):
+    """FsG1::from_bytes accepts any curve point (blst/src/types/g1.rs:65-87) and g1_lincomb is a plain sum of k_i P_i for
+    them too; the engines' GLV split is an identity of G1 only.  One / several bases outside G1 through the unprepared
+    entry point (membership test at creation -> unsplit engine), a device handle, the prepared path (table without the
+    split), and a call large enough to skip the test (unsplit engine outright): all equal the oracle's naive sum."""
+    import torch
+
+    L = oracle.lib()
+    rnd = random.Random(31)
+    for n, nbad in ((1, 1), (9, 1), (300, 3), (4096, 1), (40000, 2)):
+        pts = gen_points(L, min(n, 300), rnd)
+        if n > 300:  # large sets: repeat a few hundred random points (the oracle does not mind)
+            big = (O.G1Affine * n)()
+            for i in range(n):
+                big[i] = pts[i % 300]
+            pts = big
+        bad = curve_points_outside_g1(nbad, 1000 * n)
+        where = rnd.sample(range(n), nbad)
+        for (x, y), i in zip(bad, where):
+            pts[i].x, pts[i].y = O.fp_from_int(x), O.fp_from_int(y)
+        # sanity: the oracle agrees the planted point is on the curve and not in G1
+        probe = O.G1()
+        L.og1_from_affine(C.byref(probe), C.byref(pts[where[0]]))
+        assert L.og1_affine_on_curve(C.byref(pts[where[0]])) == 1 and L.og1_in_subgroup(C.byref(probe)) == 0
+        sc = O.fr_array([rnd.randrange(O.R) for _ in range(n)])
+        exp = O.G1()
+        (L.omsm_naive if n <= 300 else L.omsm_affine)(C.byref(exp), pts, sc, n)
+        want = compressed(L, exp)
+        assert compressed(L, as_oracle_g1(kzg.multi_scalar_mult(pts, sc, n))) == want, ("unprepared", n)
+        if n <= 4096:
+            h = kzg.prepare_multi_scalar_mult(pts, n)
+            assert compressed(L, as_oracle_g1(kzg.multi_scalar_mult_prepared(h, sc, n))) == want, ("prepared", n)
+            h.close()
+        d_pts = torch.frombuffer(bytearray(bytes(pts)), dtype=torch.uint8).cuda()
+        d_sc = torch.frombuffer(bytearray(bytes(sc)), dtype=torch.uint8).cuda()
+        d_out = torch.zeros(144, dtype=torch.uint8, device="cuda")
+        h = kzg.DeviceMsm(d_pts.data_ptr(), n, False)
+        kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr(), n, 1, True, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = O.G1()
+        C.memmove(C.byref(got), d_out.cpu().numpy().tobytes(), 144)
+        assert compressed(L, got) == want, ("device handle", n)
+        h.close()
+
+
 def test_glv_split_boundaries(oracle, kzg):
     """The variable-base engine splits k = k1 + k2*x^2 (x the BLS parameter): scalars on the quotient /
     remainder boundaries, including the largest quotient below r, through the host and the device entry points."""
