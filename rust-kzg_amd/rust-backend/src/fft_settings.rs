@@ -16,11 +16,19 @@ use rust_kzg_mi355x_sys::GpuNtt;
 use crate::g1::MiG1;
 
 /// `FsFFTSettings` plus the device context (`kzgamd_ntt_new(scale)`: twiddle tables in HBM).  Cloning shares the
-/// context; the library serialises calls on one context.
+/// context; the library serialises calls on one context.  `gpu` is `None` only for `Default::default()`: like the
+/// reference's `FsFFTSettings::default()` that is a pure host value (generic code in `kzg::` builds placeholder
+/// settings with it, also on machines without a GPU); a transform on such a value is an error, not a fallback.
 #[derive(Clone)]
 pub struct MiFFTSettings {
     pub inner: FsFFTSettings,
-    pub gpu: Arc<GpuNtt>,
+    pub gpu: Option<Arc<GpuNtt>>,
+}
+
+impl MiFFTSettings {
+    fn gpu(&self) -> Result<&GpuNtt, String> {
+        self.gpu.as_deref().ok_or_else(|| String::from("MiFFTSettings::default() has no device context; use new(scale)"))
+    }
 }
 
 impl core::fmt::Debug for MiFFTSettings {
@@ -31,7 +39,7 @@ impl core::fmt::Debug for MiFFTSettings {
 
 impl Default for MiFFTSettings {
     fn default() -> Self {
-        Self::new(0).unwrap()
+        Self { inner: FsFFTSettings::default(), gpu: None }
     }
 }
 
@@ -40,7 +48,7 @@ impl FFTSettings<FsFr> for MiFFTSettings {
     /// SCALE2_ROOT_OF_UNITY row, so host getters and device transforms agree bit for bit.
     fn new(scale: usize) -> Result<Self, String> {
         let inner = FsFFTSettings::new(scale)?;
-        let gpu = Arc::new(GpuNtt::new(scale)?);
+        let gpu = Some(Arc::new(GpuNtt::new(scale)?));
         Ok(Self { inner, gpu })
     }
     fn get_max_width(&self) -> usize {
@@ -74,9 +82,9 @@ fn fr_raw(data: &[FsFr]) -> &[blst_fr] {
 
 impl FFTFr<FsFr> for MiFFTSettings {
     /// blst/src/fft_fr.rs:112-165; the length checks and their messages come back from the library
-    /// (ntt_fr return codes 1 / 2), the butterflies run as radix-8 rounds in LDS on the GPU.
+    /// (ntt_fr return codes 1 / 2), the butterflies run as radix-4 register rounds over LDS tiles on the GPU.
     fn fft_fr(&self, data: &[FsFr], inverse: bool) -> Result<Vec<FsFr>, String> {
-        let out = self.gpu.fft_fr(fr_raw(data), inverse)?;
+        let out = self.gpu()?.fft_fr(fr_raw(data), inverse)?;
         Ok(out.into_iter().map(FsFr).collect())
     }
 }
@@ -84,7 +92,7 @@ impl FFTFr<FsFr> for MiFFTSettings {
 impl DASExtension<FsFr> for MiFFTSettings {
     /// blst/src/data_availability_sampling.rs:78-100
     fn das_fft_extension(&self, evens: &[FsFr]) -> Result<Vec<FsFr>, String> {
-        let out = self.gpu.das_fft_extension(fr_raw(evens))?;
+        let out = self.gpu()?.das_fft_extension(fr_raw(evens))?;
         Ok(out.into_iter().map(FsFr).collect())
     }
 }
@@ -94,7 +102,7 @@ impl FFTG1<MiG1> for MiFFTSettings {
     /// differs); callers that serialise or compare with `equals` see no difference.
     fn fft_g1(&self, data: &[MiG1], inverse: bool) -> Result<Vec<MiG1>, String> {
         let raw = unsafe { core::slice::from_raw_parts(data.as_ptr() as *const blst_p1, data.len()) };
-        let out = self.gpu.fft_g1(raw, inverse)?;
+        let out = self.gpu()?.fft_g1(raw, inverse)?;
         Ok(out.into_iter().map(MiG1::from_blst).collect())
     }
 }

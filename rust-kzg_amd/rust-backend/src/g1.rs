@@ -206,24 +206,20 @@ impl G1LinComb<FsFr, FsFp, MiG1Affine, MiG1ProjAddAffine> for MiG1 {
         out
     }
 
-    /// Batched form (kzg/src/lib.rs:159-181): with a device table every row goes into ONE launch
-    /// (`mult_pippenger_prepared_batch`, the shape of the wlc variant's `mult_pippenger_faster_inf`).
+    /// Batched form (kzg/src/lib.rs:159-181).  Its only caller is `compute_fk20_proofs` (kzg/src/das.rs:682-686),
+    /// which passes the 128 rows of `x_ext_fft_columns` TOGETHER WITH the settings' precomputation — and the table
+    /// `MiKZGSettings::new` builds is over `g1_values_lagrange_brp`, not over those rows.  The reference's own backends
+    /// only use a table here when it was built from the matrix (`precompute(points, matrix)`); this backend has no
+    /// such table, so the precomputation is ignored and every row is a variable-base MSM over ITS points.
+    /// (`compute_cells_and_kzg_proofs` through the C-ABI runs FK20 on the device with a table over the columns —
+    /// rust-kzg_amd/csrc/ckzg.hip `fk20_prepare` — and is the fast path.)
     fn g1_lincomb_batch(
         points: &[Vec<Self>],
         scalars: &[Vec<FsFr>],
-        precomputation: Option<&MiPrecomputation>,
+        _precomputation: Option<&MiPrecomputation>,
     ) -> Result<Vec<Self>, String> {
         if points.len() != scalars.len() {
             return Err("Invalid batch size".into());
-        }
-        if let Some(table) = precomputation {
-            let n = scalars.first().map(|r| r.len()).unwrap_or(0);
-            if scalars.iter().any(|r| r.len() != n) {
-                return Err("Invalid point count length".into());
-            }
-            let flat: Vec<blst_fr> = scalars.iter().flat_map(|r| r.iter().map(|s| s.0)).collect();
-            let out = unsafe { sys::msm_prepared_batch_raw(table.table, &flat, n) }?;
-            return Ok(out.into_iter().map(MiG1::from_blst).collect());
         }
         let mut result = Vec::with_capacity(points.len());
         for (p, s) in points.iter().zip(scalars.iter()) {
