@@ -1527,6 +1527,12 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
                     (void)hipSetDevice(dev->device);
                     ce = hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream);
                 });
+                struct Joiner {  // an exception out of the pool must not leave a joinable thread behind (std::terminate)
+                    std::thread& t;
+                    ~Joiner() {
+                        if (t.joinable()) t.join();
+                    }
+                } joiner{copier};
                 dev->pool->run(nth, work);
                 copier.join();
                 CK_HIP(ce);
@@ -2335,7 +2341,12 @@ extern "C" C_KZG_RET kzgamd_verify_blob_kzg_proof_batch_g1(blst_p1* proof_lincom
         std::vector<Bytes32> zs(n), ys(n);
         std::lock_guard<std::mutex> vlk(dev->vmu);
         verify_g1_begin(commitments, proofs, n, dev);  // decode + subgroup check run under the evaluations
-        prove_batch(nullptr, ys.data(), blobs, nullptr, commitments, n, dev, zs.data(), true);
+        try {
+            prove_batch(nullptr, ys.data(), blobs, nullptr, commitments, n, dev, zs.data(), true);
+        } catch (...) {
+            (void)hipStreamSynchronize(dev->stream2);
+            throw;
+        }
         verify_g1_finish(proof_lincomb_out, rhs_out, commitments, zs.data(), ys.data(), proofs, n, dev);
     });
 }
@@ -2461,7 +2472,12 @@ extern "C" C_KZG_RET verify_blob_kzg_proof_batch(bool* ok, const Blob* blobs, co
         {
             std::lock_guard<std::mutex> vlk(dev->vmu);
             verify_g1_begin(commitments_bytes, proofs_bytes, n, dev);  // decode + subgroup check run under the evaluations
-            prove_batch(nullptr, ys.data(), blobs, nullptr, commitments_bytes, n, dev, zs.data(), true);
+            try {
+                prove_batch(nullptr, ys.data(), blobs, nullptr, commitments_bytes, n, dev, zs.data(), true);
+            } catch (...) {
+                (void)hipStreamSynchronize(dev->stream2);  // the decode kernel reads dev->vstage's device copy: drain it
+                throw;
+            }
             verify_g1_finish(&pl, &rhs, commitments_bytes, zs.data(), ys.data(), proofs_bytes, n, dev);
         }
         blst_p2 g2gen, g2tau;

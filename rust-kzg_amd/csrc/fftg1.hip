@@ -259,6 +259,10 @@ void* kzgamd::fftg1_device(NttCtx* ctx, void* data_v, void* scratch_v, size_t n,
     try {
         const size_t total = n * nbatch, bf = total / 2;
         const int logn = ilog2(n);
+        // ctx->mu: ensure_g1_tab may reallocate the handle's tables, which kzgamd_fft_g1_batch (host buffers, its own
+        // stream, under the same mutex) uses too.  The tables stay in use by the kernels enqueued here after this
+        // returns: one stream at a time per handle, as stated above.
+        std::lock_guard<std::mutex> lk(ctx->mu);
         ensure_g1_tab(ctx, 2 * total);
         Xyzz* bufs[2] = {(Xyzz*)scratch_v, (Xyzz*)data_v};
         Xyzz* tab = (Xyzz*)ctx->d_tab;
