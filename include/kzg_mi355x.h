@@ -301,9 +301,17 @@ int kzgamd_device_count(void);
  * kzgamd_msm_create_device, kzgamd_ntt_new, load_trusted_setup(_file) — live on that GPU.  Every later call on a
  * handle, host-buffer or device-resident form, switches to the handle's GPU by itself and restores the caller's
  * current device on return; device pointers and streams passed to a *_device entry point must belong to the
- * handle's GPU.  Returns 0 / the device index (-1 on error). */
+ * handle's GPU.  kzgamd_set_device returns 0, or 1 if the runtime refuses the index; kzgamd_get_device returns the
+ * calling thread's current device, -1 on error. */
 int kzgamd_set_device(int device);
 int kzgamd_get_device(void);
+/* What a settings object got of the HBM-sized tables it asked for (they are built on first use and shrink, or are left
+ * out, when HBM is short — e.g. a second CKZGSettings on the same GPU): for which = 0 the commitment / proof table
+ * over g1_values_lagrange_brp, 1 the cell-proof table of single blobs over g1_values_monomial, 2 the FK20 table over
+ * x_ext_fft_columns — window bits, rows and the kzgamd_msm_uses_wide_table() code of the handle (0 = no wide table:
+ * the bucket engine / the direct form runs instead; results are the same, only slower).  Returns 0, 1 when that
+ * table has not been built (yet), -1 on bad arguments. */
+int kzgamd_settings_table_info(const CKZGSettings *s, int which, int *window_bits, int *rows, int *wide_table);
 const char *kzgamd_version(void);
 
 #ifdef __cplusplus

@@ -69,7 +69,7 @@ EXPORTS = [
     "kzgamd_compute_cells_and_kzg_proofs_batch", "kzgamd_compute_challenges_and_evaluate_batch",
     "kzgamd_blob_to_kzg_commitment_batch", "kzgamd_blob_to_kzg_commitment_device", "kzgamd_settings_msm_handle",
     "kzgamd_msm_reserve", "kzgamd_msm_device", "kzgamd_set_device", "kzgamd_get_device", "kzgamd_settings_device",
-    "kzgamd_settings_reserve", "kzgamd_verify_kzg_proof_batch_g1", "kzgamd_verify_blob_kzg_proof_batch_g1",
+    "kzgamd_settings_reserve", "kzgamd_settings_table_info", "kzgamd_verify_kzg_proof_batch_g1", "kzgamd_verify_blob_kzg_proof_batch_g1",
     "verify_kzg_proof", "verify_blob_kzg_proof", "verify_blob_kzg_proof_batch", "kzgamd_pairings_verify",
     "kzgamd_compute_blob_kzg_proof_device",
     "kzgamd_p2_uncompress", "kzgamd_p2_compress", "kzgamd_p2_generator", "kzgamd_p2_mult", "kzgamd_p2_add",

@@ -759,6 +759,10 @@ struct KzgAmdSettings {
     };
     static inline int MAX_LEADERS = getenv("KZGAMD_LEADERS") ? atoi(getenv("KZGAMD_LEADERS")) : 3;  // read once, at load
     CoalesceQueue q_commit, q_blob_proof, q_proof;
+    // measurement switches, read once when the settings object is created
+    bool cfg_device_sha = getenv("KZGAMD_DEVICE_SHA") && atoi(getenv("KZGAMD_DEVICE_SHA")) != 0;
+    size_t cfg_prove_chunk = getenv("KZGAMD_PROVE_CHUNK") ? (size_t)atoi(getenv("KZGAMD_PROVE_CHUNK")) : 0;
+    int cfg_fk20 = getenv("KZGAMD_FK20") ? (atoi(getenv("KZGAMD_FK20")) != 0 ? 1 : 0) : -1;  // -1: by batch size
     bool is_lane = false;
     std::atomic<bool> busy{false};
     // page-locked staging for calls of up to LANE_MAX_BLOBS blobs: copies to and from it are truly asynchronous (a
@@ -1394,8 +1398,7 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
     // blob: 2050 serial compressions, ~8 ms however many blobs) and no host threads at all.  Measured against the host
     // pool: 256 blobs 22 k vs 50 k proofs/s, 1024 blobs 47 k vs 66 k, 4096 blobs 72 k vs 78 k — the kernel only pays when
     // other batches hide it (the device-resident pipeline), so the host pool stays the default.
-    const char* dsha = getenv("KZGAMD_DEVICE_SHA");
-    const bool device_sha = derive && n >= 2 * PROVE_CHUNK && dsha && atoi(dsha) != 0 && !commitments_checked_elsewhere;
+    const bool device_sha = derive && n >= 2 * PROVE_CHUNK && dev->cfg_device_sha && !commitments_checked_elsewhere;
     if (derive) {
         cstat.assign(n, 0);
         if (!host_check && !commitments_checked_elsewhere) {
@@ -1443,8 +1446,7 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
         // blobs per pipeline chunk (median ms per call, chunk 64 / 128 / 256: 256 blobs 6.63 / 6.25 / 6.41, 512 blobs
         // 11.0 / 9.1 / 9.7, 1024 blobs 19.0 / 16.5 / 16.2)
         size_t PCH = n >= 1024 ? 4 * PROVE_CHUNK : 2 * PROVE_CHUNK;
-        if (const char* e = getenv("KZGAMD_PROVE_CHUNK")) {
-            const size_t v = (size_t)atoi(e);
+        if (const size_t v = dev->cfg_prove_chunk) {
             if (v >= 16 && v <= 4096) PCH = v;
         }
         // Large batch: a pipeline of PCH-blob chunks on rotating streams.  The pool hashes the blobs in
@@ -1715,7 +1717,7 @@ void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_
     // the batch).  A few blobs: the direct form, one more fixed-base MSM per cell over the monomial table.
     // KZGAMD_FK20 = 0 / 1 forces one or the other.
     bool fk20 = proofs && n >= FK20_MIN_BLOBS;
-    if (const char* e = getenv("KZGAMD_FK20")) fk20 = proofs && atoi(e) != 0;
+    if (dev->cfg_fk20 >= 0) fk20 = proofs && dev->cfg_fk20 != 0;
     if (dev->fk20_unavailable) fk20 = false;
     if (proofs && fk20) {
         // no HBM left for the FK20 table (creation throws, or succeeds without a wide table): the direct form computes
@@ -1803,7 +1805,8 @@ C_KZG_RET guarded(F&& f) {
         f();
         return C_KZG_OK;
     } catch (const CkErr& e) {
-        if (getenv("KZGAMD_DEBUG")) fprintf(stderr, "kzg_mi355x: %s\n", e.what.c_str());
+        static const bool debug = getenv("KZGAMD_DEBUG") != nullptr;
+        if (debug) fprintf(stderr, "kzg_mi355x: %s\n", e.what.c_str());
         return e.rc == C_KZG_MALLOC ? C_KZG_MALLOC : C_KZG_BADARGS;  // the reference maps every failure to BadArgs
     } catch (const std::bad_alloc&) {
         return C_KZG_MALLOC;
@@ -2934,6 +2937,23 @@ extern "C" C_KZG_RET kzgamd_compute_cells_and_kzg_proofs_batch(Cell* cells, KZGP
     if (!dev) return C_KZG_BADARGS;
     if (n == 0) return C_KZG_OK;
     return guarded([&] { cells_and_proofs(cells ? cells->bytes : nullptr, proofs, blobs, n, s, dev); });
+}
+
+extern "C" int kzgamd_settings_table_info(const CKZGSettings* s, int which, int* window_bits, int* rows, int* wide_table) {
+    KzgAmdSettings* dev = lookup(s);
+    if (!dev || which < 0 || which > 2) return -1;
+    kzgamd::MsmContext* h = which == 0 ? dev->msm : which == 1 ? dev->msm_monomial : dev->msm_xext;
+    if (!h) {
+        if (wide_table) *wide_table = 0;
+        return 1;
+    }
+    size_t nb = 0, np = 0;
+    int c = 0, r = 0;
+    kzgamd_msm_info(h, &c, &r, &nb, &np);
+    if (window_bits) *window_bits = c;
+    if (rows) *rows = r;
+    if (wide_table) *wide_table = kzgamd_msm_uses_wide_table(h);
+    return 0;
 }
 
 extern "C" void* kzgamd_settings_msm_handle(const CKZGSettings* s) {

@@ -7,7 +7,7 @@
 // check — two Miller loops and one final exponentiation per call, whatever the batch size — runs here.  It is not
 // a fallback for anything the GPU path computes, and it shares no code with the CPU checker of the test-suite.
 //
-// Construction (textbook; ~10 ms per check on one core):
+// Construction (textbook; ~0.7 ms per check on one core of the GPU box with the cached line tables below):
 //   tower      Fp2 = Fp[u]/(u^2+1),  Fp6 = Fp2[v]/(v^3 - xi), xi = 1+u,  Fp12 = Fp6[w]/(w^2 - v)
 //   twist      E'(Fp2): y^2 = x^3 + 4 xi  (M-type);  (x', y') -> (x' w^-2, y' w^-3) lands on E(Fp12): y^2 = x^3 + 4
 //   Miller     optimal-ate loop over |x| = 0xd201000000010000 with affine arithmetic on E', line through T evaluated

@@ -1647,13 +1647,11 @@ int choose_wide_window(size_t n, bool glv_allowed, bool* use_glv) {
     return best_c;
 }
 
-int choose_window(size_t n, bool prepared, bool glv) {
+int choose_window(size_t n, bool prepared, bool glv, int forced) {
     // minimise adds: prepared  n*ceil(256/c) + 3*2^(c-1);  unprepared  ceil(256/c) * (n + 3*2^(c-1));
     // unprepared with the GLV split: (128/c + 1) bucket sets fed by 2n half-scalars
-    if (const char* e = getenv(prepared ? "KZGAMD_WINDOW_PREPARED" : "KZGAMD_WINDOW")) {
-        int c = atoi(e);
-        if (c >= 2 && c <= 22) return c;
-    }
+    // forced: KZGAMD_WINDOW / KZGAMD_WINDOW_PREPARED as read when the handle was created (0 = by size)
+    if (forced >= 2 && forced <= 22) return forced;
     if (glv) {
         // measured on MI355X (tools/sweep_window.py, device-resident inputs): c = 16 wins from n = 2^15 up to at
         // least 2^22 — eight windows with a full top window after the balanced split; smaller n are latency-bound
@@ -1735,8 +1733,41 @@ struct Workspace {
 
 }  // namespace
 
+// The measurement switches of DESIGN.md §12, read from the environment ONCE, when a handle is created (an enqueue never
+// calls getenv); every variant computes the same result a different way.
+struct MsmTuning {
+    int spl = 0;               // KZGAMD_SPL: scalars per lane of the wide-table path (0 = by batch size)
+    bool no_wide_tail = false; // KZGAMD_NO_WIDE_TAIL=1: single-lane instead of limb-parallel tails and folds
+    int blocksum_threads = 0;  // KZGAMD_BLOCKSUM_THREADS: 64 / 128 / 256 (0 = by batch size)
+    int lgc = 0;               // KZGAMD_LGC: accumulation chunk (0 = by size)
+    int groups = 0;            // KZGAMD_GROUPS: window groups on their own streams (0 = one)
+    int fine_bits = 0;         // KZGAMD_FINE_BITS: width of the second sort level (0 = default)
+    bool one_level_sort = false, tree_tail = false, flat_digits = false, direct_scatter = false, scatter_atomics = false;
+    static MsmTuning from_env() {
+        MsmTuning t;
+        auto num = [](const char* name) {
+            const char* e = getenv(name);
+            return e ? atoi(e) : 0;
+        };
+        t.spl = num("KZGAMD_SPL") > 0 ? num("KZGAMD_SPL") : 0;
+        t.no_wide_tail = getenv("KZGAMD_NO_WIDE_TAIL") != nullptr;
+        t.blocksum_threads = num("KZGAMD_BLOCKSUM_THREADS");
+        t.lgc = num("KZGAMD_LGC");
+        t.groups = num("KZGAMD_GROUPS");
+        t.fine_bits = num("KZGAMD_FINE_BITS");
+        t.one_level_sort = getenv("KZGAMD_ONE_LEVEL_SORT") != nullptr;
+        t.tree_tail = getenv("KZGAMD_TREE_TAIL") != nullptr;
+        t.flat_digits = getenv("KZGAMD_FLAT_DIGITS") != nullptr;
+        t.direct_scatter = getenv("KZGAMD_DIRECT_SCATTER") != nullptr;
+        t.scatter_atomics = getenv("KZGAMD_SCATTER_ATOMICS") != nullptr;
+        return t;
+    }
+};
+
 struct kzgamd::MsmContext {
     std::mutex mu;
+    MsmTuning tune = MsmTuning::from_env();
+    int window_forced = 0;  // KZGAMD_WINDOW (variable base) / KZGAMD_WINDOW_PREPARED at creation, 0 = by size
     int device = 0;
     size_t n = 0;
     bool prepared = false;
@@ -1848,6 +1879,7 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->n = n;
         ctx->prepared = prepare;
+        if (const char* e = getenv(prepare ? "KZGAMD_WINDOW_PREPARED" : "KZGAMD_WINDOW")) ctx->window_forced = atoi(e);
         // The variable-base engine's GLV split (k = k1 + k2 x^2, second base psi(P) = [x^2]P) is an identity of the
         // r-torsion subgroup only, and the reference's G1::from_bytes accepts any curve point
         // (blst/src/types/g1.rs:65-87): the split is used when the caller vouches for the bases (internal callers
@@ -1891,7 +1923,7 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         // shape of the engine
         bool wide_glv = false;
         int cw = 0;
-        if (prepare && !getenv("KZGAMD_WINDOW_PREPARED")) {
+        if (prepare && !ctx->window_forced) {
             bool dummy;
             if (choose_wide_window(n, true, &dummy) != 0) {
                 // a wide table fits: its GLV form needs every base in the r-torsion subgroup (psi(P) = [x^2]P holds only
@@ -1919,7 +1951,7 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
             ctx->rows = wide_glv ? (127 + cw) / cw : 255 / cw + 1;
             ctx->nwin = ctx->rows;
         } else {
-            ctx->c = choose_window(n, prepare, ctx->glv);
+            ctx->c = choose_window(n, prepare, ctx->glv, ctx->window_forced);
             ctx->rows = prepare ? (255 / ctx->c + 1) : 1;
             ctx->nwin = ctx->glv ? (127 + ctx->c) / ctx->c : 255 / ctx->c + 1;
         }
@@ -1956,7 +1988,7 @@ void msm_reset_points(MsmContext* ctx, const void* d_affpts, size_t n) {
     DeviceGuard on_device(ctx->device);
     HIP_TRY(on_device.err);
     ctx->n = n;
-    ctx->c = choose_window(n, false, ctx->glv);
+    ctx->c = choose_window(n, false, ctx->glv, ctx->window_forced);
     ctx->rows = 1;
     ctx->nwin = ctx->glv ? (127 + ctx->c) / ctx->c : 255 / ctx->c + 1;
     ctx->nb = (size_t)1 << (ctx->c - 1);
@@ -2026,18 +2058,18 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         // (87.1 k -> 88.0 k commitments/s, three alternating runs on one box); 1 for small batches, where the lanes
         // are needed for latency
         int spl = nbatch >= 256 ? 4 : 1;
-        if (const char* e = getenv("KZGAMD_SPL")) spl = atoi(e) > 0 ? atoi(e) : spl;
+        if (ctx->tune.spl) spl = ctx->tune.spl;
         if (spl == 3 || spl > 4) spl = 4;
         if (ctx->fbw_glv) spl *= 2;  // two lanes (k1 / k2 digits) per scalar group: the same number of partial sums
         // a few MSMs over the 4096-point setup: a lane per (scalar, half) — 8 additions per lane instead of 16, twice the
         // partial sums for the fold (limb-parallel up to WIDE_FOLD_MAX MSMs, k_blocksum above)
         // (up to 8 MSMs: 8 commitments 0.79 -> 0.71 ms; 16 the same either way, 32 and 64 slower)
-        if (ctx->fbw_glv && nbatch <= 8 && npoints == 4096 && !getenv("KZGAMD_SPL") && !getenv("KZGAMD_NO_WIDE_TAIL")) spl = 1;
+        if (ctx->fbw_glv && nbatch <= 8 && npoints == 4096 && !ctx->tune.spl && !ctx->tune.no_wide_tail) spl = 1;
         const size_t lanes = (npoints + spl - 1) / spl * (ctx->fbw_glv ? 2 : 1);
         ws.buckets.ensure(nbatch * lanes);
         ws.lvlM[0].ensure(nbatch);
         if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) ws.lvlA[0].ensure(nbatch * 128);
-        const bool wide_fold = nbatch <= WIDE_FOLD_MAX && (lanes == 4096 || lanes == 8192) && !getenv("KZGAMD_NO_WIDE_TAIL");
+        const bool wide_fold = nbatch <= WIDE_FOLD_MAX && (lanes == 4096 || lanes == 8192) && !ctx->tune.no_wide_tail;
         if (wide_fold) {
             ws.wpart.ensure((nbatch * 128 + nbatch) * (size_t)WFOLD);
             ws.wcount.ensure(nbatch * 128 + nbatch);
@@ -2106,7 +2138,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             // (256 / 128 / 64 threads: 87.7 k / 88.9 k / 87.6 k commitments/s at 1024 blobs, same box)
             int bs = 256;
             if (nbatch >= 256) bs = 128;
-            if (const char* e = getenv("KZGAMD_BLOCKSUM_THREADS")) bs = atoi(e) == 64 || atoi(e) == 128 || atoi(e) == 256 ? atoi(e) : bs;
+            if (const int v = ctx->tune.blocksum_threads) bs = v == 64 || v == 128 || v == 256 ? v : bs;
             hipLaunchKernelGGL(k_blocksum, dim3((unsigned)nbatch), dim3(bs), bs * sizeof(Xyzz), stream,
                                (const Xyzz*)ws.buckets.p, sums, lanes);
         }
@@ -2130,8 +2162,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
               : npoints >= ((size_t)1 << 18) ? 5 : 4;
     // the device may pick chunks up to 4x smaller for sets with fewer entries (eff_lgc): the piece slots are sized for that
     int lgc_lo = lgc > 6 ? lgc - 2 : (lgc > 4 ? 4 : lgc);
-    if (const char* e = getenv("KZGAMD_LGC")) {
-        const int v = atoi(e);
+    if (const int v = ctx->tune.lgc) {
         if (v >= 2 && v <= 8) lgc = lgc_lo = v;
     }
     const size_t nchunk = (set_cap + ((size_t)1 << lgc_lo) - 1) >> lgc_lo;
@@ -2151,8 +2182,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     // 6.17 vs 6.22 ms on the same box.
     int G = 1;
     if (!ctx->prepared && nbatch == 1 && !ctx->profile && npoints >= 4096 && nwin >= 4) {
-        if (const char* e = getenv("KZGAMD_GROUPS")) {
-            int v = atoi(e);
+        if (const int v = ctx->tune.groups) {
             if (v >= 1 && v <= MsmContext::MAXG && v <= nwin) G = v;
         }
     }
@@ -2164,11 +2194,10 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     int pbits = 1;  // bits of a point index
     while (((size_t)1 << pbits) < max_pidx) ++pbits;
     int fb = FINE_BITS_MIN;
-    if (const char* e = getenv("KZGAMD_FINE_BITS")) {
-        const int v = atoi(e);
+    if (const int v = ctx->tune.fine_bits) {
         if (v >= FINE_BITS_MIN && v <= FINE_BITS_MAX && v <= 31 - pbits) fb = v;
     }
-    const bool two_level = !getenv("KZGAMD_ONE_LEVEL_SORT") && nb >= ((size_t)1 << fb) && fb + 1 + pbits <= 32 &&
+    const bool two_level = !ctx->tune.one_level_sort && nb >= ((size_t)1 << fb) && fb + 1 + pbits <= 32 &&
                            (nb >> fb) * sets_per_group <= MAX_BINS &&
                            npoints * nbatch >= ((size_t)1 << 15);  // below: four more launches than they save
     if (two_level) {
@@ -2185,12 +2214,12 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     ws.nheavy.ensure(G);
     const bool use_top = nsets <= 64;  // many independent sets (batched MSMs) keep plain tree levels busy on their own
     // few chains: run the serial tails limb-parallel, one point operation per wave
-    const bool wide_tail = use_top && !getenv("KZGAMD_NO_WIDE_TAIL");
+    const bool wide_tail = use_top && !ctx->tune.no_wide_tail;
     // few sets of many buckets: the digit-decomposed reduction instead of the (A, M) tree (KZGAMD_TREE_TAIL=1: the tree)
     // measured (same box, tree vs digits): n = 2^14 (4096 buckets) 1.20 vs 1.35 ms, 2^16 1.53 vs 1.48, 2^20 4.53 vs 4.35, 2^22 14.67 vs 14.26
-    const bool digit_tail = use_top && nb >= 16384 && !getenv("KZGAMD_TREE_TAIL");
+    const bool digit_tail = use_top && nb >= 16384 && !ctx->tune.tree_tail;
     // the tiled form of the digit sums (k_tile_sums); KZGAMD_FLAT_DIGITS=1: one pass over the buckets per digit
-    const bool tiled_digits = digit_tail && nb % 1024 == 0 && !getenv("KZGAMD_FLAT_DIGITS");
+    const bool tiled_digits = digit_tail && nb % 1024 == 0 && !ctx->tune.flat_digits;
     // shape of the tree (the same for every group: level 0 folds by the group size): k_top stride B + 2
     size_t top_stride = 0;
     {
@@ -2276,9 +2305,9 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             HIP_TRY(hipMemsetAsync(bin_count, 0, nbins * sizeof(u32), st));
             // entries per scalar (windows of this launch's group x halves): the staged scatter holds 16 per scalar
             const size_t per_scalar = (size_t)(G > 1 ? ns : (size_t)nwin) * (ctx->glv ? 2 : 1);
-            const bool staged = per_scalar * STAGE_T * STAGE_SCALARS <= STAGE_CAP && !getenv("KZGAMD_DIRECT_SCATTER");
+            const bool staged = per_scalar * STAGE_T * STAGE_SCALARS <= STAGE_CAP && !ctx->tune.direct_scatter;
             // per-workgroup histograms kept by the count pass (KZGAMD_SCATTER_ATOMICS=1: recount + one atomic per run)
-            const bool keep_hist = staged && G == 1 && !getenv("KZGAMD_SCATTER_ATOMICS");
+            const bool keep_hist = staged && G == 1 && !ctx->tune.scatter_atomics;
             u32 *wg_hist = nullptr, *wg_off = nullptr;
             if (keep_hist) {
                 ws.wghist.ensure(2 * (size_t)gpart * nbins);
