@@ -81,6 +81,47 @@ __global__ void __launch_bounds__(256) instr_kernel(unsigned* out, int iters, un
 #define X(k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[0]) : "v"(a), "v"(b) : "vcc");
             REP8(X) REP8(X)
 #undef X
+        } else if (OP == 12) {
+#define X(k) asm volatile("v_add_f64 %0, %1, %0" : "+v"(d[k]) : "v"(da));
+            REP8(X) REP8(X)
+#undef X
+        } else if (OP == 13) {
+#define X(k) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[k]) : "v"(acc[(k + 1) & 7]));
+            REP8(X) REP8(X)
+#undef X
+        } else if (OP == 14) {
+            float fa = (float)a, fb = 1.0f + (float)b * 1e-9f;
+#define X(k) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(x[k]) : "v"(fa), "v"(fb));
+            REP8(X) REP8(X)
+#undef X
+        } else if (OP == 15) {
+#define X(k) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(acc[k]) : "v"(acc[(k + 3) & 7]));
+            REP8(X) REP8(X)
+#undef X
+        } else if (OP == 16) {
+#define X(k) asm volatile("v_add_u32 %0, %1, %0" : "+v"(x[k]) : "v"(a));
+            REP8(X) REP8(X)
+#undef X
+        } else if (OP == 18) {
+#define X(k) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[k]) : "v"(a), "v"(b) : "vcc");
+            REP8(X) REP8(X)
+#undef X
+        } else if (OP == 17) {
+            // the double-precision-FMA limb product ("DPFP", Emmart et al.): a 52 x 52-bit product as
+            //   hi = fma_rz(a, b, 2^104); t = (2^104 + 2^52) - hi; lo = fma_rz(a, b, t)
+            // whose mantissas are the two 52-bit halves, accumulated as integers: 5 instructions per product.
+            // (round-toward-zero is the wave's DP rounding mode here; see dpfp_check for exactness)
+            const double C1 = 0x1.0p104, C2 = 0x1.0p104 + 0x1.0p52;
+#define X(k)                                                                                                  \
+    {                                                                                                         \
+        double hi_, t_, lo_;                                                                                  \
+        asm volatile("v_fma_f64 %0, %5, %6, %7\n\tv_add_f64 %1, %8, -%0\n\tv_fma_f64 %2, %5, %6, %1\n\t"     \
+                     "v_lshl_add_u64 %3, %0, 0, %3\n\tv_lshl_add_u64 %4, %2, 0, %4"                            \
+                     : "=&v"(hi_), "=&v"(t_), "=&v"(lo_), "+v"(acc[k]), "+v"(acc[(k + 4) & 7])                \
+                     : "v"(d[k]), "v"(d[(k + 1) & 7]), "v"(C1), "v"(C2));                                     \
+    }
+            REP8(X)
+#undef X
         } else if (OP == 11) {  // 64-bit add via add_co/addc pair on 8 accumulators
 #define X(k) asm volatile("v_add_co_u32 %0, vcc, %1, %0\n\tv_addc_co_u32 %2, vcc, %3, %2, vcc" : "+v"(x[k]), "+v"(a) : "v"(b), "v"(seed) : "vcc");
             REP8(X)
@@ -92,6 +133,49 @@ __global__ void __launch_bounds__(256) instr_kernel(unsigned* out, int iters, un
     for (int k = 0; k < 8; ++k) r ^= (unsigned)acc[k] ^ (unsigned)(acc[k] >> 32) ^ x[k] ^ (unsigned)d[k];
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
     if (blockIdx.x == 7 && threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+// exactness of the DPFP product: one 52 x 52-bit product per thread against the host's 128-bit integer product
+__global__ void dpfp_check(const unsigned long long* a, const unsigned long long* b, unsigned long long* hi, unsigned long long* lo) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    // MODE[3:2] (double / half rounding) = 3: toward zero
+    const double x = (double)a[t], y = (double)b[t];
+    const double C1 = 0x1.0p104, C2 = 0x1.0p104 + 0x1.0p52;
+    double h, tt, l;
+    // (the mode change is part of the same asm block: s_setreg needs wait states before a VALU instruction sees it,
+    // which the compiler cannot insert around opaque asm)
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3\n\ts_nop 7\n\t"
+                 "v_fma_f64 %0, %3, %4, %5\n\tv_add_f64 %1, %6, -%0\n\tv_fma_f64 %2, %3, %4, %1\n\t"
+                 "s_nop 7\n\ts_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0\n\ts_nop 7"
+                 : "=&v"(h), "=&v"(tt), "=&v"(l)
+                 : "v"(x), "v"(y), "v"(C1), "v"(C2));
+    hi[t] = (unsigned long long)__double_as_longlong(h) & 0xfffffffffffffull;
+    lo[t] = (unsigned long long)__double_as_longlong(l) & 0xfffffffffffffull;
+}
+static void run_dpfp_check() {
+    const int n = 1 << 16;
+    std::vector<unsigned long long> a(n), b(n), hi(n), lo(n);
+    unsigned long long s = 0x9e3779b97f4a7c15ull;
+    for (int i = 0; i < n; ++i) {
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17; a[i] = s & 0xfffffffffffffull;
+        s ^= s << 13; s ^= s >> 7; s ^= s << 17; b[i] = s & 0xfffffffffffffull;
+    }
+    a[0] = b[0] = 0xfffffffffffffull;
+    a[1] = 0; b[2] = 1;
+    unsigned long long *da, *db, *dh, *dl;
+    CK(hipMalloc(&da, n * 8)); CK(hipMalloc(&db, n * 8)); CK(hipMalloc(&dh, n * 8)); CK(hipMalloc(&dl, n * 8));
+    CK(hipMemcpy(da, a.data(), n * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, b.data(), n * 8, hipMemcpyHostToDevice));
+    dpfp_check<<<n / 256, 256>>>(da, db, dh, dl);
+    CK(hipMemcpy(hi.data(), dh, n * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(lo.data(), dl, n * 8, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+        const unsigned __int128 p = (unsigned __int128)a[i] * b[i];
+        if (hi[i] != (unsigned long long)(p >> 52) || lo[i] != ((unsigned long long)p & 0xfffffffffffffull)) ++bad;
+    }
+    printf("DPFP 52x52 product (2 x v_fma_f64 + v_add_f64, round toward zero): %d products, %d mismatches vs 128-bit integers\n", n, bad);
+    CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dh)); CK(hipFree(dl));
 }
 
 template <int OP>
@@ -125,6 +209,40 @@ static void run_instr(const char* name, int per_iter) {
 }
 
 // ---------------------------------------------------------------- multiplier throughput
+// ff28::mul with every product spelled as a SIGNED 32 x 32 multiply-add (limbs < 2^29: same value): does
+// v_mad_i64_i32 issue faster than v_mad_u64_u32?  (the instruction-rate table above says 4.75 vs 5.6 cycles)
+__device__ __host__ inline ff28::Fp28 mul28_signed(const ff28::Fp28& a, const ff28::Fp28& b) {
+    using namespace ff28;
+    u32 m[L];
+    Fp28 r;
+    long long acc = 0, acc2 = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) acc += (long long)(int)a.v[i] * (long long)(int)b.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; ++i) acc2 += (long long)(int)m[i] * (long long)(int)p28(k - i);
+        acc += acc2;
+        acc2 = 0;
+        m[k] = ((u32)acc * P0INV) & MASK;
+        acc += (long long)(int)m[k] * (long long)(int)p28(0);
+        acc = (long long)((u64)acc >> 28);
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; ++k) {
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) acc += (long long)(int)a.v[i] * (long long)(int)b.v[k - i];
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) acc2 += (long long)(int)m[i] * (long long)(int)p28(k - i);
+        acc += acc2;
+        acc2 = 0;
+        r.v[k - L] = (u32)acc & MASK;
+        acc = (long long)((u64)acc >> 28);
+    }
+    r.v[L - 1] = (u32)acc;
+    return r;
+}
+
 template <int V>
 __global__ void __launch_bounds__(256) mul_kernel(const Fp* in, Fp* out, int iters) {
     int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -151,13 +269,21 @@ __global__ void __launch_bounds__(256) mul_kernel(const Fp* in, Fp* out, int ite
         }
         out[2 * tid] = x;
         out[2 * tid + 1] = y;
+    } else if (V == 3) {
+        ff28::Fp28 a = ff28::from_sat(x), b = ff28::from_sat(y);
+        for (int i = 0; i < iters; ++i) {
+            a = mul28_signed(a, b);
+            b = mul28_signed(b, a);
+        }
+        out[2 * tid] = ff28::to_sat(a);
+        out[2 * tid + 1] = ff28::to_sat(b);
     }
 }
 
 static void host_ref(const Fp* in, Fp* out, int n, int iters, int V) {
     for (int t = 0; t < n; ++t) {
         Fp x = in[2 * t], y = in[2 * t + 1];
-        if (V == 1) {
+        if (V == 1 || V == 3) {
             ff28::Fp28 a = ff28::from_sat(x), b = ff28::from_sat(y);
             for (int i = 0; i < iters; ++i) {
                 a = ff28::mul(a, b);
@@ -238,8 +364,20 @@ int main() {
     run_instr<6>("v_lshrrev_b64", 16);
     run_instr<7>("v_add3_u32", 16);
     run_instr<9>("v_alignbit_b32", 16);
+    run_instr<16>("v_add_u32", 16);
+    run_instr<14>("v_fma_f32", 16);
+    run_instr<15>("v_pk_fma_f32", 16);
+    run_instr<12>("v_add_f64", 16);
+    run_instr<13>("v_lshl_add_u64", 16);
+    run_instr<18>("v_mad_i64_i32", 16);
+    run_instr<17>("DPFP product (5 instr) x8", 40);
+    run_dpfp_check();
+    printf("bit-products per instruction: v_mad_u64_u32 on 28-bit limbs 784; DPFP 52 x 52 in 5 instructions 541\n");
     run_mul<0>("fp mul 12x32 CIOS");
     run_mul<1>("fp mul 14x28 comba");
+    run_mul<3>("fp mul 14x28, signed mads");
+    run_mul<1>("fp mul 14x28 comba (again)");
+    run_mul<3>("fp mul 14x28, signed (again)");
     run_mul<2>("fp add+sub 12x32");
     return 0;
 }
