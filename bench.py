@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s s
 VALU_PEAK = 1024 * 2.4e9 / 4               # 1024 SIMDs x one wave64 VALU instruction per 4 cycles at the nominal 2.4 GHz
 ALG_BYTES_PER_COMMIT = 128 * N             # 96 B point + 32 B scalar per pair
 ALG_ADDS_PER_COMMIT = 20 * N + 8192        # BGMW count for the fixed-base 4096 case
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-PMC_FALLBACK = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+PMC_FALLBACK = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
 
 
 def load_pkg():
@@ -139,9 +139,18 @@ def reference_window(n):  # pippenger_window_size (kzg/src/msm/pippenger_utils.r
 
 
 def pmc_summary():
+    """The committed rocprofv3 PMC summary (tools/collect_round_profiles.sh + tools/summarize_profiles.py).  Hardware
+    counters cannot be read inside this process: rocprofv3 wraps a whole run, one counter group per pass, and serialises
+    the kernels.  The bench line therefore takes DURATIONS live (HIP events) and instruction / byte COUNTS per launch —
+    properties of the kernel binary and the workload, not of the box — from the profile run; every such field names the
+    file and the commit it was collected at."""
     for p in (PMC_SUMMARY, PMC_FALLBACK):
         try:
-            return json.load(open(p)), os.path.relpath(p, ROOT)
+            pm = json.load(open(p))
+            src = os.path.relpath(p, ROOT)
+            if pm.get("collected_at_commit"):
+                src += " (collected at commit %s)" % pm["collected_at_commit"]
+            return pm, src
         except Exception:
             continue
     return None, None
@@ -321,6 +330,10 @@ def main():
                            "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                            "traffic_source": pm_src if traffic is not None else None,
                            "kernel_ms": own_ms, "kernel_ms_in_timed_region_sharing_the_gpu": accum_ms,
+                           # what a launch costs the timed configuration: co-resident launches on the other streams fill
+                           # the issue slots a lone launch leaves idle, so this is below kernel_ms x launches
+                           "effective_ms_per_launch_in_timed_region": wall_max / args.steps * 1e3 / NB,
+                           "achieved_in_timed_region": alg_bytes / (wall_max / args.steps / NB) / 1e9,
                            "launches_per_step": NB, "pipeline_ms_per_launch": total_ms, "launches_averaged": cnt,
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "note": "MSM is integer-VALU bound, not HBM bound (SURVEY §8d); see `valu`. kernel_ms is one "
@@ -409,36 +422,47 @@ def main():
                                        "algorithmic_bytes_per_proof": ALG_BYTES_PER_COMMIT + 131120}
 
     if rank == 0 and not args.no_extras:
-        # ---- configs[3]: Fr NTT n = 4096 (batched) and n = 2^20, forward + DAS extension -------------------------
+        # ---- configs[3]: Fr NTT n = 4096 (batched) and n = 2^20, forward, inverse and the DAS extension of half -------
         fs = kzg.FFTSettings(20)
         ntt = {}
-        # HBM traffic of the NTT kernels from the committed PMC passes (tools/ntt_bench.py under rocprofv3; both bench
-        # shapes launch k_ntt_low with 256 tiles = grid 131072, the 2^20 transform adds one k_ntt_high launch)
-        npm = (pm or {}).get("ntt", {})
-        t_low = (npm.get("k_ntt_low<3> grid=131072") or {}).get("hbm_bytes_per_launch")
-        t_high = (npm.get("k_ntt_high<3> grid=131072") or {}).get("hbm_bytes_per_launch")
+        npm = (pm or {}).get("ntt", {})  # per transform call: HBM bytes and VALU instructions from the committed PMC passes
         for n, nb in ((4096, 256), (1 << 20, 1)):
             a = torch.randint(0, 2**31, (nb * n * 8,), dtype=torch.int32, device=dev)
             a[7::8] &= 0x3FFFFFFF  # any 256-bit pattern below r is a valid Montgomery residue
             b = torch.empty_like(a)
-            ms = ev_time(lambda: fs.fft_fr_device(b.data_ptr(), a.data_ptr(), n, nb, False, stream))
-            ms_inv = ev_time(lambda: fs.fft_fr_device(b.data_ptr(), a.data_ptr(), n, nb, True, stream))
+            ms = ev_time(lambda: fs.fft_fr_device(b.data_ptr(), a.data_ptr(), n, nb, False, stream), reps=9)
+            ms_inv = ev_time(lambda: fs.fft_fr_device(b.data_ptr(), a.data_ptr(), n, nb, True, stream), reps=9)
+            # DAS extension of the half-size lists (BASELINE configs[3]: "fft_fr + DAS extension"): two half-size transforms
+            h = n // 2
+            t = torch.empty(nb * h * 8, dtype=torch.int32, device=dev)
+            ms_das = ev_time(lambda: fs.das_fft_extension_device(b.data_ptr(), a.data_ptr(), t.data_ptr(), h, nb, stream), reps=9)
             alg = 64 * n * nb
             muls = nb * (n // 2) * int(math.log2(n))
-            ntt["n=%d x %d" % (n, nb)] = {
+            key = "n=%d x %d" % (n, nb)
+            pk = npm.get(key) or {}
+            winstr = pk.get("SQ_INSTS_VALU")
+            ntt[key] = {
                 "ms": ms, "ms_inverse": ms_inv, "transforms_per_s": nb / (ms * 1e-3), "fr_mul_per_s": muls / (ms * 1e-3),
-                "roofline": {"bound": "hbm", "kernel": "k_ntt_low" + ("+k_ntt_high" if n > 4096 else ""),
+                "das_extension": {"half_n": h, "lists": nb, "ms": ms_das, "algorithmic_bytes": 2 * 64 * h * nb,
+                                  "achieved_GBps": 2 * 64 * h * nb / (ms_das * 1e-3) / 1e9,
+                                  "path": "kzgamd_das_fft_extension_device: inverse + forward transform of half_n points, the "
+                                          "twist by the 2n-th roots and n^-1 in their last-pass multiplications"},
+                "roofline": {"bound": "hbm", "kernel": "k_ntt_pass" + (" x %d passes" % len(pk.get("passes", [0, 0])) if n > 4096 else ""),
                              "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "algorithmic_bytes": alg,
-                             "traffic": (t_low if n <= 4096 else (t_low + t_high if t_low and t_high else None)),
-                             "traffic_source": pm_src + " (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE, which the guide "
-                                               "calls uncalibrated for 32-byte stores; n = 2^20 crosses HBM twice: two passes)",
-                             "note": "64*n algorithmic bytes (SURVEY §8d). At ~270 VALU instructions per radix-2 butterfly "
-                                     "(9x29-bit Montgomery multiply + lazy add/sub) the transform needs "
-                                     "%.1f M wave-instructions: VALU floor %.0f us at the nominal clock"
-                                     % (muls * 270 / 64 / 1e6, muls * 270 / 64 / VALU_PEAK * 1e6)}}
-            del a, b
+                             "traffic": pk.get("hbm_bytes_per_call"),
+                             "traffic_source": (pm_src + " (FETCH_SIZE x2 per the gfx950 note + WRITE_SIZE; n = 2^20 crosses HBM "
+                                                "twice: two passes)") if pk.get("hbm_bytes_per_call") else None,
+                             "note": "64*n algorithmic bytes (SURVEY §8d); the transform is VALU-issue bound, see `valu`"},
+                "valu": None if not winstr else {
+                    "bound": "VALU issue", "achieved": winstr / (ms * 1e-3), "peak": VALU_PEAK, "unit": "VALU wave-instructions/s",
+                    "frac": winstr / (ms * 1e-3) / VALU_PEAK, "wave_instructions_per_call": winstr,
+                    "instructions_per_butterfly": winstr * 64 / muls,
+                    "floor_us_at_nominal_clock": winstr / VALU_PEAK * 1e6,
+                    "busy_frac_at_sustained_clock": pk.get("valu_busy_frac"), "scratch_bytes_per_lane": pk.get("scratch", 0),
+                    "source": "instruction count and busy fraction: %s; duration: live HIP events" % pm_src}}
+            del a, b, t
         res["ntt"] = ntt
         fs.close()
 
@@ -466,7 +490,9 @@ def main():
                           "kernel_window_bits": hi["window_bits"],
                           "roofline": {"bound": "hbm", "kernel": "k_accum (+ sort and reduction kernels)", "achieved": gbs,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                       "algorithmic_bytes": 128 * n, "traffic": None}})
+                                       "algorithmic_bytes": 128 * n,
+                                       "traffic": ((pm or {}).get("msm_sweep", {}).get(str(n)) or {}).get("hbm_bytes_per_call"),
+                                       "traffic_source": pm_src if ((pm or {}).get("msm_sweep", {}).get(str(n))) else None}})
             if logn == 20:
                 res["msm_2p20_ms"] = ms
                 res["msm_2p20_pairs_per_s"] = n / (ms * 1e-3)
@@ -496,6 +522,25 @@ def main():
         res["pcie_inclusive_proofs_per_s"] = 2 * nb / (time.perf_counter() - t0)
 
     if rank == 0 and world == 1 and not args.no_extras:
+        # ---- the reference's concurrency pattern (kzg/src/eip_4844.rs:781-805): native threads sharing one settings
+        # object, single-blob calls (tools/concurrent_bench, built by __graft_entry__.build())
+        cb = os.path.join(ROOT, "tools", "concurrent_bench")
+        if os.path.exists(cb):
+            try:
+                # its table next to this process's 137 GB one: capped so that both fit
+                env = dict(os.environ, KZGAMD_FBW_MAX_GB="100", LD_LIBRARY_PATH=os.path.join(ROOT, "rust-kzg_amd", "csrc") + ":" + os.environ.get("LD_LIBRARY_PATH", "") + ":/opt/rocm/lib")
+                o16 = json.loads(subprocess.run([cb, SETUP, "0.8", "16"], stdout=subprocess.PIPE, env=env, timeout=120).stdout.decode().strip().splitlines()[-1])
+                o1 = json.loads(subprocess.run([cb, SETUP, "0.5", "1"], stdout=subprocess.PIPE, env=env, timeout=120).stdout.decode().strip().splitlines()[-1])
+                res["concurrent_callers"] = {
+                    "threads_16": {"blob_to_kzg_commitment_per_s": o16.get("commit_threads_16"), "compute_blob_kzg_proof_per_s": o16.get("proof_threads_16")},
+                    "threads_1": {"blob_to_kzg_commitment_per_s": o1.get("commit_threads_1"), "compute_blob_kzg_proof_per_s": o1.get("proof_threads_1")},
+                    "path": "native threads, one CKZGSettings, host buffers; calls are merged into batches on up to three lanes "
+                            "(own process: its settings object is loaded next to this one)"}
+            except Exception as e:  # noqa: BLE001
+                res["concurrent_callers"] = {"error": repr(e)}
+
+
+    if rank == 0 and world == 1 and not args.no_extras:
         # ---- EIP-7594 cell proofs, 256 blobs per call (FK20 on the GPU), host buffers in and out
         ncell = min(256, B * NB)
         hbc = blobs[:ncell].cpu().numpy().tobytes()
@@ -517,6 +562,34 @@ def main():
                                        "path": "kzgamd_compute_cells_and_kzg_proofs_batch: 128 cells + 128 cell proofs per blob, "
                                                "FK20 (64 NTTs of 128, 128 MSMs of 64 points, two G1 transforms of 128)"}
         del hbc
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- EIP-7594 recovery and cell verification, one blob, host buffers -----------------------
+        blob1 = blobs[:1].cpu().numpy().tobytes()
+        cells1, proofs1 = kzg.compute_cells_and_kzg_proofs(blob1, settings)
+        cm1 = kzg.blob_to_kzg_commitment(blob1, settings)
+        half = list(range(0, 128, 2))
+        part = b"".join(cells1[2048 * i:2048 * (i + 1)] for i in half)
+        rc_, rp_ = kzg.recover_cells_and_kzg_proofs(half, part, settings)
+        assert rc_ == cells1 and rp_ == proofs1
+        t0 = time.perf_counter()
+        for _ in range(3):
+            kzg.recover_cells_and_kzg_proofs(half, part, settings)
+        t_rec = (time.perf_counter() - t0) / 3
+        t0 = time.perf_counter()
+        for _ in range(3):
+            kzg.recover_cells_and_kzg_proofs(half, part, settings, want_proofs=False)
+        t_rec_cells = (time.perf_counter() - t0) / 3
+        allidx = list(range(128))
+        assert kzg.verify_cell_kzg_proof_batch(cm1 * 128, allidx, cells1, proofs1, settings)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            kzg.verify_cell_kzg_proof_batch(cm1 * 128, allidx, cells1, proofs1, settings)
+        t_ver = (time.perf_counter() - t0) / 3
+        res["eip7594"] = {"recover_cells_and_kzg_proofs_ms": t_rec * 1e3, "recover_cells_only_ms": t_rec_cells * 1e3,
+                          "verify_cell_kzg_proof_batch_128_cells_ms": t_ver * 1e3,
+                          "path": "64 of 128 cells -> all cells (five 8192-point transforms on the GPU) + 128 proofs (direct "
+                                  "form); verification: decode + subgroup checks + one two-row MSM on the GPU, pairing on the host"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ns = min(B, 64)

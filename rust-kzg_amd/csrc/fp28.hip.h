@@ -139,6 +139,17 @@ FF_HD Fe neg(const Fe& a) {
     return r;
 }
 
+// -DFP28_ONE_CHAIN: every column on ONE accumulator chain.  The empty asm after a multiply-add makes its result
+// opaque, so the compiler cannot re-associate a column into several chains (each merge is a 64-bit addition,
+// 4.4 issue cycles); the multiply-add is still selected as one v_mad_u64_u32.
+FF_HD void chain_step(u64& acc) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(FP28_ONE_CHAIN)
+    asm("" : "+v"(acc));
+#else
+    (void)acc;
+#endif
+}
+
 // a*b*2^-392 mod p.  Product scanning with the Montgomery quotient digits
 // folded into the same column accumulators; two accumulators keep two mad
 // chains in flight.
@@ -148,24 +159,48 @@ FF_HD Fe mul_inline(const Fe& a, const Fe& b) {
     u64 acc = 0;
 #pragma unroll
     for (int k = 0; k < L; ++k) {
+#if defined(FP28_ONE_CHAIN)
+        u64& acc2 = acc;
+#else
         u64 acc2 = 0;
+#endif
 #pragma unroll
-        for (int i = 0; i <= k; ++i) acc += (u64)a.v[i] * b.v[k - i];
+        for (int i = 0; i <= k; ++i) {
+            acc += (u64)a.v[i] * b.v[k - i];
+            chain_step(acc);
+        }
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc2 += (u64)m[i] * pl(k - i);
+        for (int i = 0; i < k; ++i) {
+            acc2 += (u64)m[i] * pl(k - i);
+            chain_step(acc2);
+        }
+#if !defined(FP28_ONE_CHAIN)
         acc += acc2;
+#endif
         m[k] = ((u32)acc * P0INV) & MASK;
         acc += (u64)m[k] * pl(0);
         acc >>= 28;
     }
 #pragma unroll
     for (int k = L; k < 2 * L - 1; ++k) {
+#if defined(FP28_ONE_CHAIN)
+        u64& acc2 = acc;
+#else
         u64 acc2 = 0;
+#endif
 #pragma unroll
-        for (int i = k - L + 1; i < L; ++i) acc += (u64)a.v[i] * b.v[k - i];
+        for (int i = k - L + 1; i < L; ++i) {
+            acc += (u64)a.v[i] * b.v[k - i];
+            chain_step(acc);
+        }
 #pragma unroll
-        for (int i = k - L + 1; i < L; ++i) acc2 += (u64)m[i] * pl(k - i);
+        for (int i = k - L + 1; i < L; ++i) {
+            acc2 += (u64)m[i] * pl(k - i);
+            chain_step(acc2);
+        }
+#if !defined(FP28_ONE_CHAIN)
         acc += acc2;
+#endif
         r.v[k - L] = (u32)acc & MASK;
         acc >>= 28;
     }
@@ -182,26 +217,56 @@ FF_HD Fe sqr_inline(const Fe& a) {
     u64 acc = 0;
 #pragma unroll
     for (int k = 0; k < L; ++k) {
+#if defined(FP28_ONE_CHAIN)
+        u64& acc2 = acc;
+#else
         u64 acc2 = 0;
+#endif
 #pragma unroll
-        for (int i = 0; 2 * i < k; ++i) acc += (u64)a2[i] * a.v[k - i];
-        if ((k & 1) == 0) acc += (u64)a.v[k / 2] * a.v[k / 2];
+        for (int i = 0; 2 * i < k; ++i) {
+            acc += (u64)a2[i] * a.v[k - i];
+            chain_step(acc);
+        }
+        if ((k & 1) == 0) {
+            acc += (u64)a.v[k / 2] * a.v[k / 2];
+            chain_step(acc);
+        }
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc2 += (u64)m[i] * pl(k - i);
+        for (int i = 0; i < k; ++i) {
+            acc2 += (u64)m[i] * pl(k - i);
+            chain_step(acc2);
+        }
+#if !defined(FP28_ONE_CHAIN)
         acc += acc2;
+#endif
         m[k] = ((u32)acc * P0INV) & MASK;
         acc += (u64)m[k] * pl(0);
         acc >>= 28;
     }
 #pragma unroll
     for (int k = L; k < 2 * L - 1; ++k) {
+#if defined(FP28_ONE_CHAIN)
+        u64& acc2 = acc;
+#else
         u64 acc2 = 0;
+#endif
 #pragma unroll
-        for (int i = k - L + 1; 2 * i < k; ++i) acc += (u64)a2[i] * a.v[k - i];
-        if ((k & 1) == 0) acc += (u64)a.v[k / 2] * a.v[k / 2];
+        for (int i = k - L + 1; 2 * i < k; ++i) {
+            acc += (u64)a2[i] * a.v[k - i];
+            chain_step(acc);
+        }
+        if ((k & 1) == 0) {
+            acc += (u64)a.v[k / 2] * a.v[k / 2];
+            chain_step(acc);
+        }
 #pragma unroll
-        for (int i = k - L + 1; i < L; ++i) acc2 += (u64)m[i] * pl(k - i);
+        for (int i = k - L + 1; i < L; ++i) {
+            acc2 += (u64)m[i] * pl(k - i);
+            chain_step(acc2);
+        }
+#if !defined(FP28_ONE_CHAIN)
         acc += acc2;
+#endif
         r.v[k - L] = (u32)acc & MASK;
         acc >>= 28;
     }

@@ -156,7 +156,7 @@ struct TileGeo {
 // (measurement variants, KZGAMD_NTT_VARIANT at kzgamd_ntt_new; all three give the same bits).
 template <int KIND, int V, bool FIRST, bool LAST>
 __device__ __forceinline__ void ntt_round(u32* sh, Fr* __restrict__ out, const Fr* __restrict__ in, const PassParams& P,
-                                          const TileGeo<KIND>& G, int r, u32 tid) {
+                                          const TileGeo<KIND>& G, int r, const uint2 te) {
 #define KZG_BF(K0, K1, W)                                      \
     {                                                          \
         if constexpr (V == 0) {                                \
@@ -181,7 +181,6 @@ __device__ __forceinline__ void ntt_round(u32* sh, Fr* __restrict__ out, const F
         fr29::butterfly_lazy8(e[K0], e[K1], y_);         \
     }
     const RoundDev rd = P.rd[r];
-    const uint2 te = P.tab[r * NT + tid];
     const u32 iA = te.x & 0xffffu, iB = te.x >> 16, sA = te.y & 0xffffu, sB = te.y >> 16;
     Fe e[4];
     if constexpr (FIRST) {
@@ -280,9 +279,16 @@ __global__ void __launch_bounds__(NT) k_ntt_pass(Fr* __restrict__ out, const Fr*
     const u32 tid = threadIdx.x;
     const TileGeo<KIND> G(P);
     const int n = P.nrounds;  // >= 2 (ntt_plan.h)
-    ntt_round<KIND, V, true, false>(sh, out, in, P, G, 0, tid);
-    for (int r = 1; r < n - 1; ++r) ntt_round<KIND, V, false, false>(sh, out, in, P, G, r, tid);
-    ntt_round<KIND, V, false, true>(sh, out, in, P, G, n - 1, tid);
+    // a round's table entry is fetched one round ahead: the round starts with its LDS reads and twiddle loads, not
+    // with a dependent global load
+    uint2 te = P.tab[tid], nx = P.tab[NT + tid];
+    ntt_round<KIND, V, true, false>(sh, out, in, P, G, 0, te);
+    for (int r = 1; r < n - 1; ++r) {
+        te = nx;
+        nx = P.tab[(r + 1) * NT + tid];
+        ntt_round<KIND, V, false, false>(sh, out, in, P, G, r, te);
+    }
+    ntt_round<KIND, V, false, true>(sh, out, in, P, G, n - 1, nx);
 }
 
 }  // namespace

@@ -209,35 +209,37 @@ static void run_instr(const char* name, int per_iter) {
 }
 
 // ---------------------------------------------------------------- multiplier throughput
-// ff28::mul with every product spelled as a SIGNED 32 x 32 multiply-add (limbs < 2^29: same value): does
-// v_mad_i64_i32 issue faster than v_mad_u64_u32?  (the instruction-rate table above says 4.75 vs 5.6 cycles)
+__device__ __host__ inline void chain_step(unsigned long long& acc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(acc));
+#endif
+}
+// ff28::mul on ONE accumulator chain: the empty asm after every multiply-add keeps the compiler from re-associating
+// a column into several chains (each merge is a 64-bit addition, 4.4 cycles)
 __device__ __host__ inline ff28::Fp28 mul28_signed(const ff28::Fp28& a, const ff28::Fp28& b) {
     using namespace ff28;
     u32 m[L];
     Fp28 r;
-    long long acc = 0, acc2 = 0;
+    unsigned long long acc = 0;
 #pragma unroll
     for (int k = 0; k < L; ++k) {
 #pragma unroll
-        for (int i = 0; i <= k; ++i) acc += (long long)(int)a.v[i] * (long long)(int)b.v[k - i];
+        for (int i = 0; i <= k; ++i) { acc += (unsigned long long)a.v[i] * b.v[k - i]; chain_step(acc); }
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc2 += (long long)(int)m[i] * (long long)(int)p28(k - i);
-        acc += acc2;
-        acc2 = 0;
+        for (int i = 0; i < k; ++i) { acc += (unsigned long long)m[i] * p28(k - i); chain_step(acc); }
         m[k] = ((u32)acc * P0INV) & MASK;
-        acc += (long long)(int)m[k] * (long long)(int)p28(0);
-        acc = (long long)((u64)acc >> 28);
+        acc += (unsigned long long)m[k] * p28(0);
+        chain_step(acc);
+        acc >>= 28;
     }
 #pragma unroll
     for (int k = L; k < 2 * L - 1; ++k) {
 #pragma unroll
-        for (int i = k - L + 1; i < L; ++i) acc += (long long)(int)a.v[i] * (long long)(int)b.v[k - i];
+        for (int i = k - L + 1; i < L; ++i) { acc += (unsigned long long)a.v[i] * b.v[k - i]; chain_step(acc); }
 #pragma unroll
-        for (int i = k - L + 1; i < L; ++i) acc2 += (long long)(int)m[i] * (long long)(int)p28(k - i);
-        acc += acc2;
-        acc2 = 0;
+        for (int i = k - L + 1; i < L; ++i) { acc += (unsigned long long)m[i] * p28(k - i); chain_step(acc); }
         r.v[k - L] = (u32)acc & MASK;
-        acc = (long long)((u64)acc >> 28);
+        acc >>= 28;
     }
     r.v[L - 1] = (u32)acc;
     return r;
@@ -375,9 +377,9 @@ int main() {
     printf("bit-products per instruction: v_mad_u64_u32 on 28-bit limbs 784; DPFP 52 x 52 in 5 instructions 541\n");
     run_mul<0>("fp mul 12x32 CIOS");
     run_mul<1>("fp mul 14x28 comba");
-    run_mul<3>("fp mul 14x28, signed mads");
+    run_mul<3>("fp mul 14x28, one chain");
     run_mul<1>("fp mul 14x28 comba (again)");
-    run_mul<3>("fp mul 14x28, signed (again)");
+    run_mul<3>("fp mul 14x28, one chain (again)");
     run_mul<2>("fp add+sub 12x32");
     return 0;
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the raw rocprofv3 output tools/collect_round_profiles.sh left under gpurun_out/ into the committed
-summaries under profiles/ (round tag r02): bench line, kernel statistics (headline 4-stream run, 1-stream run, NTT,
+summaries under profiles/ (round tag TAG, default r03): bench line, kernel statistics (headline 4-stream run, 1-stream run, NTT,
 2^20 MSM timeline), the PMC counter files and r02_pmc_summary.json (what bench.py reads for roofline.traffic and
 the VALU figures, labelled with this file as their source)."""
 import collections
@@ -11,7 +11,7 @@ import os
 import shutil
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r02"
+TAG = os.environ.get("TAG", "r03")
 G = os.path.join(R, "gpurun_out")
 P = os.path.join(R, "profiles")
 
@@ -64,13 +64,13 @@ def main():
     shutil.copy(os.path.join(G, "bench_final.json"), os.path.join(P, TAG + "_bench.json"))
     B = bench["config"]["blobs_per_batch"]
     cfg = bench["config"]
-    for name in ("headline", "streams1", "ntt", "2p20", "cells"):
+    for name in ("headline", "streams1", "ntt", "2p20", "cells", "proofs"):
         d = os.path.join(G, "prof_" + name)
-        if os.path.exists(os.path.join(d, "r02_kernel_stats.csv")):
-            shutil.copy(os.path.join(d, "r02_kernel_stats.csv"), os.path.join(P, "%s_%s_kernel_stats.csv" % (TAG, name)))
-            by_grid(os.path.join(d, "r02_kernel_trace.csv"), os.path.join(P, "%s_%s_kernel_stats_by_grid.csv" % (TAG, name)))
+        if os.path.exists(os.path.join(d, TAG + "_kernel_stats.csv")):
+            shutil.copy(os.path.join(d, TAG + "_kernel_stats.csv"), os.path.join(P, "%s_%s_kernel_stats.csv" % (TAG, name)))
+            by_grid(os.path.join(d, TAG + "_kernel_trace.csv"), os.path.join(P, "%s_%s_kernel_stats_by_grid.csv" % (TAG, name)))
     # ---- headline kernel ----
-    fbw = {k: v for k, v in counters("pmc_[!n]*", "fbw_accum").items()}
+    fbw = {k: v for k, v in counters("pmc_[FWSG]*", "fbw_accum").items()}
     name = max(fbw, key=lambda k: fbw[k].get("SQ_INSTS_VALU", {}).get("avg", 0))
     ka = fbw[name]
     fetch_kb, write_kb = ka["FETCH_SIZE"]["avg"], ka["WRITE_SIZE"]["avg"]
@@ -101,24 +101,71 @@ def main():
         k["valu_busy_frac"] = k["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * xcd_cycles)
         k["valu_note"] = ("valu_busy_frac = SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): share of the "
                           "kernel's cycles in which a SIMD's VALU is executing, at the clock the chip sustained under this load")
-    # ---- NTT kernels ----
-    ntt = counters("pmc_ntt_*", "ntt")
-    nd = durations("pmc_ntt_GRBM_GUI_ACTIVE", "ntt")
-    for key, v in ntt.items():
-        e = {cn: x["avg"] for cn, x in v.items()}
+    # ---- NTT: per bench shape, summed over the passes of one transform call (tools/ntt_bench.py runs 11 calls) ----
+    def per_call(pattern, match, calls):
+        """counter totals over every dispatch of `match` kernels in the run, divided by the number of calls"""
+        tot = collections.defaultdict(float)
+        launches = collections.Counter()
+        meta = {}
+        for d in sorted(glob.glob(os.path.join(G, pattern))):
+            for f in glob.glob(os.path.join(d, TAG + "_counter_collection.csv")):
+                seen = set()
+                for row in csv.DictReader(open(f)):
+                    if match in row["Kernel_Name"]:
+                        tot[row["Counter_Name"]] += float(row["Counter_Value"])
+                        seen.add(row["Dispatch_Id"])
+                        meta = {"vgpr": row.get("VGPR_Count"), "scratch": int(float(row.get("Scratch_Size") or 0))}
+                for cn in set(r_["Counter_Name"] for r_ in csv.DictReader(open(f)) if match in r_["Kernel_Name"]):
+                    launches[cn] = len(seen)
+                shutil.copy(f, os.path.join(P, "%s_%s_counter_collection.csv" % (TAG, os.path.basename(d))))
+        e = {cn: v / calls for cn, v in tot.items()}
+        e["launches_per_call"] = (max(launches.values()) / calls) if launches else 0
+        e.update(meta)
+        return e
+
+    def per_call_duration(dirname, match, calls):
+        ds = []
+        for f in glob.glob(os.path.join(G, dirname, TAG + "_kernel_trace.csv")):
+            for row in csv.DictReader(open(f)):
+                if match in row["Kernel_Name"]:
+                    ds.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        return sum(ds) / calls * 1e-9 if ds else None
+
+    for shape, key in (("4096x256", "n=4096 x 256"), ("1048576x1", "n=1048576 x 1")):
+        e = per_call("pmc_ntt_%s_*" % shape, "k_ntt_pass", 11)
+        if not e.get("SQ_INSTS_VALU"):
+            continue
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
-            e["hbm_bytes_per_launch"] = e["FETCH_SIZE"] * 1024 * 2 + e["WRITE_SIZE"] * 1024
-        if key in nd and "GRBM_GUI_ACTIVE" in e and "SQ_ACTIVE_INST_VALU" in e:
-            dur_s = sum(nd[key]) / len(nd[key]) * 1e-9
-            e["kernel_s_in_grbm_pass"] = dur_s
-            e["effective_clock_ghz"] = e["GRBM_GUI_ACTIVE"] / 8 / dur_s / 1e9
+            e["hbm_bytes_per_call"] = e["FETCH_SIZE"] * 1024 * 2 + e["WRITE_SIZE"] * 1024
+        dur = per_call_duration("pmc_ntt_%s_GRBM_GUI_ACTIVE" % shape, "k_ntt_pass", 11)
+        if dur and "GRBM_GUI_ACTIVE" in e:
+            e["kernel_s_per_call_in_grbm_pass"] = dur
+            e["effective_clock_ghz"] = e["GRBM_GUI_ACTIVE"] / 8 / dur / 1e9
             e["valu_busy_frac"] = e["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * e["GRBM_GUI_ACTIVE"] / 8)
         summary.setdefault("ntt", {})[key] = e
+    # ---- one 2^20 variable-base MSM (4 calls per run): every kernel of the call together ----
+    e = per_call("pmc_2p20_*", "k_", 4)
+    # k_gen_points (the one-off point generator of the tool) is not part of the MSM
+    g = per_call("pmc_2p20_*", "k_gen_points", 4)
+    pi = per_call("pmc_2p20_*", "k_points_in", 4)
+    for cn in list(e):
+        if isinstance(e[cn], float):
+            e[cn] -= g.get(cn, 0.0) + pi.get(cn, 0.0)
+    if e.get("SQ_INSTS_VALU"):
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            e["hbm_bytes_per_call"] = e["FETCH_SIZE"] * 1024 * 2 + e["WRITE_SIZE"] * 1024
+        e["note"] = "all kernels of one n = 2^20 MSM call (sort, accumulation, reduction); algorithmic bytes 128 * n = 134 MB"
+        summary.setdefault("msm_sweep", {})[str(1 << 20)] = e
+    try:
+        import subprocess
+        summary["collected_at_commit"] = subprocess.check_output(["git", "-C", R, "rev-parse", "--short", "HEAD"]).decode().strip()
+    except Exception:
+        pass
     json.dump(summary, open(os.path.join(P, TAG + "_pmc_summary.json"), "w"), indent=1)
     print("k_fbw_accum: hbm bytes/launch %.3e  VALU/add %.0f  busy %.3f  clock %.2f GHz" % (
         k["hbm_bytes_per_launch"], k["valu_instructions_per_mixed_add"], k.get("valu_busy_frac", 0), k.get("effective_clock_ghz", 0)))
     for key, e in summary.get("ntt", {}).items():
-        print(key, {x: (round(y, 3) if y < 100 else int(y)) for x, y in e.items() if x in ("valu_busy_frac", "hbm_bytes_per_launch", "kernel_s_in_grbm_pass", "SQ_LDS_BANK_CONFLICT")})
+        print(key, {x: (round(y, 3) if y < 100 else int(y)) for x, y in e.items() if x in ("valu_busy_frac", "hbm_bytes_per_call", "kernel_s_per_call_in_grbm_pass", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VALU")})
 
 
 if __name__ == "__main__":
