@@ -2595,7 +2595,7 @@ extern "C" RustError mult_pippenger(blst_p1* out, const blst_p1_affine points[],
             return;
         }
         // bases outside G1 are legal input here: the membership test where it costs less than the split saves
-        // (a 1.8 ms latency chain up to ~2^16 points, 14 ms at 2^20), the unsplit engine beyond
+        // (a 1.8 ms latency chain up to ~2^16 points, 22 ms at 2^20), the unsplit engine beyond
         MsmContext* ctx = kzgamd::msm_create(points, npoints, false, false, false,
                                              npoints <= ((size_t)1 << 15) ? kzgamd::G1_CHECK : kzgamd::G1_NO_SPLIT);
         try {
