@@ -1003,6 +1003,17 @@ KzgAmdSettings* make_lane(KzgAmdSettings* parent) {
     CK_HIP(hipStreamCreateWithFlags(&ln->stream, hipStreamNonBlocking));
     ln->stream2 = ln->stream;
     ln->msm = parent->msm;
+    // the MSM workspace of this lane's stream, sized now for every batch size a lane runs: no call on a lane allocates
+    for (size_t nb = KzgAmdSettings::LANE_MAX_BLOBS; nb >= 1; --nb) {
+        kzgamd::msm_lock(parent->msm);
+        try {
+            kzgamd::msm_enqueue(parent->msm, nullptr, nullptr, N, nb, 0, ln->stream, kzgamd::OUT_COMPRESSED, true);
+        } catch (...) {
+            kzgamd::msm_unlock(parent->msm);
+            throw;
+        }
+        kzgamd::msm_unlock(parent->msm);
+    }
     ln->d_brp_roots = parent->d_brp_roots;
     ln->brp_roots = parent->brp_roots;
     ln->busy.store(true);
@@ -1023,11 +1034,9 @@ struct LaneRef {
             flagged = !dev->busy.exchange(true);
             return;
         }
+        // small calls run on lanes (their streams have MSM workspaces of their own: no cross-stream events per enqueue);
+        // the parent stays free for large batches
         bool expect = false;
-        if (dev->busy.compare_exchange_strong(expect, true)) {
-            flagged = true;
-            return;
-        }
         std::lock_guard<std::mutex> lk(dev->lanes_mu);
         for (auto& ln : dev->lanes) {
             expect = false;
@@ -1925,17 +1934,22 @@ void commit_lane_batch(KzgAmdSettings* dev, const std::vector<CommitReq*>& reqs)
     std::lock_guard<std::mutex> lk(dev->mu);
     kzgamd::DeviceGuard on_device(dev->device);
     CK_HIP(on_device.err);
-    dev->ensure(n < 4 ? 4 : KzgAmdSettings::LANE_MAX_BLOBS);
+    dev->ensure(KzgAmdSettings::LANE_MAX_BLOBS);
     dev->ensure_pinned();
     const bool host_compress = n <= HOST_COMPRESS_MAX;
     for (size_t i = 0; i < n; ++i) memcpy(dev->h_in + i * BYTES_PER_BLOB, reqs[i]->blob, BYTES_PER_BLOB);
-    CK_HIP(hipMemcpyAsync(dev->d_blobs, dev->h_in, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream));
-    commit_enqueue(dev, dev->d_out, dev->d_status, dev->d_blobs, dev->d_scalars, n, dev->stream,
-                   host_compress ? kzgamd::OUT_JACOBIAN : kzgamd::OUT_COMPRESSED);
     int* hs = reinterpret_cast<int*>(dev->h_res);
     unsigned char* ho = dev->h_res + KzgAmdSettings::LANE_MAX_BLOBS * sizeof(int);
-    CK_HIP(hipMemcpyAsync(hs, dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
-    CK_HIP(hipMemcpyAsync(ho, dev->d_out, n * (host_compress ? 144 : 48), hipMemcpyDeviceToHost, dev->stream));
+    auto enqueue_all = [&] {
+        CK_HIP(hipMemcpyAsync(dev->d_blobs, dev->h_in, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream));
+        commit_enqueue(dev, dev->d_out, dev->d_status, dev->d_blobs, dev->d_scalars, n, dev->stream,
+                       host_compress ? kzgamd::OUT_JACOBIAN : kzgamd::OUT_COMPRESSED);
+        CK_HIP(hipMemcpyAsync(hs, dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
+        CK_HIP(hipMemcpyAsync(ho, dev->d_out, n * (host_compress ? 144 : 48), hipMemcpyDeviceToHost, dev->stream));
+    };
+    // (Replaying this sequence as one captured graph per batch size was measured: 19.4 k vs 18.9 k commitments/s at 16
+    // threads, 3 991 vs 4 040 /s for one — nothing; the call-by-call form stays.  DESIGN.md §9.)
+    enqueue_all();
     CK_HIP(hipStreamSynchronize(dev->stream));
     for (size_t i = 0; i < n; ++i) {
         if (hs[i] != 0) {

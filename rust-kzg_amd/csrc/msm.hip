@@ -2006,6 +2006,10 @@ void msm_destroy(MsmContext* ctx) {
 }
 int msm_device(MsmContext* ctx) { return ctx->device; }
 bool msm_has_wide_table(MsmContext* ctx) { return ctx->fbw; }
+bool msm_private_workspace(MsmContext* ctx, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return &ctx->workspace_for(stream) != &ctx->ws;
+}
 
 // 48-byte compressed form of `count` XYZZ points (device pointers), batched inversion per 64 points
 void g1_compress_xyzz(void* d_out48, const void* d_xyzz, size_t count, hipStream_t stream) {
@@ -2039,13 +2043,17 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     Workspace& ws = ctx->workspace_for(stream);
     // Workspaces are per stream, but streams can outnumber them (and the handle's own stream shares the first one):
     // whoever gets a workspace last used on another stream first waits for that use to finish on the GPU.
+    // a workspace that only one stream ever uses (every entry of ws_extra) is ordered by that stream: no events —
+    // two runtime calls less per enqueue, and such an enqueue can be captured into a graph
     struct WsUse {
         Workspace& w;
         hipStream_t st;
-        WsUse(Workspace& w_, hipStream_t st_) : w(w_), st(st_) {
-            if (w.last_done && w.last_stream != st) (void)hipStreamWaitEvent(st, w.last_done, 0);
+        bool shared;
+        WsUse(Workspace& w_, hipStream_t st_, bool shared_) : w(w_), st(st_), shared(shared_) {
+            if (shared && w.last_done && w.last_stream != st) (void)hipStreamWaitEvent(st, w.last_done, 0);
         }
         ~WsUse() {
+            if (!shared) return;
             if (!w.last_done && hipEventCreateWithFlags(&w.last_done, hipEventDisableTiming) != hipSuccess) w.last_done = nullptr;
             if (w.last_done) (void)hipEventRecord(w.last_done, st);
             w.last_stream = st;
@@ -2076,7 +2084,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         }
         if (ctx->fbw_glv) ws.digits.ensure(nbatch * npoints * 2 * (size_t)((nwin + 3) & ~3));
         if (reserve_only) return;
-        WsUse ws_use(ws, stream);
+        WsUse ws_use(ws, stream, &ws == &ctx->ws);
         DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n, 0, 0, nwin, (u32)nseg};
         hipEvent_t* pev = nullptr;
         if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
@@ -2255,7 +2263,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         }
     }
     if (reserve_only) return;
-    WsUse ws_use(ws, stream);
+    WsUse ws_use(ws, stream, &ws == &ctx->ws);
     hipEvent_t* pev = nullptr;
     if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
         while (ctx->ev.size() < ctx->ev_used + 4) {

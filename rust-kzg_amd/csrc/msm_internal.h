@@ -25,6 +25,9 @@ void msm_reset_points(MsmContext* ctx, const void* d_affpts, size_t n);
 void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npoints, size_t nbatch, int mont,
                  hipStream_t stream, int out_mode, bool reserve_only = false, size_t nseg = 0);
 bool msm_has_wide_table(MsmContext* ctx);
+// true when `stream` has a workspace of its own on this handle (created if there is room): its enqueues use no events
+// and may be captured into a graph
+bool msm_private_workspace(MsmContext* ctx, hipStream_t stream);
 // 48-byte compressed form of `count` g1::Xyzz points (device pointers)
 void g1_compress_xyzz(void* d_out48, const void* d_xyzz, size_t count, hipStream_t stream);
 int msm_device(MsmContext* ctx);
