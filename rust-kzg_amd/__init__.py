@@ -60,7 +60,7 @@ EXPORTS = [
     "prepare_msm", "mult_pippenger_prepared", "mult_pippenger", "free_msm", "mult_pippenger_prepared_batch",
     "kzgamd_msm_prepared_batch_device", "kzgamd_msm_info", "kzgamd_msm_uses_wide_table", "kzgamd_msm_set_profile", "kzgamd_msm_get_profile",
     "kzgamd_device_count", "kzgamd_version", "kzgamd_msm_create_device", "kzgamd_generate_points",
-    "kzgamd_ntt_new", "kzgamd_ntt_free", "ntt_fr", "das_fft_extension", "kzgamd_ntt_fr_device", "kzgamd_ntt_roots", "kzgamd_ntt_plan_dump", "kzgamd_das_fft_extension_device",
+    "kzgamd_ntt_new", "kzgamd_ntt_free", "ntt_fr", "das_fft_extension", "kzgamd_ntt_fr_device", "kzgamd_ntt_roots", "kzgamd_ntt_plan_dump", "kzgamd_ntt_das_plan_dump", "kzgamd_das_fft_extension_device",
     "fft_g1", "kzgamd_fft_g1_batch", "kzgamd_g1_sum",
     "load_trusted_setup", "load_trusted_setup_file", "free_trusted_setup", "blob_to_kzg_commitment",
     "compute_kzg_proof", "compute_blob_kzg_proof", "kzgamd_compute_blob_kzg_proof_batch", "compute_challenge",

@@ -112,6 +112,40 @@ __global__ void __launch_bounds__(256) k_blob_to_scalars(u32* __restrict__ out, 
 
 
 
+// The blobs of a lane batch stay where their callers staged them (page-locked host memory, one slot per caller): the
+// kernels that read raw blob bytes take one pointer per blob and fetch them over PCIe themselves — no host-side
+// gathering into one buffer, no copy operation on the stream.
+struct BlobPtrs {
+    const u32* p[16];  // KzgAmdSettings::LANE_MAX_BLOBS
+};
+__global__ void __launch_bounds__(256) k_blob_to_scalars_ptrs(u32* __restrict__ out, int* __restrict__ status, BlobPtrs blobs,
+                                                              size_t nblobs) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblobs * N) return;
+    const uint4* src = reinterpret_cast<const uint4*>(blobs.p[t / N] + (t % N) * 8);
+    const uint4 lo = src[0], hi = src[1];
+    const u32 raw[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    u32 w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = __builtin_bswap32(raw[7 - k]);
+    u64 borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        u64 d = (u64)w[k] - ff::FrParams::p(k) - borrow;
+        borrow = (d >> 32) & 1;
+    }
+    if (!borrow) status[t / N] = 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[t * 8 + k] = w[k];
+}
+// the same blobs gathered into one device buffer (the proving kernels read a blob more than once)
+__global__ void __launch_bounds__(256) k_gather_blobs(uint4* __restrict__ out, BlobPtrs blobs, size_t nblobs) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr size_t PER = BYTES_PER_BLOB / 16;
+    if (t >= nblobs * PER) return;
+    out[t] = reinterpret_cast<const uint4*>(blobs.p[t / PER])[t % PER];
+}
+
 // ---- Fr helpers for the proving kernel (Montgomery, 8 x u32) ----
 __device__ __forceinline__ ff::Fr fr_load_be(const u32* __restrict__ w8, bool* ok) {
     // 32 big-endian bytes -> canonical limbs; *ok = value < r
@@ -775,6 +809,43 @@ struct KzgAmdSettings {
         CK_HIP(hipHostMalloc((void**)&h_in, LANE_MAX_BLOBS * BYTES_PER_BLOB, hipHostMallocDefault));
         CK_HIP(hipHostMalloc((void**)&h_res, LANE_MAX_BLOBS * 256, hipHostMallocDefault));
     }
+    // Page-locked blob slots for the callers of the coalesced entry points: a caller copies its blob into a slot on its
+    // own thread (in parallel with the other callers) before it queues its request; the batch's kernels read the
+    // slots in place.  The pool belongs to the root settings object; a caller that finds it empty leaves the copy
+    // to the leader (the lane's own staging).
+    struct PinnedSlots {
+        static constexpr int NSLOTS = 48;
+        std::mutex mu;
+        unsigned char* base = nullptr;
+        bool failed = false;
+        std::vector<unsigned char*> free_;
+        unsigned char* acquire(int device) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!base && !failed) {
+                kzgamd::DeviceGuard on_device(device);
+                if (on_device.err != hipSuccess ||
+                    hipHostMalloc((void**)&base, (size_t)NSLOTS * BYTES_PER_BLOB, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+                    base = nullptr;
+                    failed = true;
+                    (void)hipGetLastError();
+                } else {
+                    for (int i = NSLOTS; i-- > 0;) free_.push_back(base + (size_t)i * BYTES_PER_BLOB);
+                }
+            }
+            if (free_.empty()) return nullptr;
+            unsigned char* p = free_.back();
+            free_.pop_back();
+            return p;
+        }
+        void release(unsigned char* p) {
+            if (!p) return;
+            std::lock_guard<std::mutex> lk(mu);
+            free_.push_back(p);
+        }
+        ~PinnedSlots() {
+            if (base) (void)hipHostFree(base);
+        }
+    } slots;
     std::mutex lanes_mu;
     std::vector<std::unique_ptr<KzgAmdSettings>> lanes;
     std::atomic<unsigned> lane_rr{0};
@@ -1260,18 +1331,23 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
 // A compressed result costs the GPU a field inversion in one lane (~0.15 ms of latency whatever the batch); for a
 // handful of results the host-buffer entry points fetch Jacobian points instead and compress them on the host
 // (~20 us each): a single blob_to_kzg_commitment call 0.71 -> 0.5 ms.
-constexpr size_t HOST_COMPRESS_MAX = 4;
+// batches up to this size leave the device as Jacobian points and are compressed on the host with one inversion
+// (host_p1_compress_batch): k_final's one-lane inversion is 0.25 ms of latency, worth paying only when a block of 64
+// points shares it
+constexpr size_t HOST_COMPRESS_MAX = 16;
 constexpr size_t HOST_CHECK_MAX = 64;  // commitments of a proof batch validated on the host's cores up to this many
 
-void compress_on_host(uint8_t* out48, const blst_p1* jac, size_t n) {
-    for (size_t i = 0; i < n; ++i) kzgamd::host_p1_compress(out48 + 48 * i, &jac[i]);
-}
+void compress_on_host(uint8_t* out48, const blst_p1* jac, size_t n) { kzgamd::host_p1_compress_batch(out48, jac, n); }
 
 void commit_enqueue(KzgAmdSettings* dev, void* d_out, int* d_status, const void* d_blobs, u32* d_scalars, size_t n,
-                    hipStream_t stream, int out_mode = kzgamd::OUT_COMPRESSED) {
+                    hipStream_t stream, int out_mode = kzgamd::OUT_COMPRESSED, const BlobPtrs* ptrs = nullptr) {
     CK_HIP(hipMemsetAsync(d_status, 0, n * sizeof(int), stream));
-    hipLaunchKernelGGL(k_blob_to_scalars, dim3((unsigned)((n * N + 255) / 256)), dim3(256), 0, stream, d_scalars, d_status,
-                       (const u32*)d_blobs, n);
+    if (ptrs)  // a lane batch: one (page-locked host) pointer per blob
+        hipLaunchKernelGGL(k_blob_to_scalars_ptrs, dim3((unsigned)((n * N + 255) / 256)), dim3(256), 0, stream, d_scalars,
+                           d_status, *ptrs, n);
+    else
+        hipLaunchKernelGGL(k_blob_to_scalars, dim3((unsigned)((n * N + 255) / 256)), dim3(256), 0, stream, d_scalars, d_status,
+                           (const u32*)d_blobs, n);
     kzgamd::msm_lock(dev->msm);
     try {
         kzgamd::msm_enqueue(dev->msm, d_out, d_scalars, N, n, 0, stream, out_mode);
@@ -1877,14 +1953,19 @@ extern "C" void free_trusted_setup(CKZGSettings* s) {
 }
 
 namespace {
-// See KzgAmdSettings::CoalesceQueue.  Req has `bool done` and `C_KZG_RET rc`; run(batch) serves every request of the
-// batch (sets rc).  A caller returns as soon as its own request is served; leadership passes to whoever is waiting.
+// See KzgAmdSettings::CoalesceQueue.  Req has `bool done`, `C_KZG_RET rc` and `void side_work()`; run(batch) serves
+// every request of the batch (sets rc).  A caller returns as soon as its own request is served; leadership passes to
+// whoever is waiting.  side_work() is the part of a request that needs no GPU (the host-side commitment check of a blob
+// proof): a waiting caller does it before it sleeps, a leader between launching a batch and waiting for it
+// (run's implementation calls it), and whoever has not got to it by the end does it then.
 template <class Req, class Run>
 C_KZG_RET coalesced_call(KzgAmdSettings::CoalesceQueue& q, Req& me, Run&& run) {
     static const size_t gather_min = getenv("KZGAMD_GATHER_MIN") ? (size_t)atoi(getenv("KZGAMD_GATHER_MIN")) : 6;
     static const int gather_us = getenv("KZGAMD_GATHER_US") ? atoi(getenv("KZGAMD_GATHER_US")) : 60;
     std::unique_lock<std::mutex> lk(q.mu);
     q.pending.push_back(&me);
+    q.cv.notify_one();  // a leader gathering requests may have enough now
+    bool idled = false;
     while (!me.done) {
         if (q.leaders < KzgAmdSettings::MAX_LEADERS && !q.pending.empty()) {
             ++q.leaders;
@@ -1892,7 +1973,10 @@ C_KZG_RET coalesced_call(KzgAmdSettings::CoalesceQueue& q, Req& me, Run&& run) {
                 // under load (other batches in flight) a short wait lets the callers that have just been served come
                 // back with their next request: larger batches, fewer pipeline invocations
                 if (q.leaders > 1 && q.pending.size() < gather_min) {
-                    q.cv.wait_for(lk, std::chrono::microseconds(gather_us));
+                    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(gather_us);
+                    while (q.pending.size() < gather_min && !me.done &&
+                           q.cv.wait_until(lk, until) != std::cv_status::timeout) {
+                    }
                     if (me.done) break;
                     if (q.pending.empty()) continue;
                 }
@@ -1913,18 +1997,39 @@ C_KZG_RET coalesced_call(KzgAmdSettings::CoalesceQueue& q, Req& me, Run&& run) {
             }
             --q.leaders;
             q.cv.notify_all();
+        } else if (!idled) {
+            idled = true;
+            lk.unlock();
+            me.side_work();
+            lk.lock();
         } else {
             q.cv.wait(lk);
         }
     }
+    lk.unlock();
+    me.side_work();
     return me.rc;
 }
 
 struct CommitReq {
     const Blob* blob;
     KZGCommitment* out;
+    const unsigned char* staged = nullptr;  // the caller's page-locked copy of the blob (PinnedSlots), if it got a slot
     bool done = false;
     C_KZG_RET rc = C_KZG_ERROR;
+    void side_work() {}
+};
+
+// releases a caller's slot on every way out of its entry point
+struct SlotHold {
+    KzgAmdSettings* dev;
+    unsigned char* p;
+    SlotHold(KzgAmdSettings* d, const void* blob) : dev(d), p(d->slots.acquire(d->device)) {
+        if (p) memcpy(p, blob, BYTES_PER_BLOB);
+    }
+    ~SlotHold() { dev->slots.release(p); }
+    SlotHold(const SlotHold&) = delete;
+    SlotHold& operator=(const SlotHold&) = delete;
 };
 
 // up to LANE_MAX_BLOBS commitments on one lane, through its page-locked staging: every copy asynchronous, one wait at
@@ -1937,13 +2042,21 @@ void commit_lane_batch(KzgAmdSettings* dev, const std::vector<CommitReq*>& reqs)
     dev->ensure(KzgAmdSettings::LANE_MAX_BLOBS);
     dev->ensure_pinned();
     const bool host_compress = n <= HOST_COMPRESS_MAX;
-    for (size_t i = 0; i < n; ++i) memcpy(dev->h_in + i * BYTES_PER_BLOB, reqs[i]->blob, BYTES_PER_BLOB);
+    BlobPtrs ptrs;
+    for (size_t i = 0; i < KzgAmdSettings::LANE_MAX_BLOBS; ++i) ptrs.p[i] = nullptr;
+    for (size_t i = 0; i < n; ++i) {
+        const unsigned char* src = reqs[i]->staged;
+        if (!src) {  // no slot was free: this thread stages the blob
+            memcpy(dev->h_in + i * BYTES_PER_BLOB, reqs[i]->blob, BYTES_PER_BLOB);
+            src = dev->h_in + i * BYTES_PER_BLOB;
+        }
+        ptrs.p[i] = reinterpret_cast<const u32*>(src);
+    }
     int* hs = reinterpret_cast<int*>(dev->h_res);
     unsigned char* ho = dev->h_res + KzgAmdSettings::LANE_MAX_BLOBS * sizeof(int);
     auto enqueue_all = [&] {
-        CK_HIP(hipMemcpyAsync(dev->d_blobs, dev->h_in, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, dev->stream));
-        commit_enqueue(dev, dev->d_out, dev->d_status, dev->d_blobs, dev->d_scalars, n, dev->stream,
-                       host_compress ? kzgamd::OUT_JACOBIAN : kzgamd::OUT_COMPRESSED);
+        commit_enqueue(dev, dev->d_out, dev->d_status, nullptr, dev->d_scalars, n, dev->stream,
+                       host_compress ? kzgamd::OUT_JACOBIAN : kzgamd::OUT_COMPRESSED, &ptrs);
         CK_HIP(hipMemcpyAsync(hs, dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
         CK_HIP(hipMemcpyAsync(ho, dev->d_out, n * (host_compress ? 144 : 48), hipMemcpyDeviceToHost, dev->stream));
     };
@@ -1956,9 +2069,15 @@ void commit_lane_batch(KzgAmdSettings* dev, const std::vector<CommitReq*>& reqs)
             reqs[i]->rc = C_KZG_BADARGS;  // "Invalid scalar"
             continue;
         }
-        if (host_compress) compress_on_host(reqs[i]->out->bytes, reinterpret_cast<const blst_p1*>(ho) + i, 1);
-        else memcpy(reqs[i]->out->bytes, ho + 48 * i, 48);
+        if (!host_compress) memcpy(reqs[i]->out->bytes, ho + 48 * i, 48);
         reqs[i]->rc = C_KZG_OK;
+    }
+    if (host_compress) {
+        // one inversion for the whole batch; a failed request's slot holds whatever the MSM made of its zeroed scalars
+        uint8_t cb[KzgAmdSettings::LANE_MAX_BLOBS * 48];
+        compress_on_host(cb, reinterpret_cast<const blst_p1*>(ho), n);
+        for (size_t i = 0; i < n; ++i)
+            if (reqs[i]->rc == C_KZG_OK) memcpy(reqs[i]->out->bytes, cb + 48 * i, 48);
     }
 }
 
@@ -2034,6 +2153,8 @@ extern "C" C_KZG_RET blob_to_kzg_commitment(KZGCommitment* out, const Blob* blob
     CommitReq me;
     me.blob = blob;
     me.out = out;
+    SlotHold slot(dev, blob);
+    me.staged = slot.p;
     return coalesced_call(dev->q_commit, me, [&](const std::vector<CommitReq*>& batch) {
         LaneRef lane(dev, batch.size());
         commit_lane_batch(lane.use, batch);
@@ -2119,46 +2240,78 @@ namespace {
 struct ProofReq {
     const Blob* blob;
     const Bytes48* commitment;  // compute_blob_kzg_proof
-    const Bytes32* z;           // compute_kzg_proof
+    const Bytes32* z;           // compute_kzg_proof; compute_blob_kzg_proof: the derived challenge (zder)
     KZGProof* proof;
     Bytes32* y;
+    const unsigned char* staged = nullptr;  // the caller's page-locked copy of the blob, if it got a slot
+    Bytes32 zder;
+    bool commitment_ok = true, checked = false;
     bool done = false;
     C_KZG_RET rc = C_KZG_ERROR;
+    // validate_batched_input's half for the commitment (decode + subgroup, ~0.2 ms of one core): never on the GPU's
+    // critical path
+    void side_work() {
+        if (checked || !commitment) return;
+        checked = true;
+        blst_p1 c;
+        commitment_ok = kzgamd::host_p1_uncompress(&c, commitment->bytes) && kzgamd::host_p1_in_g1(&c);
+    }
 };
 
-// a batch of merged single-proof calls on one lane; prove_batch rejects the whole batch when one request is invalid:
-// then every request is served on its own, so that only the offender fails
-void proof_lane_batch(KzgAmdSettings* root, const std::vector<ProofReq*>& reqs, bool with_z) {
+// A batch of merged single-proof calls on one lane.  Every caller has staged its blob (page-locked slot), validated it
+// and derived its challenge on its own thread; here: gather the blobs on the device, quotient + MSM, results back
+// through the lane's page-locked buffer, one wait.  Status is per request (k_quotient flags a blob or an evaluation
+// point that is not canonical): an invalid request fails alone.
+void proof_lane_batch(KzgAmdSettings* root, const std::vector<ProofReq*>& reqs, ProofReq* leader) {
     const size_t n = reqs.size();
     LaneRef lane(root, n);
-    if (n == 1) {
-        ProofReq* r = reqs[0];
-        r->rc = guarded([&] { prove_batch(r->proof, r->y, r->blob, with_z ? r->z : nullptr, with_z ? nullptr : r->commitment, 1, lane.use); });
-        return;
-    }
-    std::vector<Blob> blobs(n);
-    std::vector<Bytes48> cms(with_z ? 0 : n);
-    std::vector<Bytes32> zs(with_z ? n : 0), ys(n);
-    std::vector<KZGProof> proofs(n);
-    for (size_t i = 0; i < n; ++i) {
-        memcpy(&blobs[i], reqs[i]->blob, sizeof(Blob));
-        if (with_z) zs[i] = *reqs[i]->z;
-        else cms[i] = *reqs[i]->commitment;
-    }
+    KzgAmdSettings* dev = lane.use;
     const C_KZG_RET rc = guarded([&] {
-        prove_batch(proofs.data(), with_z ? ys.data() : nullptr, blobs.data(), with_z ? zs.data() : nullptr,
-                    with_z ? nullptr : cms.data(), n, lane.use);
-    });
-    if (rc == C_KZG_OK) {
+        std::lock_guard<std::mutex> lk(dev->mu);
+        kzgamd::DeviceGuard on_device(dev->device);
+        CK_HIP(on_device.err);
+        dev->ensure(KzgAmdSettings::LANE_MAX_BLOBS);
+        dev->ensure_pinned();
+        constexpr size_t LB = KzgAmdSettings::LANE_MAX_BLOBS;
+        // lane result buffer: status | Jacobian proofs | y | z (in)
+        int* hs = reinterpret_cast<int*>(dev->h_res);
+        unsigned char* ho = dev->h_res + LB * sizeof(int);
+        u32* hy = reinterpret_cast<u32*>(ho + LB * 144);
+        unsigned char* hz = reinterpret_cast<unsigned char*>(hy) + LB * 32;
+        BlobPtrs ptrs;
+        for (size_t i = 0; i < LB; ++i) ptrs.p[i] = nullptr;
         for (size_t i = 0; i < n; ++i) {
-            *reqs[i]->proof = proofs[i];
-            if (with_z) *reqs[i]->y = ys[i];
+            const unsigned char* src = reqs[i]->staged;
+            if (!src) {
+                memcpy(dev->h_in + i * BYTES_PER_BLOB, reqs[i]->blob, BYTES_PER_BLOB);
+                src = dev->h_in + i * BYTES_PER_BLOB;
+            }
+            ptrs.p[i] = reinterpret_cast<const u32*>(src);
+            memcpy(hz + 32 * i, reqs[i]->z->bytes, 32);
+        }
+        hipLaunchKernelGGL(k_gather_blobs, dim3((unsigned)((n * (BYTES_PER_BLOB / 16) + 255) / 256)), dim3(256), 0, dev->stream,
+                           reinterpret_cast<uint4*>(dev->d_blobs), ptrs, n);
+        CK_HIP(hipMemcpyAsync(dev->d_z, hz, n * 32, hipMemcpyHostToDevice, dev->stream));
+        prove_enqueue(dev, 0, n, dev->stream, false, kzgamd::OUT_JACOBIAN);
+        CK_HIP(hipMemcpyAsync(hs, dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
+        CK_HIP(hipMemcpyAsync(hy, dev->d_y, n * 32, hipMemcpyDeviceToHost, dev->stream));
+        CK_HIP(hipMemcpyAsync(ho, dev->d_out, n * 144, hipMemcpyDeviceToHost, dev->stream));
+        if (leader) leader->side_work();  // while the GPU works
+        CK_HIP(hipStreamSynchronize(dev->stream));
+        uint8_t cb[LB * 48];
+        compress_on_host(cb, reinterpret_cast<const blst_p1*>(ho), n);
+        for (size_t i = 0; i < n; ++i) {
+            if (hs[i] != 0) {
+                reqs[i]->rc = C_KZG_BADARGS;  // "Invalid scalar"
+                continue;
+            }
+            memcpy(reqs[i]->proof->bytes, cb + 48 * i, 48);
+            if (reqs[i]->y) fr_limbs_to_be32(reqs[i]->y->bytes, hy + 8 * i);
             reqs[i]->rc = C_KZG_OK;
         }
-        return;
-    }
-    for (ProofReq* r : reqs)
-        r->rc = guarded([&] { prove_batch(r->proof, r->y, r->blob, with_z ? r->z : nullptr, with_z ? nullptr : r->commitment, 1, lane.use); });
+    });
+    if (rc != C_KZG_OK)
+        for (ProofReq* r : reqs) r->rc = rc;
 }
 }  // namespace
 
@@ -2168,7 +2321,9 @@ extern "C" C_KZG_RET compute_kzg_proof(KZGProof* proof_out, Bytes32* y_out, cons
     KzgAmdSettings* dev = lookup(s);
     if (!dev) return C_KZG_BADARGS;
     ProofReq me{blob, nullptr, z_bytes, proof_out, y_out};
-    return coalesced_call(dev->q_proof, me, [&](const std::vector<ProofReq*>& batch) { proof_lane_batch(dev, batch, true); });
+    SlotHold slot(dev, blob);
+    me.staged = slot.p;
+    return coalesced_call(dev->q_proof, me, [&](const std::vector<ProofReq*>& batch) { proof_lane_batch(dev, batch, &me); });
 }
 
 extern "C" C_KZG_RET kzgamd_compute_blob_kzg_proof_batch(KZGProof* out, const Blob* blobs, const Bytes48* commitments,
@@ -2905,8 +3060,17 @@ extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof* out, const Blob* blob, con
     KzgAmdSettings* dev = lookup(s);
     if (!dev) return C_KZG_BADARGS;
     ProofReq me{blob, commitment_bytes, nullptr, out, nullptr};
-    return coalesced_call(dev->q_blob_proof, me,
-                          [&](const std::vector<ProofReq*>& batch) { proof_lane_batch(dev, batch, false); });
+    // this thread's share, in parallel with the other callers': the page-locked copy, blob_to_polynomial's range check
+    // and the Fiat-Shamir challenge (one SHA-256 over the blob)
+    SlotHold slot(dev, blob);
+    me.staged = slot.p;
+    if (!host_blob_valid(blob->bytes)) return C_KZG_BADARGS;  // "Invalid scalar"
+    challenge_bytes(me.zder.bytes, blob->bytes, commitment_bytes->bytes);
+    me.z = &me.zder;
+    const C_KZG_RET rc = coalesced_call(dev->q_blob_proof, me,
+                                        [&](const std::vector<ProofReq*>& batch) { proof_lane_batch(dev, batch, &me); });
+    if (rc == C_KZG_OK && !me.commitment_ok) return C_KZG_BADARGS;  // "Invalid commitment"
+    return rc;
 }
 
 // The reference exports this helper with raw blst types (blst/src/eip_4844.rs:501-514): the commitment

@@ -42,6 +42,7 @@ using nttplan::KIND_B;
 constexpr int LOGT = nttplan::LOGT;
 constexpr int TILE = nttplan::TILE;  // elements per workgroup
 constexpr int NT = nttplan::NT;      // threads per workgroup: 4 elements each, 16 waves = 4 per SIMD at <= 128 VGPRs
+constexpr int PLAN_DAS = 3;          // plan-cache key of the fused DAS plans (next to the three pass kinds)
 #ifndef KZGAMD_NTT_NT_STORES
 #define KZGAMD_NTT_NT_STORES 1
 #endif
@@ -80,12 +81,15 @@ struct RoundDev {
     u32 pos;      // first stage of the round (tile-local)
     u32 M;        // stages in the round: 2, 1, or 0 (n = 1)
     u32 barrier;  // the next round belongs to another phase: workgroup barrier instead of the wave-local exchange
+    u32 flags;    // fused DAS plans: bit 0 = forward half (twiddles from tw2), bit 1 = unit twiddles at position 0,
+                  // bit 2 = multiply the results by the twist before they go to LDS
 };
 
 struct PassParams {
-    RoundDev rd[nttplan::MAXR];
+    RoundDev rd[nttplan::MAXR_DAS];
     const uint2* tab;  // [round][thread] = {idxA | idxB << 16, swz(idxA) | swz(idxB) << 16}   (ntt_plan.h)
     const Fe* tw;      // stage-major twiddles of this direction: entry (2^s - 1) + j = w_{2^(s+1)}^(+-j), times 2^261
+    const Fe* tw2;     // fused DAS plans: the forward table (tw is the inverse one)
     size_t total;      // elements in the batch
     u32 n;             // transform length
     int kind, T, nrounds;
@@ -154,7 +158,7 @@ struct TileGeo {
 // to it.  V: how a butterfly multiplies — 1 = subtractive Montgomery steps on one accumulator chain
 // (fr29::mul_signed), 2 = the same left to the compiler's re-association, 0 = round 2's additive multiplier
 // (measurement variants, KZGAMD_NTT_VARIANT at kzgamd_ntt_new; all three give the same bits).
-template <int KIND, int V, bool FIRST, bool LAST>
+template <int KIND, int V, bool FIRST, bool LAST, bool DAS = false>
 __device__ __forceinline__ void ntt_round(u32* sh, Fr* __restrict__ out, const Fr* __restrict__ in, const PassParams& P,
                                           const TileGeo<KIND>& G, int r, const uint2 te) {
 #define KZG_BF(K0, K1, W)                                      \
@@ -197,29 +201,45 @@ __device__ __forceinline__ void ntt_round(u32* sh, Fr* __restrict__ out, const F
         e[3] = lds_get(sh, sB ^ rd.sbit);
     }
     if (rd.M) {
-        constexpr bool unit = FIRST && KIND != KIND_B;
-        if constexpr (unit) {
+        // a fused DAS plan starts a transform twice: its unit rounds are a run-time property of the round
+        const bool unit = DAS ? (rd.flags & 2u) != 0 : (FIRST && KIND != KIND_B);
+        const Fe* tw = DAS && (rd.flags & 1u) ? P.tw2 : P.tw;
+        if (unit) {
             KZG_BF1(0, 1)
             KZG_BF1(2, 3)
         } else {
             // M = 2: both pairs share the twiddle (idxB = idxA | 2 << pos); M = 1: two unrelated pairs
-            const Fe w = P.tw[G.tw_ent(rd.pos, iA)];
-            const Fe w2 = P.tw[G.tw_ent(rd.pos, iB)];
+            const Fe w = tw[G.tw_ent(rd.pos, iA)];
+            const Fe w2 = tw[G.tw_ent(rd.pos, iB)];
             KZG_BF(0, 1, w)
             KZG_BF(2, 3, w2)
         }
         if (rd.M == 2) {
-            if constexpr (unit) {
+            if (unit) {
                 KZG_BF1N(0, 2)
             } else {
-                const Fe w0 = P.tw[G.tw_ent(rd.pos + 1, iA)];
+                const Fe w0 = tw[G.tw_ent(rd.pos + 1, iA)];
                 KZG_BF(0, 2, w0)
             }
-            const Fe w1 = P.tw[G.tw_ent(rd.pos + 1, iA | rd.bit)];
+            const Fe w1 = tw[G.tw_ent(rd.pos + 1, iA | rd.bit)];
             KZG_BF(1, 3, w1)
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) fr29::norm(e[k]);
+    }
+    if constexpr (DAS && !LAST) {
+        if (rd.flags & 4u) {
+            // the twist of the DAS extension: result j of the inverse transform times w^j (the 2n-th root), made
+            // positive (+ r) and renormalised: an input of the forward half like any other (value < 2r)
+            const u32 idx[4] = {iA, iA | rd.bit, iB, iB | rd.bit};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                e[k] = fr29::mul_signed<V != 2>(e[k], P.post[(size_t)(idx[k] & G.mT) * P.post_stride]);
+#pragma unroll
+                for (int l = 0; l < fr29::L; ++l) e[k].v[l] += fr29::rl(l);
+                fr29::norm(e[k]);
+            }
+        }
     }
     if constexpr (LAST) {
         const u32 idx[4] = {iA, iA | rd.bit, iB, iB | rd.bit};
@@ -317,20 +337,40 @@ Fr inv_len(size_t n) {
     return ff::inverse_bgcd(ff::to_mont(v));
 }
 
+// The DAS extension of lists of <= 2048 elements in one pass (nttplan::make_das_plan): inverse rounds, twist, forward
+// rounds, the tile never leaves the CU in between.  Same round code as k_ntt_pass; the middle rounds carry their
+// unit / twist / direction flags at run time.
+template <int V>
+__global__ void __launch_bounds__(NT) k_das_fused(Fr* __restrict__ out, const Fr* __restrict__ in, const PassParams P) {
+    extern __shared__ __attribute__((aligned(16))) u32 sh[];
+    const u32 tid = threadIdx.x;
+    const TileGeo<KIND_A1> G(P);
+    const int n = P.nrounds;  // >= 4
+    uint2 te = P.tab[tid], nx = P.tab[NT + tid];
+    ntt_round<KIND_A1, V, true, false, true>(sh, out, in, P, G, 0, te);
+    for (int r = 1; r < n - 1; ++r) {
+        te = nx;
+        nx = P.tab[(r + 1) * NT + tid];
+        ntt_round<KIND_A1, V, false, false, true>(sh, out, in, P, G, r, te);
+    }
+    ntt_round<KIND_A1, V, false, true, true>(sh, out, in, P, G, n - 1, nx);
+}
+
 // the device copy of one plan: the round table and the per-round constants
 void upload_plan(NttCtx* ctx, int kind, int T) {
-    const nttplan::Plan pl = nttplan::make_plan(kind, T);
+    const bool das = kind == PLAN_DAS;
+    const nttplan::Plan pl = das ? nttplan::make_das_plan(T) : nttplan::make_plan(kind, T);
     NttPlanDev pd;
     pd.nrounds = pl.nrounds;
     for (int r = 0; r < pl.nrounds; ++r) {
-        const u32 bit = 1u << pl.elem_bit(r);
-        pd.rd[r][0] = bit;
-        pd.rd[r][1] = nttplan::swz(bit);
+        pd.rd[r][0] = 1u << pl.elem_bit(r);
+        pd.rd[r][1] = pl.sbit[r];
         pd.rd[r][2] = (u32)pl.rounds[r].pos;
         pd.rd[r][3] = (u32)pl.rounds[r].M;
         pd.rd[r][4] = (u32)pl.rounds[r].barrier_after;
+        pd.rd[r][5] = (u32)(pl.rounds[r].part | pl.rounds[r].unit << 1 | pl.rounds[r].twist << 2);
     }
-    // tab[..][4] of u16 = {idxA, idxB, swz(idxA), swz(idxB)} is read as uint2 {idxA | idxB << 16, swzA | swzB << 16}
+    // tab[..][4] of u16 = {idxA, idxB, lds(idxA), lds(idxB)} is read as uint2 {idxA | idxB << 16, ldsA | ldsB << 16}
     NTT_TRY(hipMalloc(&pd.d_tab, pl.tab.size() * sizeof(uint16_t)));
     NTT_TRY(hipMemcpy(pd.d_tab, pl.tab.data(), pl.tab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     ctx->plans[kind * 16 + T] = pd;
@@ -338,7 +378,7 @@ void upload_plan(NttCtx* ctx, int kind, int T) {
 
 void launch_pass(NttCtx* ctx, int kind, int T, Fr* d_out, const Fr* d_in, PassParams& P, unsigned grid, hipStream_t stream) {
     const NttPlanDev& pd = ctx->plans.at(kind * 16 + T);
-    P.kind = kind;
+    P.kind = kind == PLAN_DAS ? (int)KIND_A1 : kind;
     P.T = T;
     P.nrounds = pd.nrounds;
     for (int r = 0; r < pd.nrounds; ++r) {
@@ -347,6 +387,7 @@ void launch_pass(NttCtx* ctx, int kind, int T, Fr* d_out, const Fr* d_in, PassPa
         P.rd[r].pos = pd.rd[r][2];
         P.rd[r].M = pd.rd[r][3];
         P.rd[r].barrier = pd.rd[r][4];
+        P.rd[r].flags = pd.rd[r][5];
     }
     P.tab = (const uint2*)pd.d_tab;
     const size_t lds = (size_t)TILE * sizeof(u32) * fr29::L;
@@ -355,7 +396,11 @@ void launch_pass(NttCtx* ctx, int kind, int T, Fr* d_out, const Fr* d_in, PassPa
     if (ctx->variant == 0) KZG_LAUNCH(K, 0); \
     else if (ctx->variant == 1) KZG_LAUNCH(K, 1); \
     else KZG_LAUNCH(K, 2)
-    if (kind == KIND_A1) {
+    if (kind == PLAN_DAS) {
+        if (ctx->variant == 0) hipLaunchKernelGGL(k_das_fused<0>, dim3(grid), dim3(NT), lds, stream, d_out, d_in, P);
+        else if (ctx->variant == 1) hipLaunchKernelGGL(k_das_fused<1>, dim3(grid), dim3(NT), lds, stream, d_out, d_in, P);
+        else hipLaunchKernelGGL(k_das_fused<2>, dim3(grid), dim3(NT), lds, stream, d_out, d_in, P);
+    } else if (kind == KIND_A1) {
         KZG_LAUNCH_V(KIND_A1);
     } else if (kind == KIND_A2) {
         KZG_LAUNCH_V(KIND_A2);
@@ -458,6 +503,7 @@ extern "C" void* kzgamd_ntt_new(unsigned scale) {
             upload_plan(ctx, KIND_A2, T);
             upload_plan(ctx, KIND_B, T);
         }
+        for (int T = 0; T <= 11; ++T) upload_plan(ctx, PLAN_DAS, T);
     } catch (...) {
         delete ctx;
         return nullptr;
@@ -516,6 +562,24 @@ extern "C" int ntt_fr(void* vctx, blst_fr* out, const blst_fr* in, size_t n, int
 // transform's last-pass multiplication (instead of its n^-1), the n^-1 in the forward transform's.
 namespace {
 void das_enqueue(NttCtx* ctx, Fr* d_odds, const Fr* d_evens, Fr* d_tmp, size_t n, size_t nbatch, hipStream_t stream) {
+    if (n <= (size_t)TILE / 2) {
+        // lists of <= 2048 elements: both transforms in ONE pass over the tile (nttplan::make_das_plan) — the data
+        // crosses HBM once instead of twice and the tile's load / store skeleton is paid once
+        PassParams P;
+        memset(&P, 0, sizeof(P));
+        P.n = (u32)n;
+        P.total = n * nbatch;
+        P.tw = (const Fe*)ctx->d_tw_inv;
+        P.tw2 = (const Fe*)ctx->d_tw_fwd;
+        P.post = (const Fe*)ctx->d_roots;
+        P.post_stride = (u32)(ctx->W / (2 * n));
+        P.epilogue = 1;
+        P.scale = times32(inv_len(n));
+        P.last = 1;
+        launch_pass(ctx, PLAN_DAS, ilog2(n), d_odds, d_evens, P, (unsigned)((P.total + TILE - 1) / TILE), stream);
+        NTT_TRY(hipGetLastError());
+        return;
+    }
     ntt_enqueue(ctx, d_tmp, d_evens, n, nbatch, true, stream, SCALE_INV_TWIST);
     ntt_enqueue(ctx, d_odds, d_tmp, n, nbatch, false, stream, SCALE_FWD_NINV);
 }
@@ -573,6 +637,23 @@ extern "C" int kzgamd_ntt_plan_dump(int kind, int T, int* rounds /* 6 x 4 */, ui
             rounds[4 * r + 1] = pl.rounds[r].M;
             rounds[4 * r + 2] = pl.rounds[r].barrier_after;
             rounds[4 * r + 3] = pl.elem_bit(r);
+        }
+    }
+    if (tab) memcpy(tab, pl.tab.data(), pl.tab.size() * sizeof(uint16_t));
+    return pl.nrounds;
+}
+
+extern "C" int kzgamd_ntt_das_plan_dump(int T, int* rounds /* 12 x 6 */, uint16_t* tab /* 12 x 1024 x 4 */) {
+    if (T < 0 || T > nttplan::LOGT - 1) return -1;
+    const nttplan::Plan pl = nttplan::make_das_plan(T);
+    for (int r = 0; r < pl.nrounds; ++r) {
+        if (rounds) {
+            rounds[6 * r + 0] = pl.rounds[r].pos;
+            rounds[6 * r + 1] = pl.rounds[r].M;
+            rounds[6 * r + 2] = pl.rounds[r].barrier_after;
+            rounds[6 * r + 3] = pl.elem_bit(r);
+            rounds[6 * r + 4] = pl.rounds[r].part | pl.rounds[r].unit << 1 | pl.rounds[r].twist << 2;
+            rounds[6 * r + 5] = pl.sbit[r];
         }
     }
     if (tab) memcpy(tab, pl.tab.data(), pl.tab.size() * sizeof(uint16_t));

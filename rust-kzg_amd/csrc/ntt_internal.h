@@ -21,12 +21,12 @@ struct NttErr {
 struct NttPlanDev {
     void* d_tab = nullptr;
     int nrounds = 0;
-    unsigned rd[6][5];  // bit, swz(bit), pos, M, barrier_after
+    unsigned rd[12][6];  // element bit, its LDS position bit, pos, M, barrier_after, flags (fused DAS plans)
 };
 
 struct NttCtx {
     using Fr = ff::Fr;
-    std::map<int, NttPlanDev> plans;  // key = kind * 16 + T; filled by kzgamd_ntt_new, read-only afterwards
+    std::map<int, NttPlanDev> plans;  // key = kind * 16 + T (kind 3: fused DAS plans); filled by kzgamd_ntt_new, read-only afterwards
     int device = 0;
     int variant = 1;  // butterfly multiplier of the Fr kernels (ntt.hip), read from KZGAMD_NTT_VARIANT at creation
     unsigned scale = 0;

@@ -25,6 +25,7 @@ constexpr int LOGT = 12;
 constexpr int TILE = 1 << LOGT;
 constexpr int NT = TILE / 4;  // threads per workgroup
 constexpr int MAXR = 6;       // rounds per pass
+constexpr int MAXR_DAS = 12;  // rounds of the fused DAS extension (inverse + forward transform of <= 2048 points in one pass)
 enum Kind { KIND_A1 = 0, KIND_A2 = 1, KIND_B = 2 };
 // KIND_A1: the whole transform (n <= 4096), 4096 / n contiguous transforms per tile, bit reversal folded into the load
 // KIND_A2: first pass of a longer transform: 4096 >> T blocks of 2^T positions of the bit-reversed sequence whose
@@ -44,6 +45,9 @@ inline uint32_t swz(uint32_t i) {
 
 struct Round {
     int pos = 0, M = 0, barrier_after = 0, npair = 0, conflicts = 0;
+    // fused DAS plans: part 0 = inverse transform, 1 = forward; unit = stages 0 / 1 at position 0 multiply by 1;
+    // twist = the round multiplies its results by the per-position factor before they go to LDS
+    int part = 0, unit = 0, twist = 0;
     int lane_bits[6] = {0, 0, 0, 0, 0, 0};
     int pair_bits[2] = {0, 0};
     int wave_bits[4] = {0, 0, 0, 0};
@@ -51,12 +55,24 @@ struct Round {
 
 struct Plan {
     int kind = 0, T = 0, nrounds = 0;
-    Round rounds[MAXR];
-    // [round][thread][4] = idxA, idxB, swz(idxA), swz(idxB); the thread's other two elements are idx | bit(round)
+    Round rounds[MAXR_DAS];
+    // [round][thread][4] = idxA, idxB, lds(idxA), lds(idxB); the thread's other two elements are idx | bit(round),
+    // at LDS positions lds(idx) ^ lds_bit(round) (the position map is XOR-linear)
     std::vector<uint16_t> tab;
+    std::vector<uint16_t> sbit;  // lds_bit(round)
     // bit(round): 1 << pos when the round has stages, else the first pair bit
     int elem_bit(int r) const { return rounds[r].M ? rounds[r].pos : rounds[r].pair_bits[0]; }
 };
+
+// LDS position (before the swizzle) of DIT position i when the tile holds the data in NATURAL order — the forward half
+// of a fused DAS plan reads what the inverse half left: low T bits bit-reversed, column bits unchanged
+inline uint32_t brev_pos(uint32_t i, int T) {
+    const uint32_t mT = (1u << T) - 1u;
+    uint32_t p = i & mT, r = 0;
+    for (int k = 0; k < T; ++k)
+        if ((p >> k) & 1) r |= 1u << (T - 1 - k);
+    return (i & ~mT) | r;
+}
 
 namespace detail {
 struct Phase {
@@ -114,14 +130,15 @@ inline int addr_rank(int kind, int T, int bit, bool store) {
     return stage ? 50 + bit : bit - T;
 }
 
-// extra LDS cycles of a 32-lane group whose lanes vary the idx bits bits5[0..4]
-inline int conflicts(const int* bits5) {
+// extra LDS cycles of a 32-lane group whose lanes vary the idx bits bits5[0..4]; brevT >= 0: positions through brev_pos
+inline int conflicts(const int* bits5, int brevT = -1) {
     int cnt[32] = {0};
     int worst = 0;
     for (int l = 0; l < 32; ++l) {
         uint32_t i = 0;
         for (int k = 0; k < 5; ++k)
             if ((l >> k) & 1) i |= 1u << bits5[k];
+        if (brevT >= 0) i = brev_pos(i, brevT);
         const int c = ++cnt[swz(i) & 31];
         worst = std::max(worst, c);
     }
@@ -129,8 +146,11 @@ inline int conflicts(const int* bits5) {
 }
 }  // namespace detail
 
-inline Plan make_plan(int kind, int T) {
+// first_io / last_io: the first round loads from / the last stores to global memory (its lane bits follow the
+// addresses); brev_lds: LDS positions through brev_pos (the forward half of a fused DAS plan)
+inline Plan make_plan(int kind, int T, bool first_io = true, bool last_io = true, bool brev_lds = false) {
     using namespace detail;
+    const int bT = brev_lds ? T : -1;
     Plan pl;
     pl.kind = kind;
     pl.T = T;
@@ -171,9 +191,10 @@ inline Plan make_plan(int kind, int T) {
         const bool first = r == 0, last = r == n - 1;
         R.barrier_after = (!last && last_of_phase[r]) ? 1 : 0;
         R.npair = (int)rest.size() - 6;
-        if (first || last) {
+        if ((first && first_io) || (last && last_io)) {
+            const bool store = !(first && first_io);
             std::stable_sort(rest.begin(), rest.end(),
-                             [&](int a, int b) { return addr_rank(kind, T, a, !first) < addr_rank(kind, T, b, !first); });
+                             [&](int a, int b) { return addr_rank(kind, T, a, store) < addr_rank(kind, T, b, store); });
             for (int k = 0; k < 6; ++k) R.lane_bits[k] = rest[k];
             for (int k = 0; k < R.npair; ++k) R.pair_bits[k] = rest[6 + k];
         } else {
@@ -181,28 +202,38 @@ inline Plan make_plan(int kind, int T) {
             // bit: the choice with the fewest bank conflicts, first one found in this order
             int best = 1 << 30;
             const int nrest = (int)rest.size();
-            const int npairsets = R.npair == 0 ? 1 : nrest;  // inner rounds have M = 2 (npair 0) or M = 1 (npair 1)
-            for (int ps = 0; ps < npairsets; ++ps) {
+            // the sets of npair (0, 1 or 2: M = 2, 1 or 0) bits of `rest`, in lexicographic order
+            std::vector<std::pair<int, int>> sets;
+            if (R.npair == 0) sets.push_back({-1, -1});
+            for (int a = 0; a < nrest && R.npair >= 1; ++a) {
+                if (R.npair == 1) sets.push_back({a, -1});
+                for (int b = a + 1; b < nrest && R.npair == 2; ++b) sets.push_back({a, b});
+            }
+            for (const auto& ps : sets) {
                 std::vector<int> lanes6;
                 for (int k = 0; k < nrest; ++k)
-                    if (R.npair == 0 || k != ps) lanes6.push_back(rest[k]);
+                    if (k != ps.first && k != ps.second) lanes6.push_back(rest[k]);
                 for (int h = 0; h < 6; ++h) {
                     int l5[5], m = 0;
                     for (int k = 0; k < 6; ++k)
                         if (k != h) l5[m++] = lanes6[k];
-                    const int c = conflicts(l5);
+                    const int c = conflicts(l5, bT);
                     if (c < best) {
                         best = c;
                         for (int k = 0; k < 5; ++k) R.lane_bits[k] = l5[k];
                         R.lane_bits[5] = lanes6[h];
-                        if (R.npair) R.pair_bits[0] = rest[ps];
+                        if (R.npair >= 1) R.pair_bits[0] = rest[ps.first];
+                        if (R.npair == 2) R.pair_bits[1] = rest[ps.second];
                     }
                 }
             }
         }
-        R.conflicts = conflicts(R.lane_bits);
+        R.conflicts = conflicts(R.lane_bits, bT);
     }
     pl.tab.resize((size_t)n * NT * 4);
+    pl.sbit.resize(n);
+    auto lds = [&](uint32_t i) { return swz(brev_lds ? brev_pos(i, T) : i); };
+    for (int r = 0; r < n; ++r) pl.sbit[r] = (uint16_t)lds(1u << pl.elem_bit(r));
     for (int r = 0; r < n; ++r) {
         const Round& R = pl.rounds[r];
         for (int u = 0; u < NT; ++u) {
@@ -219,10 +250,41 @@ inline Plan make_plan(int kind, int T) {
             uint16_t* t = &pl.tab[((size_t)r * NT + u) * 4];
             t[0] = (uint16_t)base;
             t[1] = (uint16_t)b2;
-            t[2] = (uint16_t)swz(base);
-            t[3] = (uint16_t)swz(b2);
+            t[2] = (uint16_t)lds(base);
+            t[3] = (uint16_t)lds(b2);
         }
     }
+    return pl;
+}
+
+// The DAS extension of lists of 2^T <= 2048 elements in ONE tile pass (data_availability_sampling.rs:14-100 computes
+// FFT(w^j IFFT(evens)_j)): the rounds of the inverse transform, whose last round multiplies result j by the twist and
+// leaves the tile in LDS in natural order, then the rounds of the forward transform reading it at bit-reversed positions.
+inline Plan make_das_plan(int T) {
+    const Plan inv = make_plan(KIND_A1, T, true, false, false);
+    const Plan fwd = make_plan(KIND_A1, T, false, true, true);
+    Plan pl;
+    pl.kind = KIND_A1;
+    pl.T = T;
+    pl.nrounds = inv.nrounds + fwd.nrounds;
+    for (int r = 0; r < inv.nrounds; ++r) {
+        pl.rounds[r] = inv.rounds[r];
+        pl.rounds[r].part = 0;
+        pl.rounds[r].unit = r == 0;
+        pl.rounds[r].twist = r == inv.nrounds - 1;
+        if (pl.rounds[r].twist) pl.rounds[r].barrier_after = 1;
+    }
+    for (int r = 0; r < fwd.nrounds; ++r) {
+        Round& R = pl.rounds[inv.nrounds + r];
+        R = fwd.rounds[r];
+        R.part = 1;
+        R.unit = r == 0;
+        R.twist = 0;
+    }
+    pl.tab = inv.tab;
+    pl.tab.insert(pl.tab.end(), fwd.tab.begin(), fwd.tab.end());
+    pl.sbit = inv.sbit;
+    pl.sbit.insert(pl.sbit.end(), fwd.sbit.begin(), fwd.sbit.end());
     return pl;
 }
 

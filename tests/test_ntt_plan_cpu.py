@@ -71,3 +71,60 @@ def test_simulated_passes_equal_a_direct_transform(L):
     rnd = random.Random(L)
     x = [rnd.randrange(S.P) for _ in range(1 << L)]
     assert S.ntt_sim(x, L) == S.ntt_ref(x, L)
+
+
+@pytest.mark.parametrize("T", range(0, 12))
+def test_cpp_das_planner_equals_prototype(kzg, T):
+    lib = kzg.lib()
+    rounds = (C.c_int * 72)()
+    tab = (C.c_uint16 * (12 * 1024 * 4))()
+    lib.kzgamd_ntt_das_plan_dump.restype = C.c_int
+    n = lib.kzgamd_ntt_das_plan_dump(T, rounds, tab)
+    pl = S.plan_das(T)
+    assert n == len(pl["rounds"]) and 4 <= n <= 12
+    bmap = S.brev_map(T)
+    for r, R in enumerate(pl["rounds"]):
+        bit = R["pos"] if R["M"] else R["pair_bits"][0]
+        pm = bmap if R["part"] else (lambda i: i)
+        flags = R["part"] | int(R["unit"]) << 1 | int(R["twist"]) << 2
+        assert list(rounds[6 * r: 6 * r + 6]) == [R["pos"], R["M"], int(R["barrier_after"]), bit, flags,
+                                                  S.swz(pm(1 << bit))], (T, r)
+        for u in range(1024):
+            e = pl["tab"][r][u]
+            got = tab[(r * 1024 + u) * 4: (r * 1024 + u) * 4 + 4]
+            assert got == [e[0], e[2], S.swz(pm(e[0])), S.swz(pm(e[2]))], (T, r, u)
+            # the position map is XOR-linear: the other two elements sit at lds ^ lds_bit
+            assert S.swz(pm(e[1])) == S.swz(pm(e[0])) ^ S.swz(pm(1 << bit))
+
+
+@pytest.mark.parametrize("T", range(0, 12))
+def test_das_plan_is_a_schedule(T):
+    pl = S.plan_das(T)
+    owner_prev, stages = None, [[], []]
+    for r, R in enumerate(pl["rounds"]):
+        pm = S.brev_map(T) if R["part"] else (lambda i: i)
+        seen = {}
+        for u in range(1024):
+            for i in pl["tab"][r][u]:
+                assert pm(i) not in seen
+                seen[pm(i)] = u >> 6
+        assert len(seen) == 4096
+        if r and not pl["rounds"][r - 1]["barrier_after"]:
+            assert seen == owner_prev
+        owner_prev = seen
+        stages[R["part"]] += [R["pos"] + k for k in range(R["M"])]
+        assert R["conflicts"] <= 1
+        assert not R["unit"] or R["pos"] == 0
+    assert stages == [list(range(T)), list(range(T))]
+    # one barrier inside each half at most, one between the halves
+    assert sum(R["barrier_after"] for R in pl["rounds"]) <= 3
+    assert sum(R["twist"] for R in pl["rounds"]) == 1
+
+
+@pytest.mark.parametrize("L", [0, 1, 2, 5, 8, 11])
+def test_simulated_fused_das_equals_two_transforms(L):
+    import random
+
+    rnd = random.Random(100 + L)
+    x = [rnd.randrange(S.P) for _ in range(1 << L)]
+    assert S.das_sim(x, L) == S.das_ref(x, L)

@@ -88,7 +88,21 @@ def rounds_of_phase(lo, hi):
     return r
 
 
-def conflicts(bits5):
+def brev_map(T):
+    """LDS position of DIT position idx when the tile holds the data in NATURAL order (the forward half of the fused DAS
+    extension reads what the inverse half left): the low T bits bit-reversed, column bits unchanged (XOR-linear)"""
+    mT = (1 << T) - 1
+
+    def f(i):
+        p, r = i & mT, 0
+        for k in range(T):
+            if (p >> k) & 1:
+                r |= 1 << (T - 1 - k)
+        return (i & ~mT) | r
+    return f
+
+
+def conflicts(bits5, posmap=None):
     """extra LDS cycles of a 32-lane group whose lanes vary the idx bits `bits5` (others fixed at 0)"""
     seen = {}
     for l in range(32):
@@ -96,12 +110,16 @@ def conflicts(bits5):
         for k, b in enumerate(bits5):
             if (l >> k) & 1:
                 i |= 1 << b
+        if posmap:
+            i = posmap(i)
         seen[bank(i)] = seen.get(bank(i), 0) + 1
     return max(seen.values()) - 1
 
 
-def plan_pass(kind, T):
-    """-> dict(rounds=[dict(pos, M, barrier_after, lane_bits[6], pair_bit or None, wave_bits[4])], tab=[[(idxA, idxB)]*1024])"""
+def plan_pass(kind, T, first_io=True, last_io=True, posmap=None):
+    """-> dict(rounds=[dict(pos, M, barrier_after, lane_bits[6], pair_bit or None, wave_bits[4])], tab=[[(idxA, idxB)]*1024])
+    first_io / last_io: the first round loads from / the last stores to global memory (lane bits follow the addresses);
+    posmap: LDS position of an index (identity when None)"""
     ph = phases_for(kind, T)
     rounds = []
     for pi, (lo, hi, F, W) in enumerate(ph):
@@ -122,8 +140,8 @@ def plan_pass(kind, T):
         R["barrier_after"] = (not last) and R["last_of_phase"]
         npair = len(rest) - 6  # bits that tell the thread's elements apart besides the stage bits
         best = None
-        if first or last:
-            rest_sorted = sorted(rest, key=lambda b: addr_rank(kind, T, b, store=not first))
+        if (first and first_io) or (last and last_io):
+            rest_sorted = sorted(rest, key=lambda b: addr_rank(kind, T, b, store=not (first and first_io)))
             # the highest-ranked bits tell the elements of a thread apart, the others are the lanes, low address bits first
             lanes, pair = rest_sorted[:6], rest_sorted[6:]
             best = (lanes, pair)
@@ -132,13 +150,13 @@ def plan_pass(kind, T):
                 lanes6 = [b for b in rest if b not in pair]
                 for hi_lane in lanes6:
                     lanes5 = [b for b in lanes6 if b != hi_lane]
-                    c = conflicts(lanes5)
+                    c = conflicts(lanes5, posmap)
                     cand = (c, lanes5 + [hi_lane], list(pair))
                     if best is None or cand[0] < best[0]:
                         best = cand
             best = (best[1], best[2])
         R["lane_bits"], R["pair_bits"] = best
-        R["conflicts"] = conflicts(R["lane_bits"][:5])
+        R["conflicts"] = conflicts(R["lane_bits"][:5], posmap)
     tab = []
     for R in rounds:
         t = []
@@ -163,6 +181,25 @@ def plan_pass(kind, T):
     return dict(kind=kind, T=T, rounds=rounds, tab=tab)
 
 
+def plan_das(T):
+    """The DAS extension of lists of 2^T <= 2048 elements in ONE tile pass: the rounds of the inverse transform, whose
+    last round multiplies result j by the twist and leaves the tile in LDS in natural order, then the rounds of the
+    forward transform reading it at bit-reversed positions.  Every round carries: part (0 inverse, 1 forward),
+    twist (multiply before the LDS store), unit (stages 0 / 1 at position 0 need no multiplication), and the forward
+    rounds the position map."""
+    inv = plan_pass(KIND_A1, T, first_io=True, last_io=False)
+    fwd = plan_pass(KIND_A1, T, first_io=False, last_io=True, posmap=brev_map(T))
+    rounds, tab = [], []
+    for r, R in enumerate(inv["rounds"]):
+        R = dict(R, part=0, unit=(r == 0), twist=(r == len(inv["rounds"]) - 1))
+        if R["twist"]:
+            R["barrier_after"] = True
+        rounds.append(R)
+    for r, R in enumerate(fwd["rounds"]):
+        rounds.append(dict(R, part=1, unit=(r == 0), twist=False))
+    return dict(kind=KIND_A1, T=T, rounds=rounds, tab=inv["tab"] + fwd["tab"], das=True)
+
+
 # ------------------------------------------------------------------------------------------ simulation
 P = 2013265921  # 15 * 2^27 + 1
 G = 31
@@ -181,42 +218,100 @@ def brev(v, bits):
     return r
 
 
-def run_tile(plan, load, store, tw):
-    """load(idx) -> value, store(idx, value), tw(stage s, idx of the lower element) -> twiddle"""
+def run_tile(plan, load, store, tw, twist=None):
+    """load(idx) -> value, store(idx, value), tw(stage s, idx of the lower element[, part]) -> twiddle,
+    twist(idx) -> multiplier (fused DAS plans)"""
     lds = {}
     owner = {}
     nr = len(plan["rounds"])
+    T = plan["T"]
+    bmap = brev_map(T)
     for r, R in enumerate(plan["rounds"]):
         newlds, newowner = {}, {}
+        part = R.get("part", 0)
+        pm = bmap if part == 1 else (lambda i: i)
         for u in range(1024):
             idx = plan["tab"][r][u]
             wave = u >> 6
             if r == 0:
                 e = [load(i) for i in idx]
             else:
-                e = [lds[i] for i in idx]
+                e = [lds[pm(i)] for i in idx]
                 if not plan["rounds"][r - 1]["barrier_after"]:
                     for i in idx:
-                        assert owner[i] == wave, "wave-local exchange reads another wave's element"
+                        assert owner[pm(i)] == wave, "wave-local exchange reads another wave's element"
             M, pos = R["M"], R["pos"]
+            twf = (lambda s_, i_: tw(s_, i_, part)) if plan.get("das") else tw
             if M >= 1:
                 for a, b in ((0, 1), (2, 3)):
                     assert idx[b] == idx[a] | (1 << pos) and not (idx[a] >> pos) & 1
-                    t = e[b] * tw(pos, idx[a]) % P
+                    t = e[b] * twf(pos, idx[a]) % P
                     e[a], e[b] = (e[a] + t) % P, (e[a] - t) % P
             if M == 2:
                 for a, b in ((0, 2), (1, 3)):
                     assert idx[b] == idx[a] | (2 << pos) and not (idx[a] >> (pos + 1)) & 1
-                    t = e[b] * tw(pos + 1, idx[a]) % P
+                    t = e[b] * twf(pos + 1, idx[a]) % P
                     e[a], e[b] = (e[a] + t) % P, (e[a] - t) % P
+            if R.get("twist"):
+                e = [v * twist(i) % P for v, i in zip(e, idx)]
             for i, v in zip(idx, e):
                 if r == nr - 1:
                     store(i, v)
                 else:
-                    assert i not in newlds
-                    newlds[i] = v
-                    newowner[i] = wave
+                    assert pm(i) not in newlds
+                    newlds[pm(i)] = v
+                    newowner[pm(i)] = wave
         lds, owner = newlds, newowner
+
+
+def das_sim(x, L):
+    """DAS extension of x (len 2^L <= 2048) through the fused plan; = fft(w2n^j * ifft(x)_j)"""
+    n = 1 << L
+    w = root_of_unity(n) if n > 1 else 1
+    w2 = root_of_unity(2 * n)
+    plan = plan_das(L)
+    data = list(x) + [0] * (TILE - n)
+    out = [None] * TILE
+    ninv = pow(n, P - 2, P)
+
+    def load(i):
+        c, p = i >> L, i & (n - 1)
+        return data[(c << L) + brev(p, L)]
+
+    def store(i, v):
+        out[i] = v * ninv % P
+
+    def tw(s, i, part):
+        j = i & ((1 << s) - 1)
+        e = j * (n >> (s + 1))
+        return pow(w, (n - e) % n if part == 0 else e, P)
+
+    def twist(i):
+        return pow(w2, i & (n - 1), P)
+
+    run_tile(plan, load, store, tw, twist)
+    return out[:n]
+
+
+def das_ref(x, L):
+    n = 1 << L
+    ninv = pow(n, P - 2, P)
+    w = root_of_unity(n) if n > 1 else 1
+    winv = pow(w, P - 2, P) if n > 1 else 1
+    w2 = root_of_unity(2 * n)
+    # inverse transform = forward with w^-1, scaled
+    a = [x[brev(i, L)] for i in range(n)]
+    for s_ in range(L):
+        half = 1 << s_
+        ws = pow(winv, n >> (s_ + 1), P)
+        for blk in range(0, n, 2 * half):
+            t = 1
+            for j in range(half):
+                u, v = a[blk + j], a[blk + j + half] * t % P
+                a[blk + j], a[blk + j + half] = (u + v) % P, (u - v) % P
+                t = t * ws % P
+    a = [v * ninv % P * pow(w2, j, P) % P for j, v in enumerate(a)]
+    return ntt_ref(a, L)
 
 
 def split_passes(L):
@@ -386,3 +481,12 @@ if __name__ == "__main__":
         got = ntt_sim(x, L)
         assert got == ntt_ref(x, L), L
         print("L = %2d ok  (passes %s)" % (L, [L] if L <= LOGT else split_passes(L)))
+    dworst = 0
+    for L in range(0, 12):
+        pl = plan_das(L)
+        dworst = max(dworst, max(R["conflicts"] for R in pl["rounds"]))
+        x = [rnd.randrange(P) for _ in range(1 << L)]
+        assert das_sim(x, L) == das_ref(x, L), L
+        if verbose:
+            print("das T %2d\n   %s" % (L, describe(pl)))
+    print("fused DAS plans ok for 2^0 .. 2^11, worst bank conflict", dworst)
