@@ -1541,6 +1541,62 @@ __global__ void __launch_bounds__(256) k_blocksum(const Xyzz* __restrict__ in_al
     if (threadIdx.x == 0) out[set] = acc;
 }
 
+// The fold of a few MSMs' partial sums (2 .. 16 commitments per call: the batches of concurrent callers), shaped by
+// the two addition latencies: a single-lane XYZZ addition is a ~16 us chain whatever the number of live lanes, a
+// limb-parallel one (g1w) ~2.7 us but takes the whole wave.  BSH_PARTS workgroups per MSM: every lane adds its strided
+// share, three single-lane tree rounds (256 -> 32 sums), then each wave adds 8 of them limb-parallel, wave 0 adds the
+// four results and the workgroup's sum goes to `part`; the last workgroup of an MSM to finish (a counter per MSM,
+// reset for the next call) adds the BSH_PARTS sums.  One launch, 1 + 3 single-lane and 8 + 4 + 16 limb-parallel
+// additions deep, against 1 + 8 and then 1 + 6 single-lane ones in two launches of k_blocksum.
+constexpr int BSH_PARTS = 16;
+__global__ void __launch_bounds__(256) k_blocksum_hybrid(const Xyzz* __restrict__ in_all, Xyzz* __restrict__ out,
+                                                         Xyzz* __restrict__ part, u32* __restrict__ counter, size_t n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Xyzz* sh = reinterpret_cast<Xyzz*>(smem);  // 256 sums, then 4 wave sums at [64 ..]
+    __shared__ u32 scr[4][16];
+    const size_t set = blockIdx.x / BSH_PARTS;
+    const int sub = (int)(blockIdx.x % BSH_PARTS);
+    const size_t per = n / BSH_PARTS;
+    const Xyzz* in = in_all + set * n + (size_t)sub * per;
+    Xyzz acc;
+    g1::set_inf(acc);
+    for (size_t k = threadIdx.x; k < per; k += blockDim.x) {
+        Xyzz b = in[k];
+        g1::dadd(acc, b);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int stride = 128; stride >= 32; stride >>= 1) {
+        if ((int)threadIdx.x < stride) {
+            Xyzz b = sh[threadIdx.x + stride];
+            g1::dadd(acc, b);
+            sh[threadIdx.x] = acc;
+        }
+        __syncthreads();
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const fpw::Lane lc = fpw::lane_consts(lane);
+    g1w::WPt w;
+    g1w::set_inf(w);
+    for (int k = 0; k < 8; ++k) g1w::dadd(w, g1w::load(sh + wave * 8 + k, lane), lc, scr[wave], lane);
+    g1w::store(sh + 64 + wave, w, lc, lane);
+    __syncthreads();
+    if (wave != 0) return;
+    g1w::set_inf(w);
+    for (int k = 0; k < 4; ++k) g1w::dadd(w, g1w::load(sh + 64 + k, lane), lc, scr[0], lane);
+    g1w::store(part + set * BSH_PARTS + sub, w, lc, lane);
+    __threadfence();
+    u32 seen = 0;
+    if (lane == 0) seen = atomicAdd(counter + set, 1u);
+    seen = (u32)__builtin_amdgcn_readfirstlane((int)seen);
+    if (seen != (u32)(BSH_PARTS - 1)) return;
+    __threadfence();
+    g1w::set_inf(w);
+    for (int k = 0; k < BSH_PARTS; ++k) g1w::dadd(w, g1w::load(part + set * BSH_PARTS + k, lane), lc, scr[0], lane);
+    g1w::store(out + set, w, lc, lane);
+    if (lane == 0) counter[set] = 0;
+}
+
 // out[m] = sum of the n (<= 64) consecutive partial sums of MSM m: one lane per MSM
 __global__ void __launch_bounds__(64) k_lane_sum(const Xyzz* __restrict__ in, Xyzz* __restrict__ out, size_t n, size_t count) {
     const size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1696,6 +1752,8 @@ struct Workspace {
     DevBuf<u32> counts, offsets, sorted, scalars, ranks, tmp, bins, digits, wghist;
     DevBuf<Xyzz> buckets, lvlA[2], lvlM[2], top, win, dense, wpart;
     DevBuf<u32> wcount;
+    DevBuf<u32> bcount;  // k_blocksum_hybrid's counters: zeroed when allocated, left at zero by every launch
+    DevBuf<Xyzz> bpart;
     DevBuf<unsigned char> heavy;
     DevBuf<u32> heavy_list, nheavy;
     DevBuf<ff::Fp> out;
@@ -1723,6 +1781,8 @@ struct Workspace {
         dense.release();
         wpart.release();
         wcount.release();
+        bcount.release();
+        bpart.release();
         win.release();
         heavy.release();
         heavy_list.release();
@@ -1738,6 +1798,9 @@ struct Workspace {
 struct MsmTuning {
     int spl = 0;               // KZGAMD_SPL: scalars per lane of the wide-table path (0 = by batch size)
     bool no_wide_tail = false; // KZGAMD_NO_WIDE_TAIL=1: single-lane instead of limb-parallel tails and folds
+    bool no_hybrid_fold = false;  // KZGAMD_NO_HYBRID_FOLD=1: two launches of k_blocksum for 5 .. 16 MSMs
+    int wide_fold_max = 0;     // KZGAMD_WIDE_FOLD_MAX: MSMs per call folded limb-parallel (0 = WIDE_FOLD_MAX)
+    int spl1_max = 0;          // KZGAMD_SPL1_MAX: MSMs per call that get a lane per (scalar, half) (0 = 8)
     int blocksum_threads = 0;  // KZGAMD_BLOCKSUM_THREADS: 64 / 128 / 256 (0 = by batch size)
     int lgc = 0;               // KZGAMD_LGC: accumulation chunk (0 = by size)
     int groups = 0;            // KZGAMD_GROUPS: window groups on their own streams (0 = one)
@@ -1751,6 +1814,9 @@ struct MsmTuning {
         };
         t.spl = num("KZGAMD_SPL") > 0 ? num("KZGAMD_SPL") : 0;
         t.no_wide_tail = getenv("KZGAMD_NO_WIDE_TAIL") != nullptr;
+        t.no_hybrid_fold = getenv("KZGAMD_NO_HYBRID_FOLD") != nullptr;
+        t.wide_fold_max = num("KZGAMD_WIDE_FOLD_MAX");
+        t.spl1_max = num("KZGAMD_SPL1_MAX");
         t.blocksum_threads = num("KZGAMD_BLOCKSUM_THREADS");
         t.lgc = num("KZGAMD_LGC");
         t.groups = num("KZGAMD_GROUPS");
@@ -2072,17 +2138,29 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         // a few MSMs over the 4096-point setup: a lane per (scalar, half) — 8 additions per lane instead of 16, twice the
         // partial sums for the fold (limb-parallel up to WIDE_FOLD_MAX MSMs, k_blocksum above)
         // (up to 8 MSMs: 8 commitments 0.79 -> 0.71 ms; 16 the same either way, 32 and 64 slower)
-        if (ctx->fbw_glv && nbatch <= 8 && npoints == 4096 && !ctx->tune.spl && !ctx->tune.no_wide_tail) spl = 1;
+        const size_t spl1_max = ctx->tune.spl1_max > 0 ? (size_t)ctx->tune.spl1_max : 8;
+        if (ctx->fbw_glv && nbatch <= spl1_max && npoints == 4096 && !ctx->tune.spl && !ctx->tune.no_wide_tail) spl = 1;
         const size_t lanes = (npoints + spl - 1) / spl * (ctx->fbw_glv ? 2 : 1);
         ws.buckets.ensure(nbatch * lanes);
         ws.lvlM[0].ensure(nbatch);
         if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) ws.lvlA[0].ensure(nbatch * 128);
-        const bool wide_fold = nbatch <= WIDE_FOLD_MAX && (lanes == 4096 || lanes == 8192) && !ctx->tune.no_wide_tail;
+        const bool hybrid_fold = nbatch <= 16 && lanes % (16 * 256) == 0 && !ctx->tune.no_wide_tail && !ctx->tune.no_hybrid_fold;
+        bool bcount_new = false;
+        if (hybrid_fold) {
+            ws.bpart.ensure(16 * (size_t)BSH_PARTS);
+            if (ws.bcount.cap < 16) {
+                ws.bcount.ensure(16);
+                bcount_new = true;
+            }
+        }
+        const size_t wf_max = ctx->tune.wide_fold_max > 0 ? (size_t)ctx->tune.wide_fold_max : WIDE_FOLD_MAX;
+        const bool wide_fold = nbatch <= wf_max && (lanes == 4096 || lanes == 8192) && !ctx->tune.no_wide_tail;
         if (wide_fold) {
             ws.wpart.ensure((nbatch * 128 + nbatch) * (size_t)WFOLD);
             ws.wcount.ensure(nbatch * 128 + nbatch);
         }
         if (ctx->fbw_glv) ws.digits.ensure(nbatch * npoints * 2 * (size_t)((nwin + 3) & ~3));
+        if (bcount_new) HIP_TRY(hipMemsetAsync(ws.bcount.p, 0, 16 * sizeof(u32), stream));
         if (reserve_only) return;
         WsUse ws_use(ws, stream, &ws == &ctx->ws);
         DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n, 0, 0, nwin, (u32)nseg};
@@ -2133,6 +2211,9 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                                ws.lvlA[0].p, ws.wpart.p, ws.wcount.p, 8);
             hipLaunchKernelGGL(k_wide_fold64, dim3((unsigned)(c2 * WFOLD)), dim3(64), 0, stream, (const Xyzz*)ws.lvlA[0].p, sums,
                                ws.wpart.p + c1 * WFOLD, ws.wcount.p + c1, pw2);
+        } else if (hybrid_fold) {
+            hipLaunchKernelGGL(k_blocksum_hybrid, dim3((unsigned)(nbatch * BSH_PARTS)), dim3(256), 256 * sizeof(Xyzz), stream,
+                               (const Xyzz*)ws.buckets.p, sums, ws.bpart.p, ws.bcount.p, lanes);
         } else if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) {
             // a few MSMs: the one-workgroup-per-MSM fold is a latency chain (16 strided additions + 8 tree rounds);
             // 16 workgroups per MSM and a second small fold take 9 + 6 rounds instead (single commitment call

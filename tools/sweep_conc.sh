@@ -1,7 +1,9 @@
+# 16-thread throughput of the coalesced entry points against the leader / gather settings (KZGAMD_LEADERS,
+# KZGAMD_GATHER_MIN, KZGAMD_GATHER_US are read once per process)
 export LD_LIBRARY_PATH=rust-kzg_amd/csrc:/opt/rocm/lib
-for cfg in "4 4 0" "4 4 40" "4 8 80" "2 8 60" "3 6 60" "6 4 40" "4 6 120"; do
+for cfg in "3 6 60" "3 5 40" "3 8 100" "4 4 40" "4 5 60" "2 8 60" "2 8 120" "5 4 40" "3 6 0"; do
   set -- $cfg
   echo "LEADERS=$1 GATHER_MIN=$2 GATHER_US=$3"
   KZGAMD_LEADERS=$1 KZGAMD_GATHER_MIN=$2 KZGAMD_GATHER_US=$3 timeout 100 tools/concurrent_bench tests/golden/trusted_setup.txt 0.6 16
-  KZGAMD_LEADERS=$1 KZGAMD_GATHER_MIN=$2 KZGAMD_GATHER_US=$3 timeout 100 tools/concurrent_bench tests/golden/trusted_setup.txt 0.4 1
+  echo
 done
