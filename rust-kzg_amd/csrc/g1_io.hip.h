@@ -85,13 +85,13 @@ FF_HD Fe pow_sat(const Fe& a, ExpFn e) {
 FF_HD Fe inverse_fermat(const Fe& a) {
     return pow_sat(a, [](int i) -> u32 { return i == 0 ? ff::FpParams::p(0) - 2 : ff::FpParams::p(i); });
 }
-// a^-1 in the 2^392 Montgomery domain via the binary-Euclid inverse of the plain residue:
+// a^-1 in the 2^392 Montgomery domain via the (batched) binary-Euclid inverse of the plain residue:
 // (x*R')^-1 = x^-1 * R'^-1, then two multiplications by R'^2 give x^-1 * R'
 FF_HD Fe inverse(const Fe& a) {
     ff::Fp s = fp28::pack(a);  // normalized, value < 2^384 (callers pass mul outputs, < 2p)
     ff::reduce_once(s);
     ff::reduce_once(s);
-    const ff::Fp inv = ff::inverse_plain_bgcd(s);
+    const ff::Fp inv = ff::inverse_plain_fast(s);
     Fe c;
 #pragma unroll
     for (int i = 0; i < 14; ++i) c.v[i] = r2_392_l(i);

@@ -273,3 +273,19 @@ int main() {
     exe = tmp_path / "fieldcheck"
     subprocess.check_call([cxx, "-O2", "-std=c++17", "-x", "c++", str(src), "-o", str(exe)])
     assert subprocess.check_output([str(exe)]).strip() == b"0"
+
+
+def test_batched_binary_gcd_inverse_equals_the_bit_by_bit_one(tmp_path):
+    """ff::inverse_plain_fast (30 halving steps per multiword update; the inversion behind every inverse_bgcd call, host
+    and device) against ff::inverse_plain_bgcd on edge and random values of Fr and Fp (tools/inv_check.cpp); no call
+    may need the fallback."""
+    import shutil
+    import subprocess
+
+    cxx = shutil.which("g++") or shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    exe = tmp_path / "inv_check"
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "rust-kzg_amd", "csrc"),
+                           os.path.join(ROOT, "tools", "inv_check.cpp"), "-o", str(exe)])
+    out = subprocess.check_output([str(exe), "60000"]).decode()
+    assert "Fr: 0 mismatches" in out and "Fp: 0 mismatches" in out, out
+    assert out.count("fallbacks so far 0") == 2, out
