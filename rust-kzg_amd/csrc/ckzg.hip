@@ -228,7 +228,7 @@ constexpr int QT = 512;            // threads per blob
 constexpr size_t FK20_MIN_BLOBS = 16;  // cell proofs by FK20 from this batch size (measured crossover: 25 ms either way)
 constexpr size_t PROVE_CHUNK = 64;  // blobs per pipeline stage of a large compute_blob_kzg_proof batch
 constexpr size_t COMMIT_CHUNK = 256;  // blobs per pipeline stage of a large blob_to_kzg_commitment batch
-constexpr size_t QSPLIT_MAX = 4;   // up to this many blobs run the multi-workgroup variant (k_quotient_a/b)
+constexpr size_t QSPLIT_MAX = 16;  // up to this many blobs (a lane batch) run the multi-workgroup variant (k_quotient_a/b)
 constexpr int QE = (int)(N / QT);  // elements per thread (8), element index i = k*QT + t
 
 // compute_kzg_proof_rust up to the MSM (kzg/src/eip_4844.rs:437-510): y = p(z) by the barycentric
@@ -376,6 +376,15 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
 constexpr int QS = (int)(N / QT);  // workgroups per blob (8)
 constexpr size_t QSCR_FR = N + 2 * QS;                   // Fr slots per blob
 constexpr size_t QSCR_BYTES = QSCR_FR * sizeof(ff::Fr) + 16;  // + m, ticket
+
+// m = -1 (z outside the domain), ticket = 0 for every blob of a k_quotient_a / _b pair
+__global__ void __launch_bounds__(64) k_quotient_init(unsigned char* __restrict__ scratch, size_t nblobs) {
+    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblobs) return;
+    int* w = reinterpret_cast<int*>(scratch + b * QSCR_BYTES + QSCR_FR * sizeof(ff::Fr));
+    w[0] = -1;
+    w[1] = w[2] = w[3] = 0;
+}
 
 __global__ void __launch_bounds__(QT) k_quotient_a(unsigned char* __restrict__ scratch, int* __restrict__ status,
                                                    const u32* __restrict__ blobs, const u32* __restrict__ z_be,
@@ -1382,11 +1391,7 @@ void prove_enqueue(KzgAmdSettings* dev, size_t off, size_t n, hipStream_t stream
     if (n <= QSPLIT_MAX) {
         // a few blobs: QS workgroups per blob, two phases (k_quotient alone is 0.4 ms of latency per call)
         if (!dev->d_qscratch) CK_HIP(hipMalloc(&dev->d_qscratch, QSPLIT_MAX * QSCR_BYTES));
-        for (size_t b = 0; b < n; ++b) {
-            const int init[4] = {-1, 0, 0, 0};  // m = -1, ticket = 0
-            CK_HIP(hipMemcpyAsync(dev->d_qscratch + b * QSCR_BYTES + QSCR_FR * sizeof(ff::Fr), init, 16, hipMemcpyHostToDevice,
-                                  stream));
-        }
+        hipLaunchKernelGGL(k_quotient_init, dim3(1), dim3(64), 0, stream, dev->d_qscratch, n);
         hipLaunchKernelGGL(k_quotient_a, dim3((unsigned)(n * QS)), dim3(QT), 0, stream, dev->d_qscratch, stat, bl, zv,
                            (const ff::Fr*)dev->d_brp_roots);
         hipLaunchKernelGGL(k_quotient_b, dim3((unsigned)(n * QS)), dim3(QT), 0, stream, scal, yv, dev->d_qscratch, bl, zv,
