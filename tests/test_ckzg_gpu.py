@@ -446,7 +446,7 @@ def test_concurrent_callers_share_one_settings_handle(kzg, settings, oracle, ora
     assert not errors, errors
 
 
-def test_sixteen_concurrent_callers_every_result_against_the_oracle(kzg, settings, oracle, oracle_settings):
+def test_sixteen_concurrent_callers_every_result_against_the_oracle(kzg, settings, oracle, oracle_settings, golden):
     """16 threads on ONE CKZGSettings, as the reference's rayon workers use it (kzg/src/eip_4844.rs:781-805): single
     commitments, single proofs, proofs at explicit points and small batches interleaved (the calls overlap on the
     lanes of the settings object, see ckzg.hip), a large batch on the parent's own pipeline in the middle; every
@@ -476,6 +476,19 @@ def test_sixteen_concurrent_callers_every_result_against_the_oracle(kzg, setting
         want_zp.append((pz.raw, y.raw))
     bad = bytearray(blobs[0])
     bad[:32] = O.R.to_bytes(32, "big")  # element == r
+    # an element of the blob's evaluation domain
+    brp = (O.Fr * 8192).from_address(settings.c.brp_roots_of_unity)
+    zd, f = C.create_string_buffer(32), O.Fr()
+    C.memmove(C.byref(f), C.byref(brp[5]), 32)
+    L.ofr_to_be32(zd, C.byref(f))
+    z_dom = zd.raw
+    # the reference's invalid-commitment vectors: bad flags, x >= p, not on the curve, not in the subgroup
+    bad_cms = [bytes.fromhex(c["commitment"][2:]) for c in golden["compute_blob_kzg_proof"] if "invalid_commitment" in c["name"]]
+    bad_cms = [c for c in bad_cms if len(c) == 48]
+    assert len(bad_cms) >= 2
+    pz, y = C.create_string_buffer(48), C.create_string_buffer(32)
+    assert L.ocompute_kzg_proof(pz, y, blobs[9], z_dom, C.byref(oracle_settings)) == 0
+    want_dom = (pz.raw, y.raw)
     errors = []
     start = threading.Barrier(nthreads)
 
@@ -498,6 +511,59 @@ def test_sixteen_concurrent_callers_every_result_against_the_oracle(kzg, setting
                         kzg.blob_to_kzg_commitment(bytes(bad), settings)
                     with pytest.raises(kzg.KzgAmdError):
                         kzg.compute_blob_kzg_proof(bytes(bad), want_c[0], settings)
+                    with pytest.raises(kzg.KzgAmdError):
+                        kzg.compute_kzg_proof(bytes(bad), zs[i], settings)
+                if i == 7:
+                    # a commitment that is not a point of G1, an evaluation point that is not canonical: each fails
+                    # alone, inside whatever batch the call was merged into
+                    for cm in bad_cms:
+                        with pytest.raises(kzg.KzgAmdError):
+                            kzg.compute_blob_kzg_proof(blobs[i], cm, settings)
+                    with pytest.raises(kzg.KzgAmdError):
+                        kzg.compute_kzg_proof(blobs[i], O.R.to_bytes(32, "big"), settings)
+                if i == 9:
+                    # an evaluation point inside the domain (the quotient's special column), merged with the others
+                    assert kzg.compute_kzg_proof(blobs[i], z_dom, settings) == want_dom
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(nthreads)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+
+
+def test_more_concurrent_callers_than_staging_slots(kzg, settings, oracle, oracle_settings):
+    """64 threads on one CKZGSettings: more callers than page-locked staging slots (48) — the ones that find no slot
+    leave the copy of their blob to the batch leader; every result against the oracle."""
+    import threading
+
+    L = oracle.lib()
+    rnd = random.Random(64)
+    nthreads, ndistinct = 64, 8
+    blobs, want_c, want_p = [], [], []
+    for _ in range(ndistinct):
+        b = bytearray(rnd.randbytes(BLOB))
+        for i in range(0, BLOB, 32):
+            b[i] = 0
+        blobs.append(bytes(b))
+        c, pr = C.create_string_buffer(48), C.create_string_buffer(48)
+        assert L.oblob_to_kzg_commitment(c, blobs[-1], C.byref(oracle_settings)) == 0
+        assert L.ocompute_blob_kzg_proof(pr, blobs[-1], c.raw, C.byref(oracle_settings)) == 0
+        want_c.append(c.raw)
+        want_p.append(pr.raw)
+    errors = []
+    start = threading.Barrier(nthreads)
+
+    def worker(i):
+        try:
+            k = i % ndistinct
+            start.wait()
+            for rep in range(3):
+                assert kzg.blob_to_kzg_commitment(blobs[k], settings) == want_c[k]
+                assert kzg.compute_blob_kzg_proof(blobs[k], want_c[k], settings) == want_p[k]
         except Exception as e:  # noqa: BLE001
             errors.append((i, repr(e)))
 
