@@ -805,6 +805,7 @@ struct KzgAmdSettings {
     // measurement switches, read once when the settings object is created
     bool cfg_device_sha = getenv("KZGAMD_DEVICE_SHA") && atoi(getenv("KZGAMD_DEVICE_SHA")) != 0;
     size_t cfg_prove_chunk = getenv("KZGAMD_PROVE_CHUNK") ? (size_t)atoi(getenv("KZGAMD_PROVE_CHUNK")) : 0;
+    size_t cfg_prove_first = getenv("KZGAMD_PROVE_FIRST") ? (size_t)atoi(getenv("KZGAMD_PROVE_FIRST")) : 0;
     int cfg_fk20 = getenv("KZGAMD_FK20") ? (atoi(getenv("KZGAMD_FK20")) != 0 ? 1 : 0) : -1;  // -1: by batch size
     bool is_lane = false;
     std::atomic<bool> busy{false};
@@ -1237,7 +1238,15 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
     try {
         CK_HIP(hipGetDevice(&dev->device));
         CK_HIP(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
-        CK_HIP(hipStreamCreateWithFlags(&dev->stream2, hipStreamNonBlocking));
+        // stream2 carries the long one-lane latency chains that nothing waits for until the end of a call (the
+        // commitment checks of a proof batch: 1.9 ms): a low-priority stream gets a hardware queue of its own — on a
+        // queue shared with a pipeline stream it held that stream's chunk back until it was done (kernel trace of a
+        // 256-blob proof call: chunk 2 started when k_check_commitments ended)
+        {
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+            CK_HIP(hipStreamCreateWithPriority(&dev->stream2, hipStreamNonBlocking, least));
+        }
         // bytes: [0,N) monomial, [N,2N) Lagrange in bit-reversed order (reverse_bit_order, eip_4844.rs:1070)
         std::vector<uint8_t> stage(2 * N * 48);
         memcpy(stage.data(), g1_mono, N * 48);
@@ -1535,16 +1544,28 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
     } else if (derive && nth > 1 && n >= 2 * PROVE_CHUNK) {
         // blobs per pipeline chunk (median ms per call, chunk 64 / 128 / 256: 256 blobs 6.63 / 6.25 / 6.41, 512 blobs
         // 11.0 / 9.1 / 9.7, 1024 blobs 19.0 / 16.5 / 16.2)
-        size_t PCH = n >= 1024 ? 4 * PROVE_CHUNK : 2 * PROVE_CHUNK;
+        // (this round, 256 blobs, ms per call by first / later chunk size: 128 / 128 5.0, 64 / 64 4.9, 32 / 64 5.2,
+        //  32 / 96 4.75, 48 / 104 4.73 — multiples of 32 blobs fill whole rounds of two waves per SIMD in k_fbw_accum)
+        size_t PCH = n >= 1024 ? 4 * PROVE_CHUNK : (n >= 512 ? 2 * PROVE_CHUNK : PROVE_CHUNK + PROVE_CHUNK / 2);
         if (const size_t v = dev->cfg_prove_chunk) {
             if (v >= 16 && v <= 4096) PCH = v;
         }
+        // the first chunk is short: nothing runs on the GPU until its blobs are hashed and staged (trace of a 256-blob
+        // call with equal chunks of 128: first kernel at 1.17 ms of 5.1)
+        size_t first = dev->cfg_prove_first ? dev->cfg_prove_first : (PCH % 64 ? PCH / 3 : PCH / 2);
+        if (first > PCH || first < 8) first = PCH;
         // Large batch: a pipeline of PCH-blob chunks on rotating streams.  The pool hashes the blobs in
         // index order, a copier thread stages chunk after chunk (pageable memory: each copy call blocks until the
         // bytes are staged), and this thread enqueues the kernels of a chunk as soon as its challenges and its
         // blobs are there: the GPU proves chunk k while the host is still hashing chunk k+1, and the low-occupancy
         // tails of neighbouring chunks overlap (one MSM workspace per stream).
-        const size_t nchunks = (n + PCH - 1) / PCH;
+        std::vector<size_t> coff{0};  // chunk k = blobs [coff[k], coff[k + 1])
+        for (size_t at = first < n ? first : n; ; at = at + PCH < n ? at + PCH : n) {
+            coff.push_back(at);
+            if (at == n) break;
+        }
+        const size_t nchunks = coff.size() - 1;
+        auto chunk_of = [&](size_t i) { return i < first ? (size_t)0 : 1 + (i - first) / PCH; };
         std::vector<char> blob_ok(n, 1);
         std::vector<std::atomic<unsigned>> hashed(nchunks);
         for (auto& h : hashed) h.store(0);
@@ -1556,7 +1577,7 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
         std::thread copier([&] {
             (void)hipSetDevice(dev->device);
             for (size_t k = 0; k < nchunks; ++k) {
-                const size_t off = k * PCH, cn = off + PCH <= n ? PCH : n - off;
+                const size_t off = coff[k], cn = coff[k + 1] - off;
                 if (hipMemcpyAsync(dev->d_blobs + off * BYTES_PER_BLOB, blobs + off, cn * BYTES_PER_BLOB, hipMemcpyHostToDevice,
                                    cs[k]) != hipSuccess)
                     copy_err.store(1);
@@ -1568,7 +1589,7 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
                 for (size_t i = w; i < n; i += nth) {
                     blob_ok[i] = host_blob_valid(blobs[i].bytes) ? 1 : 0;
                     if (blob_ok[i]) challenge_bytes(zbuf[i].bytes, blobs[i].bytes, commitments[i].bytes);
-                    hashed[i / PCH].fetch_add(1, std::memory_order_release);
+                    hashed[chunk_of(i)].fetch_add(1, std::memory_order_release);
                 }
             });
         });
@@ -1581,7 +1602,7 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
         } joiner{copier, hasher};
         bool all_ok = true;
         for (size_t k = 0; k < nchunks && all_ok; ++k) {
-            const size_t off = k * PCH, cn = off + PCH <= n ? PCH : n - off;
+            const size_t off = coff[k], cn = coff[k + 1] - off;
             while (hashed[k].load(std::memory_order_acquire) < cn || copied.load(std::memory_order_acquire) <= k)
                 std::this_thread::yield();
             for (size_t i = off; i < off + cn; ++i) all_ok = all_ok && blob_ok[i];
