@@ -189,7 +189,11 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or let --gpus N launch them)"
                          % (args.gpus, world))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+        sys.stderr.write("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback\n")
+        sys.stderr.flush()
+        if world > 1:  # the launcher ends the other ranks as soon as one exits: let every rank say why first
+            time.sleep(3)
+        raise SystemExit(2)
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("bench.py: rank %d needs GPU %d but only %d visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
