@@ -142,7 +142,7 @@ int kzgamd_ntt_roots(void *ctx, blst_fr *roots /*W+1*/, blst_fr *reverse_roots /
  * {first stage, stages, barrier after, element bit}; tab[(r*1024 + thread)*4..] = {idxA, idxB, lds(idxA), lds(idxB)}.
  * Returns the number of rounds (<= 6), -1 on bad arguments. */
 int kzgamd_ntt_plan_dump(int kind, int T, int *rounds /* 6 x 4 */, uint16_t *tab /* 6 x 1024 x 4 */);
-/* The same for the one-pass DAS extension of lists of 2^T <= 2048 elements (inverse rounds, twist, forward rounds in
+/* The same for the one-pass DAS extension of lists of 2^T <= 4096 elements (inverse rounds, twist, forward rounds in
  * one tile): rounds[6*r..] = {first stage, stages, barrier after, element bit, flags (1 forward half, 2 unit
  * twiddles, 4 twist before the LDS store), LDS position bit of the element bit}.  Returns the rounds (<= 12). */
 int kzgamd_ntt_das_plan_dump(int T, int *rounds /* 12 x 6 */, uint16_t *tab /* 12 x 1024 x 4 */);

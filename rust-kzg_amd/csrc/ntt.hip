@@ -337,7 +337,7 @@ Fr inv_len(size_t n) {
     return ff::inverse_bgcd(ff::to_mont(v));
 }
 
-// The DAS extension of lists of <= 2048 elements in one pass (nttplan::make_das_plan): inverse rounds, twist, forward
+// The DAS extension of lists of <= 4096 elements in one pass (nttplan::make_das_plan): inverse rounds, twist, forward
 // rounds, the tile never leaves the CU in between.  Same round code as k_ntt_pass; the middle rounds carry their
 // unit / twist / direction flags at run time.
 template <int V>
@@ -503,7 +503,7 @@ extern "C" void* kzgamd_ntt_new(unsigned scale) {
             upload_plan(ctx, KIND_A2, T);
             upload_plan(ctx, KIND_B, T);
         }
-        for (int T = 0; T <= 11; ++T) upload_plan(ctx, PLAN_DAS, T);
+        for (int T = 0; T <= nttplan::LOGT; ++T) upload_plan(ctx, PLAN_DAS, T);
     } catch (...) {
         delete ctx;
         return nullptr;
@@ -562,8 +562,8 @@ extern "C" int ntt_fr(void* vctx, blst_fr* out, const blst_fr* in, size_t n, int
 // transform's last-pass multiplication (instead of its n^-1), the n^-1 in the forward transform's.
 namespace {
 void das_enqueue(NttCtx* ctx, Fr* d_odds, const Fr* d_evens, Fr* d_tmp, size_t n, size_t nbatch, hipStream_t stream) {
-    if (n <= (size_t)TILE / 2) {
-        // lists of <= 2048 elements: both transforms in ONE pass over the tile (nttplan::make_das_plan) — the data
+    if (n <= (size_t)TILE) {
+        // lists of <= 4096 elements: both transforms in ONE pass over the tile (nttplan::make_das_plan) — the data
         // crosses HBM once instead of twice and the tile's load / store skeleton is paid once
         PassParams P;
         memset(&P, 0, sizeof(P));
@@ -644,7 +644,7 @@ extern "C" int kzgamd_ntt_plan_dump(int kind, int T, int* rounds /* 6 x 4 */, ui
 }
 
 extern "C" int kzgamd_ntt_das_plan_dump(int T, int* rounds /* 12 x 6 */, uint16_t* tab /* 12 x 1024 x 4 */) {
-    if (T < 0 || T > nttplan::LOGT - 1) return -1;
+    if (T < 0 || T > nttplan::LOGT) return -1;
     const nttplan::Plan pl = nttplan::make_das_plan(T);
     for (int r = 0; r < pl.nrounds; ++r) {
         if (rounds) {

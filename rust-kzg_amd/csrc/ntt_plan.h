@@ -25,7 +25,7 @@ constexpr int LOGT = 12;
 constexpr int TILE = 1 << LOGT;
 constexpr int NT = TILE / 4;  // threads per workgroup
 constexpr int MAXR = 6;       // rounds per pass
-constexpr int MAXR_DAS = 12;  // rounds of the fused DAS extension (inverse + forward transform of <= 2048 points in one pass)
+constexpr int MAXR_DAS = 12;  // rounds of the fused DAS extension (inverse + forward transform of <= 4096 points in one pass)
 enum Kind { KIND_A1 = 0, KIND_A2 = 1, KIND_B = 2 };
 // KIND_A1: the whole transform (n <= 4096), 4096 / n contiguous transforms per tile, bit reversal folded into the load
 // KIND_A2: first pass of a longer transform: 4096 >> T blocks of 2^T positions of the bit-reversed sequence whose
@@ -257,7 +257,7 @@ inline Plan make_plan(int kind, int T, bool first_io = true, bool last_io = true
     return pl;
 }
 
-// The DAS extension of lists of 2^T <= 2048 elements in ONE tile pass (data_availability_sampling.rs:14-100 computes
+// The DAS extension of lists of 2^T <= 4096 elements in ONE tile pass (data_availability_sampling.rs:14-100 computes
 // FFT(w^j IFFT(evens)_j)): the rounds of the inverse transform, whose last round multiplies result j by the twist and
 // leaves the tile in LDS in natural order, then the rounds of the forward transform reading it at bit-reversed positions.
 inline Plan make_das_plan(int T) {

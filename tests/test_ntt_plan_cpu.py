@@ -73,7 +73,7 @@ def test_simulated_passes_equal_a_direct_transform(L):
     assert S.ntt_sim(x, L) == S.ntt_ref(x, L)
 
 
-@pytest.mark.parametrize("T", range(0, 12))
+@pytest.mark.parametrize("T", range(0, 13))
 def test_cpp_das_planner_equals_prototype(kzg, T):
     lib = kzg.lib()
     rounds = (C.c_int * 72)()
@@ -97,7 +97,7 @@ def test_cpp_das_planner_equals_prototype(kzg, T):
             assert S.swz(pm(e[1])) == S.swz(pm(e[0])) ^ S.swz(pm(1 << bit))
 
 
-@pytest.mark.parametrize("T", range(0, 12))
+@pytest.mark.parametrize("T", range(0, 13))
 def test_das_plan_is_a_schedule(T):
     pl = S.plan_das(T)
     owner_prev, stages = None, [[], []]
@@ -121,7 +121,7 @@ def test_das_plan_is_a_schedule(T):
     assert sum(R["twist"] for R in pl["rounds"]) == 1
 
 
-@pytest.mark.parametrize("L", [0, 1, 2, 5, 8, 11])
+@pytest.mark.parametrize("L", [0, 1, 2, 5, 8, 11, 12])
 def test_simulated_fused_das_equals_two_transforms(L):
     import random
 

@@ -39,7 +39,7 @@ for n, nb in shapes:
     ms = min(ts)
     res["%d x %d" % (n, nb)] = {"us": ms * 1e3, "alg_GBps": 64 * n * nb / (ms * 1e-3) / 1e9,
                                 "G_fr_mul_per_s": nb * (n / 2) * math.log2(n) / (ms * 1e-3) / 1e9}
-for n, nb in ((2048, 256), (1 << 19, 1)):
+for n, nb in ((2048, 256), (4096, 256), (1 << 19, 1)):
     if 2 * n > (1 << scale) or len(sys.argv) > 2:
         continue
     a = torch.randint(0, 2**31, (nb * n * 8,), dtype=torch.int32, device=dev)

@@ -182,7 +182,7 @@ def plan_pass(kind, T, first_io=True, last_io=True, posmap=None):
 
 
 def plan_das(T):
-    """The DAS extension of lists of 2^T <= 2048 elements in ONE tile pass: the rounds of the inverse transform, whose
+    """The DAS extension of lists of 2^T <= 4096 elements in ONE tile pass: the rounds of the inverse transform, whose
     last round multiplies result j by the twist and leaves the tile in LDS in natural order, then the rounds of the
     forward transform reading it at bit-reversed positions.  Every round carries: part (0 inverse, 1 forward),
     twist (multiply before the LDS store), unit (stages 0 / 1 at position 0 need no multiplication), and the forward
@@ -482,11 +482,11 @@ if __name__ == "__main__":
         assert got == ntt_ref(x, L), L
         print("L = %2d ok  (passes %s)" % (L, [L] if L <= LOGT else split_passes(L)))
     dworst = 0
-    for L in range(0, 12):
+    for L in range(0, 13):
         pl = plan_das(L)
         dworst = max(dworst, max(R["conflicts"] for R in pl["rounds"]))
         x = [rnd.randrange(P) for _ in range(1 << L)]
         assert das_sim(x, L) == das_ref(x, L), L
         if verbose:
             print("das T %2d\n   %s" % (L, describe(pl)))
-    print("fused DAS plans ok for 2^0 .. 2^11, worst bank conflict", dworst)
+    print("fused DAS plans ok for 2^0 .. 2^12, worst bank conflict", dworst)
