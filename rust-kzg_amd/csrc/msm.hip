@@ -1281,7 +1281,8 @@ __global__ void __launch_bounds__(64) k_digit_bits_wide(const Xyzz* __restrict__
 // one to finish adds the eight partial sums (the fold of a single commitment's partial sums: two launches instead of
 // the 13 single-lane tree levels of k_blocksum)
 constexpr int WFOLD = 8;
-constexpr size_t WIDE_FOLD_MAX = 4;  // MSMs per launch folded this way (8 and 16 measured slower than k_blocksum, whose levels are then busy)
+constexpr size_t WIDE_FOLD_MAX = 1;  // MSMs per launch folded this way (2 .. 4: k_blocksum_hybrid is faster, 0.27 / 0.28 / 0.29 ms per
+                                     // commitment call against 0.29 / 0.33 / 0.37; 8 and 16 were slower than k_blocksum already)
 __global__ void __launch_bounds__(64) k_wide_fold64(const Xyzz* __restrict__ in, Xyzz* __restrict__ out, Xyzz* __restrict__ part,
                                                     u32* __restrict__ counter, int per_wave) {
     __shared__ u32 sh[16];
@@ -1549,6 +1550,8 @@ __global__ void __launch_bounds__(256) k_blocksum(const Xyzz* __restrict__ in_al
 // reset for the next call) adds the BSH_PARTS sums.  One launch, 1 + 3 single-lane and 8 + 4 + 16 limb-parallel
 // additions deep, against 1 + 8 and then 1 + 6 single-lane ones in two launches of k_blocksum.
 constexpr int BSH_PARTS = 16;
+constexpr size_t BSH_MAX = 64;   // MSMs per call folded this way by default (KZGAMD_HYBRID_MAX)
+constexpr size_t BSH_CAP = 128;  // ... at most
 __global__ void __launch_bounds__(256) k_blocksum_hybrid(const Xyzz* __restrict__ in_all, Xyzz* __restrict__ out,
                                                          Xyzz* __restrict__ part, u32* __restrict__ counter, size_t n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1799,6 +1802,7 @@ struct MsmTuning {
     int spl = 0;               // KZGAMD_SPL: scalars per lane of the wide-table path (0 = by batch size)
     bool no_wide_tail = false; // KZGAMD_NO_WIDE_TAIL=1: single-lane instead of limb-parallel tails and folds
     bool no_hybrid_fold = false;  // KZGAMD_NO_HYBRID_FOLD=1: two launches of k_blocksum for 5 .. 16 MSMs
+    int hybrid_max = 0;           // KZGAMD_HYBRID_MAX: MSMs per call folded by k_blocksum_hybrid (0 = BSH_MAX)
     int wide_fold_max = 0;     // KZGAMD_WIDE_FOLD_MAX: MSMs per call folded limb-parallel (0 = WIDE_FOLD_MAX)
     int spl1_max = 0;          // KZGAMD_SPL1_MAX: MSMs per call that get a lane per (scalar, half) (0 = 8)
     int blocksum_threads = 0;  // KZGAMD_BLOCKSUM_THREADS: 64 / 128 / 256 (0 = by batch size)
@@ -1815,6 +1819,7 @@ struct MsmTuning {
         t.spl = num("KZGAMD_SPL") > 0 ? num("KZGAMD_SPL") : 0;
         t.no_wide_tail = getenv("KZGAMD_NO_WIDE_TAIL") != nullptr;
         t.no_hybrid_fold = getenv("KZGAMD_NO_HYBRID_FOLD") != nullptr;
+        t.hybrid_max = num("KZGAMD_HYBRID_MAX");
         t.wide_fold_max = num("KZGAMD_WIDE_FOLD_MAX");
         t.spl1_max = num("KZGAMD_SPL1_MAX");
         t.blocksum_threads = num("KZGAMD_BLOCKSUM_THREADS");
@@ -2144,23 +2149,26 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         ws.buckets.ensure(nbatch * lanes);
         ws.lvlM[0].ensure(nbatch);
         if (nbatch <= 16 && lanes % 16 == 0 && lanes >= 1024) ws.lvlA[0].ensure(nbatch * 128);
-        const bool hybrid_fold = nbatch <= 16 && lanes % (16 * 256) == 0 && !ctx->tune.no_wide_tail && !ctx->tune.no_hybrid_fold;
+        const size_t hybrid_max = ctx->tune.hybrid_max > 0 ? (size_t)ctx->tune.hybrid_max : BSH_MAX;
+        const bool hybrid_fold = nbatch <= hybrid_max && nbatch <= BSH_CAP && lanes % (16 * 256) == 0 &&
+                                 !ctx->tune.no_wide_tail && !ctx->tune.no_hybrid_fold;
         bool bcount_new = false;
         if (hybrid_fold) {
-            ws.bpart.ensure(16 * (size_t)BSH_PARTS);
-            if (ws.bcount.cap < 16) {
-                ws.bcount.ensure(16);
+            ws.bpart.ensure(BSH_CAP * (size_t)BSH_PARTS);
+            if (ws.bcount.cap < BSH_CAP) {
+                ws.bcount.ensure(BSH_CAP);
                 bcount_new = true;
             }
         }
-        const size_t wf_max = ctx->tune.wide_fold_max > 0 ? (size_t)ctx->tune.wide_fold_max : WIDE_FOLD_MAX;
+        const size_t wf_max = ctx->tune.wide_fold_max > 0 ? (size_t)ctx->tune.wide_fold_max
+                              : (ctx->tune.wide_fold_max < 0 ? (size_t)0 : WIDE_FOLD_MAX);  // negative: never
         const bool wide_fold = nbatch <= wf_max && (lanes == 4096 || lanes == 8192) && !ctx->tune.no_wide_tail;
         if (wide_fold) {
             ws.wpart.ensure((nbatch * 128 + nbatch) * (size_t)WFOLD);
             ws.wcount.ensure(nbatch * 128 + nbatch);
         }
         if (ctx->fbw_glv) ws.digits.ensure(nbatch * npoints * 2 * (size_t)((nwin + 3) & ~3));
-        if (bcount_new) HIP_TRY(hipMemsetAsync(ws.bcount.p, 0, 16 * sizeof(u32), stream));
+        if (bcount_new) HIP_TRY(hipMemsetAsync(ws.bcount.p, 0, BSH_CAP * sizeof(u32), stream));
         if (reserve_only) return;
         WsUse ws_use(ws, stream, &ws == &ctx->ws);
         DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n, 0, 0, nwin, (u32)nseg};
