@@ -227,7 +227,7 @@ class WorkerPool {
 constexpr int QT = 512;            // threads per blob
 constexpr size_t FK20_MIN_BLOBS = 16;  // cell proofs by FK20 from this batch size (measured crossover: 25 ms either way)
 constexpr size_t PROVE_CHUNK = 64;  // blobs per pipeline stage of a large compute_blob_kzg_proof batch
-constexpr size_t COMMIT_CHUNK = 256;  // blobs per pipeline stage of a large blob_to_kzg_commitment batch
+constexpr size_t COMMIT_CHUNK = 64;   // smallest pipeline stage of a blob_to_kzg_commitment batch (batches from twice this are pipelined)
 constexpr size_t QSPLIT_MAX = 16;  // up to this many blobs (a lane batch) run the multi-workgroup variant (k_quotient_a/b)
 constexpr int QE = (int)(N / QT);  // elements per thread (8), element index i = k*QT + t
 
@@ -806,6 +806,8 @@ struct KzgAmdSettings {
     bool cfg_device_sha = getenv("KZGAMD_DEVICE_SHA") && atoi(getenv("KZGAMD_DEVICE_SHA")) != 0;
     size_t cfg_prove_chunk = getenv("KZGAMD_PROVE_CHUNK") ? (size_t)atoi(getenv("KZGAMD_PROVE_CHUNK")) : 0;
     size_t cfg_prove_first = getenv("KZGAMD_PROVE_FIRST") ? (size_t)atoi(getenv("KZGAMD_PROVE_FIRST")) : 0;
+    size_t cfg_commit_first = getenv("KZGAMD_COMMIT_FIRST") ? (size_t)atoi(getenv("KZGAMD_COMMIT_FIRST")) : 0;
+    size_t cfg_commit_chunk = getenv("KZGAMD_COMMIT_CHUNK") ? (size_t)atoi(getenv("KZGAMD_COMMIT_CHUNK")) : 0;
     int cfg_fk20 = getenv("KZGAMD_FK20") ? (atoi(getenv("KZGAMD_FK20")) != 0 ? 1 : 0) : -1;  // -1: by batch size
     bool is_lane = false;
     std::atomic<bool> busy{false};
@@ -2142,17 +2144,27 @@ extern "C" C_KZG_RET kzgamd_blob_to_kzg_commitment_batch(KZGCommitment* out, con
             // its chunk is staged — while this thread stages chunk k + 1 the GPU commits to chunk k, and the tails of
             // neighbouring chunks overlap (one MSM workspace per stream).  PCIe and compute run concurrently instead
             // of back to back.
-            // a quarter of the call per chunk, between 256 blobs (the first copy, which nothing hides, stays short) and
-            // 1024 (where the MSM kernels run at their full rate)
-            size_t chunk = n / 4;
-            chunk = chunk < COMMIT_CHUNK ? COMMIT_CHUNK : (chunk > 4 * COMMIT_CHUNK ? 4 * COMMIT_CHUNK : chunk);
-            const size_t nchunks = (n + chunk - 1) / chunk;
-            for (size_t k = 0; k < nchunks; ++k) {
-                const size_t off = k * chunk, cn = off + chunk <= n ? chunk : n - off;
+            // Chunk sizes: nothing runs until the first chunk is copied, so it is short (an eighth of the call, 32 .. 256
+            // blobs); the others take a third of the rest each, at most 1024 blobs (where the MSM kernels run at their
+            // full rate), in multiples of 32 blobs (whole rounds of two waves per SIMD in k_fbw_accum).  Small kernels
+            // pay the per-launch fold and latency tails again, so there are few of them.
+            // (256 blobs: one chunk 3.99 ms, 4 x 64 4.08, 64 + 192 see DESIGN.md §6)
+            auto round32 = [](size_t v) { return (v + 31) / 32 * 32; };
+            size_t first = round32(n / 8);
+            first = first < 32 ? 32 : (first > 256 ? 256 : first);
+            if (const size_t v = dev->cfg_commit_first) first = v;
+            size_t chunk = round32((n - first + 2) / 3);
+            chunk = chunk < COMMIT_CHUNK ? COMMIT_CHUNK : (chunk > 1024 ? 1024 : chunk);
+            if (const size_t v = dev->cfg_commit_chunk) chunk = v;
+            if (first > n) first = n;
+            size_t off = 0;
+            for (size_t k = 0; off < n; ++k) {
+                const size_t cn = k == 0 ? first : (off + chunk <= n ? chunk : n - off);
                 hipStream_t cs = dev->pipe_stream(k);
                 CK_HIP(hipMemcpyAsync(dev->d_blobs + off * BYTES_PER_BLOB, blobs + off, cn * BYTES_PER_BLOB, hipMemcpyHostToDevice, cs));
                 commit_enqueue(dev, dev->d_out + off * 48, dev->d_status + off, dev->d_blobs + off * BYTES_PER_BLOB,
                                dev->d_scalars + off * N * 8, cn, cs, kzgamd::OUT_COMPRESSED);
+                off += cn;
             }
             dev->pipe_join();
         } else {
