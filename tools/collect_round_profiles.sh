@@ -36,3 +36,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 ls $R/gpurun_out | head -40
 # 5. kernel trace of the FK20 cell-proof batches (tools/time_cells.py)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cells -o $TAG -- python $R/tools/time_cells.py 256 > $R/gpurun_out/prof_cells.log 2>&1
+# 6. kernel stats of 16 concurrent callers on one settings object (lane batches: k_blob_to_scalars_ptrs, k_gather_blobs,
+#    k_quotient_a/b, k_blocksum_hybrid)
+LD_LIBRARY_PATH=$R/rust-kzg_amd/csrc:/opt/rocm/lib KZGAMD_FBW_MAX_GB=100 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_conc -o $TAG -- $R/tools/concurrent_bench $R/tests/golden/trusted_setup.txt 0.5 16 > $R/gpurun_out/prof_conc.log 2>&1
+tail -1 $R/gpurun_out/prof_conc.log
