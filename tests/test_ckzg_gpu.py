@@ -241,11 +241,12 @@ def test_compute_cells_vectors_pin_gpu_ntt(kzg, golden, blob_loader, oracle):
     fs.close()
 
 
-def test_batch_rejects_invalid_commitments_device_path(kzg, settings, golden, blob_loader):
-    # n > 4 takes the device-side commitment check (k_check_commitments); every invalid-commitment vector of
-    # compute_blob_kzg_proof (bad flags, x >= p, not on curve, not in the subgroup) must fail the batch
+@pytest.mark.parametrize("n", [6, 70])
+def test_batch_rejects_invalid_commitments_host_and_device_checks(kzg, settings, golden, blob_loader, n):
+    # batches of up to 64 blobs validate their commitments on the host's cores while the GPU proves, larger ones on the
+    # device (k_check_commitments, one lane each on a low-priority stream); every invalid-commitment vector of
+    # compute_blob_kzg_proof (bad flags, x >= p, not on curve, not in the subgroup) must fail the batch either way
     rnd = random.Random(31)
-    n = 6
     blobs = bytearray(rnd.randbytes(n * BLOB))
     for i in range(0, n * BLOB, 32):
         blobs[i] = 0
@@ -258,7 +259,7 @@ def test_batch_rejects_invalid_commitments_device_path(kzg, settings, golden, bl
         cm = bytes.fromhex(c["commitment"][2:])
         if len(cm) != 48:
             continue
-        for pos in (0, 5):
+        for pos in (0, n - 1):
             mixed = list(cms)
             mixed[pos] = cm
             with pytest.raises(kzg.KzgAmdError):
