@@ -202,11 +202,19 @@ __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __rest
     const u32 half = 1u << (P.c - 1);
     const int lane = threadIdx.x & 63;
     const u64 lt_mask = ((u64)1 << lane) - 1;
+    const u32 cmask = (1u << P.c) - 1u;
     for (int part = 0; part <= P.glv; ++part) {
-        const u32* sv = part ? s2 : s;
+        // the scalar (half) in registers, shifted down one window at a time: static indices only (a dynamic index
+        // into the words is scratch traffic)
+        u32 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = part ? s2[q] : s[q];
         u32 carry = 0;
         for (int w = 0; w < P.w1; ++w) {
-            u32 d = window_bits(sv, w * P.c, P.c) + carry;
+            u32 d = (v[0] & cmask) + carry;
+#pragma unroll
+            for (int x = 0; x < 7; ++x) v[x] = (v[x] >> P.c) | (v[x + 1] << (32 - P.c));
+            v[7] >>= P.c;
             u32 neg = 0;
             carry = 0;
             if (d > half) {
