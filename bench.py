@@ -425,6 +425,27 @@ def main():
                                                "Fiat-Shamir SHA-256 on host threads",
                                        "algorithmic_bytes_per_proof": ALG_BYTES_PER_COMMIT + 131120}
 
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- host-buffer calls of 1 .. 256 blobs (the reference-shaped entry points; median of 7 calls each) ----------
+        table = []
+        for nb_ in (1, 4, 16, 64, 256):
+            hbn = blobs[:nb_].cpu().numpy().tobytes()
+            cmn = b"".join(kzg.blob_to_kzg_commitment_batch(hbn, nb_, settings))
+            row = {"blobs": nb_}
+            for key, fn in (("commit_ms", lambda: kzg.blob_to_kzg_commitment_batch(hbn, nb_, settings)),
+                            ("proof_ms", lambda: kzg.compute_blob_kzg_proof_batch(hbn, cmn, nb_, settings))):
+                fn()
+                ts = []
+                for _ in range(7):
+                    t0 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - t0)
+                ts.sort()
+                row[key] = ts[3] * 1e3
+            table.append(row)
+        res["host_buffer_batch_calls"] = {"rows": table, "path": "kzgamd_blob_to_kzg_commitment_batch / "
+                                          "kzgamd_compute_blob_kzg_proof_batch through the ctypes mirror, host buffers in and out"}
+
     if rank == 0 and not args.no_extras:
         # ---- configs[3]: Fr NTT n = 4096 (batched) and n = 2^20, forward, inverse and the DAS extension of half -------
         fs = kzg.FFTSettings(20)
