@@ -203,6 +203,39 @@ def test_blob_proof_batch_equals_singles_and_oracle(kzg, settings, oracle, oracl
     assert kzg.compute_blob_kzg_proof(blobs[:BLOB], inf, settings) == ep.raw
 
 
+@pytest.mark.parametrize("n", [3, 7, 16, 40])
+def test_batches_with_zero_and_constant_blobs(kzg, settings, oracle, oracle_settings, n):
+    """Points at infinity inside a batch (the all-zero blob commits to infinity and so does its proof; a constant blob's
+    proof is infinity too): the host-side batch compression of small batches shares one inversion over the finite
+    points only, the device-side one (above 16 blobs) likewise; every result against the oracle."""
+    L = oracle.lib()
+    rnd = random.Random(300 + n)
+    blobs = []
+    for i in range(n):
+        if i % 3 == 0:
+            blobs.append(bytes(BLOB))
+        elif i % 3 == 1:
+            blobs.append(rnd.randrange(O.R).to_bytes(32, "big") * 4096)
+        else:
+            b = bytearray(rnd.randbytes(BLOB))
+            for k in range(0, BLOB, 32):
+                b[k] = 0
+            blobs.append(bytes(b))
+    flat = b"".join(blobs)
+    cms = kzg.blob_to_kzg_commitment_batch(flat, n, settings)
+    proofs = kzg.compute_blob_kzg_proof_batch(flat, b"".join(cms), n, settings)
+    for i in range(n):
+        ec, ep = C.create_string_buffer(48), C.create_string_buffer(48)
+        assert L.oblob_to_kzg_commitment(ec, blobs[i], C.byref(oracle_settings)) == 0
+        assert cms[i] == ec.raw, (n, i)
+        assert L.ocompute_blob_kzg_proof(ep, blobs[i], ec.raw, C.byref(oracle_settings)) == 0
+        assert proofs[i] == ep.raw, (n, i)
+        if i % 3 == 0:
+            assert cms[i] == b"\xc0" + bytes(47)
+        if i % 3 != 2:
+            assert proofs[i] == b"\xc0" + bytes(47)
+
+
 def test_compute_cells_vectors_pin_gpu_ntt(kzg, golden, blob_loader, oracle):
     # polynomial half of compute_cells (kzg/src/das.rs:258-279) through the GPU NTT:
     # ifft(brp(blob)) -> zero-extend -> fft 8192 -> brp, against the c-kzg vectors
