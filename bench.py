@@ -559,8 +559,11 @@ def main():
                 res["concurrent_callers"] = {
                     "threads_16": {"blob_to_kzg_commitment_per_s": o16.get("commit_threads_16"), "compute_blob_kzg_proof_per_s": o16.get("proof_threads_16")},
                     "threads_1": {"blob_to_kzg_commitment_per_s": o1.get("commit_threads_1"), "compute_blob_kzg_proof_per_s": o1.get("proof_threads_1")},
+                    "failed_or_different_from_the_serial_results": (o16.get("failed_or_different_from_the_serial_results", 0) or 0)
+                                                                   + (o1.get("failed_or_different_from_the_serial_results", 0) or 0),
                     "path": "native threads, one CKZGSettings, host buffers; calls are merged into batches on up to three lanes "
-                            "(own process: its settings object is loaded next to this one)"}
+                            "(own process: its settings object is loaded next to this one); every result is compared with "
+                            "the one a serial call gave"}
             except Exception as e:  # noqa: BLE001
                 res["concurrent_callers"] = {"error": repr(e)}
 
