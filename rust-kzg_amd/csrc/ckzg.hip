@@ -22,6 +22,7 @@
 #include "ff.hip.h"
 #include "fr29.hip.h"
 #include "g1_io.hip.h"
+#include "g1w.hip.h"
 #include "host_g1.h"
 #include "host_pairing.h"
 #include "msm_internal.h"
@@ -650,6 +651,7 @@ __device__ __forceinline__ bool affpt_in_g1(const AffPt& p) {
 
 // compressed bytes -> table slots + status: 0 ok, 1 not a valid encoding, 2 on the curve but outside the r-torsion
 // subgroup (one square root per point: the decode and the membership test of batched verification in one kernel)
+template <bool CHECK>
 __global__ void __launch_bounds__(64) k_decode_check_g1(AffPt* __restrict__ out, int* __restrict__ status,
                                                         const unsigned char* __restrict__ in, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -662,7 +664,68 @@ __global__ void __launch_bounds__(64) k_decode_check_g1(AffPt* __restrict__ out,
         return;
     }
     out[i] = p;
-    status[i] = affpt_in_g1(p) ? 0 : 2;
+    status[i] = !CHECK || affpt_in_g1(p) ? 0 : 2;
+}
+
+// The membership test of affpt_in_g1 with ONE WAVE PER POINT (g1w: the limbs of a coordinate across the lanes of a DPP
+// row, the independent products of a point formula in the four rows): 2 x (63 doublings + 5 additions) of 3 / 4
+// multiplication steps each instead of ~1 000 single-lane multiplications — the test is a latency chain (1.1 ms in one
+// lane) in front of every batched verification, and a few hundred points leave the chip empty anyway.
+// status[i] != 0 (not decoded) is left alone; a point that fails gets 2.
+__device__ __forceinline__ void wide_mul_by_abs_x(g1w::WPt& acc, const g1w::WPt& b, const fpw::Lane& lc, u32* sh, int lane) {
+    // |x| = 0xd201000000010000: bits 63, 62, 60, 57, 48, 16
+    acc = b;
+    const int runs[6] = {1, 2, 3, 9, 32, 16};
+#pragma unroll 1
+    for (int r = 0; r < 6; ++r) {
+#pragma unroll 1
+        for (int k = 0; k < runs[r]; ++k) g1w::dbl(acc, lc, lane);  // odd group order: never infinity
+        if (r < 5) g1w::dadd(acc, b, lc, sh, lane);
+    }
+}
+__global__ void __launch_bounds__(64) k_affpts_in_g1_wide(int* __restrict__ status, const AffPt* __restrict__ pts, size_t n) {
+    __shared__ u32 sh[16];
+    const size_t i = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (i >= n || status[i] != 0) return;
+    const u32* w = reinterpret_cast<const u32*>(pts + i);
+    if (w[2 * fp28::L] & 1u) return;  // infinity
+    const fpw::Lane lc = fpw::lane_consts(lane);
+    const int li = lane & 15;
+    g1w::WPt P, q1, q2;
+    P.x = li < fp28::L ? w[li] : 0u;
+    P.y = li < fp28::L ? w[fp28::L + li] : 0u;
+    P.zz = P.zzz = fpw::to_wide(fp28::one(), sh, lane);
+    wide_mul_by_abs_x(q1, P, lc, sh, lane);
+    wide_mul_by_abs_x(q2, q1, lc, sh, lane);
+    bool ok = !g1w::is_inf(q2);
+    if (ok) {
+        fp28::Fe beta;
+        {
+            constexpr u32 t[14] = {0xa75929au, 0x681b798u, 0x22a3e9du, 0xabc02bfu, 0x4e5bb45u, 0x55e6e7eu, 0x4814117u,
+                                   0x6d04f1bu, 0xae3387du, 0x54acb0cu, 0xa4c74bu, 0x56138b5u, 0xb64e066u, 0x76f2u};
+#pragma unroll
+            for (int k = 0; k < 14; ++k) beta.v[k] = t[k];
+        }
+        const u32 bw = fpw::to_wide(beta, sh, lane);
+        // phi(P) == -Q2  <=>  beta*x*ZZ == X  and  y*ZZZ == -Y   (as in affpt_in_g1)
+        const u32 dx = fpw::wsub32(fpw::wmul(fpw::wmul(bw, P.x, lc), q2.zz, lc), q2.x, lc);
+        const u32 dy = fpw::waddn(fpw::wmul(P.y, q2.zzz, lc), q2.y, lc);
+        ok = g1w::is_zero_mod_p(dx, sh, lane) && g1w::is_zero_mod_p(dy, sh, lane);
+    }
+    if (!ok && lane == 0) status[i] = 2;
+}
+
+// decode + membership test of np compressed points: up to WIDE_CHECK_MAX points the test runs one wave per point
+constexpr size_t WIDE_CHECK_MAX = 4096;
+void decode_check_enqueue(AffPt* d_pts, int* d_stat, const unsigned char* d_bytes, size_t np, hipStream_t st, bool wide) {
+    const dim3 grid((unsigned)((np + 63) / 64));
+    if (wide && np <= WIDE_CHECK_MAX) {
+        hipLaunchKernelGGL(k_decode_check_g1<false>, grid, dim3(64), 0, st, d_pts, d_stat, d_bytes, np);
+        hipLaunchKernelGGL(k_affpts_in_g1_wide, dim3((unsigned)np), dim3(64), 0, st, d_stat, (const AffPt*)d_pts, np);
+    } else {
+        hipLaunchKernelGGL(k_decode_check_g1<true>, grid, dim3(64), 0, st, d_pts, d_stat, d_bytes, np);
+    }
 }
 
 // commitment bytes -> status: 0 ok (valid encoding, and infinity or in the r-torsion subgroup), 1 bad
@@ -805,6 +868,7 @@ struct KzgAmdSettings {
     // measurement switches, read once when the settings object is created
     bool cfg_device_sha = getenv("KZGAMD_DEVICE_SHA") && atoi(getenv("KZGAMD_DEVICE_SHA")) != 0;
     size_t cfg_prove_chunk = getenv("KZGAMD_PROVE_CHUNK") ? (size_t)atoi(getenv("KZGAMD_PROVE_CHUNK")) : 0;
+    bool cfg_wide_check = !(getenv("KZGAMD_WIDE_CHECK") && atoi(getenv("KZGAMD_WIDE_CHECK")) == 0);  // 0: single-lane tests
     size_t cfg_prove_first = getenv("KZGAMD_PROVE_FIRST") ? (size_t)atoi(getenv("KZGAMD_PROVE_FIRST")) : 0;
     size_t cfg_commit_first = getenv("KZGAMD_COMMIT_FIRST") ? (size_t)atoi(getenv("KZGAMD_COMMIT_FIRST")) : 0;
     size_t cfg_commit_chunk = getenv("KZGAMD_COMMIT_CHUNK") ? (size_t)atoi(getenv("KZGAMD_COMMIT_CHUNK")) : 0;
@@ -2434,8 +2498,7 @@ void verify_g1_begin(const Bytes48* commitments, const Bytes48* proofs, size_t n
     CK_HIP(hipMemcpyAsync(dev->d_vbytes, dev->vstage.data(), dev->vstage.size(), hipMemcpyHostToDevice, st));
     CK_HIP(hipMemsetAsync(dev->d_vstat, 0, np * sizeof(int), st));
     CK_HIP(hipMemsetAsync(dev->d_vpts, 0, np * sizeof(AffPt), st));
-    hipLaunchKernelGGL(k_decode_check_g1, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st, dev->d_vpts, dev->d_vstat,
-                       (const unsigned char*)dev->d_vbytes, np);
+    decode_check_enqueue(dev->d_vpts, dev->d_vstat, (const unsigned char*)dev->d_vbytes, np, st, dev->cfg_wide_check);
     CK_HIP(hipGetLastError());
 }
 
@@ -2773,8 +2836,7 @@ void decode_points_begin(KzgAmdSettings* dev, const std::vector<uint8_t>& bytes,
     CK_HIP(hipMemcpyAsync(dev->d_vbytes, dev->vstage.data(), np * 48, hipMemcpyHostToDevice, st));
     CK_HIP(hipMemsetAsync(dev->d_vstat, 0, np * sizeof(int), st));
     CK_HIP(hipMemsetAsync(dev->d_vpts, 0, np * sizeof(AffPt), st));
-    hipLaunchKernelGGL(k_decode_check_g1, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st, dev->d_vpts, dev->d_vstat,
-                       (const unsigned char*)dev->d_vbytes, np);
+    decode_check_enqueue(dev->d_vpts, dev->d_vstat, (const unsigned char*)dev->d_vbytes, np, st, dev->cfg_wide_check);
     CK_HIP(hipGetLastError());
 }
 std::vector<int> decode_points_status(KzgAmdSettings* dev, size_t np) {
