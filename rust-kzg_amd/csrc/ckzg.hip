@@ -1001,6 +1001,25 @@ struct KzgAmdSettings {
     ff::Fr* d_pow7 = nullptr;        // 7^i and 7^-i, i < 8192 (coset shifts, das.rs:463-491)
     ff::Fr* d_pow7inv = nullptr;
     bool fk20_unavailable = false;   // the FK20 table could not be built (no HBM left): batches use the direct form
+    // verify_cell_kzg_proof_batch: the cells (canonical limbs), their columns and the powers of r, for k_vcell_agg
+    u32* d_vc_cells = nullptr;
+    u32* d_vc_cols = nullptr;
+    ff::Fr* d_vc_pw = nullptr;
+    size_t cap_vc = 0;
+    void ensure_vcells(size_t n) {
+        if (n <= cap_vc) return;
+        if (d_vc_cells) (void)hipFree(d_vc_cells);
+        if (d_vc_cols) (void)hipFree(d_vc_cols);
+        if (d_vc_pw) (void)hipFree(d_vc_pw);
+        d_vc_cells = d_vc_cols = nullptr;
+        d_vc_pw = nullptr;
+        cap_vc = 0;
+        const size_t cap = n < 128 ? 128 : n;
+        CK_HIP(hipMalloc(&d_vc_cells, cap * CELL_SIZE * 32));
+        CK_HIP(hipMalloc(&d_vc_cols, cap * sizeof(u32)));
+        CK_HIP(hipMalloc(&d_vc_pw, cap * sizeof(ff::Fr)));
+        cap_vc = cap;
+    }
     void ensure_recover() {
         if (d_rec[0]) return;
         for (int k = 0; k < 4; ++k) CK_HIP(hipMalloc(&d_rec[k], 2 * N * sizeof(ff::Fr)));
@@ -1052,6 +1071,9 @@ struct KzgAmdSettings {
         if (d_brp_roots) (void)hipFree(d_brp_roots);
         for (int k = 0; k < 4; ++k)
             if (d_rec[k]) (void)hipFree(d_rec[k]);
+        if (d_vc_cells) (void)hipFree(d_vc_cells);
+        if (d_vc_cols) (void)hipFree(d_vc_cols);
+        if (d_vc_pw) (void)hipFree(d_vc_pw);
         if (d_rec_in) (void)hipFree(d_rec_in);
         if (d_rec_idx) (void)hipFree(d_rec_idx);
         if (d_pow7) (void)hipFree(d_pow7);
@@ -2851,32 +2873,46 @@ std::vector<int> decode_points_status(KzgAmdSettings* dev, size_t np) {
 
 // inverse transform of 64 values on the host (fft_fr(.., inverse = true) of a column, das.rs:818-819): exact field
 // arithmetic, so any butterfly order gives the reference's values.  roots = roots_of_unity[0..=8192].
-void host_ifft64(ff::Fr* a, const ff::Fr* roots) {
-    for (u32 i = 0; i < 64; ++i) {
-        u32 j = 0;
-        for (int b = 0; b < 6; ++b)
-            if (i & (1u << b)) j |= 1u << (5 - b);
-        if (j > i) std::swap(a[i], a[j]);
+// The aggregated interpolation polynomial of verify_cell_kzg_proof_batch
+// (compute_commitment_to_aggregated_interpolation_poly, kzg/src/das.rs:778-835) on the GPU — on the host its ~50 000
+// field multiplications were three quarters of a 128-cell call.
+// k_vcell_agg: agg[col][brp6(f)] = sum over the cells i of column col of r^i * cell_i[f]  (r^i Montgomery, the cell
+// elements canonical: the products and sums stay canonical; columns nobody asked about stay zero);
+// then 128 inverse transforms of 64 values (ntt.hip);
+// k_vcell_interp: interp[k] = sum_col v[col][k] * h_col^-k,  h_col^-k = roots_of_unity[(8192 - rbl7(col)) k mod 8192].
+__global__ void __launch_bounds__(256) k_vcell_agg(ff::Fr* __restrict__ agg, const u32* __restrict__ cells,
+                                                   const u32* __restrict__ cols, const ff::Fr* __restrict__ pw, size_t n) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= CELLS_PER_EXT_BLOB * CELL_SIZE) return;
+    const u32 col = t >> 6, f = t & 63u;
+    ff::Fr acc = ff::Fr::zero();
+    for (size_t i = 0; i < n; ++i) {
+        if (cols[i] != col) continue;
+        ff::Fr c;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c.v[k] = cells[(i * CELL_SIZE + f) * 8 + k];
+        acc = ff::add(acc, fmul(pw[i], c));
     }
-    for (u32 len = 2; len <= 64; len <<= 1) {
-        const u32 half = len >> 1, step = (u32)(2 * N) / len;
-        for (u32 i = 0; i < 64; i += len)
-            for (u32 j = 0; j < half; ++j) {
-                const ff::Fr w = roots[2 * N - j * step];  // w^-j
-                const ff::Fr u = a[i + j], v = ff::mul(a[i + j + half], w);
-                a[i + j] = ff::add(u, v);
-                a[i + j + half] = ff::sub(u, v);
-            }
+    agg[col * CELL_SIZE + (__builtin_bitreverse32(f) >> 26)] = acc;
+}
+__global__ void __launch_bounds__(128) k_vcell_interp(ff::Fr* __restrict__ out, const ff::Fr* __restrict__ v,
+                                                      const ff::Fr* __restrict__ roots8192) {
+    __shared__ ff::Fr sh[CELLS_PER_EXT_BLOB];
+    const u32 k = blockIdx.x, col = threadIdx.x;
+    const u32 rbl = __builtin_bitreverse32(col) >> 25;  // CELL_INDICES_RBL (das.rs:87-96)
+    const u32 idx = ((2u * (u32)N - rbl) * k) & (2u * (u32)N - 1u);
+    sh[col] = fmul(roots8192[idx], v[col * CELL_SIZE + k]);  // Montgomery x canonical -> canonical
+    __syncthreads();
+    for (u32 off = CELLS_PER_EXT_BLOB / 2; off > 0; off >>= 1) {
+        if (col < off) sh[col] = ff::add(sh[col], sh[col + off]);
+        __syncthreads();
     }
-    ff::Fr k64 = ff::Fr::zero();
-    k64.v[0] = 64;
-    const ff::Fr inv64 = ff::inverse_bgcd(ff::to_mont(k64));
-    for (u32 i = 0; i < 64; ++i) a[i] = ff::mul(a[i], inv64);
+    if (col == 0) out[k] = sh[0];
 }
 
-// verify_cell_kzg_proof_batch (kzg/src/das.rs:294-389).  Host: parsing, the Fiat-Shamir scalar, the powers of r,
-// the aggregated interpolation polynomial (<= 128 inverse transforms of 64 values; compute_commitment_to_aggregated_
-// interpolation_poly, :778-835).  GPU: decoding + subgroup checks of proofs and commitments, and every linear
+// verify_cell_kzg_proof_batch (kzg/src/das.rs:294-389).  Host: parsing, the Fiat-Shamir scalar, the powers of r.
+// GPU: the aggregated interpolation polynomial (k_vcell_agg, <= 128 inverse transforms of 64 values, k_vcell_interp;
+// compute_commitment_to_aggregated_interpolation_poly, :778-835), decoding + subgroup checks of proofs and commitments, and every linear
 // combination as ONE two-row MSM over [proofs | unique commitments | g1_monomial[0..64)]:
 //     row 0:  r^i             0          0        -> proof_lincomb
 //     row 1:  r^i h_k(i)^64   weight_j   -I_k     -> sum_j w_j C_j - [I(s)] + sum_i r^i h^64 proof_i
@@ -2910,37 +2946,44 @@ void verify_cells(bool* ok, const Bytes48* commitments_bytes, const uint64_t* ce
     const ff::Fr* roots = reinterpret_cast<const ff::Fr*>(cs->roots_of_unity);
     const ff::Fr r = cell_batch_challenge(uniq.data(), m, cidx.data(), cell_indices, cells, proofs_bytes, n);
     std::vector<ff::Fr> sc(2 * np, ff::Fr::zero());
-    std::vector<ff::Fr> agg(CELLS_PER_EXT_BLOB * CELL_SIZE, ff::Fr::zero());
-    std::vector<char> used(CELLS_PER_EXT_BLOB, 0);
+    std::vector<ff::Fr> pws(n);
+    std::vector<u32> cols32(n);
     ff::Fr pw = ff::Fr::one();
     for (size_t i = 0; i < n; ++i) {
         const size_t col = (size_t)cell_indices[i];
         sc[i] = pw;                                                                     // row 0: proofs
         sc[np + i] = ff::mul(pw, roots[rbl7((u32)col) * CELL_SIZE]);                    // row 1: r^i * h_k^64 (:837-884)
         sc[np + n + cidx[i]] = ff::add(sc[np + n + cidx[i]], pw);                       // row 1: commitment weights (:698-743)
-        for (size_t f = 0; f < CELL_SIZE; ++f)
-            agg[col * CELL_SIZE + f] = ff::add(agg[col * CELL_SIZE + f], ff::mul(ff::to_mont(cf[i * CELL_SIZE + f]), pw));
-        used[col] = 1;
+        pws[i] = pw;
+        cols32[i] = (u32)col;
         pw = ff::mul(pw, r);
     }
-    std::vector<ff::Fr> interp(CELL_SIZE, ff::Fr::zero());
-    for (size_t col = 0; col < CELLS_PER_EXT_BLOB; ++col) {
-        if (!used[col]) continue;
-        ff::Fr colv[CELL_SIZE];
-        for (u32 f = 0; f < CELL_SIZE; ++f) {  // reverse_bit_order of the column
-            u32 j = 0;
-            for (int b = 0; b < 6; ++b)
-                if (f & (1u << b)) j |= 1u << (5 - b);
-            colv[j] = agg[col * CELL_SIZE + f];
+    // the aggregated interpolation polynomial (:778-835) on the GPU: k_vcell_agg, 128 inverse transforms of 64, k_vcell_interp
+    std::vector<ff::Fr> interp(CELL_SIZE);
+    {
+        std::lock_guard<std::mutex> lk(dev->mu);
+        kzgamd::DeviceGuard on_device(dev->device);
+        CK_HIP(on_device.err);
+        dev->ensure_recover();
+        dev->ensure_vcells(n);
+        if (!dev->d_roots8192) {
+            CK_HIP(hipMalloc(&dev->d_roots8192, (2 * N + 1) * sizeof(ff::Fr)));
+            CK_HIP(hipMemcpy(dev->d_roots8192, cs->roots_of_unity, (2 * N + 1) * sizeof(ff::Fr), hipMemcpyHostToDevice));
         }
-        host_ifft64(colv, roots);
-        const ff::Fr inv_shift = roots[2 * N - rbl7((u32)col)];  // h_k^-1 (:746-776)
-        ff::Fr fp = ff::Fr::one();
-        for (size_t k = 0; k < CELL_SIZE; ++k) {  // shift_poly + accumulate
-            interp[k] = ff::add(interp[k], k == 0 ? colv[0] : ff::mul(colv[k], fp));
-            fp = ff::mul(fp, inv_shift);
-        }
+        hipStream_t st = dev->stream;
+        CK_HIP(hipMemcpyAsync(dev->d_vc_cells, cf.data(), n * CELL_SIZE * 32, hipMemcpyHostToDevice, st));
+        CK_HIP(hipMemcpyAsync(dev->d_vc_cols, cols32.data(), n * sizeof(u32), hipMemcpyHostToDevice, st));
+        CK_HIP(hipMemcpyAsync(dev->d_vc_pw, pws.data(), n * sizeof(ff::Fr), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_vcell_agg, dim3((unsigned)(CELLS_PER_EXT_BLOB * CELL_SIZE / 256)), dim3(256), 0, st, dev->d_rec[0],
+                           (const u32*)dev->d_vc_cells, (const u32*)dev->d_vc_cols, (const ff::Fr*)dev->d_vc_pw, n);
+        if (kzgamd_ntt_fr_device(dev->ntt, dev->d_rec[1], dev->d_rec[0], CELL_SIZE, CELLS_PER_EXT_BLOB, 1, st) != 0)
+            throw CkErr{C_KZG_ERROR, "ntt"};
+        hipLaunchKernelGGL(k_vcell_interp, dim3((unsigned)CELL_SIZE), dim3((unsigned)CELLS_PER_EXT_BLOB), 0, st, dev->d_rec[2],
+                           (const ff::Fr*)dev->d_rec[1], (const ff::Fr*)dev->d_roots8192);
+        CK_HIP(hipMemcpyAsync(interp.data(), dev->d_rec[2], CELL_SIZE * sizeof(ff::Fr), hipMemcpyDeviceToHost, st));
+        CK_HIP(hipStreamSynchronize(st));
     }
+    for (size_t k = 0; k < CELL_SIZE; ++k) interp[k] = ff::to_mont(interp[k]);  // the kernels work on canonical values
     for (size_t k = 0; k < CELL_SIZE; ++k) sc[np + n + m + k] = ff::neg(interp[k]);
     const std::vector<int> stat = decode_points_status(dev, np);
     for (size_t i = 0; i < np; ++i) CK_REQUIRE(stat[i] != 1, "Invalid G1 encoding");

@@ -140,3 +140,34 @@ def test_compute_erase_recover_verify_round_trip(kzg, settings, golden, blob_loa
     bad[CELL * 3 + 31] ^= 1
     assert not kzg.verify_cell_kzg_proof_batch(commitment * len(pick), pick, bytes(bad),
                                                b"".join(rp[48 * i: 48 * (i + 1)] for i in pick), settings)
+
+
+def test_verify_many_cells_of_several_blobs(kzg, settings):
+    # more cells than one extended blob has (the device staging of the cells grows), three commitments, the same
+    # column asked about several times (its cells add up in the aggregated interpolation polynomial) and a repeated
+    # (cell, proof) pair; then one wrong proof / one cell of another blob make the batch fail
+    rnd = random.Random(44)
+    blobs = []
+    for _ in range(3):
+        b = bytearray(rnd.randbytes(131072))
+        for i in range(0, 131072, 32):
+            b[i] = 0
+        blobs.append(bytes(b))
+    cms = [kzg.blob_to_kzg_commitment(b, settings) for b in blobs]
+    cp = [kzg.compute_cells_and_kzg_proofs(b, settings) for b in blobs]
+    picks = [(k, i) for k in range(3) for i in range(128)] + [(0, 5), (2, 5), (1, 77)]
+    rnd.shuffle(picks)
+    coms = b"".join(cms[k] for k, _ in picks)
+    idx = [i for _, i in picks]
+    cells = b"".join(cp[k][0][CELL * i: CELL * (i + 1)] for k, i in picks)
+    proofs = b"".join(cp[k][1][48 * i: 48 * (i + 1)] for k, i in picks)
+    assert len(idx) == 387
+    assert kzg.verify_cell_kzg_proof_batch(coms, idx, cells, proofs, settings)
+    wrong = bytearray(proofs)
+    wrong[48 * 200: 48 * 201] = proofs[48 * 201: 48 * 202]  # a valid G1 point, the wrong proof
+    if picks[200] != picks[201]:
+        assert not kzg.verify_cell_kzg_proof_batch(coms, idx, cells, bytes(wrong), settings)
+    k, i = picks[10]
+    other = bytearray(cells)
+    other[CELL * 10: CELL * 11] = cp[(k + 1) % 3][0][CELL * i: CELL * (i + 1)]
+    assert not kzg.verify_cell_kzg_proof_batch(coms, idx, bytes(other), proofs, settings)
