@@ -617,7 +617,7 @@ def main():
         res["eip7594"] = {"recover_cells_and_kzg_proofs_ms": t_rec * 1e3, "recover_cells_only_ms": t_rec_cells * 1e3,
                           "verify_cell_kzg_proof_batch_128_cells_ms": t_ver * 1e3,
                           "path": "64 of 128 cells -> all cells (five 8192-point transforms on the GPU) + 128 proofs (direct "
-                                  "form); verification: decode + subgroup checks + one two-row MSM on the GPU, pairing on the host"}
+                                  "form); verification: interpolation polynomial, decode, subgroup checks and one two-row MSM on the GPU, pairing on the host"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         ns = min(B, 64)
