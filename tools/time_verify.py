@@ -41,3 +41,4 @@ cells, cproofs = kzg.compute_cells_and_kzg_proofs(bl[0], s)
 idx = list(range(128))
 assert kzg.verify_cell_kzg_proof_batch(cms[0] * 128, idx, cells, cproofs, s)
 print("verify_cell_kzg_proof_batch(128 cells): %.3f ms" % med(lambda: kzg.verify_cell_kzg_proof_batch(cms[0] * 128, idx, cells, cproofs, s)))
+print("verify_blob_kzg_proof (single): %.3f ms" % med(lambda: kzg.verify_blob_kzg_proof(bl[0], cms[0], prs[0], s)))
