@@ -2735,19 +2735,20 @@ extern "C" C_KZG_RET verify_blob_kzg_proof(bool* ok, const Blob* blob, const Byt
         // the two points are decoded and subgroup-checked (0.3 ms of one core each) on two helper threads while this
         // one hashes the challenge and the GPU evaluates the polynomial
         bool c_ok = false, pr_ok = false;
-        std::thread tc([&] {
-            c_ok = kzgamd::host_p1_uncompress(&c, commitment_bytes->bytes) && kzgamd::host_p1_in_g1(&c);  // infinity passes
-        });
-        std::thread tp([&] {
-            pr_ok = kzgamd::host_p1_uncompress(&pr, proof_bytes->bytes) && kzgamd::host_p1_in_g1(&pr);
-        });
-        struct Joiner {
-            std::thread &a, &b;
+        std::thread tc, tp;
+        struct Joiner {  // declared before the threads start: an exception (also out of the second thread's creation)
+            std::thread &a, &b;  // must not leave a joinable thread behind
             ~Joiner() {
                 if (a.joinable()) a.join();
                 if (b.joinable()) b.join();
             }
         } joiner{tc, tp};
+        tc = std::thread([&] {
+            c_ok = kzgamd::host_p1_uncompress(&c, commitment_bytes->bytes) && kzgamd::host_p1_in_g1(&c);  // infinity passes
+        });
+        tp = std::thread([&] {
+            pr_ok = kzgamd::host_p1_uncompress(&pr, proof_bytes->bytes) && kzgamd::host_p1_in_g1(&pr);
+        });
         Bytes32 zb, yb;
         {
             LaneRef lane(dev, 1);
