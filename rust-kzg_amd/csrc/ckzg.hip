@@ -2889,8 +2889,6 @@ std::vector<int> decode_points_status(KzgAmdSettings* dev, size_t np) {
     return stat;
 }
 
-// inverse transform of 64 values on the host (fft_fr(.., inverse = true) of a column, das.rs:818-819): exact field
-// arithmetic, so any butterfly order gives the reference's values.  roots = roots_of_unity[0..=8192].
 // The aggregated interpolation polynomial of verify_cell_kzg_proof_batch
 // (compute_commitment_to_aggregated_interpolation_poly, kzg/src/das.rs:778-835) on the GPU — on the host its ~50 000
 // field multiplications were three quarters of a 128-cell call.
@@ -2937,8 +2935,6 @@ __global__ void __launch_bounds__(128) k_vcell_interp(ff::Fr* __restrict__ out, 
 // then one pairing check e(row 1, G2) == e(row 0, [s^64]G2) on the host.
 void verify_cells(bool* ok, const Bytes48* commitments_bytes, const uint64_t* cell_indices, const Cell* cells,
                   const Bytes48* proofs_bytes, size_t n, const CKZGSettings* cs, KzgAmdSettings* dev) {
-    std::vector<ff::Fr> cf;
-    CK_REQUIRE(cells_to_limbs(cf, cells, n), "Invalid scalar");
     for (size_t i = 0; i < n; ++i) CK_REQUIRE(cell_indices[i] < CELLS_PER_EXT_BLOB, "Invalid cell index");
     // deduplicate_with_indices (das.rs:57-76): first occurrences, in order
     std::vector<Bytes48> uniq;
@@ -2960,7 +2956,12 @@ void verify_cells(bool* ok, const Bytes48* commitments_bytes, const uint64_t* ce
     memcpy(stage.data() + n * 48, uniq.data(), m * 48);
     memcpy(stage.data() + (n + m) * 48, dev->mono64_bytes.data(), CELL_SIZE * 48);
     decode_points_begin(dev, stage, np);
-    // host, meanwhile
+    // host, meanwhile (the decode + subgroup tests are 0.75 ms of GPU latency): the cells' field elements, ...
+    std::vector<ff::Fr> cf;
+    if (!cells_to_limbs(cf, cells, n)) {
+        (void)decode_points_status(dev, np);  // nothing of this call stays in flight
+        throw CkErr{C_KZG_BADARGS, "Invalid scalar"};
+    }
     const ff::Fr* roots = reinterpret_cast<const ff::Fr*>(cs->roots_of_unity);
     const ff::Fr r = cell_batch_challenge(uniq.data(), m, cidx.data(), cell_indices, cells, proofs_bytes, n);
     std::vector<ff::Fr> sc(2 * np, ff::Fr::zero());
