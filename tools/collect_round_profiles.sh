@@ -40,3 +40,6 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 #    k_quotient_a/b, k_blocksum_hybrid)
 LD_LIBRARY_PATH=$R/rust-kzg_amd/csrc:/opt/rocm/lib KZGAMD_FBW_MAX_GB=100 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_conc -o $TAG -- $R/tools/concurrent_bench $R/tests/golden/trusted_setup.txt 0.5 16 > $R/gpurun_out/prof_conc.log 2>&1
 tail -1 $R/gpurun_out/prof_conc.log
+# 7. kernel stats of the verification entry points (k_decode_check_g1, k_affpts_in_g1_wide, k_vcell_agg / _interp, the two-row MSM)
+KZGAMD_FBW_MAX_GB=100 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_verify -o $TAG -- python $R/tools/time_verify.py > $R/gpurun_out/prof_verify.log 2>&1
+tail -4 $R/gpurun_out/prof_verify.log

@@ -64,7 +64,7 @@ def main():
     shutil.copy(os.path.join(G, "bench_final.json"), os.path.join(P, TAG + "_bench.json"))
     B = bench["config"]["blobs_per_batch"]
     cfg = bench["config"]
-    for name in ("headline", "streams1", "ntt", "2p20", "cells", "proofs", "conc"):
+    for name in ("headline", "streams1", "ntt", "2p20", "cells", "proofs", "conc", "verify"):
         d = os.path.join(G, "prof_" + name)
         if os.path.exists(os.path.join(d, TAG + "_kernel_stats.csv")):
             shutil.copy(os.path.join(d, TAG + "_kernel_stats.csv"), os.path.join(P, "%s_%s_kernel_stats.csv" % (TAG, name)))
