@@ -291,6 +291,40 @@ int kzgamd_settings_device(const CKZGSettings *s);
  * on `stream` (see kzgamd_msm_reserve) */
 C_KZG_RET kzgamd_settings_reserve(const CKZGSettings *s, size_t n, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU from ONE process, inside the library (rust-kzg_amd/csrc/multi.hip).  The reference's callers are
+ * one Rust process that parallelises inside itself over groups of blobs (kzg/src/eip_4844.rs:770-816) around one shared
+ * precomputation handle (kzg/src/msm/sppark.rs:24-44); its GPU path is single-device
+ * (arkworks3-sppark-wlc/sppark/msm/pippenger.cuh:573-575).  Here: s[0..ndev) are settings objects loaded from the
+ * same trusted setup, normally one per GPU (two on one GPU work too — e.g. under KZGAMD_FBW_MAX_GB — and are how the
+ * path is tested on a one-GPU box).  Blob i of the batch goes to s[k] for the k with lo_k <= i < hi_k, contiguous slabs
+ * whose sizes differ by at most one; one host thread per settings object drives that object's single-device pipeline;
+ * results land in place in out[].  Nothing is exchanged between devices (no collective): blobs are independent and
+ * every device has its own replica of the tables.  Per-blob results equal the single-device calls; any failing slab
+ * fails the call (C_KZG_BADARGS, like the reference).  n < ndev uses the first n objects.
+ * ------------------------------------------------------------------------------------------ */
+/* one CKZGSettings per entry of devices[] (NULL = GPUs 0 .. ndev-1) from one setup file, loaded in parallel; all or
+ * nothing: on failure every out[d] is left empty.  The caller's current device is left alone. */
+C_KZG_RET kzgamd_load_trusted_setup_file_multi(CKZGSettings out[], const int devices[], size_t ndev, FILE *in);
+void kzgamd_free_trusted_setup_multi(CKZGSettings s[], size_t ndev);
+C_KZG_RET kzgamd_blob_to_kzg_commitment_batch_multi(KZGCommitment *out, const Blob *blobs, size_t n,
+                                                    const CKZGSettings *const s[], size_t ndev);
+C_KZG_RET kzgamd_compute_blob_kzg_proof_batch_multi(KZGProof *out, const Blob *blobs, const Bytes48 *commitments, size_t n,
+                                                    const CKZGSettings *const s[], size_t ndev);
+C_KZG_RET kzgamd_compute_cells_and_kzg_proofs_batch_multi(Cell *cells, KZGProof *proofs, const Blob *blobs, size_t n,
+                                                          const CKZGSettings *const s[], size_t ndev);
+/* the reference verifies a large batch as groups and ANDs the verdicts (kzg/src/eip_4844.rs:770-816); the groups here
+ * are the devices' slabs: one pairing check per device */
+C_KZG_RET kzgamd_verify_blob_kzg_proof_batch_multi(bool *ok, const Blob *blobs, const Bytes48 *commitments,
+                                                   const Bytes48 *proofs, size_t n, const CKZGSettings *const s[],
+                                                   size_t ndev);
+/* One large MSM sharded by index range: msm[d] was prepared (prepare_msm after kzgamd_set_device(d), or
+ * kzgamd_msm_create_device) over points[offsets[d] .. offsets[d+1]); scalars is the whole array (offsets[ndev]
+ * elements, Montgomery blst_fr as mult_pippenger_prepared).  Every device sums its slice, the ndev 144-byte partials are
+ * added on the host (kzgamd_g1_sum). */
+RustError kzgamd_mult_pippenger_prepared_multi(void *const msm[], size_t ndev, blst_p1 *out, const size_t offsets[],
+                                               const blst_fr scalars[]);
+
 /* Multi-GPU combine step of one large MSM sharded by index range over G ranks: every rank computes
  * its partial with mult_pippenger / the device entry points over its slice of (points, scalars); the G
  * 144-byte Jacobian partials are all-gathered and summed locally with this host-side helper (a G1 addition is

@@ -73,6 +73,9 @@ EXPORTS = [
     "verify_kzg_proof", "verify_blob_kzg_proof", "verify_blob_kzg_proof_batch", "kzgamd_pairings_verify",
     "kzgamd_compute_blob_kzg_proof_device",
     "kzgamd_p2_uncompress", "kzgamd_p2_compress", "kzgamd_p2_generator", "kzgamd_p2_mult", "kzgamd_p2_add",
+    "kzgamd_load_trusted_setup_file_multi", "kzgamd_free_trusted_setup_multi", "kzgamd_blob_to_kzg_commitment_batch_multi",
+    "kzgamd_compute_blob_kzg_proof_batch_multi", "kzgamd_compute_cells_and_kzg_proofs_batch_multi",
+    "kzgamd_verify_blob_kzg_proof_batch_multi", "kzgamd_mult_pippenger_prepared_multi",
 ]
 
 
@@ -214,6 +217,20 @@ def lib():
     L.kzgamd_p2_mult.argtypes = [vp, vp, vp]
     L.kzgamd_p2_add.restype = None
     L.kzgamd_p2_add.argtypes = [vp, vp, vp]
+    L.kzgamd_load_trusted_setup_file_multi.restype = C.c_int
+    L.kzgamd_load_trusted_setup_file_multi.argtypes = [vp, vp, sz, vp]
+    L.kzgamd_free_trusted_setup_multi.restype = None
+    L.kzgamd_free_trusted_setup_multi.argtypes = [vp, sz]
+    L.kzgamd_blob_to_kzg_commitment_batch_multi.restype = C.c_int
+    L.kzgamd_blob_to_kzg_commitment_batch_multi.argtypes = [vp, vp, sz, vp, sz]
+    L.kzgamd_compute_blob_kzg_proof_batch_multi.restype = C.c_int
+    L.kzgamd_compute_blob_kzg_proof_batch_multi.argtypes = [vp, vp, vp, sz, vp, sz]
+    L.kzgamd_compute_cells_and_kzg_proofs_batch_multi.restype = C.c_int
+    L.kzgamd_compute_cells_and_kzg_proofs_batch_multi.argtypes = [vp, vp, vp, sz, vp, sz]
+    L.kzgamd_verify_blob_kzg_proof_batch_multi.restype = C.c_int
+    L.kzgamd_verify_blob_kzg_proof_batch_multi.argtypes = [bp, vp, vp, vp, sz, vp, sz]
+    L.kzgamd_mult_pippenger_prepared_multi.restype = RustError
+    L.kzgamd_mult_pippenger_prepared_multi.argtypes = [vp, sz, vp, vp, vp]
     _lib = L
     return L
 
@@ -759,3 +776,85 @@ def compute_cells_and_kzg_proofs_batch(blobs: bytes, n: int, settings: KZGSettin
     if rc != C_KZG_OK:
         raise KzgAmdError("kzgamd_compute_cells_and_kzg_proofs_batch: C_KZG_RET %d" % rc)
     return cells.raw, proofs.raw
+
+
+# ---------------------------------------------------------------- multi-GPU inside the library (csrc/multi.hip)
+class MultiKZGSettings:
+    """ndev CKZGSettings objects of one trusted setup, one per entry of `devices` (kzgamd_load_trusted_setup_file_multi):
+    the in-process multi-GPU path — contiguous slabs of blobs per settings object, one host thread each, inside the
+    library.  Two entries may name the same GPU (how the path is tested on a one-GPU box)."""
+
+    def __init__(self, path, devices):
+        self.ndev = len(devices)
+        self.devices = list(devices)
+        self.arr = (CKZGSettings * self.ndev)()
+        self.loaded = False
+        devs = (C.c_int * self.ndev)(*self.devices)
+        f = _fopen(path)
+        try:
+            rc = lib().kzgamd_load_trusted_setup_file_multi(self.arr, devs, self.ndev, f)
+        finally:
+            _libc.fclose(f)
+        if rc != C_KZG_OK:
+            raise KzgAmdError("kzgamd_load_trusted_setup_file_multi: C_KZG_RET %d" % rc)
+        self.loaded = True
+        self.ptrs = (C.POINTER(CKZGSettings) * self.ndev)(*[C.pointer(self.arr[d]) for d in range(self.ndev)])
+
+    def settings_devices(self):
+        return [lib().kzgamd_settings_device(C.byref(self.arr[d])) for d in range(self.ndev)]
+
+    def table_info(self, d, which=0):
+        c, rows, wide = C.c_int(), C.c_int(), C.c_int()
+        rc = lib().kzgamd_settings_table_info(C.byref(self.arr[d]), which, C.byref(c), C.byref(rows), C.byref(wide))
+        return {"rc": rc, "window_bits": c.value, "rows": rows.value, "wide_table": wide.value}
+
+    def commit_batch(self, blobs: bytes, n: int):
+        out = C.create_string_buffer(48 * max(n, 1))
+        rc = lib().kzgamd_blob_to_kzg_commitment_batch_multi(out, blobs, n, self.ptrs, self.ndev)
+        if rc != C_KZG_OK:
+            raise KzgAmdError("kzgamd_blob_to_kzg_commitment_batch_multi: C_KZG_RET %d" % rc)
+        raw = out.raw
+        return [raw[48 * i:48 * i + 48] for i in range(n)]
+
+    def proof_batch(self, blobs: bytes, commitments: bytes, n: int):
+        out = C.create_string_buffer(48 * max(n, 1))
+        rc = lib().kzgamd_compute_blob_kzg_proof_batch_multi(out, blobs, commitments, n, self.ptrs, self.ndev)
+        if rc != C_KZG_OK:
+            raise KzgAmdError("kzgamd_compute_blob_kzg_proof_batch_multi: C_KZG_RET %d" % rc)
+        raw = out.raw
+        return [raw[48 * i:48 * i + 48] for i in range(n)]
+
+    def cells_and_proofs_batch(self, blobs: bytes, n: int):
+        cells = C.create_string_buffer(max(n, 1) * 128 * 2048)
+        proofs = C.create_string_buffer(max(n, 1) * 128 * 48)
+        rc = lib().kzgamd_compute_cells_and_kzg_proofs_batch_multi(cells, proofs, blobs, n, self.ptrs, self.ndev)
+        if rc != C_KZG_OK:
+            raise KzgAmdError("kzgamd_compute_cells_and_kzg_proofs_batch_multi: C_KZG_RET %d" % rc)
+        return cells.raw[:n * 128 * 2048], proofs.raw[:n * 128 * 48]
+
+    def verify_blob_batch(self, blobs: bytes, commitments: bytes, proofs: bytes, n: int) -> bool:
+        ok = C.c_bool(False)
+        return _verdict(lib().kzgamd_verify_blob_kzg_proof_batch_multi(C.byref(ok), blobs, commitments, proofs, n, self.ptrs,
+                                                                       self.ndev), ok, "kzgamd_verify_blob_kzg_proof_batch_multi")
+
+    def close(self):
+        if self.loaded:
+            lib().kzgamd_free_trusted_setup_multi(self.arr, self.ndev)
+            self.loaded = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def mult_pippenger_prepared_multi(handles, offsets, scalars):
+    """kzgamd_mult_pippenger_prepared_multi: handles[d] prepared over points[offsets[d]:offsets[d+1]]; returns BlstP1."""
+    nd = len(handles)
+    hs = (C.c_void_p * nd)(*[h.handle for h in handles])
+    offs = (C.c_size_t * (nd + 1))(*offsets)
+    out = BlstP1()
+    _check(lib().kzgamd_mult_pippenger_prepared_multi(hs, nd, C.byref(out), offs, _addr(scalars)),
+           "kzgamd_mult_pippenger_prepared_multi")
+    return out

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libkzg_mi355x.so")
-SOURCES = ["msm.hip", "ckzg.hip", "ntt.hip", "fftg1.hip"]
+SOURCES = ["msm.hip", "ckzg.hip", "ntt.hip", "fftg1.hip", "multi.hip"]
 HEADERS = ["ff.hip.h", "fp28.hip.h", "g1_28.hip.h", "g1_io.hip.h", "msm_internal.h", "ckzg_internal.h", "sha256.h", "host_g1.h", "host_pairing.h", "host_fp64.h", "ff28.hip.h", "fr29.hip.h", "ntt_internal.h", "device_guard.h", "fpw.hip.h", "g1w.hip.h", "glv.hip.h", "ntt_plan.h",
            os.path.join("..", "..", "include", "kzg_mi355x.h")]
 
@@ -54,6 +54,27 @@ def build_prefixed(verbose=False):
     return LIB_PREFIXED
 
 
+def _obj_stale(src, obj):
+    """An object is rebuilt when its source, or any header the compiler listed in its .d file, is newer."""
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    if os.path.getmtime(src) > t:
+        return True
+    dep = obj[:-2] + ".d"
+    if not os.path.exists(dep):
+        return True
+    with open(dep) as f:
+        names = f.read().replace("\\\n", " ").split()
+    for name in names[1:]:
+        if name.startswith("/opt/") or name.startswith("/usr/"):
+            continue
+        path = name if os.path.isabs(name) else os.path.join(CSRC, name)
+        if not os.path.exists(path) or os.path.getmtime(path) > t:
+            return True
+    return False
+
+
 def build(force=False, verbose=False):
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if not force and not _stale():
@@ -63,11 +84,13 @@ def build(force=False, verbose=False):
     procs = []
     for s in srcs:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, s), "-o", o]
+        objs.append(o)
+        if not force and not _obj_stale(os.path.join(CSRC, s), o):
+            continue
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-MD", "-MF", o[:-2] + ".d", "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, cwd=CSRC)))
-        objs.append(o)
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + s)

@@ -267,3 +267,133 @@ def test_bench_two_ranks_on_a_two_gpu_box(kzg):
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and sorted(d["device"] for d in line["devices"]) == [0, 1]
+
+
+# ---------------------------------------------------------------- multi-GPU inside the library (csrc/multi.hip)
+def _random_blobs(seed, n):
+    import random
+
+    rnd = random.Random(seed)
+    blobs = []
+    for _ in range(n):
+        b = bytearray(rnd.randbytes(131072))
+        for i in range(0, 131072, 32):
+            b[i] = 0
+        blobs.append(bytes(b))
+    return blobs
+
+
+def _in_process_multi(kzg, oracle, oracle_settings, devices):
+    import ctypes as C
+    import random
+
+    L = oracle.lib()
+    ms = kzg.MultiKZGSettings(SETUP, devices)
+    try:
+        assert ms.settings_devices() == list(devices)
+        assert kzg.get_device() == 0  # loading on other devices left the caller's device alone
+        blobs = _random_blobs(41, 37)
+        want_c, want_p = [], []
+        for b in blobs:
+            o = C.create_string_buffer(48)
+            assert L.oblob_to_kzg_commitment(o, b, C.byref(oracle_settings)) == 0
+            want_c.append(o.raw)
+            p = C.create_string_buffer(48)
+            assert L.ocompute_blob_kzg_proof(p, b, o.raw, C.byref(oracle_settings)) == 0
+            want_p.append(p.raw)
+        # slabs of 19 + 18 (each object's pipelined large-batch path), 3 + 2 (lane path), 1 (first object only), 0
+        for n in (37, 5, 1, 0):
+            joined = b"".join(blobs[:n])
+            assert ms.commit_batch(joined, n) == want_c[:n], n
+            assert ms.proof_batch(joined, b"".join(want_c[:n]), n) == want_p[:n], n
+        # a blob with an element >= r in the SECOND slab fails the call like the reference (BadArgs)
+        bad = bytearray(blobs[30])
+        bad[64:96] = bytes.fromhex("73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001")
+        spoiled = blobs[:30] + [bytes(bad)] + blobs[31:]
+        with pytest.raises(kzg.KzgAmdError, match="C_KZG_RET 1"):
+            ms.commit_batch(b"".join(spoiled), 37)
+        with pytest.raises(kzg.KzgAmdError, match="C_KZG_RET 1"):
+            ms.proof_batch(b"".join(spoiled), b"".join(want_c), 37)
+        # batched verification: groups = slabs, verdicts ANDed (kzg/src/eip_4844.rs:770-816)
+        allb, allc, allp = b"".join(blobs), b"".join(want_c), b"".join(want_p)
+        assert ms.verify_blob_batch(allb, allc, allp, 37) is True
+        swapped = want_p[:35] + [want_p[36], want_p[35]]
+        assert ms.verify_blob_batch(allb, allc, b"".join(swapped), 37) is False
+        assert ms.verify_blob_batch(b"", b"", b"", 0) is True
+        # EIP-7594 cells + proofs, 3 blobs as 2 + 1, against the single-device entry point on the first object
+        one = kzg.KZGSettings()  # a borrowed view of ms.arr[0] (loaded stays False: never freed through it)
+        C.memmove(C.byref(one.c), C.byref(ms.arr[0]), C.sizeof(kzg.CKZGSettings))
+        cells, proofs = ms.cells_and_proofs_batch(b"".join(blobs[:3]), 3)
+        for i in range(3):
+            c1, p1 = kzg.compute_cells_and_kzg_proofs(blobs[i], one)
+            assert cells[i * 262144:(i + 1) * 262144] == c1
+            assert proofs[i * 6144:(i + 1) * 6144] == p1
+    finally:
+        ms.close()
+    # one MSM sharded by index range over two prepared handles: partials on the devices, sum on the host
+    rnd = random.Random(5)
+    n = 5000
+    g = oracle.G1()
+    L.og1_generator(C.byref(g))
+    pts = (oracle.G1Affine * n)()
+    base = oracle.G1()
+    k0 = oracle.fr_from_int(rnd.randrange(1, oracle.R))
+    L.og1_mul(C.byref(base), C.byref(g), C.byref(k0))
+    acc = oracle.G1()
+    C.memmove(C.byref(acc), C.byref(base), 144)
+    for i in range(n):
+        L.og1_to_affine(C.byref(pts[i]), C.byref(acc))
+        L.og1_add_or_dbl(C.byref(acc), C.byref(acc), C.byref(g))
+    sc = oracle.fr_array([rnd.randrange(oracle.R) for _ in range(n)])
+    offsets = [0, 2600, n]
+    handles = []
+    try:
+        for d in range(2):
+            kzg.set_device(devices[d])
+            handles.append(kzg.prepare_multi_scalar_mult(C.cast(C.byref(pts, offsets[d] * 96), C.POINTER(kzg.BlstP1Affine)),
+                                                         offsets[d + 1] - offsets[d]))
+        kzg.set_device(0)
+        got = kzg.mult_pippenger_prepared_multi(handles, offsets, sc)
+    finally:
+        kzg.set_device(0)
+        for h in handles:
+            h.close()
+    full = oracle.G1()
+    L.omsm_affine(C.byref(full), pts, sc, n)
+    a = oracle.G1()
+    C.memmove(C.byref(a), bytes(got), 144)
+    assert L.og1_equal(C.byref(a), C.byref(full)) == 1
+
+
+@pytest.mark.gpu
+def test_in_process_multi_two_settings_objects_on_gpu0(kzg, oracle, oracle_settings, monkeypatch):
+    # the in-library multi-GPU path on the hardware there is: two settings objects on GPU 0 (table budget capped so
+    # that both fit), every result against the oracle
+    monkeypatch.setenv("KZGAMD_FBW_MAX_GB", "40")
+    _in_process_multi(kzg, oracle, oracle_settings, [0, 0])
+
+
+@pytest.mark.gpu
+def test_in_process_multi_two_gpus(kzg, oracle, oracle_settings):
+    if kzg.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _in_process_multi(kzg, oracle, oracle_settings, [0, 1])
+
+
+def test_multi_entry_points_reject_bad_arguments_without_a_gpu(kzg):
+    import ctypes as C
+
+    L = kzg.lib()
+    out = C.create_string_buffer(48)
+    blob = bytes(131072)
+    empty = kzg.CKZGSettings()  # never loaded: not in the registry
+    ptrs = (C.POINTER(kzg.CKZGSettings) * 1)(C.pointer(empty))
+    assert L.kzgamd_blob_to_kzg_commitment_batch_multi(out, blob, 1, ptrs, 1) == kzg.C_KZG_BADARGS
+    assert L.kzgamd_blob_to_kzg_commitment_batch_multi(out, blob, 1, ptrs, 0) == kzg.C_KZG_BADARGS
+    assert L.kzgamd_blob_to_kzg_commitment_batch_multi(out, blob, 1, None, 1) == kzg.C_KZG_BADARGS
+    assert L.kzgamd_compute_blob_kzg_proof_batch_multi(out, blob, out, 1, ptrs, 1) == kzg.C_KZG_BADARGS
+    ok = C.c_bool(True)
+    assert L.kzgamd_verify_blob_kzg_proof_batch_multi(C.byref(ok), blob, out, out, 1, ptrs, 1) == kzg.C_KZG_BADARGS
+    arr = (kzg.CKZGSettings * 2)()
+    assert L.kzgamd_load_trusted_setup_file_multi(arr, None, 2, None) == kzg.C_KZG_BADARGS
+    L.kzgamd_free_trusted_setup_multi(arr, 2)  # empty objects: a no-op
