@@ -863,15 +863,21 @@ struct KzgAmdSettings {
         std::deque<void*> pending;
         int leaders = 0;
     };
-    static inline int MAX_LEADERS = getenv("KZGAMD_LEADERS") ? atoi(getenv("KZGAMD_LEADERS")) : 3;  // read once, at load
+    static int env_int(const char* name, int dflt, int lo, int hi) {  // a measurement switch, clamped to [lo, hi]
+        const char* v = getenv(name);
+        if (!v) return dflt;
+        const long x = strtol(v, nullptr, 10);
+        return x < lo ? lo : (x > hi ? hi : (int)x);
+    }
+    static inline int MAX_LEADERS = env_int("KZGAMD_LEADERS", 3, 1, 64);  // read once, at load; never below one leader
     CoalesceQueue q_commit, q_blob_proof, q_proof;
     // measurement switches, read once when the settings object is created
     bool cfg_device_sha = getenv("KZGAMD_DEVICE_SHA") && atoi(getenv("KZGAMD_DEVICE_SHA")) != 0;
-    size_t cfg_prove_chunk = getenv("KZGAMD_PROVE_CHUNK") ? (size_t)atoi(getenv("KZGAMD_PROVE_CHUNK")) : 0;
+    size_t cfg_prove_chunk = (size_t)env_int("KZGAMD_PROVE_CHUNK", 0, 0, 1 << 20);
     bool cfg_wide_check = !(getenv("KZGAMD_WIDE_CHECK") && atoi(getenv("KZGAMD_WIDE_CHECK")) == 0);  // 0: single-lane tests
-    size_t cfg_prove_first = getenv("KZGAMD_PROVE_FIRST") ? (size_t)atoi(getenv("KZGAMD_PROVE_FIRST")) : 0;
-    size_t cfg_commit_first = getenv("KZGAMD_COMMIT_FIRST") ? (size_t)atoi(getenv("KZGAMD_COMMIT_FIRST")) : 0;
-    size_t cfg_commit_chunk = getenv("KZGAMD_COMMIT_CHUNK") ? (size_t)atoi(getenv("KZGAMD_COMMIT_CHUNK")) : 0;
+    size_t cfg_prove_first = (size_t)env_int("KZGAMD_PROVE_FIRST", 0, 0, 1 << 20);
+    size_t cfg_commit_first = (size_t)env_int("KZGAMD_COMMIT_FIRST", 0, 0, 1 << 20);
+    size_t cfg_commit_chunk = (size_t)env_int("KZGAMD_COMMIT_CHUNK", 0, 0, 1 << 20);
     int cfg_fk20 = getenv("KZGAMD_FK20") ? (atoi(getenv("KZGAMD_FK20")) != 0 ? 1 : 0) : -1;  // -1: by batch size
     bool is_lane = false;
     std::atomic<bool> busy{false};
@@ -1970,9 +1976,11 @@ void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_
 // provided cells (canonical little-endian limbs, already checked < r on the host) -> the 8192 evaluations in
 // bit-reversed order, Montgomery form, missing positions and the reference's "null" sentinel as zero
 // (recover_cells: `if cells_brp[i].is_null() { zero }`, das.rs:611-617; Fr::null() = from_u64_arr([u64::MAX; 4]),
-// blst/src/types/fr.rs:36-38 — a provided element equal to it is dropped by the reference too)
+// blst/src/types/fr.rs:36-38 — a provided element equal to it is dropped by the reference too).  drop_null is false
+// when all 128 cells are given: the reference then skips recover_cells (das.rs:172-181) and hands the values as they
+// are to poly_lagrange_to_monomial (:186-188), the sentinel value included.
 __global__ void __launch_bounds__(256) k_rec_scatter(ff::Fr* __restrict__ ev_brp, const u32* __restrict__ limbs,
-                                                     const u32* __restrict__ cell_idx, size_t ncells) {
+                                                     const u32* __restrict__ cell_idx, size_t ncells, bool drop_null) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ncells * CELL_SIZE) return;
     const u32 c = cell_idx[t >> 6], j = (u32)t & 63;
@@ -1984,7 +1992,7 @@ __global__ void __launch_bounds__(256) k_rec_scatter(ff::Fr* __restrict__ ev_brp
 #pragma unroll
     for (int k = 0; k < 8; ++k) nul.v[k] = 0xffffffffu;
     nul = ff::to_mont(nul);  // from_u64_arr reduces: (2^256 - 1) mod r in Montgomery form
-    if (v == nul) v = ff::Fr::zero();
+    if (drop_null && v == nul) v = ff::Fr::zero();
     ev_brp[brev32(c * (u32)CELL_SIZE + j, 13)] = v;
 }
 __global__ void __launch_bounds__(256) k_fr_mul(ff::Fr* __restrict__ out, const ff::Fr* __restrict__ a, const ff::Fr* __restrict__ b,
@@ -2074,10 +2082,18 @@ namespace {
 // (run's implementation calls it), and whoever has not got to it by the end does it then.
 template <class Req, class Run>
 C_KZG_RET coalesced_call(KzgAmdSettings::CoalesceQueue& q, Req& me, Run&& run) {
-    static const size_t gather_min = getenv("KZGAMD_GATHER_MIN") ? (size_t)atoi(getenv("KZGAMD_GATHER_MIN")) : 6;
-    static const int gather_us = getenv("KZGAMD_GATHER_US") ? atoi(getenv("KZGAMD_GATHER_US")) : 60;
-    std::unique_lock<std::mutex> lk(q.mu);
-    q.pending.push_back(&me);
+    static const size_t gather_min = (size_t)KzgAmdSettings::env_int("KZGAMD_GATHER_MIN", 6, 1, (int)KzgAmdSettings::LANE_MAX_BLOBS);
+    static const int gather_us = KzgAmdSettings::env_int("KZGAMD_GATHER_US", 60, 0, 100000);
+    // everything that can allocate happens before the request is visible to other callers: nothing below throws
+    std::vector<Req*> batch;
+    std::unique_lock<std::mutex> lk(q.mu, std::defer_lock);
+    try {
+        batch.reserve(KzgAmdSettings::LANE_MAX_BLOBS);
+        lk.lock();
+        q.pending.push_back(&me);
+    } catch (...) {
+        return C_KZG_MALLOC;
+    }
     q.cv.notify_one();  // a leader gathering requests may have enough now
     bool idled = false;
     while (!me.done) {
@@ -2094,17 +2110,18 @@ C_KZG_RET coalesced_call(KzgAmdSettings::CoalesceQueue& q, Req& me, Run&& run) {
                     if (me.done) break;
                     if (q.pending.empty()) continue;
                 }
-                std::vector<Req*> batch;
+                batch.clear();
                 while (!q.pending.empty() && batch.size() < KzgAmdSettings::LANE_MAX_BLOBS) {
                     batch.push_back(static_cast<Req*>(q.pending.front()));
                     q.pending.pop_front();
                 }
                 lk.unlock();
-                try {
-                    run(batch);
-                } catch (...) {
-                    for (Req* r : batch) r->rc = C_KZG_ERROR;
-                }
+                // a failure of the batch as a whole (a HIP error, no memory) fails every request of it, with the same
+                // mapping as every other entry point (guarded: BadArgs like the reference, or Malloc); run() has waited
+                // for the lane's stream before it throws, so the callers' staged blobs are no longer being read
+                const C_KZG_RET brc = guarded([&] { run(batch); });
+                if (brc != C_KZG_OK)
+                    for (Req* r : batch) r->rc = brc;
                 lk.lock();
                 for (Req* r : batch) r->done = true;
                 q.cv.notify_all();
@@ -2176,7 +2193,12 @@ void commit_lane_batch(KzgAmdSettings* dev, const std::vector<CommitReq*>& reqs)
     };
     // (Replaying this sequence as one captured graph per batch size was measured: 19.4 k vs 18.9 k commitments/s at 16
     // threads, 3 991 vs 4 040 /s for one — nothing; the call-by-call form stays.  DESIGN.md §9.)
-    enqueue_all();
+    try {
+        enqueue_all();
+    } catch (...) {
+        (void)hipStreamSynchronize(dev->stream);  // whatever was enqueued still reads the callers' slots
+        throw;
+    }
     CK_HIP(hipStreamSynchronize(dev->stream));
     for (size_t i = 0; i < n; ++i) {
         if (hs[i] != 0) {
@@ -2413,13 +2435,18 @@ void proof_lane_batch(KzgAmdSettings* root, const std::vector<ProofReq*>& reqs, 
             ptrs.p[i] = reinterpret_cast<const u32*>(src);
             memcpy(hz + 32 * i, reqs[i]->z->bytes, 32);
         }
-        hipLaunchKernelGGL(k_gather_blobs, dim3((unsigned)((n * (BYTES_PER_BLOB / 16) + 255) / 256)), dim3(256), 0, dev->stream,
-                           reinterpret_cast<uint4*>(dev->d_blobs), ptrs, n);
-        CK_HIP(hipMemcpyAsync(dev->d_z, hz, n * 32, hipMemcpyHostToDevice, dev->stream));
-        prove_enqueue(dev, 0, n, dev->stream, false, kzgamd::OUT_JACOBIAN);
-        CK_HIP(hipMemcpyAsync(hs, dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
-        CK_HIP(hipMemcpyAsync(hy, dev->d_y, n * 32, hipMemcpyDeviceToHost, dev->stream));
-        CK_HIP(hipMemcpyAsync(ho, dev->d_out, n * 144, hipMemcpyDeviceToHost, dev->stream));
+        try {
+            hipLaunchKernelGGL(k_gather_blobs, dim3((unsigned)((n * (BYTES_PER_BLOB / 16) + 255) / 256)), dim3(256), 0, dev->stream,
+                               reinterpret_cast<uint4*>(dev->d_blobs), ptrs, n);
+            CK_HIP(hipMemcpyAsync(dev->d_z, hz, n * 32, hipMemcpyHostToDevice, dev->stream));
+            prove_enqueue(dev, 0, n, dev->stream, false, kzgamd::OUT_JACOBIAN);
+            CK_HIP(hipMemcpyAsync(hs, dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, dev->stream));
+            CK_HIP(hipMemcpyAsync(hy, dev->d_y, n * 32, hipMemcpyDeviceToHost, dev->stream));
+            CK_HIP(hipMemcpyAsync(ho, dev->d_out, n * 144, hipMemcpyDeviceToHost, dev->stream));
+        } catch (...) {
+            (void)hipStreamSynchronize(dev->stream);  // whatever was enqueued still reads the callers' slots
+            throw;
+        }
         if (leader) leader->side_work();  // while the GPU works
         CK_HIP(hipStreamSynchronize(dev->stream));
         uint8_t cb[LB * 48];
@@ -3076,7 +3103,7 @@ void recover_cells(Cell* recovered_cells, KZGProof* recovered_proofs, const uint
     CK_HIP(hipMemcpyAsync(dev->d_rec_in, cf.data(), ncells * CELL_SIZE * 32, hipMemcpyHostToDevice, st));
     CK_HIP(hipMemcpyAsync(dev->d_rec_idx, idx32.data(), ncells * sizeof(u32), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_rec_scatter, dim3((unsigned)((ncells * CELL_SIZE + 255) / 256)), dim3(256), 0, st, A,
-                       (const u32*)dev->d_rec_in, (const u32*)dev->d_rec_idx, ncells);
+                       (const u32*)dev->d_rec_in, (const u32*)dev->d_rec_idx, ncells, ncells != CELLS_PER_EXT_BLOB);
     std::vector<ff::Fr> vanishing;  // must outlive the copy below
     if (ncells != CELLS_PER_EXT_BLOB) {
         // vanishing_polynomial_for_missing_cells (:520-551): roots w^(64 * brp7(i)) for the missing cells i, short
@@ -3221,7 +3248,8 @@ extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof* out, const Blob* blob, con
     if (!out || !blob || !commitment_bytes) return C_KZG_BADARGS;
     KzgAmdSettings* dev = lookup(s);
     if (!dev) return C_KZG_BADARGS;
-    ProofReq me{blob, commitment_bytes, nullptr, out, nullptr};
+    KZGProof proof;  // *out is written only when the call succeeds (an invalid commitment is found after the proof)
+    ProofReq me{blob, commitment_bytes, nullptr, &proof, nullptr};
     // this thread's share, in parallel with the other callers': the page-locked copy, blob_to_polynomial's range check
     // and the Fiat-Shamir challenge (one SHA-256 over the blob)
     SlotHold slot(dev, blob);
@@ -3232,6 +3260,7 @@ extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof* out, const Blob* blob, con
     const C_KZG_RET rc = coalesced_call(dev->q_blob_proof, me,
                                         [&](const std::vector<ProofReq*>& batch) { proof_lane_batch(dev, batch, &me); });
     if (rc == C_KZG_OK && !me.commitment_ok) return C_KZG_BADARGS;  // "Invalid commitment"
+    if (rc == C_KZG_OK) *out = proof;
     return rc;
 }
 

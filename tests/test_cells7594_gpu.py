@@ -171,3 +171,29 @@ def test_verify_many_cells_of_several_blobs(kzg, settings):
     other = bytearray(cells)
     other[CELL * 10: CELL * 11] = cp[(k + 1) % 3][0][CELL * i: CELL * (i + 1)]
     assert not kzg.verify_cell_kzg_proof_batch(coms, idx, bytes(other), proofs, settings)
+
+
+def test_null_sentinel_valued_cell_element(kzg, settings, kats):
+    """A cell element equal to Fr::null() = (2^256 - 1) mod r (a valid canonical scalar, blst/src/types/fr.rs:36-38).
+    All 128 cells given: the reference skips recover_cells and keeps the value (das.rs:172-188) — cells come back as
+    given and the proofs are the blob's.  Fewer cells: recover_cells treats the element as missing (:611-617) — checked
+    against the Python restatement (tests/recover_model.py, pinned on the reference's vectors)."""
+    import recover_model as M
+
+    rnd = random.Random(77)
+    blob = bytearray(rnd.randbytes(131072))
+    for i in range(0, 131072, 32):
+        blob[i] = 0
+    blob[32 * 70: 32 * 71] = M.NULL.to_bytes(32, "big")  # element 70 = cell 1, position 6
+    blob = bytes(blob)
+    cells, proofs = kzg.compute_cells_and_kzg_proofs(blob, settings)
+    assert cells[: 131072] == blob  # the first 64 cells are the blob itself
+    allc, allp = kzg.recover_cells_and_kzg_proofs(list(range(128)), cells, settings)
+    assert allc == cells and allp == proofs
+    limbs = kats["scale2_root_of_unity"]["limbs"][13]
+    root = sum(int(x) << (64 * i) for i, x in enumerate(limbs))
+    idx = list(range(0, 64))  # includes cell 1
+    got, _ = kzg.recover_cells_and_kzg_proofs(idx, cells[: 64 * CELL], settings)
+    want = M.recover_cells({i: M.cell_to_ints(cells[CELL * i: CELL * (i + 1)]) for i in idx}, root)
+    assert got == b"".join(M.ints_to_cell(c) for c in want)
+    assert got != cells  # the reference's quirk: the dropped element changes the outcome

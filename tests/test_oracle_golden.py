@@ -2,6 +2,7 @@
 (SURVEY.md §8c): c-kzg-4844 mainnet vectors + hard-coded known-answer constants.  CPU only."""
 import ctypes as C
 import hashlib
+import os
 import random
 
 import pytest
@@ -381,3 +382,32 @@ def test_fft_g1_properties(oracle):
     assert L.offt_g1(C.byref(fs), big, big, 12, 0) == 2
     L.offt_settings_free(C.byref(fs))
     L.offt_settings_free(C.byref(fs2))
+
+
+def test_recover_model_pinned_on_reference_vectors(kats):
+    """tests/recover_model.py (the Python restatement of recover_cells, das.rs:566-657) against the reference's three
+    half-missing recover_cells_and_kzg_proofs vectors: every recovered cell."""
+    import gzip
+    import json
+
+    import recover_model as M
+    from conftest import GOLDEN
+
+    with open(os.path.join(GOLDEN, "kzg_mainnet_7594.json")) as f:
+        v = json.load(f)
+    with gzip.open(os.path.join(GOLDEN, v["cells_file"]), "rb") as f:
+        raw = f.read()
+    cells = [raw[i: i + 2048] for i in range(0, len(raw), 2048)]
+    limbs = kats["scale2_root_of_unity"]["limbs"][13]
+    root = sum(int(x) << (64 * i) for i, x in enumerate(limbs))
+    assert pow(root, 8192, M.R) == 1 and pow(root, 4096, M.R) != 1
+    n = 0
+    for case in v["recover_cells_and_kzg_proofs"]:
+        if case["output"] is None or len(case["cell_indices"]) == 128:
+            continue
+        provided = {i: M.cell_to_ints(cells[ref]) for i, ref in zip(case["cell_indices"], case["cells"])}
+        got = M.recover_cells(provided, root)
+        want = [cells[ref] for ref in case["output"]["cells"]]
+        assert [M.ints_to_cell(c) for c in got] == want, case["name"]
+        n += 1
+    assert n == 3
