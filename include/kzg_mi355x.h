@@ -321,7 +321,7 @@ C_KZG_RET kzgamd_verify_blob_kzg_proof_batch_multi(bool *ok, const Blob *blobs, 
 /* One large MSM sharded by index range: msm[d] was prepared (prepare_msm after kzgamd_set_device(d), or
  * kzgamd_msm_create_device) over points[offsets[d] .. offsets[d+1]); scalars is the whole array (offsets[ndev]
  * elements, Montgomery blst_fr as mult_pippenger_prepared).  Every device sums its slice, the ndev 144-byte partials are
- * added on the host (kzgamd_g1_sum). */
+ * added on the host (kzgamd_g1_sum).  An empty slice (offsets[d] == offsets[d+1]) may have a NULL handle. */
 RustError kzgamd_mult_pippenger_prepared_multi(void *const msm[], size_t ndev, blst_p1 *out, const size_t offsets[],
                                                const blst_fr scalars[]);
 

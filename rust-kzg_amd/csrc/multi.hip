@@ -186,7 +186,8 @@ extern "C" RustError kzgamd_mult_pippenger_prepared_multi(void* const msm[], siz
     };
     if (!msm || ndev == 0 || !out || !offsets || !scalars) return fail("kzgamd_mult_pippenger_prepared_multi: null argument");
     for (size_t d = 0; d < ndev; ++d)
-        if (!msm[d] || offsets[d + 1] < offsets[d]) return fail("kzgamd_mult_pippenger_prepared_multi: bad handle or offsets");
+        if (offsets[d + 1] < offsets[d] || (!msm[d] && offsets[d + 1] != offsets[d]))  // an empty slice needs no handle
+            return fail("kzgamd_mult_pippenger_prepared_multi: bad handle or offsets");
     std::vector<blst_p1> part(ndev);
     std::vector<RustError> errs(ndev);
     for (auto& e : errs) e = RustError{0, nullptr};

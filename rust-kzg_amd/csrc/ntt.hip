@@ -475,6 +475,15 @@ extern "C" void* kzgamd_ntt_new(unsigned scale) {
         ctx->scale = scale;
         ctx->W = (size_t)1 << scale;
         if (const char* v = getenv("KZGAMD_NTT_VARIANT")) ctx->variant = atoi(v);
+        auto env_size = [](const char* name, size_t& out) {
+            if (const char* v = getenv(name)) {
+                const long x = strtol(v, nullptr, 10);
+                out = x < 0 ? 0 : (size_t)x;
+            }
+        };
+        env_size("KZGAMD_G1_WIDE_MAX", ctx->g1_wide_max);
+        env_size("KZGAMD_G1_QUAD_MAX", ctx->g1_quad_max);
+        env_size("KZGAMD_G1_PAIR_MAX", ctx->g1_pair_max);
         kzgamd::expand_roots(ctx->roots, scale);
         // device twiddles in the 2^261 domain, w*2^261 = (w*2^256) * 2^5, already sliced into the 9 x 29-bit limbs
         // the butterflies multiply with (36 bytes per root instead of 32, ~27 instructions less per butterfly)

@@ -42,6 +42,10 @@ struct NttCtx {
     void* d_kroots = nullptr;  // (W + 1) x RootSplit
     void *d_p1 = nullptr, *d_pts = nullptr, *d_tab = nullptr;
     size_t cap_g1 = 0, cap_tab = 0;
+    // G1 stages (fftg1.hip) by their number of half-butterflies: up to g1_wide_max a wave each (limb-parallel), up to
+    // g1_quad_max four lanes each, up to g1_pair_max two lanes each, one lane each above
+    // (KZGAMD_G1_WIDE_MAX / _QUAD_MAX / _PAIR_MAX, read at creation; 0 disables a form)
+    size_t g1_wide_max = 4096, g1_quad_max = 16384, g1_pair_max = 32768;
     ~NttCtx() {
         if (d_roots) (void)hipFree(d_roots);
         if (d_tw_fwd) (void)hipFree(d_tw_fwd);

@@ -9,6 +9,21 @@ import oracle_ffi as O
 
 pytestmark = pytest.mark.gpu
 
+# The four forms of a stage (fftg1.hip): a wave / four lanes / two lanes / one lane per half-butterfly.  They are chosen
+# by grid size; the switches (read when the handle is created) force one of them for every size so that each is
+# checked against the oracle on the same cases.
+FORMS = {"by_size": {}, "wave": {"KZGAMD_G1_WIDE_MAX": "1000000"},
+         "four_lanes": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "1000000"},
+         "two_lanes": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "0", "KZGAMD_G1_PAIR_MAX": "1000000"},
+         "one_lane": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "0", "KZGAMD_G1_PAIR_MAX": "0"}}
+
+
+@pytest.fixture(params=list(FORMS))
+def form(request, monkeypatch):
+    for k, v in FORMS[request.param].items():
+        monkeypatch.setenv(k, v)
+    return request.param
+
 
 def make_data(L, n):
     """kzg-bench/src/tests/fft_g1.rs make_data: G, 2G, 3G, ... (Jacobian, Z != 1 after the first)"""
@@ -45,7 +60,7 @@ def compressed(L, arr, n):
 
 
 @pytest.mark.parametrize("logn", [0, 1, 3, 6])
-def test_fft_g1_matches_oracle(kzg, oracle, logn):
+def test_fft_g1_matches_oracle(kzg, oracle, logn, form):
     L = oracle.lib()
     scale = max(logn, 1)
     n = 1 << logn
@@ -65,7 +80,7 @@ def test_fft_g1_matches_oracle(kzg, oracle, logn):
     L.offt_settings_free(C.byref(ofs))
 
 
-def test_fft_g1_exceptional_inputs(kzg, oracle):
+def test_fft_g1_exceptional_inputs(kzg, oracle, form):
     """all points equal (every first-stage butterfly doubles / cancels), all infinity, P and -P pairs"""
     L = oracle.lib()
     n = 16
@@ -120,7 +135,7 @@ def test_fft_g1_roundtrip_scale_10(kzg, oracle):
     L.offt_settings_free(C.byref(ofs))
 
 
-def test_fft_g1_stride_and_batch(kzg, oracle):
+def test_fft_g1_stride_and_batch(kzg, oracle, form):
     # stride_fft: the same data through settings of scale 9 and 12 gives the same result
     L = oracle.lib()
     n = 1 << 9
