@@ -14,14 +14,19 @@ N > 1 shards whole blobs across ranks (weak scaling, table replicated, no data-p
 launcher the world size must equal --gpus.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import csv
 import ctypes as C
+import glob
+import hashlib
 import importlib.util
 import json
 import math
 import os
+import shutil
 import socket
 import subprocess
 import sys
+import tempfile
 import threading
 import time
 
@@ -33,8 +38,23 @@ HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s s
 VALU_PEAK = 1024 * 2.4e9 / 4               # 1024 SIMDs x one wave64 VALU instruction per 4 cycles at the nominal 2.4 GHz
 ALG_BYTES_PER_COMMIT = 128 * N             # 96 B point + 32 B scalar per pair
 ALG_ADDS_PER_COMMIT = 20 * N + 8192        # BGMW count for the fixed-base 4096 case
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
-PMC_FALLBACK = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+PMC_FALLBACK = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+CSRC = os.path.join(ROOT, "rust-kzg_amd", "csrc")
+# the sources a kernel family is compiled from: counters collected from another text of these files are not printed
+KERNEL_SOURCES = {
+    "msm": ["msm.hip", "msm_internal.h", "fp28.hip.h", "ff28.hip.h", "g1_28.hip.h", "g1_io.hip.h", "ff.hip.h", "glv.hip.h", "fpw.hip.h", "g1w.hip.h"],
+    "ntt": ["ntt.hip", "ntt_internal.h", "ntt_plan.h", "fr29.hip.h", "ff.hip.h"],
+}
+
+
+def source_hash(family):
+    """sha256 over the sources of a kernel family (what the kernel binary is a function of, with the pinned toolchain)"""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES[family]:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
 
 
 def load_pkg():
@@ -139,21 +159,77 @@ def reference_window(n):  # pippenger_window_size (kzg/src/msm/pippenger_utils.r
 
 
 def pmc_summary():
-    """The committed rocprofv3 PMC summary (tools/collect_round_profiles.sh + tools/summarize_profiles.py).  Hardware
-    counters cannot be read inside this process: rocprofv3 wraps a whole run, one counter group per pass, and serialises
-    the kernels.  The bench line therefore takes DURATIONS live (HIP events) and instruction / byte COUNTS per launch —
-    properties of the kernel binary and the workload, not of the box — from the profile run; every such field names the
-    file and the commit it was collected at."""
+    """The committed rocprofv3 PMC summary (tools/collect_round_profiles.sh + tools/summarize_profiles.py), used for the
+    counter fields this run does not collect itself (collect_counters() covers the headline kernel; the NTT and 2^20 MSM
+    counters come from here).  A family's counters are only used when the summary records the hash of the sources the
+    profiled kernels were built from and it equals the hash of the sources in this tree: a summary of other kernels
+    yields null fields, not stale numbers."""
     for p in (PMC_SUMMARY, PMC_FALLBACK):
         try:
             pm = json.load(open(p))
-            src = os.path.relpath(p, ROOT)
-            if pm.get("collected_at_commit"):
-                src += " (collected at commit %s)" % pm["collected_at_commit"]
-            return pm, src
         except Exception:
             continue
-    return None, None
+        src = os.path.relpath(p, ROOT)
+        if pm.get("collected_at_commit"):
+            src += " (collected at commit %s)" % pm["collected_at_commit"]
+        valid = {fam: (pm.get("source_sha256", {}).get(fam) == source_hash(fam)) for fam in KERNEL_SOURCES}
+        return pm, src, valid
+    return None, None, {fam: False for fam in KERNEL_SOURCES}
+
+
+def collect_counters(batch, timeout_s=150):
+    """Hardware counters of the headline kernel, collected by THIS run: rocprofv3 wraps a short serialised run of this
+    script (--streams 1: a launch runs alone), one counter group per pass (the HBM guide's recipe: separate --pmc
+    passes, --kernel-trace only), outside the timed region and after this process has freed its tables.  Returns
+    (per-launch dict, note); the dict is None when rocprofv3 is missing or a pass fails."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found: counter fields come from the committed profile if its kernels are these"
+    passes = ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES", "GRBM_GUI_ACTIVE"]
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--batches-per-step", "2",
+             "--batch", str(batch), "--streams", "1", "--no-cpu-baseline", "--no-extras", "--no-counters"]
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="kzg_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for i, p in enumerate(passes):
+            d = os.path.join(tmp, "pass%d" % i)
+            r = subprocess.run([exe, "--pmc"] + p.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--"] + child,
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 pass %r failed (rc %d)" % (p, r.returncode)
+            agg = {}
+            for row in csv.DictReader(open(files[0])):
+                if "fbw_accum" in row["Kernel_Name"]:
+                    agg.setdefault((row["Kernel_Name"], row["Grid_Size"]), {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            if not agg:
+                return None, "no k_fbw_accum dispatch in the counter pass"
+            # the batch-sized launches (the largest grid)
+            key = max(agg, key=lambda k: int(k[1]))
+            for cn, v in agg[key].items():
+                out[cn] = sum(v) / len(v)
+            out["kernel"] = key[0].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            if "GRBM_GUI_ACTIVE" in p:
+                durs = []
+                for tf in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                    for row in csv.DictReader(open(tf)):
+                        if row["Kernel_Name"] == key[0] and (row.get("Grid_Size_X") or row.get("Grid_Size")) in (key[1], str(int(key[1]))):
+                            durs.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+                if durs:
+                    out["kernel_s_in_grbm_pass"] = sum(durs) / len(durs) * 1e-9
+    except Exception as e:  # noqa: BLE001
+        return None, "counter collection failed: %r" % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {"hbm_bytes_per_launch": out["FETCH_SIZE"] * 1024 * 2 + out["WRITE_SIZE"] * 1024,  # gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md)
+           "SQ_INSTS_VALU": out["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": out["SQ_ACTIVE_INST_VALU"], "kernel": out["kernel"], "batch": batch}
+    if "kernel_s_in_grbm_pass" in out:
+        xcd_cycles = out["GRBM_GUI_ACTIVE"] / 8
+        res["effective_clock_ghz"] = xcd_cycles / out["kernel_s_in_grbm_pass"] / 1e9
+        res["valu_busy_frac"] = out["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * xcd_cycles)
+        res["kernel_ms_in_grbm_pass"] = out["kernel_s_in_grbm_pass"] * 1e3
+    return res, "collected by this run: rocprofv3 --pmc <one group per pass> --kernel-trace -- python bench.py --streams 1 (4 passes)"
 
 
 def main():
@@ -168,6 +244,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only: skip the NTT / MSM sweep / proof / host-buffer legs")
     ap.add_argument("--no-large", action="store_true", help="alias of --no-extras")
+    ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 counter passes over the headline kernel")
+    ap.add_argument("--no-multi", action="store_true", help="skip the in-process multi-GPU leg (kzgamd_*_batch_multi)")
     args = ap.parse_args()
     if args.no_large:
         args.no_extras = True
@@ -318,21 +396,16 @@ def main():
     }
     if gather_ms is not None:
         res["result_allgather_ms"] = gather_ms
-    pm, pm_src = pmc_summary()
+    pm, pm_src, pm_valid = pmc_summary()
+    kern = "k_fbw_accum" if info.get("wide_table") else "k_accum"
+    own_ms = None
     if prof is not None:
         accum_ms, total_ms, cnt = prof
         alg_bytes = ALG_BYTES_PER_COMMIT * B
         own_ms = prof_alone[0] if (prof_alone and NS > 1) else accum_ms
         ach = alg_bytes / (own_ms * 1e-3) / 1e9
-        kern = "k_fbw_accum" if info.get("wide_table") else "k_accum"
-        traffic = None
-        pk = None
-        if pm and info.get("wide_table") and pm.get("window_bits") == info["window_bits"] and kern in pm:
-            pk = pm[kern]
-            traffic = pk["hbm_bytes_per_launch"] / pm["batch"] * B
         res["roofline"] = {"bound": "hbm", "kernel": kern, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                           "traffic_source": pm_src if traffic is not None else None,
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                            "kernel_ms": own_ms, "kernel_ms_in_timed_region_sharing_the_gpu": accum_ms,
                            # what a launch costs the timed configuration: co-resident launches on the other streams fill
                            # the issue slots a lone launch leaves idle, so this is below kernel_ms x launches
@@ -342,17 +415,28 @@ def main():
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "note": "MSM is integer-VALU bound, not HBM bound (SURVEY §8d); see `valu`. kernel_ms is one "
                                    "launch (one batch) running alone; a step is launches_per_step of them"}
-        if pk is not None:
-            wave_instr = pk["SQ_INSTS_VALU"] / pm["batch"] * B
-            res["valu"] = {"bound": "VALU issue", "kernel": kern, "achieved": wave_instr / (own_ms * 1e-3), "peak": VALU_PEAK,
-                           "unit": "VALU wave-instructions/s", "frac": wave_instr / (own_ms * 1e-3) / VALU_PEAK,
-                           "kernel_ms_alone": own_ms, "valu_instructions_per_mixed_add": wave_instr * 64 / (B * N * info["adds_per_scalar"]),
-                           "busy_frac_at_sustained_clock": pk.get("valu_busy_frac"),
-                           "sustained_clock_ghz": pk.get("effective_clock_ghz"),
-                           "source": "instruction count, busy fraction and clock: %s (rocprofv3 PMC passes of this kernel); "
-                                     "duration: live HIP events" % pm_src,
-                           "note": "frac is against the nominal 2.4 GHz; under this all-VALU load the chip sustains "
-                                   "~2.0 GHz, where the VALUs are busy busy_frac of the kernel's cycles"}
+
+    def fill_counters(pk, pk_batch, source):
+        """roofline.traffic and the `valu` object from per-launch counters of the headline kernel (pk, collected on
+        launches of pk_batch blobs), durations from this run's HIP events"""
+        if own_ms is None or pk is None:
+            return
+        res["roofline"]["traffic"] = pk["hbm_bytes_per_launch"] / pk_batch * B
+        res["roofline"]["traffic_source"] = source
+        wave_instr = pk["SQ_INSTS_VALU"] / pk_batch * B
+        res["valu"] = {"bound": "VALU issue", "kernel": kern, "achieved": wave_instr / (own_ms * 1e-3), "peak": VALU_PEAK,
+                       "unit": "VALU wave-instructions/s", "frac": wave_instr / (own_ms * 1e-3) / VALU_PEAK,
+                       "kernel_ms_alone": own_ms, "valu_instructions_per_mixed_add": wave_instr * 64 / (B * N * info["adds_per_scalar"]),
+                       "busy_frac_at_sustained_clock": pk.get("valu_busy_frac"),
+                       "sustained_clock_ghz": pk.get("effective_clock_ghz"),
+                       "kernel_ms_in_counter_pass": pk.get("kernel_ms_in_grbm_pass"),
+                       "source": "instruction count, busy fraction and clock: %s; duration: live HIP events" % source,
+                       "note": "frac is against the nominal 2.4 GHz; under this all-VALU load the chip sustains "
+                               "sustained_clock_ghz (GRBM_GUI_ACTIVE / 8 XCDs / kernel time), where the VALUs are busy "
+                               "busy_frac of the kernel's cycles"}
+
+    if pm and pm_valid["msm"] and info.get("wide_table") and pm.get("window_bits") == info["window_bits"] and kern in pm:
+        fill_counters(pm[kern], pm["batch"], pm_src + " (same kernel sources as this tree)")
 
     def ev_time(fn, reps=5):
         """min over reps of the HIP-event time of fn() on torch's current stream (the library launches there)"""
@@ -450,7 +534,8 @@ def main():
         # ---- configs[3]: Fr NTT n = 4096 (batched) and n = 2^20, forward, inverse and the DAS extension of half -------
         fs = kzg.FFTSettings(20)
         ntt = {}
-        npm = (pm or {}).get("ntt", {})  # per transform call: HBM bytes and VALU instructions from the committed PMC passes
+        # per transform call: HBM bytes and VALU instructions from the committed PMC passes — only if they are of these kernels
+        npm = (pm or {}).get("ntt", {}) if pm_valid["ntt"] else {}
         for n, nb in ((4096, 256), (1 << 20, 1)):
             a = torch.randint(0, 2**31, (nb * n * 8,), dtype=torch.int32, device=dev)
             a[7::8] &= 0x3FFFFFFF  # any 256-bit pattern below r is a valid Montgomery residue
@@ -502,6 +587,7 @@ def main():
         sc[:, 31] &= 0x3F  # little-endian canonical scalars < 2^254 < r
         o = torch.zeros(144, dtype=torch.uint8, device=dev)
         sweep = []
+        sweep_pm = (pm or {}).get("msm_sweep", {}) if pm_valid["msm"] else {}
         for logn in (16, 18, 20, 21, 22):
             n = 1 << logn
             h = kzg.DeviceMsm(pts.data_ptr(), n, False)
@@ -516,8 +602,8 @@ def main():
                           "roofline": {"bound": "hbm", "kernel": "k_accum (+ sort and reduction kernels)", "achieved": gbs,
                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                        "algorithmic_bytes": 128 * n,
-                                       "traffic": ((pm or {}).get("msm_sweep", {}).get(str(n)) or {}).get("hbm_bytes_per_call"),
-                                       "traffic_source": pm_src if ((pm or {}).get("msm_sweep", {}).get(str(n))) else None}})
+                                       "traffic": (sweep_pm.get(str(n)) or {}).get("hbm_bytes_per_call"),
+                                       "traffic_source": pm_src if sweep_pm.get(str(n)) else None}})
             if logn == 20:
                 res["msm_2p20_ms"] = ms
                 res["msm_2p20_pairs_per_s"] = n / (ms * 1e-3)
@@ -586,6 +672,19 @@ def main():
         cells_call()
         cells_call()
         dtc = (time.perf_counter() - t0) / 2
+        def cells_n(nn):
+            rc = kzg.lib().kzgamd_compute_cells_and_kzg_proofs_batch(cbuf, pbuf, hbc, nn, C_.byref(settings.c))
+            if rc != 0:
+                raise RuntimeError("kzgamd_compute_cells_and_kzg_proofs_batch: %d" % rc)
+
+        small = {}
+        for nn in (16, 64):
+            cells_n(nn)
+            t0 = time.perf_counter()
+            cells_n(nn)
+            cells_n(nn)
+            small["ms_per_call_%d_blobs" % nn] = (time.perf_counter() - t0) / 2 * 1e3
+        res["cells_and_proofs_small_batches"] = small
         res["cells_and_proofs_256"] = {"ms_per_call": dtc * 1e3, "cell_proofs_per_s": ncell * 128 / dtc, "blobs_per_s": ncell / dtc,
                                        "path": "kzgamd_compute_cells_and_kzg_proofs_batch: 128 cells + 128 cell proofs per blob, "
                                                "FK20 (64 NTTs of 128, 128 MSMs of 64 points, two G1 transforms of 128)"}
@@ -624,12 +723,96 @@ def main():
         host = blobs[:ns].cpu().numpy()
         gpu = outs[0][:ns * 48].cpu().numpy().tobytes()
         res["cpu_baseline"] = cpu_baseline([host[i].tobytes() for i in range(ns)], [gpu[48 * i:48 * i + 48] for i in range(ns)])
+    # ---- everything below runs after this rank has freed its tables ------------------------------------------------
+    host_blobs = None
+    if rank == 0 and not args.no_multi and not args.no_extras:
+        host_blobs = blobs[:min(B * NB, 1024 * max(1, world))].cpu().numpy().tobytes() if world == 1 else \
+            (blobs[:min(B * NB, 1024)].cpu().numpy().tobytes() * world)
+    settings.close()
+    del blobs, outs, scratch
+    torch.cuda.empty_cache()
+    if dist is not None:
+        dist.barrier()
+
+    if rank == 0 and not args.no_counters:
+        # ---- hardware counters of the headline kernel, collected by this run (separate rocprofv3 passes) ------------
+        pk, note = collect_counters(B) if info.get("wide_table") else (None, "bucket engine: no k_fbw_accum")
+        res["counters"] = {"collected": pk is not None, "note": note, "kernel_source_sha256": {f: source_hash(f) for f in KERNEL_SOURCES}}
+        if pk is not None:
+            fill_counters(pk, pk["batch"], note)
+
+    if rank == 0 and not args.no_multi and not args.no_extras:
+        # ---- multi-GPU from ONE process, inside the library (csrc/multi.hip): one settings object per GPU, contiguous
+        # slabs of the batch, one host thread per device; host buffers in and out (PCIe both ways — never `value`).
+        # Under torchrun the other ranks have freed their tables and wait at the barrier below.
+        try:
+            ndev = min(world, kzg.device_count())
+            ms = kzg.MultiKZGSettings(SETUP, list(range(ndev)))
+            nmb = len(host_blobs) // BLOB
+            cms = ms.commit_batch(host_blobs, nmb)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                cms = ms.commit_batch(host_blobs, nmb)
+            t_c = (time.perf_counter() - t0) / 3
+            cmb = b"".join(cms)
+            ms.proof_batch(host_blobs, cmb, nmb)
+            t0 = time.perf_counter()
+            for _ in range(2):
+                prs = ms.proof_batch(host_blobs, cmb, nmb)
+            t_p = (time.perf_counter() - t0) / 2
+            ok = ms.verify_blob_batch(host_blobs[:64 * BLOB], cmb[:64 * 48], b"".join(prs[:64]), min(64, nmb))
+            res["in_process_multi"] = {
+                "devices": ms.settings_devices(), "blobs_per_call": nmb, "commitments_per_s": nmb / t_c, "proofs_per_s": nmb / t_p,
+                "first_64_proofs_verify": bool(ok),
+                "path": "kzgamd_blob_to_kzg_commitment_batch_multi / kzgamd_compute_blob_kzg_proof_batch_multi: one process, "
+                        "%d settings object(s), slabs of the batch per device on one host thread each, host buffers in and out "
+                        "(PCIe both ways); no torch.distributed, no collective" % ndev}
+            ms.close()
+        except Exception as e:  # noqa: BLE001
+            res["in_process_multi"] = {"error": repr(e)}
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- what a smaller commitment table costs (KZGAMD_FBW_MAX_GB): device-resident commitments/s per HBM budget ----
+        rows = []
+        dblobs = make_blobs(torch, 1024, 99, dev)
+        dout = torch.zeros(1024 * 48, dtype=torch.uint8, device=dev)
+        dstat = torch.zeros(1024, dtype=torch.int32, device=dev)
+        dscr = [torch.empty(1024 * BLOB, dtype=torch.uint8, device=dev) for _ in range(2)]
+        sts = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        for gb in (10, 20, 40, 80, 160):
+            os.environ["KZGAMD_FBW_MAX_GB"] = str(gb)
+            try:
+                sb = kzg.KZGSettings.from_file(SETUP)
+                hi = kzg.PreparedMsm.info(type("H", (), {"handle": sb.msm_handle()})())
+                for st_ in sts:
+                    sb.reserve(1024, st_.cuda_stream)
+
+                def run(reps):
+                    for i in range(reps):
+                        kzg.blob_to_kzg_commitment_device(dout.data_ptr(), dstat.data_ptr(), dscr[i % 2].data_ptr(), dblobs.data_ptr(), 1024,
+                                                          sb, sts[i % 2].cuda_stream)
+                    torch.cuda.synchronize()
+
+                run(2)
+                t0 = time.perf_counter()
+                run(6)
+                dt = time.perf_counter() - t0
+                rows.append({"budget_gb": gb, "window_bits": hi["window_bits"], "rows": hi["rows"], "glv": hi["wide_glv"],
+                             "wide_table": hi["wide_table"], "mixed_adds_per_scalar": hi["adds_per_scalar"],
+                             "table_gb": (hi["rows"] * N * (1 << (hi["window_bits"] - 1)) * 128 / 1e9) if hi["wide_table"] else 0.0,
+                             "commitments_per_s": 6 * 1024 / dt})
+                sb.close()
+            except Exception as e:  # noqa: BLE001
+                rows.append({"budget_gb": gb, "error": repr(e)})
+        os.environ.pop("KZGAMD_FBW_MAX_GB", None)
+        res["throughput_vs_table_budget"] = {"rows": rows, "path": "device-resident commitments, batches of 1024 on two streams, a "
+                                             "settings object per KZGAMD_FBW_MAX_GB value (the default budget is 160 GB)"}
+
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(res))
-    settings.close()
 
 
 if __name__ == "__main__":

@@ -19,6 +19,13 @@
 #include <stdio.h>
 #include <string.h>
 
+// -DKZGAMD_FFTG1_OUTLINE_MUL: fp28::mul / sqr as real functions in this file (a window step shrinks from 60 - 130 KB of
+// code to under 20 KB).  Measured, not adopted: the long-lane kernels run one or two waves per SIMD and might have been
+// bound by instruction fetch (64 KB instruction cache per two CUs) — they are not: FK20 of 256 blobs 23.9 -> 27.6 ms,
+// one lane per half-butterfly 31.6 -> 37.8 ms (the argument marshalling of the calls), DESIGN.md §9.
+#ifdef KZGAMD_FFTG1_OUTLINE_MUL
+#define FP28_OUTLINE_MUL 1
+#endif
 #include "../../include/kzg_mi355x.h"
 #include "ff.hip.h"
 #include "g1_28.hip.h"
@@ -37,6 +44,8 @@ namespace {
 constexpr int WIN = 4;              // scalar window
 constexpr int NTAB = (1 << WIN) - 1;  // multiples 1..15
 constexpr int NTHREADS = 64;        // one wave per workgroup: long serial lanes, spread over all CUs
+constexpr int MAXTHREADS = 256;     // ... or four waves per workgroup once there is a wave for every SIMD (block_threads)
+constexpr int BOUND = 512;          // launch bound of the long-lane kernels: two waves per SIMD must fit (<= 256 registers)
 
 // one root (or n^-1) split for the two lanes of a butterfly: 127-bit magnitudes and their signs
 struct RootSplit {
@@ -136,7 +145,7 @@ __global__ void __launch_bounds__(256) k_g1_load(Xyzz* __restrict__ out, const f
 // twiddle w_n^(j * n / 2^(s+1)) = roots[j * (W >> (s+1))]  (fft_g1.rs:22-29 unrolled); two lanes per butterfly
 // (out of place: the two lanes of a butterfly both read x and y, so the stage writes to the other half of a
 // ping-pong buffer instead of relying on the pair running in lockstep)
-__global__ void __launch_bounds__(NTHREADS) k_g1_stage(Xyzz* __restrict__ dst, const Xyzz* __restrict__ data, Xyzz* __restrict__ tab,
+__global__ void __launch_bounds__(BOUND) k_g1_stage(Xyzz* __restrict__ dst, const Xyzz* __restrict__ data, Xyzz* __restrict__ tab,
                                                        const RootSplit* __restrict__ kroots, u32 n, int s, u32 W, int inverse,
                                                        size_t total) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // total = 2 * butterflies, even
@@ -159,7 +168,7 @@ __global__ void __launch_bounds__(NTHREADS) k_g1_stage(Xyzz* __restrict__ dst, c
 }
 
 // XYZZ -> blst Jacobian; an inverse transform multiplies by n^-1 first (fft_g1.rs:72-79), two lanes per point
-__global__ void __launch_bounds__(NTHREADS) k_g1_store(ff::Fp* __restrict__ out, const Xyzz* __restrict__ data,
+__global__ void __launch_bounds__(BOUND) k_g1_store(ff::Fp* __restrict__ out, const Xyzz* __restrict__ data,
                                                        Xyzz* __restrict__ tab, RootSplit inv_n, int scale, size_t total) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // total = 2 * points
     if (t >= total) return;
@@ -178,7 +187,7 @@ __global__ void __launch_bounds__(256) k_g1_brp_xyzz(Xyzz* __restrict__ out, con
     out[t] = in[xf * n + brev((u32)(t % n), logn)];
 }
 // data[p] *= n^-1 (two lanes per point, both in one wave: the loads of a pair precede its store)
-__global__ void __launch_bounds__(NTHREADS) k_g1_scale_xyzz(Xyzz* __restrict__ data, Xyzz* __restrict__ tab, RootSplit inv_n,
+__global__ void __launch_bounds__(BOUND) k_g1_scale_xyzz(Xyzz* __restrict__ data, Xyzz* __restrict__ tab, RootSplit inv_n,
                                                             size_t total) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // total = 2 * points
     if (t >= total) return;
@@ -399,7 +408,7 @@ __device__ __forceinline__ Xyzz from_partner(const Xyzz& p) {
 
 // stage s with G lanes per half-butterfly (see above); total = 2 * G * butterflies lanes
 template <int G>
-__global__ void __launch_bounds__(NTHREADS) k_g1_stage_grp(Xyzz* __restrict__ dst, const Xyzz* __restrict__ data, Xyzz* __restrict__ tab,
+__global__ void __launch_bounds__(BOUND) k_g1_stage_grp(Xyzz* __restrict__ dst, const Xyzz* __restrict__ data, Xyzz* __restrict__ tab,
                                                            const RootSplit* __restrict__ kroots, u32 n, int s, u32 W, int inverse,
                                                            size_t total) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -438,7 +447,7 @@ __global__ void __launch_bounds__(NTHREADS) k_g1_stage_grp(Xyzz* __restrict__ ds
 
 // data[i] *= inv_n, G lanes per half
 template <int G>
-__global__ void __launch_bounds__(NTHREADS) k_g1_scale_grp(Xyzz* __restrict__ data, Xyzz* __restrict__ tab, RootSplit inv_n, size_t total) {
+__global__ void __launch_bounds__(BOUND) k_g1_scale_grp(Xyzz* __restrict__ data, Xyzz* __restrict__ tab, RootSplit inv_n, size_t total) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // total = 2 * G * points
     if (t >= total) return;
     const int r = (int)(t % G);
@@ -667,12 +676,27 @@ RootSplit split_scalar(const Fr& plain) {  // canonical (non-Montgomery) scalar 
     return rs;
 }
 
+// Threads per workgroup of the long-lane kernels for a launch of `lanes` lanes: one wave per workgroup, or four once
+// there is a wave for every SIMD (measured: no difference either way — the hardware spreads single-wave workgroups
+// over the SIMDs of a CU as evenly as the waves of one workgroup).
+inline unsigned block_threads(size_t lanes) { return lanes >= (size_t)1024 * 64 ? MAXTHREADS : NTHREADS; }
+inline dim3 grid_for(size_t lanes) {
+    const unsigned bt = block_threads(lanes);
+    return dim3((unsigned)((lanes + bt - 1) / bt));
+}
+
 // the stages of one batch of transforms on bit-reversed-order data in bufs[0]; returns the index of the buffer that
 // holds the result.  Stages whose half-butterflies (units) are few enough run limb-parallel (see above).
 int enqueue_stages(NttCtx* ctx, Xyzz* bufs[2], Xyzz* tab, size_t n, size_t nbatch, int inverse, hipStream_t st) {
     const size_t total = n * nbatch, bf = total / 2;
     const int logn = ilog2(n);
     const bool wide = 2 * bf <= ctx->g1_wide_max;
+    // Between g1_quad_max and g1_pair_max half-butterflies the better form depends on the transform: the twiddles of
+    // short transforms (FK20: 128 points) are low-order roots whose GLV halves are short — two lanes per half win
+    // (256 blobs: 23.8 ms against 28.6 with four) — while the full-length chains of a long transform want four
+    // (2^15 points: 24.5 ms against 38 with two, 42.7 with one).
+    const size_t quad_max = n > 256 && ctx->g1_quad_max ? (ctx->g1_pair_max > ctx->g1_quad_max ? ctx->g1_pair_max : ctx->g1_quad_max)
+                                                        : ctx->g1_quad_max;
     for (int s = 0; s < logn; ++s) {
         Xyzz* dst = bufs[(s + 1) & 1];
         const Xyzz* src = bufs[s & 1];
@@ -682,14 +706,14 @@ int enqueue_stages(NttCtx* ctx, Xyzz* bufs[2], Xyzz* tab, size_t n, size_t nbatc
                                    (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0);
             hipLaunchKernelGGL(k_g1_stage_bfly_wide, dim3((unsigned)bf), dim3(64), 0, st, dst, src, (const Xyzz*)tab, (u32)n, s,
                                (u32)ctx->W);
-        } else if (s > 0 && 2 * bf <= ctx->g1_quad_max) {
-            hipLaunchKernelGGL(k_g1_stage_grp<4>, dim3((unsigned)((8 * bf + NTHREADS - 1) / NTHREADS)), dim3(NTHREADS), 0, st, dst, src, tab,
+        } else if (s > 0 && 2 * bf <= quad_max) {
+            hipLaunchKernelGGL(k_g1_stage_grp<4>, grid_for(8 * bf), dim3(block_threads(8 * bf)), 0, st, dst, src, tab,
                                (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0, 8 * bf);
         } else if (s > 0 && 2 * bf <= ctx->g1_pair_max) {
-            hipLaunchKernelGGL(k_g1_stage_grp<2>, dim3((unsigned)((4 * bf + NTHREADS - 1) / NTHREADS)), dim3(NTHREADS), 0, st, dst, src, tab,
+            hipLaunchKernelGGL(k_g1_stage_grp<2>, grid_for(4 * bf), dim3(block_threads(4 * bf)), 0, st, dst, src, tab,
                                (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0, 4 * bf);
         } else {  // stage 0 (unit twiddles: one addition per lane) and the grids that fill the chip on their own
-            hipLaunchKernelGGL(k_g1_stage, dim3((unsigned)((2 * bf + NTHREADS - 1) / NTHREADS)), dim3(NTHREADS), 0, st, dst, src, tab,
+            hipLaunchKernelGGL(k_g1_stage, grid_for(2 * bf), dim3(block_threads(2 * bf)), 0, st, dst, src, tab,
                                (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0, 2 * bf);
         }
     }
@@ -702,13 +726,13 @@ void enqueue_scale(NttCtx* ctx, Xyzz* data, Xyzz* tab, const RootSplit& inv_n, s
         hipLaunchKernelGGL(k_g1_scale_mul_wide, dim3((unsigned)(2 * total)), dim3(64), 0, st, tab, (const Xyzz*)data, inv_n);
         hipLaunchKernelGGL(k_g1_scale_sum_wide, dim3((unsigned)total), dim3(64), 0, st, data, (const Xyzz*)tab);
     } else if (2 * total <= ctx->g1_quad_max) {
-        hipLaunchKernelGGL(k_g1_scale_grp<4>, dim3((unsigned)((8 * total + NTHREADS - 1) / NTHREADS)), dim3(NTHREADS), 0, st, data, tab,
+        hipLaunchKernelGGL(k_g1_scale_grp<4>, grid_for(8 * total), dim3(block_threads(8 * total)), 0, st, data, tab,
                            inv_n, 8 * total);
     } else if (2 * total <= ctx->g1_pair_max) {
-        hipLaunchKernelGGL(k_g1_scale_grp<2>, dim3((unsigned)((4 * total + NTHREADS - 1) / NTHREADS)), dim3(NTHREADS), 0, st, data, tab,
+        hipLaunchKernelGGL(k_g1_scale_grp<2>, grid_for(4 * total), dim3(block_threads(4 * total)), 0, st, data, tab,
                            inv_n, 4 * total);
     } else {
-        hipLaunchKernelGGL(k_g1_scale_xyzz, dim3((unsigned)((2 * total + NTHREADS - 1) / NTHREADS)), dim3(NTHREADS), 0, st, data, tab,
+        hipLaunchKernelGGL(k_g1_scale_xyzz, grid_for(2 * total), dim3(block_threads(2 * total)), 0, st, data, tab,
                            inv_n, 2 * total);
     }
 }
@@ -826,7 +850,7 @@ extern "C" int kzgamd_fft_g1_batch(void* vctx, blst_p1* out, const blst_p1* in, 
                 scale = 0;
             }
         }
-        hipLaunchKernelGGL(k_g1_store, dim3((unsigned)((2 * total + NTHREADS - 1) / NTHREADS)), dim3(NTHREADS), 0, st,
+        hipLaunchKernelGGL(k_g1_store, grid_for(2 * total), dim3(block_threads(2 * total)), 0, st,
                            (ff::Fp*)ctx->d_p1, (const Xyzz*)res, tab, inv_n, scale, 2 * total);
         NTT_TRY(hipGetLastError());
         NTT_TRY(hipMemcpyAsync(out, ctx->d_p1, total * sizeof(blst_p1), hipMemcpyDeviceToHost, st));

@@ -4,12 +4,12 @@
 #   3. kernel trace + stats and PMC passes of the NTT kernels (tools/ntt_bench.py)
 #   4. kernel trace of one 2^20 MSM (tools/prof_2p20.py)
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 mkdir -p $R/gpurun_out
-timeout 900 python $R/bench.py > $R/gpurun_out/bench_final.json 2> $R/gpurun_out/bench_final.err; tail -2 $R/gpurun_out/bench_final.err
+timeout 1500 python $R/bench.py > $R/gpurun_out/bench_final.json 2> $R/gpurun_out/bench_final.err; tail -2 $R/gpurun_out/bench_final.err
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_* $R/gpurun_out/pmc_*
-B="python $R/bench.py --steps 3 --warmup 1 --batches-per-step 4 --no-cpu-baseline --no-extras"
+B="python $R/bench.py --steps 3 --warmup 1 --batches-per-step 4 --no-cpu-baseline --no-extras --no-counters"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_headline -o $TAG -- $B > $R/gpurun_out/prof_headline.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_streams1 -o $TAG -- $B --streams 1 > $R/gpurun_out/prof_streams1.log 2>&1
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_WAVES" "GRBM_GUI_ACTIVE"; do
@@ -35,7 +35,15 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_ou
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_2p20 -o $TAG -- python $R/tools/prof_2p20.py > $R/gpurun_out/prof_2p20.log 2>&1
 ls $R/gpurun_out | head -40
 # 5. kernel trace of the FK20 cell-proof batches (tools/time_cells.py)
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cells -o $TAG -- python $R/tools/time_cells.py 256 > $R/gpurun_out/prof_cells.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cells -o $TAG -- python $R/tools/time_g1.py --only-cells 4096,16384,32768 > $R/gpurun_out/prof_cells.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_fftg1 -o $TAG -- python $R/tools/time_g1.py --only-fft 4096,16384,32768 > $R/gpurun_out/prof_fftg1.log 2>&1
+# counters of the latency-bound kernels: the G1 transform stages (FK20 batches of 16 .. 256 blobs) and the proof pipeline's
+# k_quotient / k_challenge_sha256 / k_check_commitments
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES" "GRBM_GUI_ACTIVE"; do
+  tag=$(echo $pass | cut -d' ' -f1)
+  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmc_cells_$tag -o $TAG -- python $R/tools/time_g1.py --only-cells 4096,16384,32768 > $R/gpurun_out/pmc_cells_$tag.log 2>&1
+  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmc_proofs_$tag -o $TAG -- python $R/tools/prof_proof_dev.py > $R/gpurun_out/pmc_proofs_$tag.log 2>&1
+done
 # 6. kernel stats of 16 concurrent callers on one settings object (lane batches: k_blob_to_scalars_ptrs, k_gather_blobs,
 #    k_quotient_a/b, k_blocksum_hybrid)
 LD_LIBRARY_PATH=$R/rust-kzg_amd/csrc:/opt/rocm/lib KZGAMD_FBW_MAX_GB=100 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_conc -o $TAG -- $R/tools/concurrent_bench $R/tests/golden/trusted_setup.txt 0.5 16 > $R/gpurun_out/prof_conc.log 2>&1

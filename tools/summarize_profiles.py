@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the raw rocprofv3 output tools/collect_round_profiles.sh left under gpurun_out/ into the committed
-summaries under profiles/ (round tag TAG, default r03): bench line, kernel statistics (headline 4-stream run, 1-stream run, NTT,
+summaries under profiles/ (round tag TAG, default r04): bench line, kernel statistics (headline 4-stream run, 1-stream run, NTT,
 2^20 MSM timeline), the PMC counter files and r02_pmc_summary.json (what bench.py reads for roofline.traffic and
 the VALU figures, labelled with this file as their source)."""
 import collections
@@ -11,7 +11,7 @@ import os
 import shutil
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = os.environ.get("TAG", "r03")
+TAG = os.environ.get("TAG", "r04")
 G = os.path.join(R, "gpurun_out")
 P = os.path.join(R, "profiles")
 
@@ -64,7 +64,7 @@ def main():
     shutil.copy(os.path.join(G, "bench_final.json"), os.path.join(P, TAG + "_bench.json"))
     B = bench["config"]["blobs_per_batch"]
     cfg = bench["config"]
-    for name in ("headline", "streams1", "ntt", "2p20", "cells", "proofs", "conc", "verify"):
+    for name in ("headline", "streams1", "ntt", "2p20", "cells", "proofs", "conc", "verify", "fftg1"):
         d = os.path.join(G, "prof_" + name)
         if os.path.exists(os.path.join(d, TAG + "_kernel_stats.csv")):
             shutil.copy(os.path.join(d, TAG + "_kernel_stats.csv"), os.path.join(P, "%s_%s_kernel_stats.csv" % (TAG, name)))
@@ -114,7 +114,10 @@ def main():
                     if match in row["Kernel_Name"]:
                         tot[row["Counter_Name"]] += float(row["Counter_Value"])
                         seen.add(row["Dispatch_Id"])
-                        meta = {"vgpr": row.get("VGPR_Count"), "scratch": int(float(row.get("Scratch_Size") or 0))}
+                        # registers / scratch PER KERNEL NAME (a call is several kernels: the last row seen is not "the" kernel)
+                        kn = short(row["Kernel_Name"])
+                        meta.setdefault("vgpr_by_kernel", {})[kn] = int(float(row.get("VGPR_Count") or 0))
+                        meta["scratch"] = max(meta.get("scratch", 0), int(float(row.get("Scratch_Size") or 0)))
                 for cn in set(r_["Counter_Name"] for r_ in csv.DictReader(open(f)) if match in r_["Kernel_Name"]):
                     launches[cn] = len(seen)
                 shutil.copy(f, os.path.join(P, "%s_%s_counter_collection.csv" % (TAG, os.path.basename(d))))
@@ -157,6 +160,23 @@ def main():
             e["hbm_bytes_per_call"] = e["FETCH_SIZE"] * 1024 * 2 + e["WRITE_SIZE"] * 1024
         e["note"] = "all kernels of one n = 2^20 MSM call (sort, accumulation, reduction); algorithmic bytes 128 * n = 134 MB"
         summary.setdefault("msm_sweep", {})[str(1 << 20)] = e
+    # the sources the profiled kernels were built from: bench.py prints these counters only for the same sources
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kzg_bench", os.path.join(R, "bench.py"))
+    bench_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench_mod)
+    summary["source_sha256"] = {fam: bench_mod.source_hash(fam) for fam in bench_mod.KERNEL_SOURCES}
+    # ---- the latency-bound kernels: counters per launch, by kernel and grid ----
+    lat = {}
+    for tag_dir, match in (("pmc_cells_*", "k_g1_st"), ("pmc_cells_*", "k_fbw_accum"), ("pmc_proofs_*", "k_quotient"),
+                           ("pmc_proofs_*", "k_challenge_sha256"), ("pmc_proofs_*", "k_check_commitments")):
+        for name, cs in counters(tag_dir, match).items():
+            lat[name] = {cn: v["avg"] for cn, v in cs.items()}
+            lat[name]["launches"] = max(v["launches"] for v in cs.values())
+            if "FETCH_SIZE" in lat[name] and "WRITE_SIZE" in lat[name]:
+                lat[name]["hbm_bytes_per_launch"] = lat[name]["FETCH_SIZE"] * 1024 * 2 + lat[name]["WRITE_SIZE"] * 1024
+    if lat:
+        summary["latency_bound_kernels"] = lat
     try:
         import subprocess
         summary["collected_at_commit"] = subprocess.check_output(["git", "-C", R, "rev-parse", "--short", "HEAD"]).decode().strip()
