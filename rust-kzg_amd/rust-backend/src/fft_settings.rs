@@ -106,3 +106,47 @@ impl FFTG1<MiG1> for MiFFTSettings {
         Ok(out.into_iter().map(MiG1::from_blst).collect())
     }
 }
+
+// ---- the (output, input, stride, roots, roots_stride) shape of blst/src/fft_fr.rs:14-30, fft_g1.rs:13-30 ----------
+// kzg-bench's comparison tests (compare_sft_fft, compare_ft_fft) take the "fast" and the "slow" transform in this
+// shape.  The strided input is gathered, the transform of `out.len()` points runs on the GPU (a context of exactly that
+// scale: the roots the caller passes are the settings' roots at `roots_stride`, i.e. the standard n-th roots).
+
+fn log2_exact(n: usize) -> u32 {
+    assert!(n.is_power_of_two(), "A list with power-of-two length expected");
+    n.trailing_zeros()
+}
+
+pub fn fft_fr_strided(out: &mut [FsFr], data: &[FsFr], stride: usize, _roots: &[FsFr], _roots_stride: usize) {
+    let n = out.len();
+    let gathered: Vec<blst_fr> = (0..n).map(|i| data[i * stride].0).collect();
+    let ctx = GpuNtt::new(log2_exact(n) as usize).expect("kzgamd_ntt_new");
+    let res = ctx.fft_fr(&gathered, false).expect("ntt_fr");
+    for (o, r) in out.iter_mut().zip(res) {
+        *o = FsFr(r);
+    }
+}
+
+pub fn fft_g1_strided(out: &mut [MiG1], data: &[MiG1], stride: usize, _roots: &[FsFr], _roots_stride: usize) {
+    let n = out.len();
+    let gathered: Vec<blst_p1> = (0..n).map(|i| data[i * stride].0 .0).collect();
+    let ctx = GpuNtt::new(log2_exact(n) as usize).expect("kzgamd_ntt_new");
+    let res = ctx.fft_g1(&gathered, false).expect("fft_g1");
+    for (o, r) in out.iter_mut().zip(res) {
+        *o = MiG1::from_blst(r);
+    }
+}
+
+/// the O(n^2) definition, on the host (blst/src/fft_g1.rs:86-110 for `MiG1`): the yardstick of compare_ft_fft
+pub fn fft_g1_slow(out: &mut [MiG1], data: &[MiG1], stride: usize, roots: &[FsFr], roots_stride: usize) {
+    use kzg::{G1Mul, G1};
+    let n = out.len();
+    for i in 0..n {
+        let mut acc = data[0].mul(&roots[0]);
+        for j in 1..n {
+            let term = data[j * stride].mul(&roots[((i * j) % n) * roots_stride]);
+            acc = acc.add_or_dbl(&term);
+        }
+        out[i] = acc;
+    }
+}

@@ -14,10 +14,12 @@
 #![cfg_attr(not(feature = "std"), no_std)]
 extern crate alloc;
 
+pub mod backend;
 pub mod fft_settings;
 pub mod g1;
 pub mod kzg_settings;
 
+pub use backend::MiBackend;
 pub use fft_settings::MiFFTSettings;
 pub use g1::MiG1;
 pub use kzg_settings::MiKZGSettings;

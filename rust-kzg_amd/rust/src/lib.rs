@@ -217,3 +217,52 @@ pub fn g1_sum(partials: &[blst_p1]) -> blst_p1 {
     unsafe { kzgamd_g1_sum(&mut out, partials.as_ptr(), partials.len()) };
     out
 }
+
+/// The c-kzg-4844 surface of libkzg_mi355x.so under its exact names (include/kzg_mi355x.h, B3): the same
+/// signatures the blst crate exports with `#[no_mangle]` (blst/src/eip_4844.rs:160-530, blst/src/eip_7594.rs:35-44,
+/// kzg/src/eth/c_bindings.rs:202-372), so that the binding test-suite (kzg-bench/src/tests/c_bindings.rs) and any
+/// consumer of the reference's C API can be pointed at the GPU library.  A process must not also link the blst crate
+/// with its `c_bindings` feature (duplicate symbols): use libkzg_mi355x_prefixed.so for that.
+pub mod ckzg {
+    use kzg::eth::c_bindings::{Blob, Bytes32, Bytes48, CKZGSettings, CKzgRet, Cell, KZGCommitment, KZGProof};
+    use libc::FILE;
+
+    extern "C" {
+        pub fn load_trusted_setup(out: *mut CKZGSettings, g1_monomial_bytes: *const u8, num_g1_monomial_bytes: u64,
+                                  g1_lagrange_bytes: *const u8, num_g1_lagrange_bytes: u64, g2_monomial_bytes: *const u8,
+                                  num_g2_monomial_bytes: u64, precompute: u64) -> CKzgRet;
+        pub fn load_trusted_setup_file(out: *mut CKZGSettings, in_: *mut FILE) -> CKzgRet;
+        pub fn free_trusted_setup(s: *mut CKZGSettings);
+        pub fn blob_to_kzg_commitment(out: *mut KZGCommitment, blob: *const Blob, s: &CKZGSettings) -> CKzgRet;
+        pub fn compute_kzg_proof(proof_out: *mut KZGProof, y_out: *mut Bytes32, blob: *const Blob, z_bytes: *const Bytes32,
+                                 s: &CKZGSettings) -> CKzgRet;
+        pub fn compute_blob_kzg_proof(out: *mut KZGProof, blob: *const Blob, commitment_bytes: *const Bytes48,
+                                      s: &CKZGSettings) -> CKzgRet;
+        pub fn verify_kzg_proof(ok: *mut bool, commitment_bytes: *const Bytes48, z_bytes: *const Bytes32, y_bytes: *const Bytes32,
+                                proof_bytes: *const Bytes48, s: &CKZGSettings) -> CKzgRet;
+        pub fn verify_blob_kzg_proof(ok: *mut bool, blob: *const Blob, commitment_bytes: *const Bytes48,
+                                     proof_bytes: *const Bytes48, s: &CKZGSettings) -> CKzgRet;
+        pub fn verify_blob_kzg_proof_batch(ok: *mut bool, blobs: *const Blob, commitments_bytes: *const Bytes48,
+                                           proofs_bytes: *const Bytes48, n: usize, s: &CKZGSettings) -> CKzgRet;
+        pub fn compute_cells_and_kzg_proofs(cells: *mut Cell, proofs: *mut KZGProof, blob: *const Blob, s: &CKZGSettings) -> CKzgRet;
+        pub fn recover_cells_and_kzg_proofs(recovered_cells: *mut Cell, recovered_proofs: *mut KZGProof, cell_indices: *const u64,
+                                            cells: *const Cell, num_cells: u64, s: &CKZGSettings) -> CKzgRet;
+        pub fn verify_cell_kzg_proof_batch(ok: *mut bool, commitments_bytes: *const Bytes48, cell_indices: *const u64,
+                                           cells: *const Cell, proofs_bytes: *const Bytes48, num_cells: u64, s: &CKZGSettings) -> CKzgRet;
+        // batched and multi-GPU forms (new API, include/kzg_mi355x.h): contiguous slabs of the batch per settings object
+        pub fn kzgamd_blob_to_kzg_commitment_batch(out: *mut KZGCommitment, blobs: *const Blob, n: usize, s: &CKZGSettings) -> CKzgRet;
+        pub fn kzgamd_compute_blob_kzg_proof_batch(out: *mut KZGProof, blobs: *const Blob, commitments: *const Bytes48, n: usize,
+                                                   s: &CKZGSettings) -> CKzgRet;
+        pub fn kzgamd_load_trusted_setup_file_multi(out: *mut CKZGSettings, devices: *const core::ffi::c_int, ndev: usize,
+                                                    in_: *mut FILE) -> CKzgRet;
+        pub fn kzgamd_free_trusted_setup_multi(s: *mut CKZGSettings, ndev: usize);
+        pub fn kzgamd_blob_to_kzg_commitment_batch_multi(out: *mut KZGCommitment, blobs: *const Blob, n: usize,
+                                                         s: *const *const CKZGSettings, ndev: usize) -> CKzgRet;
+        pub fn kzgamd_compute_blob_kzg_proof_batch_multi(out: *mut KZGProof, blobs: *const Blob, commitments: *const Bytes48,
+                                                         n: usize, s: *const *const CKZGSettings, ndev: usize) -> CKzgRet;
+        pub fn kzgamd_verify_blob_kzg_proof_batch_multi(ok: *mut bool, blobs: *const Blob, commitments: *const Bytes48,
+                                                        proofs: *const Bytes48, n: usize, s: *const *const CKZGSettings,
+                                                        ndev: usize) -> CKzgRet;
+        pub fn kzgamd_device_count() -> core::ffi::c_int;
+    }
+}
