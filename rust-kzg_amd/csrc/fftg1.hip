@@ -387,6 +387,61 @@ __device__ void scalar_mul128(Xyzz& acc, const u32 k[4], Xyzz* tab, size_t tab_s
     }
 }
 
+// Booth digit w (4 bits, in [-8, 8]) of a 127-bit k
+__device__ __forceinline__ int booth4(const u32 k[4], int w) {
+    const int bit = 4 * w - 1;
+    u32 v;
+    if (bit < 0) v = (k[0] << 1) & 31u;
+    else {
+        const u64 two = ((u64)(bit / 32 + 1 < 4 ? k[bit / 32 + 1] : 0u) << 32) | k[bit / 32];
+        v = (u32)(two >> (bit & 31)) & 31u;
+    }
+    return (int)((v + 1) >> 1) - (int)((v >> 4) << 4);
+}
+
+// acc = (+-k1) * acc + (+-k2) * [x^2]acc in ONE chain (Straus / Shamir): the doublings are shared by the two halves,
+//   k * P = s1 k1 * P - s2 k2 * Q,   Q = (beta X, Y) = -[x^2]P,   d * Q = (beta X_d, Y_d) for the table entry d * P,
+// so a window is four doublings and two additions (P-table, Q-table) — against the two-chains form (a lane group per
+// half, the halves added at the end) the same number of additions and HALF the doublings, on half the lanes.
+// tab: 16 slots of this butterfly (d * P at slot d - 1, d * Q at slot 8 + d - 1), written by role 0.
+template <int G>
+__device__ void scalar_mul_glv(Xyzz& acc, const RootSplit& rs, Xyzz* tab, size_t tab_stride, int r) {
+    if (g1::is_inf(acc)) return;
+    const fp28::Fe beta = beta28();
+    Xyzz m = acc;
+    for (int e = 0; e < 8; ++e) {
+        if (e == 1) dbl<G>(m, r);
+        else if (e > 1) dadd<G>(m, acc, r);
+        Xyzz q = m;
+        q.x = fp28::mul(m.x, beta);  // the same product on every lane of the group
+        if (r == 0) {
+            tab[(size_t)e * tab_stride] = m;
+            tab[(size_t)(8 + e) * tab_stride] = q;
+        }
+    }
+    const bool neg1 = rs.neg[0] != 0, neg2 = rs.neg[1] == 0;  // the Q half carries the minus of [x^2]P = -Q
+    g1::set_inf(acc);
+    for (int w = 31; w >= 0; --w) {
+        if (!g1::is_inf(acc)) {
+            dbl<G>(acc, r);
+            dbl<G>(acc, r);
+            dbl<G>(acc, r);
+            dbl<G>(acc, r);
+        }
+        const int d1 = booth4(rs.k[0], w), d2 = booth4(rs.k[1], w);
+        if (d1 != 0) {
+            Xyzz q = tab[(size_t)((d1 < 0 ? -d1 : d1) - 1) * tab_stride];
+            if ((d1 < 0) != neg1) q.y = fp28::neg<8>(q.y);
+            dadd<G>(acc, q, r);
+        }
+        if (d2 != 0) {
+            Xyzz q = tab[(size_t)(8 + (d2 < 0 ? -d2 : d2) - 1) * tab_stride];
+            if ((d2 < 0) != neg2) q.y = fp28::neg<8>(q.y);
+            dadd<G>(acc, q, r);
+        }
+    }
+}
+
 // the partner group's point (the other half of the same butterfly): lanes G apart
 template <int G>
 __device__ __forceinline__ Xyzz from_partner(const Xyzz& p) {
@@ -443,6 +498,46 @@ __global__ void __launch_bounds__(BOUND) k_g1_stage_grp(Xyzz* __restrict__ dst, 
     if (half) y.y = fp28::neg<8>(y.y);
     grp::dadd<G>(x, y, r);
     if (r == 0) dst[xf * n + (half ? i1 : i0)] = x;
+}
+
+// stage s with G lanes per BUTTERFLY and the two GLV halves in one chain (grp::scalar_mul_glv); total = G * butterflies
+template <int G>
+__global__ void __launch_bounds__(BOUND) k_g1_stage_bf(Xyzz* __restrict__ dst, const Xyzz* __restrict__ data, Xyzz* __restrict__ tab,
+                                                        const RootSplit* __restrict__ kroots, u32 n, int s, u32 W, int inverse,
+                                                        size_t total) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int r = (int)(t % G);
+    const size_t bf = t / G;
+    const u32 halfn = n >> 1;
+    const size_t xf = bf / halfn;
+    const u32 b = (u32)(bf % halfn);
+    const u32 hs = 1u << s, j = b & (hs - 1);
+    const u32 i0 = ((b >> s) << (s + 1)) | j, i1 = i0 + hs;
+    const Xyzz* base = data + xf * n;
+    Xyzz y = base[i1];
+    const u32 idx = j * (W >> (s + 1));
+    if (idx != 0) grp::scalar_mul_glv<G>(y, kroots[inverse ? W - idx : idx], tab + bf, total / G, r);
+    const Xyzz x = base[i0];
+    Xyzz a = x;
+    grp::dadd<G>(a, y, r);
+    if (r == 0) dst[xf * n + i0] = a;
+    if (!g1::is_inf(y)) y.y = fp28::neg<8>(y.y);
+    a = x;
+    grp::dadd<G>(a, y, r);
+    if (r == 0) dst[xf * n + i1] = a;
+}
+
+// data[i] *= inv_n, G lanes per point, one chain
+template <int G>
+__global__ void __launch_bounds__(BOUND) k_g1_scale_bf(Xyzz* __restrict__ data, Xyzz* __restrict__ tab, RootSplit inv_n, size_t total) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // total = G * points
+    if (t >= total) return;
+    const int r = (int)(t % G);
+    const size_t i = t / G;
+    Xyzz p = data[i];
+    grp::scalar_mul_glv<G>(p, inv_n, tab + i, total / G, r);
+    if (r == 0) data[i] = p;
 }
 
 // data[i] *= inv_n, G lanes per half
@@ -706,6 +801,9 @@ int enqueue_stages(NttCtx* ctx, Xyzz* bufs[2], Xyzz* tab, size_t n, size_t nbatc
                                    (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0);
             hipLaunchKernelGGL(k_g1_stage_bfly_wide, dim3((unsigned)bf), dim3(64), 0, st, dst, src, (const Xyzz*)tab, (u32)n, s,
                                (u32)ctx->W);
+        } else if (s > 0 && 2 * bf <= ctx->g1_bf_max) {
+            hipLaunchKernelGGL(k_g1_stage_bf<4>, grid_for(4 * bf), dim3(block_threads(4 * bf)), 0, st, dst, src, tab,
+                               (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0, 4 * bf);
         } else if (s > 0 && 2 * bf <= quad_max) {
             hipLaunchKernelGGL(k_g1_stage_grp<4>, grid_for(8 * bf), dim3(block_threads(8 * bf)), 0, st, dst, src, tab,
                                (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0, 8 * bf);
@@ -725,6 +823,8 @@ void enqueue_scale(NttCtx* ctx, Xyzz* data, Xyzz* tab, const RootSplit& inv_n, s
     if (2 * total <= ctx->g1_wide_max) {
         hipLaunchKernelGGL(k_g1_scale_mul_wide, dim3((unsigned)(2 * total)), dim3(64), 0, st, tab, (const Xyzz*)data, inv_n);
         hipLaunchKernelGGL(k_g1_scale_sum_wide, dim3((unsigned)total), dim3(64), 0, st, data, (const Xyzz*)tab);
+    } else if (2 * total <= ctx->g1_bf_max) {
+        hipLaunchKernelGGL(k_g1_scale_bf<4>, grid_for(4 * total), dim3(block_threads(4 * total)), 0, st, data, tab, inv_n, 4 * total);
     } else if (2 * total <= ctx->g1_quad_max) {
         hipLaunchKernelGGL(k_g1_scale_grp<4>, grid_for(8 * total), dim3(block_threads(8 * total)), 0, st, data, tab,
                            inv_n, 8 * total);
@@ -844,7 +944,7 @@ extern "C" int kzgamd_fft_g1_batch(void* vctx, blst_p1* out, const blst_p1* in, 
             v.v[0] = (u32)n;
             v.v[1] = (u32)((u64)n >> 32);
             inv_n = split_scalar(ff::from_mont(ff::inverse_bgcd(ff::to_mont(v))));
-            if (2 * total <= ctx->g1_wide_max || 2 * total <= ctx->g1_quad_max || 2 * total <= ctx->g1_pair_max) {
+            if (2 * total <= ctx->g1_wide_max || 2 * total <= ctx->g1_bf_max || 2 * total <= ctx->g1_quad_max || 2 * total <= ctx->g1_pair_max) {
                 // not enough points to fill the chip one lane each: the shorter-chain scaling, then a plain store
                 enqueue_scale(ctx, res, tab, inv_n, total, st);
                 scale = 0;

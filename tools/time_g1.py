@@ -29,7 +29,12 @@ MONO = bytes((kzg.BlstP1 * 4096).from_address(_st.c.g1_values_monomial))
 _st.close()
 ref = {}
 for v in variants:
-    os.environ["KZGAMD_G1_WIDE_MAX"], os.environ["KZGAMD_G1_QUAD_MAX"], os.environ["KZGAMD_G1_PAIR_MAX"] = v.split(",")
+    parts = v.split(",")
+    os.environ["KZGAMD_G1_WIDE_MAX"], os.environ["KZGAMD_G1_QUAD_MAX"], os.environ["KZGAMD_G1_PAIR_MAX"] = parts[:3]
+    if len(parts) > 3:
+        os.environ["KZGAMD_G1_BF_MAX"] = parts[3]  # four lanes per butterfly, both GLV halves on one chain
+    else:
+        os.environ.pop("KZGAMD_G1_BF_MAX", None)
     s = kzg.KZGSettings.from_file(eb.SETUP)
     for n in (() if ONLY_FFT else (16, 32, 64, 128, 256)):
         proofs = C.create_string_buffer(n * 128 * 48)
