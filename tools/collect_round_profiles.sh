@@ -30,6 +30,12 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE
   tag=$(echo $pass | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmc_2p20_$tag -o $TAG -- python $R/tools/prof_2p20.py > $R/gpurun_out/pmc_2p20_$tag.log 2>&1
 done
+# HBM traffic of the other sizes of the sweep (msm_sweep[*].roofline.traffic): FETCH_SIZE / WRITE_SIZE passes only
+for logn in 16 18 21 22; do
+for pass in "FETCH_SIZE" "WRITE_SIZE"; do
+  timeout 300 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmc_msm${logn}_$pass -o $TAG -- python $R/tools/prof_2p20.py $logn > $R/gpurun_out/pmc_msm${logn}_$pass.log 2>&1
+done
+done
 # kernel stats of the device-resident proof pipeline (k_challenge_sha256, k_quotient, the MSM)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_proofs -o $TAG -- python $R/tools/prof_proof_dev.py > $R/gpurun_out/prof_proofs.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_2p20 -o $TAG -- python $R/tools/prof_2p20.py > $R/gpurun_out/prof_2p20.log 2>&1

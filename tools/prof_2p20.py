@@ -1,3 +1,4 @@
+"""One variable-base MSM of 2^logn points, four calls on one handle (for rocprofv3): prof_2p20.py [logn]"""
 import importlib.util, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -6,7 +7,7 @@ import torch
 kzg = eb.load_pkg()
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
-n = 1 << 20
+n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 20)  # log2 of the MSM size
 pts = torch.empty(n * 96, dtype=torch.uint8, device=dev)
 kzg.generate_points(pts.data_ptr(), n, 2, stream)
 torch.cuda.synchronize()  # handles copy the points on their own non-blocking streams
