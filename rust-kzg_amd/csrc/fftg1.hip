@@ -42,7 +42,7 @@ using g1::Xyzz;
 namespace {
 
 constexpr int WIN = 4;              // scalar window
-constexpr int NTAB = (1 << WIN) - 1;  // multiples 1..15
+constexpr int NTAB = (1 << WIN) - 1;  // table slots reserved per lane (the chain kernels use 9: multiples 1 .. 8 and the half's product)
 constexpr int NTHREADS = 64;        // one wave per workgroup: long serial lanes, spread over all CUs
 constexpr int MAXTHREADS = 256;     // ... or four waves per workgroup once there is a wave for every SIMD (block_threads)
 constexpr int BOUND = 512;          // launch bound of the long-lane kernels: two waves per SIMD must fit (<= 256 registers)
@@ -57,13 +57,6 @@ static_assert(sizeof(RootSplit) == 48, "RootSplit");
 
 __device__ __forceinline__ u32 brev(u32 v, int bits) { return bits == 0 ? 0u : __builtin_bitreverse32(v) >> (32 - bits); }
 
-// The point routines are kept out of line here: a lane executes ~170 of them per butterfly, and inlining each
-// (20-35 KB of code apiece) buys nothing against their ~6000-instruction bodies.
-__device__ __noinline__ void pt_dbl(Xyzz& a) {
-    if (!g1::is_inf(a)) g1::dbl(a);
-}
-__device__ __noinline__ void pt_add(Xyzz& a, const Xyzz& b) { g1::dadd(a, b); }
-
 __device__ __forceinline__ fp28::Fe beta28() {  // cube root of unity, Montgomery 2^392 (see msm.hip)
     constexpr u32 t[14] = {0xa75929au, 0x681b798u, 0x22a3e9du, 0xabc02bfu, 0x4e5bb45u, 0x55e6e7eu, 0x4814117u,
                            0x6d04f1bu, 0xae3387du, 0x54acb0cu, 0xa4c74bu, 0x56138b5u, 0xb64e066u, 0x76f2u};
@@ -71,53 +64,6 @@ __device__ __forceinline__ fp28::Fe beta28() {  // cube root of unity, Montgomer
 #pragma unroll
     for (int k = 0; k < 14; ++k) b.v[k] = t[k];
     return b;
-}
-
-// acc = k * acc for a 128-bit k (little-endian words); tab = this lane's 15 table slots, slot e at tab[e * stride]
-__device__ void scalar_mul128(Xyzz& acc, const u32 k[4], Xyzz* tab, size_t tab_stride) {
-    if (g1::is_inf(acc)) return;
-    tab[0] = acc;
-    Xyzz m = acc;
-    pt_dbl(m);
-    tab[tab_stride] = m;
-    for (int e = 2; e < NTAB; ++e) {
-        pt_add(m, acc);
-        tab[(size_t)e * tab_stride] = m;
-    }
-    g1::set_inf(acc);
-    for (int w = 128 / WIN - 1; w >= 0; --w) {
-        if (!g1::is_inf(acc)) {
-            pt_dbl(acc);
-            pt_dbl(acc);
-            pt_dbl(acc);
-            pt_dbl(acc);
-        }
-        const u32 d = (k[w >> 3] >> ((w & 7) * WIN)) & (u32)NTAB;
-        if (d) {
-            Xyzz q = tab[(size_t)(d - 1) * tab_stride];
-            pt_add(acc, q);
-        }
-    }
-}
-
-// this lane's half of  rs * p :  half 0 -> +-k1 * p,  half 1 -> +-k2 * [x^2]p;  then the sum of both halves,
-// exchanged with the neighbouring lane (lanes 2m and 2m+1 hold the two halves of the same product)
-__device__ void glv_mul_pair(Xyzz& p, const RootSplit& rs, int half, Xyzz* tab, size_t tab_stride) {
-    if (!g1::is_inf(p)) {
-        bool negate = rs.neg[half] != 0;
-        if (half) {
-            p.x = fp28::mul(p.x, beta28());
-            negate = !negate;  // [x^2]p = (beta*X, -Y)
-        }
-        if (negate) p.y = fp28::neg<8>(p.y);
-        scalar_mul128(p, rs.k[half], tab, tab_stride);
-    }
-    Xyzz other;
-    u32* o = (u32*)&other;
-    const u32* mine = (const u32*)&p;
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(Xyzz) / 4); ++k) o[k] = __shfl_xor(mine[k], 1, 64);
-    pt_add(p, other);
 }
 
 // blst Jacobian (X, Y, Z) -> XYZZ (X, Y, Z^2, Z^3), written at the bit-reversed position of its transform
@@ -141,43 +87,6 @@ __global__ void __launch_bounds__(256) k_g1_load(Xyzz* __restrict__ out, const f
     out[t] = p;
 }
 
-// stage s of the DIT network on bit-reversed-order data: pairs i0 and i0 + 2^s,
-// twiddle w_n^(j * n / 2^(s+1)) = roots[j * (W >> (s+1))]  (fft_g1.rs:22-29 unrolled); two lanes per butterfly
-// (out of place: the two lanes of a butterfly both read x and y, so the stage writes to the other half of a
-// ping-pong buffer instead of relying on the pair running in lockstep)
-__global__ void __launch_bounds__(BOUND) k_g1_stage(Xyzz* __restrict__ dst, const Xyzz* __restrict__ data, Xyzz* __restrict__ tab,
-                                                       const RootSplit* __restrict__ kroots, u32 n, int s, u32 W, int inverse,
-                                                       size_t total) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // total = 2 * butterflies, even
-    if (t >= total) return;
-    const int half = (int)(t & 1);
-    const size_t bf = t >> 1;
-    const u32 halfn = n >> 1;
-    const size_t xf = bf / halfn;
-    const u32 b = (u32)(bf % halfn);
-    const u32 hs = 1u << s, j = b & (hs - 1);
-    const u32 i0 = ((b >> s) << (s + 1)) | j, i1 = i0 + hs;
-    const Xyzz* base = data + xf * n;
-    Xyzz y = base[i1];
-    const u32 idx = j * (W >> (s + 1));
-    if (idx != 0) glv_mul_pair(y, kroots[inverse ? W - idx : idx], half, tab + t, total);
-    Xyzz x = base[i0];
-    if (half) y.y = fp28::neg<8>(y.y);  // lane 1: x - t   (Y < 8p is within what dadd/dbl accept)
-    pt_add(x, y);
-    dst[xf * n + (half ? i1 : i0)] = x;
-}
-
-// XYZZ -> blst Jacobian; an inverse transform multiplies by n^-1 first (fft_g1.rs:72-79), two lanes per point
-__global__ void __launch_bounds__(BOUND) k_g1_store(ff::Fp* __restrict__ out, const Xyzz* __restrict__ data,
-                                                       Xyzz* __restrict__ tab, RootSplit inv_n, int scale, size_t total) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // total = 2 * points
-    if (t >= total) return;
-    const int half = (int)(t & 1);
-    Xyzz p = data[t >> 1];
-    if (scale) glv_mul_pair(p, inv_n, half, tab + t, total);
-    if (half == 0) g1::to_blst_jacobian(out + (t >> 1) * 3, p);
-}
-
 // device-resident form: XYZZ in natural order -> bit-reversed order of each transform
 __global__ void __launch_bounds__(256) k_g1_brp_xyzz(Xyzz* __restrict__ out, const Xyzz* __restrict__ in, u32 n, int logn,
                                                      size_t total) {
@@ -186,26 +95,21 @@ __global__ void __launch_bounds__(256) k_g1_brp_xyzz(Xyzz* __restrict__ out, con
     const size_t xf = t / n;
     out[t] = in[xf * n + brev((u32)(t % n), logn)];
 }
-// data[p] *= n^-1 (two lanes per point, both in one wave: the loads of a pair precede its store)
-__global__ void __launch_bounds__(BOUND) k_g1_scale_xyzz(Xyzz* __restrict__ data, Xyzz* __restrict__ tab, RootSplit inv_n,
-                                                            size_t total) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // total = 2 * points
-    if (t >= total) return;
-    const int half = (int)(t & 1);
-    Xyzz p = data[t >> 1];
-    glv_mul_pair(p, inv_n, half, tab + t, total);
-    if (half == 0) data[t >> 1] = p;
-}
 
-// ---------------------------------------------------------------- lane-group stages (mid-size grids)
-// Between "a wave per half-butterfly" (limb-parallel, ~5x the instructions) and "a lane per half-butterfly" (the
-// shortest instruction total, a 1.6 ms chain) sits a group of G = 2 or 4 neighbouring lanes per half-butterfly: every
-// lane of the group keeps the whole point state and the single-lane multiplier, and the INDEPENDENT products of a point
-// formula run side by side on the lanes of the group — each lane multiplies the operand pair of its role, the G results
-// go round the group with DPP quad permutes.  A doubling is 5 / 3 multiplications deep instead of 9, an addition 7 / 4
-// instead of 14; with signed 4-bit windows (8 multiples) a half-butterfly is ~890 / ~530 dependent multiplications
-// instead of 1 760, on 2x / 4x the lanes.  Worth it while those lanes still find an idle SIMD: a stage with up to 2^15
-// half-butterflies (256 blobs of FK20, a 2^15-point transform) runs on two lanes each, up to 2^14 on four.
+// ---------------------------------------------------------------- the chain kernels: 1, 2 or 4 lanes per half-butterfly
+// One half of a butterfly's scalar multiplication is a chain of ~170 point operations (signed 4-bit windows: 7 for
+// the table of 1 .. 8 P, then 31 x (4 doublings + 1 addition)).  A group of G = 1, 2 or 4 neighbouring lanes runs it:
+// every lane of the group keeps the whole point state and the single-lane multiplier, and the INDEPENDENT products of
+// a point formula run side by side on the lanes of the group — each lane multiplies the operand pair of its role, the
+// G results go round the group with DPP quad permutes.  A doubling is 9 / 5 / 3 multiplications deep for G = 1 / 2 / 4,
+// an addition 14 / 7 / 4: the chain is 1 / 0.57 / 0.39 as long, on 1 / 2 / 4 times the lanes (1 / 1.14 / 1.55 times the
+// instructions).  Which G a stage gets depends on how many half-butterflies it has (enqueue_stages).
+//
+// The kernels are ONE loop over the steps of the chain with ONE inlined doubling and ONE inlined addition in its body
+// (the step number says which; the addition's second operand always comes from memory: a table slot, the partner
+// half's product, the butterfly's other input).  No calls, so nothing lives in scratch: round 3's form called the point
+// routines out of line with their 224-byte operands by reference — 688 B of scratch per lane and, at 1024 waves, more
+// HBM traffic for call frames (2.6 GB per stage) than for the tables.
 namespace grp {
 using fp28::Fe;
 
@@ -237,16 +141,23 @@ __device__ __forceinline__ Fe pick4(int r, const Fe& a0, const Fe& a1, const Fe&
     return pick(r < 2, pick(r == 0, a0, a1), pick(r == 2, a2, a3));
 }
 
+// acc = 2 * acc, acc != infinity (dbl-2008-s-1, the bounds of g1::dbl)
 template <int G>
-__device__ void dbl(Xyzz& acc, int r);
+__device__ __forceinline__ void dbl_body(Xyzz& acc, int r);
+// acc += b (add-2008-s, the bounds and exceptional cases of g1::dadd).  Returns true when b == acc: the caller doubles
+// acc (the one doubling of the loop body serves that case too).  Every lane of a group holds the same values, so the
+// group branches as one.
 template <int G>
-__device__ void dadd(Xyzz& acc, const Xyzz& b, int r);
+__device__ __forceinline__ bool dadd_body(Xyzz& acc, const Xyzz& b, int r);
 
-// dbl-2008-s-1 as in g1::dbl (same bounds): [V, M] [W, S] [MM, ZZ3] [M3*(S - X3), W*Y] [ZZZ3]
 template <>
-__device__ __noinline__ void dbl<2>(Xyzz& acc, int r) {
+__device__ __forceinline__ void dbl_body<1>(Xyzz& acc, int) {
+    g1::dbl(acc);
+}
+// [V, M] [W, S] [MM, ZZ3] [M3*(S - X3), W*Y] [ZZZ3]
+template <>
+__device__ __forceinline__ void dbl_body<2>(Xyzz& acc, int r) {
     using namespace fp28;
-    if (g1::is_inf(acc)) return;
     const bool r0 = r == 0;
     const Fe u = addn(acc.y, acc.y);
     Fe t = mul(pick(r0, u, acc.x), pick(r0, u, acc.x));
@@ -266,9 +177,8 @@ __device__ __noinline__ void dbl<2>(Xyzz& acc, int r) {
 }
 // [V, M, -, -] [W, S, ZZ3, MM] [M3*(S - X3), W*Y, ZZZ3, -]
 template <>
-__device__ __noinline__ void dbl<4>(Xyzz& acc, int r) {
+__device__ __forceinline__ void dbl_body<4>(Xyzz& acc, int r) {
     using namespace fp28;
-    if (g1::is_inf(acc)) return;
     const Fe u = addn(acc.y, acc.y);
     const bool lo = (r & 1) == 0;
     Fe t = mul(pick(lo, u, acc.x), pick(lo, u, acc.x));  // roles 2, 3 repeat 0, 1
@@ -284,15 +194,41 @@ __device__ __noinline__ void dbl<4>(Xyzz& acc, int r) {
     acc.zz = zz3;
 }
 
-// add-2008-s as in g1::dadd, exceptional cases included (every lane of a group holds the same values, so the group
-// branches as one): [U, U2] [S, S2] [PP, RR] [PPP, Q] [ZZ12, ZZZ12] [R*(Q - X3), S*PPP] [ZZ3, ZZZ3]
 template <>
-__device__ __noinline__ void dadd<2>(Xyzz& acc, const Xyzz& b, int r) {
+__device__ __forceinline__ bool dadd_body<1>(Xyzz& acc, const Xyzz& b, int) {
     using namespace fp28;
-    if (g1::is_inf(b)) return;
+    if (g1::is_inf(b)) return false;
     if (g1::is_inf(acc)) {
         acc = b;
-        return;
+        return false;
+    }
+    const Fe u = mul(acc.x, b.zz);
+    const Fe s = mul(acc.y, b.zzz);
+    const Fe p = sub<4>(mul(b.x, acc.zz), u);
+    const Fe rr_ = sub<4>(mul(b.y, acc.zzz), s);
+    if (is_zero_mod_p(p)) {
+        if (is_zero_mod_p(rr_)) return true;
+        g1::set_inf(acc);
+        return false;
+    }
+    const Fe pp = sqr(p);
+    const Fe ppp = mul(p, pp);
+    const Fe q = mul(u, pp);
+    const Fe x3 = sub<8>(sqr(rr_), addn(add(q, q), ppp));
+    acc.y = sub<4>(mul(rr_, sub<16>(q, x3)), mul(s, ppp));
+    acc.x = x3;
+    acc.zz = mul(mul(acc.zz, b.zz), pp);
+    acc.zzz = mul(mul(acc.zzz, b.zzz), ppp);
+    return false;
+}
+// [U, U2] [S, S2] [PP, RR] [PPP, Q] [ZZ12, ZZZ12] [R*(Q - X3), S*PPP] [ZZ3, ZZZ3]
+template <>
+__device__ __forceinline__ bool dadd_body<2>(Xyzz& acc, const Xyzz& b, int r) {
+    using namespace fp28;
+    if (g1::is_inf(b)) return false;
+    if (g1::is_inf(acc)) {
+        acc = b;
+        return false;
     }
     const bool r0 = r == 0;
     Fe t = mul(pick(r0, acc.x, b.x), pick(r0, b.zz, acc.zz));
@@ -302,9 +238,9 @@ __device__ __noinline__ void dadd<2>(Xyzz& acc, const Xyzz& b, int r) {
     const Fe s = from_role<2, 0>(t);
     const Fe rr_ = sub<4>(from_role<2, 1>(t), s);
     if (is_zero_mod_p(p)) {
-        if (is_zero_mod_p(rr_)) dbl<2>(acc, r);
-        else g1::set_inf(acc);
-        return;
+        if (is_zero_mod_p(rr_)) return true;
+        g1::set_inf(acc);
+        return false;
     }
     t = mul(pick(r0, p, rr_), pick(r0, p, rr_));
     const Fe pp = from_role<2, 0>(t), rr = from_role<2, 1>(t);
@@ -319,23 +255,24 @@ __device__ __noinline__ void dadd<2>(Xyzz& acc, const Xyzz& b, int r) {
     acc.zz = from_role<2, 0>(t);
     acc.zzz = from_role<2, 1>(t);
     acc.x = x3;
+    return false;
 }
 // [U, S, U2, S2] [PP, RR, ZZ12, ZZZ12] [PPP, Q, ZZ3, -] [R*(Q - X3), S*PPP, ZZZ3, -]
 template <>
-__device__ __noinline__ void dadd<4>(Xyzz& acc, const Xyzz& b, int r) {
+__device__ __forceinline__ bool dadd_body<4>(Xyzz& acc, const Xyzz& b, int r) {
     using namespace fp28;
-    if (g1::is_inf(b)) return;
+    if (g1::is_inf(b)) return false;
     if (g1::is_inf(acc)) {
         acc = b;
-        return;
+        return false;
     }
     Fe t = mul(pick4(r, acc.x, acc.y, b.x, b.y), pick4(r, b.zz, b.zzz, acc.zz, acc.zzz));
     const Fe u = from_role<4, 0>(t), s = from_role<4, 1>(t);
     const Fe p = sub<4>(from_role<4, 2>(t), u), rr_ = sub<4>(from_role<4, 3>(t), s);
     if (is_zero_mod_p(p)) {
-        if (is_zero_mod_p(rr_)) dbl<4>(acc, r);
-        else g1::set_inf(acc);
-        return;
+        if (is_zero_mod_p(rr_)) return true;
+        g1::set_inf(acc);
+        return false;
     }
     t = mul(pick4(r, p, rr_, acc.zz, acc.zzz), pick4(r, p, rr_, b.zz, b.zzz));
     const Fe pp = from_role<4, 0>(t), rr = from_role<4, 1>(t), zz12 = from_role<4, 2>(t), zzz12 = from_role<4, 3>(t);
@@ -347,129 +284,105 @@ __device__ __noinline__ void dadd<4>(Xyzz& acc, const Xyzz& b, int r) {
     acc.zzz = from_role<4, 2>(t);
     acc.x = x3;
     acc.zz = zz3;
+    return false;
 }
 
-// acc = k * acc for a 127-bit k, Booth digits in [-8, 8] (d_w = k[4w-1] + k[4w] + 2 k[4w+1] + 4 k[4w+2] - 8 k[4w+3]);
-// tab = this group's 8 table slots (slot e at tab[e * stride]), written by role 0 and read by the whole group
-template <int G>
-__device__ void scalar_mul128(Xyzz& acc, const u32 k[4], Xyzz* tab, size_t tab_stride, int r) {
-    if (g1::is_inf(acc)) return;
-    if (r == 0) tab[0] = acc;
-    Xyzz m = acc;
-    dbl<G>(m, r);
-    if (r == 0) tab[tab_stride] = m;
-    for (int e = 2; e < 8; ++e) {
-        dadd<G>(m, acc, r);
-        if (r == 0) tab[(size_t)e * tab_stride] = m;
-    }
-    g1::set_inf(acc);
-    for (int w = 31; w >= 0; --w) {
-        if (!g1::is_inf(acc)) {
-            dbl<G>(acc, r);
-            dbl<G>(acc, r);
-            dbl<G>(acc, r);
-            dbl<G>(acc, r);
-        }
-        // the five bits k[4w+3 .. 4w-1]
-        const int bit = 4 * w - 1;
-        u32 v;
-        if (bit < 0) v = (k[0] << 1) & 31u;
-        else {
-            const u64 two = ((u64)(bit / 32 + 1 < 4 ? k[bit / 32 + 1] : 0u) << 32) | k[bit / 32];
-            v = (u32)(two >> (bit & 31)) & 31u;
-        }
-        const int d = (int)((v + 1) >> 1) - (int)((v >> 4) << 4);
-        if (d != 0) {
-            Xyzz q = tab[(size_t)((d < 0 ? -d : d) - 1) * tab_stride];
-            if (d < 0) q.y = fp28::neg<8>(q.y);
-            dadd<G>(acc, q, r);
-        }
-    }
-}
-
-// Booth digit w (4 bits, in [-8, 8]) of a 127-bit k
-__device__ __forceinline__ int booth4(const u32 k[4], int w) {
+// Booth digit w (4 bits, in [-8, 8]) of a 127-bit k:  d_w = k[4w-1] + k[4w] + 2 k[4w+1] + 4 k[4w+2] - 8 k[4w+3].
+// w is the same for the whole wave; the words are picked with selects (a dynamic index would put k in scratch).
+__device__ __forceinline__ int booth4(u32 k0, u32 k1, u32 k2, u32 k3, int w) {
     const int bit = 4 * w - 1;
     u32 v;
-    if (bit < 0) v = (k[0] << 1) & 31u;
-    else {
-        const u64 two = ((u64)(bit / 32 + 1 < 4 ? k[bit / 32 + 1] : 0u) << 32) | k[bit / 32];
-        v = (u32)(two >> (bit & 31)) & 31u;
+    if (bit < 0) {
+        v = (k0 << 1) & 31u;
+    } else {
+        const int q = bit >> 5;
+        const u32 lo = q == 0 ? k0 : q == 1 ? k1 : q == 2 ? k2 : k3;
+        const u32 hi = q == 0 ? k1 : q == 1 ? k2 : q == 2 ? k3 : 0u;
+        v = (u32)((((u64)hi << 32) | lo) >> (bit & 31)) & 31u;
     }
     return (int)((v + 1) >> 1) - (int)((v >> 4) << 4);
 }
 
-// acc = (+-k1) * acc + (+-k2) * [x^2]acc in ONE chain (Straus / Shamir): the doublings are shared by the two halves,
-//   k * P = s1 k1 * P - s2 k2 * Q,   Q = (beta X, Y) = -[x^2]P,   d * Q = (beta X_d, Y_d) for the table entry d * P,
-// so a window is four doublings and two additions (P-table, Q-table) — against the two-chains form (a lane group per
-// half, the halves added at the end) the same number of additions and HALF the doublings, on half the lanes.
-// tab: 16 slots of this butterfly (d * P at slot d - 1, d * Q at slot 8 + d - 1), written by role 0.
-template <int G>
-__device__ void scalar_mul_glv(Xyzz& acc, const RootSplit& rs, Xyzz* tab, size_t tab_stride, int r) {
-    if (g1::is_inf(acc)) return;
-    const fp28::Fe beta = beta28();
-    Xyzz m = acc;
-    for (int e = 0; e < 8; ++e) {
-        if (e == 1) dbl<G>(m, r);
-        else if (e > 1) dadd<G>(m, acc, r);
-        Xyzz q = m;
-        q.x = fp28::mul(m.x, beta);  // the same product on every lane of the group
-        if (r == 0) {
-            tab[(size_t)e * tab_stride] = m;
-            tab[(size_t)(8 + e) * tab_stride] = q;
+constexpr int TAB_STEPS = 7;            // 2P, then 3P .. 8P
+constexpr int MAIN_STEPS = 32 * 5;      // per window: four doublings and an addition
+constexpr int SLOT_HALF = 8;            // table slot 8: this half's finished product, for the partner group
+
+// The chain of one half-butterfly.  On entry acc = the point (endomorphism and sign already applied) and `mul` says
+// whether it is multiplied at all (not for a unit twiddle or a point at infinity); slots: this group's column of the
+// table (slot e at slots[e * stride]), written by role 0 and read by the whole group.  Steps 0 .. 6 build the table,
+// 7 .. 166 are the windows; then `tail_steps` additions whose operand tail(i) names:
+//   tail(i).src == nullptr: nothing;  tail(i).negate_acc: acc <- -acc first (the x - t output).
+// After the last main step the product is published in slot SLOT_HALF (publish == true) for the partner's first tail step.
+struct TailOp {
+    const Xyzz* src;
+    bool negate_acc;
+};
+template <int G, class Tail>
+__device__ __forceinline__ void run_chain(Xyzz& acc, bool mul, u32 k0, u32 k1, u32 k2, u32 k3, Xyzz* slots, size_t stride,
+                                          bool publish, int tail_steps, Tail&& tail, int r) {
+    if (mul && r == 0) slots[0] = acc;
+    const int last = TAB_STEPS + MAIN_STEPS + tail_steps;
+#pragma unroll 1
+    for (int step = 0; step < last; ++step) {
+        const bool in_tab = step < TAB_STEPS, in_tail = step >= TAB_STEPS + MAIN_STEPS;
+        if (step == TAB_STEPS && mul) g1::set_inf(acc);  // the windows start from infinity; P is in slot 0
+        bool want_dbl = false, need_dbl = false;
+        const Xyzz* src = nullptr;
+        bool neg_src = false;
+        if (in_tab) {
+            want_dbl = step == 0;
+            if (!want_dbl && mul) src = slots;
+        } else if (!in_tail) {
+            const int q = step - TAB_STEPS, w = 31 - q / 5;
+            want_dbl = q % 5 < 4;
+            if (!want_dbl && mul) {
+                const int d = booth4(k0, k1, k2, k3, w);
+                if (d != 0) {
+                    src = slots + (size_t)((d < 0 ? -d : d) - 1) * stride;
+                    neg_src = d < 0;
+                }
+            }
+        } else {
+            const TailOp op = tail(step - TAB_STEPS - MAIN_STEPS);
+            src = op.src;
+            if (op.negate_acc && !g1::is_inf(acc)) acc.y = fp28::neg<8>(acc.y);
         }
-    }
-    const bool neg1 = rs.neg[0] != 0, neg2 = rs.neg[1] == 0;  // the Q half carries the minus of [x^2]P = -Q
-    g1::set_inf(acc);
-    for (int w = 31; w >= 0; --w) {
-        if (!g1::is_inf(acc)) {
-            dbl<G>(acc, r);
-            dbl<G>(acc, r);
-            dbl<G>(acc, r);
-            dbl<G>(acc, r);
+        if (src) {
+            Xyzz qv = *src;
+            if (neg_src) qv.y = fp28::neg<8>(qv.y);
+            need_dbl = dadd_body<G>(acc, qv, r);
         }
-        const int d1 = booth4(rs.k[0], w), d2 = booth4(rs.k[1], w);
-        if (d1 != 0) {
-            Xyzz q = tab[(size_t)((d1 < 0 ? -d1 : d1) - 1) * tab_stride];
-            if ((d1 < 0) != neg1) q.y = fp28::neg<8>(q.y);
-            dadd<G>(acc, q, r);
-        }
-        if (d2 != 0) {
-            Xyzz q = tab[(size_t)(8 + (d2 < 0 ? -d2 : d2) - 1) * tab_stride];
-            if ((d2 < 0) != neg2) q.y = fp28::neg<8>(q.y);
-            dadd<G>(acc, q, r);
+        if (want_dbl ? (mul && !g1::is_inf(acc)) : need_dbl) dbl_body<G>(acc, r);
+        if (in_tab && mul && r == 0) slots[(size_t)(step + 1) * stride] = acc;
+        if (step == TAB_STEPS + MAIN_STEPS - 1 && publish) {
+            if (r == 0) slots[(size_t)SLOT_HALF * stride] = acc;
+            __threadfence_block();  // the partner group (same wave) reads it in its next step
         }
     }
 }
 
-// the partner group's point (the other half of the same butterfly): lanes G apart
-template <int G>
-__device__ __forceinline__ Xyzz from_partner(const Xyzz& p) {
-    Xyzz o;
-    if (G == 2) {
-        o.x = dpp<0x4E>(p.x);  // quad_perm [2, 3, 0, 1]
-        o.y = dpp<0x4E>(p.y);
-        o.zzz = dpp<0x4E>(p.zzz);
-        o.zz = dpp<0x4E>(p.zz);
-    } else {
-        u32* d = (u32*)&o;
-        const u32* sck = (const u32*)&p;
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(Xyzz) / 4); ++i) d[i] = __shfl_xor(sck[i], G, 64);
+// (+-k) * (half ? [x^2]p : p): the endomorphism and the sign go into the point before the chain
+__device__ __forceinline__ void apply_half(Xyzz& p, bool negate, int half) {
+    if (half) {
+        p.x = fp28::mul(p.x, beta28());
+        negate = !negate;  // [x^2](X, Y) = (beta * X, -Y)
     }
-    return o;
+    if (negate) p.y = fp28::neg<8>(p.y);
 }
 }  // namespace grp
 
-// stage s with G lanes per half-butterfly (see above); total = 2 * G * butterflies lanes
+// stage s of the DIT network on bit-reversed-order data: pairs i0 and i0 + 2^s,
+// twiddle w_n^(j * n / 2^(s+1)) = roots[j * (W >> (s+1))]  (fft_g1.rs:22-29 unrolled); 2 * G lanes per butterfly:
+// the two halves of w^j * y on neighbouring groups, t = their sum, half 0 writes x + t, half 1 writes x - t
+// (out of place: both halves read x and y).  total = 2 * G * butterflies lanes.
 template <int G>
-__global__ void __launch_bounds__(BOUND) k_g1_stage_grp(Xyzz* __restrict__ dst, const Xyzz* __restrict__ data, Xyzz* __restrict__ tab,
+__global__ void __launch_bounds__(BOUND) k_g1_stage_chain(Xyzz* __restrict__ dst, const Xyzz* __restrict__ data, Xyzz* __restrict__ tab,
                                                            const RootSplit* __restrict__ kroots, u32 n, int s, u32 W, int inverse,
                                                            size_t total) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;  // total is a multiple of 2 * G: whole butterflies drop out together
     const int r = (int)(t % G);
-    const size_t unit = t / G;
+    const size_t unit = t / G, nunits = total / G;
     const int half = (int)(unit & 1);
     const size_t bf = unit >> 1;
     const u32 halfn = n >> 1;
@@ -478,90 +391,59 @@ __global__ void __launch_bounds__(BOUND) k_g1_stage_grp(Xyzz* __restrict__ dst, 
     const u32 hs = 1u << s, j = b & (hs - 1);
     const u32 i0 = ((b >> s) << (s + 1)) | j, i1 = i0 + hs;
     const Xyzz* base = data + xf * n;
-    Xyzz y = base[i1];
+    Xyzz acc = base[i1];
     const u32 idx = j * (W >> (s + 1));
-    if (idx != 0) {
-        const RootSplit& rs = kroots[inverse ? W - idx : idx];
-        if (!g1::is_inf(y)) {
-            bool negate = rs.neg[half] != 0;
-            if (half) {
-                y.x = fp28::mul(y.x, beta28());
-                negate = !negate;
-            }
-            if (negate) y.y = fp28::neg<8>(y.y);
-            grp::scalar_mul128<G>(y, rs.k[half], tab + unit, total / G, r);
-        }
-        const Xyzz other = grp::from_partner<G>(y);
-        grp::dadd<G>(y, other, r);
+    const bool twiddled = idx != 0;
+    const bool mul = twiddled && !g1::is_inf(acc);
+    u32 k0 = 0, k1 = 0, k2 = 0, k3 = 0;
+    if (twiddled) {
+        const RootSplit* rs = kroots + (inverse ? W - idx : idx);
+        k0 = rs->k[half][0];
+        k1 = rs->k[half][1];
+        k2 = rs->k[half][2];
+        k3 = rs->k[half][3];
+        if (mul) grp::apply_half(acc, rs->neg[half] != 0, half);
     }
-    Xyzz x = base[i0];
-    if (half) y.y = fp28::neg<8>(y.y);
-    grp::dadd<G>(x, y, r);
-    if (r == 0) dst[xf * n + (half ? i1 : i0)] = x;
+    Xyzz* slots = tab + unit;
+    const Xyzz* partner = tab + (unit ^ 1) + (size_t)grp::SLOT_HALF * nunits;
+    const Xyzz* xin = base + i0;
+    grp::run_chain<G>(acc, mul, k0, k1, k2, k3, slots, nunits, twiddled, 2,
+                      [&](int i) {
+                          if (i == 0) return grp::TailOp{twiddled ? partner : nullptr, false};  // t = both halves
+                          return grp::TailOp{xin, half != 0};                                   // x + t  /  x - t
+                      },
+                      r);
+    if (r == 0) dst[xf * n + (half ? i1 : i0)] = acc;
 }
 
-// stage s with G lanes per BUTTERFLY and the two GLV halves in one chain (grp::scalar_mul_glv); total = G * butterflies
+// data[i] *= inv_n (the n^-1 of an inverse transform): 2 * G lanes per point, in place (both groups of a point are in
+// one wave: the loads of a pair precede its store)
 template <int G>
-__global__ void __launch_bounds__(BOUND) k_g1_stage_bf(Xyzz* __restrict__ dst, const Xyzz* __restrict__ data, Xyzz* __restrict__ tab,
-                                                        const RootSplit* __restrict__ kroots, u32 n, int s, u32 W, int inverse,
-                                                        size_t total) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const int r = (int)(t % G);
-    const size_t bf = t / G;
-    const u32 halfn = n >> 1;
-    const size_t xf = bf / halfn;
-    const u32 b = (u32)(bf % halfn);
-    const u32 hs = 1u << s, j = b & (hs - 1);
-    const u32 i0 = ((b >> s) << (s + 1)) | j, i1 = i0 + hs;
-    const Xyzz* base = data + xf * n;
-    Xyzz y = base[i1];
-    const u32 idx = j * (W >> (s + 1));
-    if (idx != 0) grp::scalar_mul_glv<G>(y, kroots[inverse ? W - idx : idx], tab + bf, total / G, r);
-    const Xyzz x = base[i0];
-    Xyzz a = x;
-    grp::dadd<G>(a, y, r);
-    if (r == 0) dst[xf * n + i0] = a;
-    if (!g1::is_inf(y)) y.y = fp28::neg<8>(y.y);
-    a = x;
-    grp::dadd<G>(a, y, r);
-    if (r == 0) dst[xf * n + i1] = a;
-}
-
-// data[i] *= inv_n, G lanes per point, one chain
-template <int G>
-__global__ void __launch_bounds__(BOUND) k_g1_scale_bf(Xyzz* __restrict__ data, Xyzz* __restrict__ tab, RootSplit inv_n, size_t total) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // total = G * points
-    if (t >= total) return;
-    const int r = (int)(t % G);
-    const size_t i = t / G;
-    Xyzz p = data[i];
-    grp::scalar_mul_glv<G>(p, inv_n, tab + i, total / G, r);
-    if (r == 0) data[i] = p;
-}
-
-// data[i] *= inv_n, G lanes per half
-template <int G>
-__global__ void __launch_bounds__(BOUND) k_g1_scale_grp(Xyzz* __restrict__ data, Xyzz* __restrict__ tab, RootSplit inv_n, size_t total) {
+__global__ void __launch_bounds__(BOUND) k_g1_scale_chain(Xyzz* __restrict__ data, Xyzz* __restrict__ tab, RootSplit inv_n, size_t total) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // total = 2 * G * points
     if (t >= total) return;
     const int r = (int)(t % G);
-    const size_t unit = t / G;
+    const size_t unit = t / G, nunits = total / G;
     const int half = (int)(unit & 1);
-    Xyzz p = data[unit >> 1];
-    if (!g1::is_inf(p)) {
-        bool negate = inv_n.neg[half] != 0;
-        if (half) {
-            p.x = fp28::mul(p.x, beta28());
-            negate = !negate;
-        }
-        if (negate) p.y = fp28::neg<8>(p.y);
-        grp::scalar_mul128<G>(p, inv_n.k[half], tab + unit, total / G, r);
-    }
-    const Xyzz other = grp::from_partner<G>(p);
-    grp::dadd<G>(p, other, r);
-    if (half == 0 && r == 0) data[unit >> 1] = p;
+    Xyzz acc = data[unit >> 1];
+    const bool mul = !g1::is_inf(acc);
+    const u32 k0 = half ? inv_n.k[1][0] : inv_n.k[0][0], k1 = half ? inv_n.k[1][1] : inv_n.k[0][1];
+    const u32 k2 = half ? inv_n.k[1][2] : inv_n.k[0][2], k3 = half ? inv_n.k[1][3] : inv_n.k[0][3];
+    if (mul) grp::apply_half(acc, (half ? inv_n.neg[1] : inv_n.neg[0]) != 0, half);
+    Xyzz* slots = tab + unit;
+    const Xyzz* partner = tab + (unit ^ 1) + (size_t)grp::SLOT_HALF * nunits;
+    grp::run_chain<G>(acc, mul, k0, k1, k2, k3, slots, nunits, true, 1, [&](int) { return grp::TailOp{partner, false}; }, r);
+    if (half == 0 && r == 0) data[unit >> 1] = acc;
 }
+
+// XYZZ -> blst Jacobian, one lane per point
+__global__ void __launch_bounds__(256) k_g1_store(ff::Fp* __restrict__ out, const Xyzz* __restrict__ data, size_t total) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const Xyzz p = data[t];
+    g1::to_blst_jacobian(out + t * 3, p);
+}
+
 
 // ---------------------------------------------------------------- limb-parallel stages (small grids)
 // A stage is one 128-bit scalar multiplication deep however few butterflies it has: a single lane runs ~170 dependent
@@ -786,12 +668,7 @@ int enqueue_stages(NttCtx* ctx, Xyzz* bufs[2], Xyzz* tab, size_t n, size_t nbatc
     const size_t total = n * nbatch, bf = total / 2;
     const int logn = ilog2(n);
     const bool wide = 2 * bf <= ctx->g1_wide_max;
-    // Between g1_quad_max and g1_pair_max half-butterflies the better form depends on the transform: the twiddles of
-    // short transforms (FK20: 128 points) are low-order roots whose GLV halves are short — two lanes per half win
-    // (256 blobs: 23.8 ms against 28.6 with four) — while the full-length chains of a long transform want four
-    // (2^15 points: 24.5 ms against 38 with two, 42.7 with one).
-    const size_t quad_max = n > 256 && ctx->g1_quad_max ? (ctx->g1_pair_max > ctx->g1_quad_max ? ctx->g1_pair_max : ctx->g1_quad_max)
-                                                        : ctx->g1_quad_max;
+    const size_t quad_max = ctx->g1_quad_max;
     for (int s = 0; s < logn; ++s) {
         Xyzz* dst = bufs[(s + 1) & 1];
         const Xyzz* src = bufs[s & 1];
@@ -801,17 +678,14 @@ int enqueue_stages(NttCtx* ctx, Xyzz* bufs[2], Xyzz* tab, size_t n, size_t nbatc
                                    (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0);
             hipLaunchKernelGGL(k_g1_stage_bfly_wide, dim3((unsigned)bf), dim3(64), 0, st, dst, src, (const Xyzz*)tab, (u32)n, s,
                                (u32)ctx->W);
-        } else if (s > 0 && 2 * bf <= ctx->g1_bf_max) {
-            hipLaunchKernelGGL(k_g1_stage_bf<4>, grid_for(4 * bf), dim3(block_threads(4 * bf)), 0, st, dst, src, tab,
-                               (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0, 4 * bf);
         } else if (s > 0 && 2 * bf <= quad_max) {
-            hipLaunchKernelGGL(k_g1_stage_grp<4>, grid_for(8 * bf), dim3(block_threads(8 * bf)), 0, st, dst, src, tab,
+            hipLaunchKernelGGL(k_g1_stage_chain<4>, grid_for(8 * bf), dim3(block_threads(8 * bf)), 0, st, dst, src, tab,
                                (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0, 8 * bf);
         } else if (s > 0 && 2 * bf <= ctx->g1_pair_max) {
-            hipLaunchKernelGGL(k_g1_stage_grp<2>, grid_for(4 * bf), dim3(block_threads(4 * bf)), 0, st, dst, src, tab,
+            hipLaunchKernelGGL(k_g1_stage_chain<2>, grid_for(4 * bf), dim3(block_threads(4 * bf)), 0, st, dst, src, tab,
                                (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0, 4 * bf);
         } else {  // stage 0 (unit twiddles: one addition per lane) and the grids that fill the chip on their own
-            hipLaunchKernelGGL(k_g1_stage, grid_for(2 * bf), dim3(block_threads(2 * bf)), 0, st, dst, src, tab,
+            hipLaunchKernelGGL(k_g1_stage_chain<1>, grid_for(2 * bf), dim3(block_threads(2 * bf)), 0, st, dst, src, tab,
                                (const RootSplit*)ctx->d_kroots, (u32)n, s, (u32)ctx->W, inverse ? 1 : 0, 2 * bf);
         }
     }
@@ -823,17 +697,12 @@ void enqueue_scale(NttCtx* ctx, Xyzz* data, Xyzz* tab, const RootSplit& inv_n, s
     if (2 * total <= ctx->g1_wide_max) {
         hipLaunchKernelGGL(k_g1_scale_mul_wide, dim3((unsigned)(2 * total)), dim3(64), 0, st, tab, (const Xyzz*)data, inv_n);
         hipLaunchKernelGGL(k_g1_scale_sum_wide, dim3((unsigned)total), dim3(64), 0, st, data, (const Xyzz*)tab);
-    } else if (2 * total <= ctx->g1_bf_max) {
-        hipLaunchKernelGGL(k_g1_scale_bf<4>, grid_for(4 * total), dim3(block_threads(4 * total)), 0, st, data, tab, inv_n, 4 * total);
     } else if (2 * total <= ctx->g1_quad_max) {
-        hipLaunchKernelGGL(k_g1_scale_grp<4>, grid_for(8 * total), dim3(block_threads(8 * total)), 0, st, data, tab,
-                           inv_n, 8 * total);
+        hipLaunchKernelGGL(k_g1_scale_chain<4>, grid_for(8 * total), dim3(block_threads(8 * total)), 0, st, data, tab, inv_n, 8 * total);
     } else if (2 * total <= ctx->g1_pair_max) {
-        hipLaunchKernelGGL(k_g1_scale_grp<2>, grid_for(4 * total), dim3(block_threads(4 * total)), 0, st, data, tab,
-                           inv_n, 4 * total);
+        hipLaunchKernelGGL(k_g1_scale_chain<2>, grid_for(4 * total), dim3(block_threads(4 * total)), 0, st, data, tab, inv_n, 4 * total);
     } else {
-        hipLaunchKernelGGL(k_g1_scale_xyzz, grid_for(2 * total), dim3(block_threads(2 * total)), 0, st, data, tab,
-                           inv_n, 2 * total);
+        hipLaunchKernelGGL(k_g1_scale_chain<1>, grid_for(2 * total), dim3(block_threads(2 * total)), 0, st, data, tab, inv_n, 2 * total);
     }
 }
 
@@ -936,22 +805,14 @@ extern "C" int kzgamd_fft_g1_batch(void* vctx, blst_p1* out, const blst_p1* in, 
                            (u32)n, logn, total);
         Xyzz* bufs[2] = {pts, pts + total};
         Xyzz* res = bufs[enqueue_stages(ctx, bufs, tab, n, nbatch, inverse, st)];
-        RootSplit inv_n;
-        memset(&inv_n, 0, sizeof inv_n);
-        int scale = inverse && n > 1 ? 1 : 0;
-        if (scale) {
+        if (inverse && n > 1) {
             Fr v = Fr::zero();
             v.v[0] = (u32)n;
             v.v[1] = (u32)((u64)n >> 32);
-            inv_n = split_scalar(ff::from_mont(ff::inverse_bgcd(ff::to_mont(v))));
-            if (2 * total <= ctx->g1_wide_max || 2 * total <= ctx->g1_bf_max || 2 * total <= ctx->g1_quad_max || 2 * total <= ctx->g1_pair_max) {
-                // not enough points to fill the chip one lane each: the shorter-chain scaling, then a plain store
-                enqueue_scale(ctx, res, tab, inv_n, total, st);
-                scale = 0;
-            }
+            enqueue_scale(ctx, res, tab, split_scalar(ff::from_mont(ff::inverse_bgcd(ff::to_mont(v)))), total, st);
         }
-        hipLaunchKernelGGL(k_g1_store, grid_for(2 * total), dim3(block_threads(2 * total)), 0, st,
-                           (ff::Fp*)ctx->d_p1, (const Xyzz*)res, tab, inv_n, scale, 2 * total);
+        hipLaunchKernelGGL(k_g1_store, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (ff::Fp*)ctx->d_p1, (const Xyzz*)res,
+                           total);
         NTT_TRY(hipGetLastError());
         NTT_TRY(hipMemcpyAsync(out, ctx->d_p1, total * sizeof(blst_p1), hipMemcpyDeviceToHost, st));
         NTT_TRY(hipStreamSynchronize(st));

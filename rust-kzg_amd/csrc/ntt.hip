@@ -484,7 +484,6 @@ extern "C" void* kzgamd_ntt_new(unsigned scale) {
         env_size("KZGAMD_G1_WIDE_MAX", ctx->g1_wide_max);
         env_size("KZGAMD_G1_QUAD_MAX", ctx->g1_quad_max);
         env_size("KZGAMD_G1_PAIR_MAX", ctx->g1_pair_max);
-        env_size("KZGAMD_G1_BF_MAX", ctx->g1_bf_max);
         kzgamd::expand_roots(ctx->roots, scale);
         // device twiddles in the 2^261 domain, w*2^261 = (w*2^256) * 2^5, already sliced into the 9 x 29-bit limbs
         // the butterflies multiply with (36 bytes per root instead of 32, ~27 instructions less per butterfly)

@@ -46,8 +46,7 @@ struct NttCtx {
     // g1_quad_max four lanes each, up to g1_pair_max two lanes each, one lane each above
     // (KZGAMD_G1_WIDE_MAX / _QUAD_MAX / _PAIR_MAX, read at creation; 0 disables a form)
     size_t g1_wide_max = 4096, g1_quad_max = 16384, g1_pair_max = 32768;
-    // ... and, tried before those two: four lanes per BUTTERFLY with both GLV halves on one chain (KZGAMD_G1_BF_MAX)
-    size_t g1_bf_max = 0;
+
     ~NttCtx() {
         if (d_roots) (void)hipFree(d_roots);
         if (d_tw_fwd) (void)hipFree(d_tw_fwd);

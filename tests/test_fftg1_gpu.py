@@ -13,10 +13,9 @@ pytestmark = pytest.mark.gpu
 # by grid size; the switches (read when the handle is created) force one of them for every size so that each is
 # checked against the oracle on the same cases.
 FORMS = {"by_size": {}, "wave": {"KZGAMD_G1_WIDE_MAX": "1000000"},
-         "four_lanes": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "1000000", "KZGAMD_G1_BF_MAX": "0"},
-         "two_lanes": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "0", "KZGAMD_G1_PAIR_MAX": "1000000", "KZGAMD_G1_BF_MAX": "0"},
-         "four_lanes_per_butterfly": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_BF_MAX": "1000000"},
-         "one_lane": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "0", "KZGAMD_G1_PAIR_MAX": "0", "KZGAMD_G1_BF_MAX": "0"}}
+         "four_lanes": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "1000000"},
+         "two_lanes": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "0", "KZGAMD_G1_PAIR_MAX": "1000000"},
+         "one_lane": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "0", "KZGAMD_G1_PAIR_MAX": "0"}}
 
 
 @pytest.fixture(params=list(FORMS))

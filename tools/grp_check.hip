@@ -1,5 +1,5 @@
-// Differential check of the lane-group point routines of fftg1.hip (grp::dbl<G>, grp::dadd<G>, grp::scalar_mul128<G>)
-// against the single-lane ones (g1::dbl, g1::dadd, scalar_mul128) on multiples of the generator.
+// Differential check of the chain routines of fftg1.hip (grp::dbl_body<G>, grp::dadd_body<G>, grp::run_chain<G>, G = 1, 2, 4)
+// against the single-lane ones of g1_28.hip.h (g1::dbl, g1::dadd, a plain double-and-add) on multiples of the generator.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/grp_check.hip -o tools/grp_check -Lrust-kzg_amd/csrc -lkzg_mi355x
 #include "../rust-kzg_amd/csrc/fftg1.hip"
 
@@ -12,6 +12,16 @@ __device__ bool same_point(const Xyzz& a, const Xyzz& b) {
     const bool x = is_zero_mod_p(sub<4>(mul(a.x, b.zz), mul(b.x, a.zz)));
     const bool y = is_zero_mod_p(sub<4>(mul(a.y, b.zzz), mul(b.y, a.zzz)));
     return x && y;
+}
+
+// plain double-and-add over the 128 bits of k with the single-lane routines of g1_28.hip.h: the yardstick
+__device__ void mul_plain(Xyzz& acc, const u32 k[4]) {
+    const Xyzz base = acc;
+    g1::set_inf(acc);
+    for (int b = 127; b >= 0; --b) {
+        if (!g1::is_inf(acc)) g1::dbl(acc);
+        if ((k[b >> 5] >> (b & 31)) & 1) g1::dadd(acc, base);
+    }
 }
 
 template <int G>
@@ -29,7 +39,7 @@ __global__ void __launch_bounds__(64) k_check(int* __restrict__ bad, const Xyzz*
         g1::dadd(c, P);
         if (!same_point(a, c)) atomicOr(&bad[g], 32);  // single-lane dbl == single-lane P + P
     }
-    grp::dbl<G>(b, r);
+    grp::dbl_body<G>(b, r);
     if (!same_point(a, b)) atomicOr(&bad[g], 1);
     if (g == 0 && out) {
         out[2 * r] = a;
@@ -38,18 +48,15 @@ __global__ void __launch_bounds__(64) k_check(int* __restrict__ bad, const Xyzz*
     a = P;
     b = P;
     g1::dadd(a, Q);
-    grp::dadd<G>(b, Q, r);
+    if (grp::dadd_body<G>(b, Q, r)) atomicOr(&bad[g], 64);  // distinct points: no doubling asked for
     if (!same_point(a, b)) atomicOr(&bad[g], 2);
-    a = P;
     b = P;
-    g1::dadd(a, P);
-    grp::dadd<G>(b, P, r);  // P + P: the doubling branch
-    if (!same_point(a, b)) atomicOr(&bad[g], 4);
+    if (!grp::dadd_body<G>(b, P, r)) atomicOr(&bad[g], 4);  // P + P: the caller is told to double
     u32 k[4] = {0x9e3779b9u * (u32)(g + 1), 0x85ebca6bu ^ (u32)g, 0xc2b2ae35u + (u32)g, 0x27d4eb2fu >> 1};
     a = P;
     b = P;
-    scalar_mul128(a, k, tab + (ngroups * 8) + t, ngroups * G);  // single-lane tables behind the group tables
-    grp::scalar_mul128<G>(b, k, tab + g, ngroups, r);
+    mul_plain(a, k);
+    grp::run_chain<G>(b, true, k[0], k[1], k[2], k[3], tab + g, ngroups, false, 0, [](int) { return grp::TailOp{nullptr, false}; }, r);
     if (!same_point(a, b)) atomicOr(&bad[g], 8);
 }
 }  // namespace
@@ -82,16 +89,17 @@ int main() {
     hipMemcpy(d_in, host.data(), n * sizeof(blst_p1), hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_g1_load, dim3(1), dim3(256), 0, 0, (Xyzz*)d_pts, (const ff::Fp*)d_in, 64u, 6, (size_t)64);  // 64 distinct points (bit-reversed order)
     int rc = 0;
-    for (int G : {2, 4}) {
+    for (int G : {1, 2, 4}) {
         hipMemset(d_bad, 0, 64 * sizeof(int));
         const size_t ng = 64;
-        if (G == 2) hipLaunchKernelGGL(k_check<2>, dim3(2), dim3(64), 0, 0, d_bad, (const Xyzz*)d_pts, (Xyzz*)d_tab, ng, (Xyzz*)d_out);
+        if (G == 1) hipLaunchKernelGGL(k_check<1>, dim3(1), dim3(64), 0, 0, d_bad, (const Xyzz*)d_pts, (Xyzz*)d_tab, ng, (Xyzz*)d_out);
+        else if (G == 2) hipLaunchKernelGGL(k_check<2>, dim3(2), dim3(64), 0, 0, d_bad, (const Xyzz*)d_pts, (Xyzz*)d_tab, ng, (Xyzz*)d_out);
         else hipLaunchKernelGGL(k_check<4>, dim3(4), dim3(64), 0, 0, d_bad, (const Xyzz*)d_pts, (Xyzz*)d_tab, ng, (Xyzz*)d_out);
         int bad[64];
         hipError_t he = hipMemcpy(bad, d_bad, sizeof bad, hipMemcpyDeviceToHost);
         int any = 0;
         for (int i = 0; i < 64; ++i) any |= bad[i];
-        printf("G=%d: %s  flags(or)=%d  (1 dbl, 2 add, 4 add-as-dbl, 8 scalar mul)  first groups: %d %d %d %d  hip=%d\n", G,
+        printf("G=%d: %s  flags(or)=%d  (1 dbl, 2 add, 4 add-as-dbl, 8 scalar mul, 64 spurious dbl request)  first groups: %d %d %d %d  hip=%d\n", G,
                any ? "MISMATCH" : "ok", any, bad[0], bad[1], bad[2], bad[3], (int)he);
         rc |= any;
         Xyzz o[8];

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 MODE=${1:---only-fft}
-for v in ${VARIANTS:-0,0,0 0,0,32768 0,32768,65536}; do
+for v in ${VARIANTS:-0,0,0 0,0,65536 0,65536,65536}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$v -o x -- python $R/tools/time_g1.py $MODE $v > /tmp/log_$v.txt 2>&1
   echo "== $v"; grep "2\^15\|n=256\|n=128\|n=64" /tmp/log_$v.txt
   python3 - <<PY

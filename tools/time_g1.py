@@ -10,13 +10,17 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch
+
+torch.cuda.init()  # before the library pulls in libamdhip64 (both resolve the same SONAME; first loaded wins)
 import extra_bench as eb
 
 kzg = eb.load_pkg()
 L = kzg.lib()
 BLOB = 131072
 rnd = random.Random(3)
-nmax = 256
+SIZES = tuple(int(x) for x in os.environ.get("TIME_G1_BLOBS", "16,32,64,128,256").split(","))
+nmax = max(SIZES)
 blobs = bytearray(rnd.randbytes(nmax * BLOB))
 for i in range(0, nmax * BLOB, 32):
     blobs[i] = 0
@@ -24,19 +28,28 @@ blobs = bytes(blobs)
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 ONLY_FFT, ONLY_CELLS = "--only-fft" in sys.argv, "--only-cells" in sys.argv
 variants = args or ["0,0,0", "4096,16384,32768"]  # wide_max,quad_max,pair_max
-_st = kzg.KZGSettings.from_file(eb.SETUP)
-MONO = bytes((kzg.BlstP1 * 4096).from_address(_st.c.g1_values_monomial))
-_st.close()
+def distinct_points(n):
+    """n distinct G1 points as Jacobian blst_p1 (Z = 1) on the host: the library's generator (h_i * G), so that no
+    stage of a transform sees equal or cancelling inputs (a periodic test input makes the early stages trivial)"""
+    dev = torch.device("cuda", 0)
+    aff = torch.empty(n * 96, dtype=torch.uint8, device=dev)
+    kzg.generate_points(aff.data_ptr(), n, 11, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    a = aff.cpu().numpy().reshape(n, 96)
+    import numpy as np
+
+    one = np.frombuffer(bytes.fromhex("fdff02000000097602000cc40b00f4ebba58c7535798485f455752705358ce776dec56a2971a075c93e480fac35ef615"), dtype=np.uint8)
+    out = np.concatenate([a, np.tile(one, (n, 1))], axis=1)
+    return out.tobytes()
+
+
+MONO = distinct_points(1 << 15)
 ref = {}
 for v in variants:
     parts = v.split(",")
     os.environ["KZGAMD_G1_WIDE_MAX"], os.environ["KZGAMD_G1_QUAD_MAX"], os.environ["KZGAMD_G1_PAIR_MAX"] = parts[:3]
-    if len(parts) > 3:
-        os.environ["KZGAMD_G1_BF_MAX"] = parts[3]  # four lanes per butterfly, both GLV halves on one chain
-    else:
-        os.environ.pop("KZGAMD_G1_BF_MAX", None)
     s = kzg.KZGSettings.from_file(eb.SETUP)
-    for n in (() if ONLY_FFT else (16, 32, 64, 128, 256)):
+    for n in (() if ONLY_FFT else SIZES):
         proofs = C.create_string_buffer(n * 128 * 48)
 
         def run():
@@ -56,7 +69,7 @@ for v in variants:
     for logn in (() if ONLY_CELLS else (7, 10, 12, 15)):
         n = 1 << logn
         pts = (kzg.BlstP1 * n)()
-        raw = (MONO * ((n * 144 + len(MONO) - 1) // len(MONO)))[: n * 144]  # the setup's monomial points, repeated
+        raw = MONO[: n * 144]
         C.memmove(pts, raw, n * 144)
         out = (kzg.BlstP1 * n)()
         for inverse in (0, 1):
