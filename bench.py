@@ -190,7 +190,11 @@ def collect_counters(batch, timeout_s=150):
              "--batch", str(batch), "--streams", "1", "--no-cpu-baseline", "--no-extras", "--no-counters"]
     out = {}
     tmp = tempfile.mkdtemp(prefix="kzg_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
+    # the child is a plain one-GPU run, whatever launched this process (a torchrun rank passes its rendezvous on)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS")}
+    env["TMPDIR"] = "/tmp"
     try:
         for i, p in enumerate(passes):
             d = os.path.join(tmp, "pass%d" % i)
