@@ -148,22 +148,34 @@ __device__ __forceinline__ void keep_in_vgprs(fp28::Fe& a) {
     for (int k = 0; k < fp28::L; ++k) asm volatile("" : "+v"(a.v[k]));
 }
 
-// single-lane element (the same value in every lane) <-> wide, through 16 words of LDS
+// Ordering of LDS accesses WITHIN a wave: the LDS executes one wave's operations in issue order, so lanes of a wave
+// can exchange through it without a workgroup barrier; the compiler only has to keep the accesses in program order.
+// (Round 3 used __syncthreads() here.  In a workgroup of several waves that each run their own chain — the hybrid block
+// sum — one wave's rare exact zero test then executed barriers the others did not, let it run ahead of a later real
+// barrier and read partial sums that were not written yet: a wrong result about once per 10^5 small batches, found by
+// tools/fuzz_ckzg.py in round 4; tests/golden/sparse_blob_hybrid_fold.json.)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// single-lane element (the same value in every lane) <-> wide, through 16 words of LDS THAT BELONG TO THE CALLING WAVE
 __device__ __forceinline__ u32 to_wide(const fp28::Fe& a, u32* sh, int lane) {
-    __syncthreads();
+    wave_sync();
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < fp28::L; ++k) sh[k] = a.v[k];
         sh[14] = 0;
         sh[15] = 0;
     }
-    __syncthreads();
+    wave_sync();
     return sh[lane & 15];
 }
 __device__ __forceinline__ fp28::Fe from_wide(u32 w, u32* sh, int lane) {
-    __syncthreads();
+    wave_sync();
     sh[lane & 15] = w;
-    __syncthreads();
+    wave_sync();
     fp28::Fe r;
 #pragma unroll
     for (int k = 0; k < fp28::L; ++k) r.v[k] = sh[k];

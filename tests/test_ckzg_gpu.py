@@ -743,3 +743,27 @@ def test_settings_fk20_columns_match_oracle(kzg, settings, oracle, oracle_settin
             got = O.G1()
             C.memmove(C.byref(got), C.byref(rows[row][offset]), 144)
             assert L.og1_equal(C.byref(got), C.byref(want[row])) == 1, (offset, row)
+
+
+def test_hybrid_fold_exact_zero_test_regression(kzg, settings, oracle, oracle_settings):
+    """A sparse blob whose quotient polynomial sends the limb-parallel addition of the small-batch fold
+    (k_blocksum_hybrid: four waves, each on its own chain) into its rare exact zero test.  Until round 4 that test
+    ran workgroup barriers the other waves did not, and batches of 2 .. 8 such blobs got a wrong proof (about one
+    small batch in 10^5; found by tools/fuzz_ckzg.py).  Every batch size against the single call and the oracle."""
+    import json
+
+    with open(os.path.join(GOLDEN, "sparse_blob_hybrid_fold.json")) as f:
+        fx = json.load(f)
+    blob = bytearray(BLOB)
+    for i, h in fx["elements"]:
+        blob[32 * i: 32 * i + 32] = bytes.fromhex(h)
+    blob = bytes(blob)
+    cm = bytes.fromhex(fx["commitment"])
+    L = oracle.lib()
+    want = C.create_string_buffer(48)
+    assert L.ocompute_blob_kzg_proof(want, blob, cm, C.byref(oracle_settings)) == 0
+    assert kzg.blob_to_kzg_commitment(blob, settings) == cm
+    assert kzg.compute_blob_kzg_proof(blob, cm, settings) == want.raw
+    for n in (1, 2, 3, 5, 8, 9, 16, 17):
+        assert kzg.compute_blob_kzg_proof_batch(blob * n, cm * n, n, settings) == [want.raw] * n, n
+        assert kzg.blob_to_kzg_commitment_batch(blob * n, n, settings) == [cm] * n, n

@@ -63,7 +63,13 @@ while time.time() < t_end:
         assert L.oblob_to_kzg_commitment(ec, blobs[b], C.byref(os_)) == 0
         assert cms[b] == ec.raw, ("commit", n, b, seed, cases)
         assert L.ocompute_blob_kzg_proof(ep, blobs[b], ec.raw, C.byref(os_)) == 0
-        assert proofs[b] == ep.raw, ("blob proof", n, b, seed, cases)
+        if proofs[b] != ep.raw:
+            again = kzg.compute_blob_kzg_proof_batch(flat, b"".join(cms), n, s)
+            single = kzg.compute_blob_kzg_proof(blobs[b], cms[b], s)
+            print("blob proof mismatch: n", n, "b", b, "seed", seed, "case", cases, "second batch call right:", again[b] == ep.raw,
+                  "single call right:", single == ep.raw, "got", proofs[b].hex()[:20], "want", ep.raw.hex()[:20],
+                  "blob head", blobs[b][:64].hex(), "distinct blobs", len(set(blobs)), flush=True)
+            raise AssertionError(("blob proof", n, b, seed, cases))
         ey = C.create_string_buffer(32)
         assert L.ocompute_kzg_proof(ep, ey, blobs[b], zs[b], C.byref(os_)) == 0
         assert ys[b] == ey.raw, ("evaluate", n, b, seed, cases)
