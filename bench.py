@@ -177,7 +177,7 @@ def pmc_summary():
     return None, None, {fam: False for fam in KERNEL_SOURCES}
 
 
-def collect_counters(batch, timeout_s=150):
+def collect_counters(batch, timeout_s=90):
     """Hardware counters of the headline kernel, collected by THIS run: rocprofv3 wraps a short serialised run of this
     script (--streams 1: a launch runs alone), one counter group per pass (the HBM guide's recipe: separate --pmc
     passes, --kernel-trace only), outside the timed region and after this process has freed its tables.  Returns
