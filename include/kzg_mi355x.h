@@ -303,6 +303,10 @@ C_KZG_RET kzgamd_settings_reserve(const CKZGSettings *s, size_t n, void *stream)
  * every device has its own replica of the tables.  Per-blob results equal the single-device calls; any failing slab
  * fails the call (C_KZG_BADARGS, like the reference).  n < ndev uses the first n objects.
  * ------------------------------------------------------------------------------------------ */
+/* the slab [*lo, *hi) of part k when n items are cut into `parts` contiguous slabs whose sizes differ by at most one
+ * (what every *_multi entry point uses; with n < parts the first n parts get one item).  Returns 0, 1 on bad arguments.
+ * No GPU involved. */
+int kzgamd_shard_range(size_t n, size_t parts, size_t k, size_t *lo, size_t *hi);
 /* one CKZGSettings per entry of devices[] (NULL = GPUs 0 .. ndev-1) from one setup file, loaded in parallel; all or
  * nothing: on failure every out[d] is left empty.  The caller's current device is left alone. */
 C_KZG_RET kzgamd_load_trusted_setup_file_multi(CKZGSettings out[], const int devices[], size_t ndev, FILE *in);

@@ -75,7 +75,7 @@ EXPORTS = [
     "kzgamd_p2_uncompress", "kzgamd_p2_compress", "kzgamd_p2_generator", "kzgamd_p2_mult", "kzgamd_p2_add",
     "kzgamd_load_trusted_setup_file_multi", "kzgamd_free_trusted_setup_multi", "kzgamd_blob_to_kzg_commitment_batch_multi",
     "kzgamd_compute_blob_kzg_proof_batch_multi", "kzgamd_compute_cells_and_kzg_proofs_batch_multi",
-    "kzgamd_verify_blob_kzg_proof_batch_multi", "kzgamd_mult_pippenger_prepared_multi",
+    "kzgamd_verify_blob_kzg_proof_batch_multi", "kzgamd_mult_pippenger_prepared_multi", "kzgamd_shard_range",
 ]
 
 
@@ -229,6 +229,8 @@ def lib():
     L.kzgamd_compute_cells_and_kzg_proofs_batch_multi.argtypes = [vp, vp, vp, sz, vp, sz]
     L.kzgamd_verify_blob_kzg_proof_batch_multi.restype = C.c_int
     L.kzgamd_verify_blob_kzg_proof_batch_multi.argtypes = [bp, vp, vp, vp, sz, vp, sz]
+    L.kzgamd_shard_range.restype = C.c_int
+    L.kzgamd_shard_range.argtypes = [sz, sz, sz, C.POINTER(sz), C.POINTER(sz)]
     L.kzgamd_mult_pippenger_prepared_multi.restype = RustError
     L.kzgamd_mult_pippenger_prepared_multi.argtypes = [vp, sz, vp, vp, vp]
     _lib = L

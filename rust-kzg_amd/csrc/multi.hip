@@ -70,6 +70,12 @@ bool settings_ok(const CKZGSettings* const s[], size_t ndev) {
 
 }  // namespace
 
+extern "C" int kzgamd_shard_range(size_t n, size_t parts, size_t k, size_t* lo, size_t* hi) {
+    if (parts == 0 || k >= parts || !lo || !hi) return 1;
+    shard_range(n, parts, k, *lo, *hi);
+    return 0;
+}
+
 extern "C" C_KZG_RET kzgamd_load_trusted_setup_file_multi(CKZGSettings out[], const int devices[], size_t ndev, FILE* in) {
     if (!out) return C_KZG_BADARGS;
     for (size_t d = 0; d < ndev; ++d) memset(&out[d], 0, sizeof out[d]);

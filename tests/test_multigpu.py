@@ -397,3 +397,27 @@ def test_multi_entry_points_reject_bad_arguments_without_a_gpu(kzg):
     arr = (kzg.CKZGSettings * 2)()
     assert L.kzgamd_load_trusted_setup_file_multi(arr, None, 2, None) == kzg.C_KZG_BADARGS
     L.kzgamd_free_trusted_setup_multi(arr, 2)  # empty objects: a no-op
+
+
+def test_library_slabs_equal_the_python_partition(kzg):
+    """kzgamd_shard_range (what the *_multi entry points cut a batch with) == sharding.shard_range, the partition of the
+    torch.distributed form: both multi-GPU paths agree on who owns a blob.  No GPU needed."""
+    import ctypes as C
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("sharding", os.path.join(ROOT, "rust-kzg_amd", "sharding.py"))
+    sh = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sh)
+    L = kzg.lib()
+    lo, hi = C.c_size_t(), C.c_size_t()
+    for n in (0, 1, 5, 8, 9, 37, 256, 4097):
+        for parts in (1, 2, 3, 8):
+            prev = 0
+            for k in range(parts):
+                assert L.kzgamd_shard_range(n, parts, k, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == sh.shard_range(n, parts, k)
+                assert lo.value == prev
+                prev = hi.value
+            assert prev == n
+    assert L.kzgamd_shard_range(5, 0, 0, C.byref(lo), C.byref(hi)) == 1
+    assert L.kzgamd_shard_range(5, 2, 2, C.byref(lo), C.byref(hi)) == 1
