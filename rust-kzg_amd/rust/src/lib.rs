@@ -264,5 +264,7 @@ pub mod ckzg {
                                                         proofs: *const Bytes48, n: usize, s: *const *const CKZGSettings,
                                                         ndev: usize) -> CKzgRet;
         pub fn kzgamd_device_count() -> core::ffi::c_int;
+        /// the slab [lo, hi) the `_multi` entry points give settings object `k` of `parts` for a batch of `n`
+        pub fn kzgamd_shard_range(n: usize, parts: usize, k: usize, lo: *mut usize, hi: *mut usize) -> core::ffi::c_int;
     }
 }
