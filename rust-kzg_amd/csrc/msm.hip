@@ -1966,8 +1966,22 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         // (blst/src/types/g1.rs:65-87): the split is used when the caller vouches for the bases (internal callers
         // that have just subgroup-checked them), or after every base has passed the membership test here; otherwise
         // the engine runs on the 255-bit scalars.
-        ctx->glv = !prepare && g1_policy != G1_NO_SPLIT;
+        // A prepared handle too large for any wide table (n >= 2^19 with the default budget) would run the bucket engine
+        // over table rows 2^(c j) P with one bucket set.  Measured (tools/time_prepared.py, 2^20 / 2^21 / 2^22 points):
+        // 4.57 / 9.7 / 16.8 ms against 3.51 / 6.5 / 13.1 ms for the GLV-split engine on the plain bases — the rows make
+        // the gathers of the accumulation miss every cache (2 GB of table) and one set of 2^19 buckets costs the reduction
+        // more than eight sets of 2^15 — so such a handle takes the variable-base shape when its bases pass
+        // the subgroup test.  KZGAMD_FIXED_AS_VARIABLE_MIN: log2 of the smallest such n (0 = never).
+        bool as_variable = false;
+        if (prepare && !ctx->window_forced && g1_policy != G1_NO_SPLIT) {
+            int lg = 19;
+            if (const char* e = getenv("KZGAMD_FIXED_AS_VARIABLE_MIN")) lg = atoi(e);
+            bool dummy;
+            as_variable = lg > 0 && lg < 40 && n >= ((size_t)1 << lg) && choose_wide_window(n, true, &dummy) == 0;
+        }
+        ctx->glv = (!prepare || as_variable) && g1_policy != G1_NO_SPLIT;
         if (const char* e = getenv("KZGAMD_GLV")) ctx->glv = ctx->glv && atoi(e) != 0;
+        if (!ctx->glv) as_variable = false;
         // the bases first (row 0 of the table; the variable-base engine appends the [x^2]P images)
         DevBuf<AffPt> row0;
         row0.ensure(ctx->glv ? 2 * n : n);
@@ -1999,6 +2013,13 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
             HIP_TRY(hipStreamSynchronize(ctx->stream));
             bad.release();
             if (nbad != 0) ctx->glv = false;  // a base outside G1: no split (row0 keeps its 2n slots, n are used)
+        }
+        if (as_variable && ctx->glv) {
+            prepare = false;
+            ctx->prepared = false;
+            if (getenv("KZGAMD_VERBOSE"))
+                fprintf(stderr, "kzg_mi355x: prepared handle over %zu points on GPU %d: no wide table fits, GLV-split bucket engine on the plain bases\n",
+                        n, ctx->device);
         }
         bases_in(ctx->glv ? 1 : 0);
         // shape of the engine

@@ -410,6 +410,39 @@ def test_prepared_bucket_path_without_wide_table(oracle, kzg, monkeypatch):
     h.close()
 
 
+@pytest.mark.parametrize("outside", [False, True])
+def test_large_prepared_handle_takes_the_variable_base_shape(oracle, kzg, monkeypatch, outside):
+    """A prepared handle too large for a wide table (here: the threshold lowered to 2^9 points, the table disabled) runs the
+    GLV-split engine on the plain bases instead of table rows — unless a base fails the subgroup test, then it keeps
+    the rows.  Same results either way, single call and batch."""
+    L = oracle.lib()
+    monkeypatch.setenv("KZGAMD_FBW_MAX_GB", "0")
+    monkeypatch.setenv("KZGAMD_FIXED_AS_VARIABLE_MIN", "9")
+    rnd = random.Random(16)
+    n = 700
+    pts = gen_points(L, n, rnd)
+    pts[13] = O.G1Affine()
+    if outside:
+        x, y = curve_points_outside_g1(1, 5)[0]
+        pts[7].x, pts[7].y = O.fp_from_int(x), O.fp_from_int(y)
+    h = kzg.prepare_multi_scalar_mult(pts, n)
+    info = h.info()
+    assert not info["wide_table"]
+    assert (info["rows"] > 1) == outside, info
+    vals = [rnd.randrange(O.R) for _ in range(n)]
+    vals[0], vals[1], vals[2] = 0, O.R - 1, 1
+    batches = [vals, [rnd.randrange(1 << 200) for _ in range(n)], [vals[5]] * n, [0] * n]
+    for v in batches[:2]:
+        check(L, kzg, pts, O.fr_array(v), n, prepared=h, unprepared=False)
+    flat = O.fr_array([x for v in batches for x in v])
+    got = kzg.multi_scalar_mult_prepared_batch(h, flat, n, len(batches))
+    for b, v in enumerate(batches):
+        exp = O.G1()
+        L.omsm_affine(C.byref(exp), pts, O.fr_array(v), n)
+        assert compressed(L, as_oracle_g1(got[b])) == compressed(L, exp), b
+    h.close()
+
+
 @pytest.mark.parametrize("env", [{"KZGAMD_FBW_MAX_GB": "2.0"}, {"KZGAMD_FBW_MAX_GB": "0.6"}, {"KZGAMD_FBW_MAX_GB": "0.3"},
                                  {"KZGAMD_FBW_MAX_GB": "0.1"}, {"KZGAMD_FBW_MAX_GB": "2.0", "KZGAMD_FBW_GLV": "0"},
                                  {"KZGAMD_FBW_MAX_GB": "0.3", "KZGAMD_FBW_GLV": "0"}])

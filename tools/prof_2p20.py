@@ -1,4 +1,5 @@
-"""One variable-base MSM of 2^logn points, four calls on one handle (for rocprofv3): prof_2p20.py [logn]"""
+"""One MSM of 2^logn points on the bucket engine, four calls on one handle (for rocprofv3): prof_2p20.py [logn] [fixed]
+(fixed: a prepared handle — table rows 2^(c j) P, one bucket set; KZGAMD_WINDOW_PREPARED picks c)"""
 import importlib.util, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -14,7 +15,7 @@ torch.cuda.synchronize()  # handles copy the points on their own non-blocking st
 g = torch.Generator(device="cpu"); g.manual_seed(2)
 sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g); sc[:, 31] &= 0x3F; sc = sc.to(dev)
 out = torch.zeros(144, dtype=torch.uint8, device=dev)
-h = kzg.DeviceMsm(pts.data_ptr(), n, False)
+h = kzg.DeviceMsm(pts.data_ptr(), n, len(sys.argv) > 2 and sys.argv[2] == "fixed")
 for _ in range(4):
     kzg.msm_prepared_batch_device(h, out.data_ptr(), sc.data_ptr(), n, 1, False, stream)
 torch.cuda.synchronize()
