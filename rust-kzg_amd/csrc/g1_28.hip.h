@@ -111,6 +111,37 @@ FF_HD void madd(Xyzz& acc, const Fe& x2, const Fe& y2) {
     acc.zzz = mul(acc.zzz, ppp);
 }
 
+// acc += b   (add-2008-s) for b != acc; returns true and leaves acc alone when the two are the same point — the caller
+// doubles.  Kernels that run their additions as ONE inlined site inside a loop (k_tile_sums) keep the doubling, which
+// never runs on random data, as one site of its own instead of one per addition.
+FF_HD bool dadd_unequal(Xyzz& acc, const Xyzz& b) {
+    using namespace fp28;
+    if (is_inf(b)) return false;
+    if (is_inf(acc)) {
+        acc = b;
+        return false;
+    }
+    Fe u = mul(acc.x, b.zz);
+    Fe s = mul(acc.y, b.zzz);
+    Fe p = sub<4>(mul(b.x, acc.zz), u);
+    Fe r = sub<4>(mul(b.y, acc.zzz), s);
+    if (is_zero_mod_p(p)) {
+        if (is_zero_mod_p(r)) return true;
+        set_inf(acc);
+        return false;
+    }
+    Fe pp = sqr(p);
+    Fe ppp = mul(p, pp);
+    Fe q = mul(u, pp);
+    Fe x3 = sub<8>(sqr(r), addn(add(q, q), ppp));
+    Fe y3 = sub<4>(mul(r, sub<16>(q, x3)), mul(s, ppp));
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = mul(mul(acc.zz, b.zz), pp);
+    acc.zzz = mul(mul(acc.zzz, b.zzz), ppp);
+    return false;
+}
+
 // acc += b   (add-2008-s)
 FF_HD void dadd(Xyzz& acc, const Xyzz& b) {
     using namespace fp28;

@@ -950,6 +950,85 @@ __global__ void __launch_bounds__(TILE_T) k_tile_sums(const Xyzz* __restrict__ p
     }
 }
 
+// The same sums with every addition at one of TWO inlined sites, each the body of a loop whose second operand comes from
+// memory (the form that took the scratch out of the G1 stages): loop 1 folds the pieces of the lane's two
+// buckets, loop 2 is a ten-step schedule — the pair of buckets, four row-tree levels, the pair of rows, four column-tree
+// levels — in which a step only chooses where the operand comes from and where the sum goes.  k_tile_sums above has five
+// sites (each with its own never-taken doubling): 256 VGPRs, 86 of them spilled.
+__global__ void __launch_bounds__(TILE_T) k_tile_sums_loop(const Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
+                                                           const unsigned char* __restrict__ heavy, Xyzz* __restrict__ dense,
+                                                           Xyzz* __restrict__ Gs, Xyzz* __restrict__ Cp, size_t nb,
+                                                           size_t nchunk, ChunkSel cs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ts[];
+    Xyzz* sh = (Xyzz*)smem_ts;
+    const size_t ntiles = nb >> 10;
+    const size_t set = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
+    const size_t k0 = tile << 10;
+    const int t = threadIdx.x;
+    const int r = t >> 4, q = t & 15;   // rows: buckets 32 r + 2 q, + 1
+    const int c = t & 31, rg = t >> 5;  // columns: rows 2 rg, 2 rg + 1 of column c
+    const size_t kb = k0 + (size_t)(32 * r + 2 * q);
+    Xyzz* dn = dense + set * nb;
+    Xyzz acc;
+    g1::set_inf(acc);
+    {
+        const Xyzz* pz = partials + set * (nb + nchunk);
+        const u32* off = offsets + set * (nb + 1);
+        const unsigned char* hv = heavy + set * nb;
+        const int lgc = eff_lgc(off[nb], cs);
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) {
+            const size_t bk = kb + i;
+            const u32 beg = off[bk], end = off[bk + 1];
+            g1::set_inf(acc);
+            if (end != beg) {
+                const u32 t0 = beg >> lgc, t1 = hv[bk] ? t0 : (end - 1) >> lgc;
+                acc = pz[bk + t0];
+#pragma unroll 1
+                for (u32 tt = t0 + 1; tt <= t1; ++tt) {
+                    Xyzz v = pz[bk + tt];
+                    if (g1::dadd_unequal(acc, v)) g1::dbl(acc);
+                }
+            }
+            dn[bk] = acc;
+        }
+    }
+    // acc = bucket kb + 1; step 0 adds bucket kb (this lane wrote it)
+#pragma unroll 1
+    for (int s = 0; s < 10; ++s) {
+        const int lvl = s < 5 ? s - 1 : s - 6;         // tree steps 1..4 / 6..9: strides 8, 4, 2, 1
+        const int stride = lvl >= 0 ? 8 >> lvl : 0;
+        bool active = true;
+        Xyzz v;
+        if (s == 0) {
+            v = dn[kb];
+        } else if (s == 5) {
+            v = dn[k0 + (size_t)(32 * (2 * rg + 1) + c)];
+        } else {
+            active = s < 5 ? t < 32 * stride : rg < stride;
+            if (active) v = sh[t + 32 * stride];
+        }
+        if (active && g1::dadd_unequal(acc, v)) g1::dbl(acc);
+        if (s == 0) {
+            // the row tree runs q-major (slot 32 q + r): the lanes still adding at a level are the first 32 * stride of
+            // the workgroup, whole waves drop out level by level
+            sh[32 * q + r] = acc;
+            __syncthreads();
+            acc = sh[t];  // slot t is only ever written by lane t from here on
+        } else {
+            if (active) sh[t] = acc;
+            __syncthreads();
+        }
+        if (s == 4) {
+            if (t < 32) Gs[set * (nb >> 5) + (k0 >> 5) + t] = acc;
+            __threadfence();  // the folded buckets this workgroup wrote are read back by other lanes
+            __syncthreads();
+            acc = dn[k0 + (size_t)(32 * (2 * rg) + c)];
+        }
+    }
+    if (rg == 0) Cp[(set * ntiles + tile) * 32 + c] = acc;
+}
+
 // S[set][0][d] = sum over the tiles of Cp[set][tile][d];  S[set][j][d], j >= 1, = sum of the groups whose digit j - 1
 // (base 32, of the group index) equals d.  One 64-thread workgroup per cell, nb / 1024 values each (32 at 2^15 buckets).
 __global__ void __launch_bounds__(64) k_digit_sums2(const Xyzz* __restrict__ Gs, const Xyzz* __restrict__ Cp,
@@ -1820,6 +1899,7 @@ struct MsmTuning {
     int groups = 0;            // KZGAMD_GROUPS: window groups on their own streams (0 = one)
     int fine_bits = 0;         // KZGAMD_FINE_BITS: width of the second sort level (0 = default)
     bool one_level_sort = false, tree_tail = false, flat_digits = false, direct_scatter = false, scatter_atomics = false;
+    bool tile_v1 = false;      // KZGAMD_TILE_V1=1: k_tile_sums in its five-site form
     static MsmTuning from_env() {
         MsmTuning t;
         auto num = [](const char* name) {
@@ -1841,6 +1921,7 @@ struct MsmTuning {
         t.flat_digits = getenv("KZGAMD_FLAT_DIGITS") != nullptr;
         t.direct_scatter = getenv("KZGAMD_DIRECT_SCATTER") != nullptr;
         t.scatter_atomics = getenv("KZGAMD_SCATTER_ATOMICS") != nullptr;
+        t.tile_v1 = getenv("KZGAMD_TILE_V1") != nullptr;
         return t;
     }
 };
@@ -2509,9 +2590,9 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             if (tiled_digits) {
                 Xyzz* Gs = ws.lvlA[1].p + set0 * (nb >> 5);
                 Xyzz* Cp = ws.lvlM[1].p + set0 * (nb >> 5);
-                hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)(ns * (nb >> 10))), dim3(TILE_T), TILE_T * sizeof(Xyzz), st,
-                                   (const Xyzz*)buckets, (const u32*)offsets, (const unsigned char*)heavy, dense, Gs, Cp, nb,
-                                   nchunk, csel);
+                hipLaunchKernelGGL(ctx->tune.tile_v1 ? k_tile_sums : k_tile_sums_loop, dim3((unsigned)(ns * (nb >> 10))),
+                                   dim3(TILE_T), TILE_T * sizeof(Xyzz), st, (const Xyzz*)buckets, (const u32*)offsets,
+                                   (const unsigned char*)heavy, dense, Gs, Cp, nb, nchunk, csel);
                 if (wide_tail) {
                     // cells of this group: [0, ns * J * 32) digit sums, then ns * (logNb + 2) bit sums
                     const size_t c1 = ns * (size_t)(J * 32), c2 = ns * (size_t)(logNb + 2);

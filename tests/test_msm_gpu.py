@@ -516,7 +516,8 @@ def test_variable_base_device_handle_batched(oracle, kzg, nbatch):
                                  {"KZGAMD_FINE_BITS": "9"}, {"KZGAMD_FINE_BITS": "10", "KZGAMD_LGC": "3"},
                                  {"KZGAMD_LGC": "7"}, {"KZGAMD_FLAT_DIGITS": "1"},
                                  {"KZGAMD_FLAT_DIGITS": "1", "KZGAMD_NO_WIDE_TAIL": "1"}, {"KZGAMD_DIRECT_SCATTER": "1"}, {"KZGAMD_SCATTER_ATOMICS": "1"},
-                                 {"KZGAMD_NO_WIDE_TAIL": "1", "KZGAMD_FINE_BITS": "8"}])
+                                 {"KZGAMD_NO_WIDE_TAIL": "1", "KZGAMD_FINE_BITS": "8"}, {"KZGAMD_TILE_V1": "1"},
+                                 {"KZGAMD_TILE_V1": "1", "KZGAMD_LGC": "3"}, {"KZGAMD_LGC": "4"}])
 def test_variable_base_engine_variants(oracle, kzg, monkeypatch, env):
     """Every selectable shape of the variable-base engine (two-level / one-level sort, window groups on their own
     streams, limb-parallel / single-lane tails, digit-decomposed / tree bucket reduction) on the same 40 000-point MSM
