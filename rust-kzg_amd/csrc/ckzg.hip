@@ -238,6 +238,7 @@ constexpr int QE = (int)(N / QT);  // elements per thread (8), element index i =
 // the 4096 inversions are one Fermat inversion per blob via a block-wide product scan
 // (the reference's fr_batch_inv :882-914 is the same trick, serial).
 // Outputs: q as canonical little-endian scalars (ready for the MSM), y canonical.
+template <bool ARRAYS>
 __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* __restrict__ y_out, int* __restrict__ status,
                                                  const u32* __restrict__ blobs, const u32* __restrict__ z_be,
                                                  const ff::Fr* __restrict__ roots_brp, ff::Fr ninv) {
@@ -257,8 +258,29 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
     ff::Fr z = ff::to_mont(fr_load_be(z_be + blob * 8, &zok));
     if (!zok && t == 0) sh_bad = 1;
 
+    // The thread's QE prefix products, then its QE inverses, are kept in the element's own 32-byte slot of q_out until the
+    // quotient overwrites them (same lane, same address).  ARRAYS (KZGAMD_QUOTIENT_ARRAYS=1): as per-thread arrays, which
+    // are 536 bytes of scratch per lane — the loops are too large to unroll with the multiplications inlined, so the
+    // arrays are indexed dynamically.
+    uint4* qslot = reinterpret_cast<uint4*>(q_out + blob * (N * 8));
+    ff::Fr held[ARRAYS ? QE : 1];
+    auto put = [&](int k, int i, const ff::Fr& x) {
+        if (ARRAYS) {
+            held[ARRAYS ? k : 0] = x;
+            return;
+        }
+        qslot[2 * i] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+        qslot[2 * i + 1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+    };
+    auto get = [&](int k, int i) {
+        if (ARRAYS) return held[ARRAYS ? k : 0];
+        const uint4 lo = qslot[2 * i], hi = qslot[2 * i + 1];
+        ff::Fr x;
+        x.v[0] = lo.x, x.v[1] = lo.y, x.v[2] = lo.z, x.v[3] = lo.w;
+        x.v[4] = hi.x, x.v[5] = hi.y, x.v[6] = hi.z, x.v[7] = hi.w;
+        return x;
+    };
     // d_k = z - w_i, prefix products within the thread
-    ff::Fr pre[QE];
     ff::Fr prod = ff::Fr::one();
 #pragma unroll
     for (int k = 0; k < QE; ++k) {
@@ -268,7 +290,7 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
             sh_m = i;
             d = ff::Fr::one();
         }
-        pre[k] = prod;
+        put(k, i, prod);
         prod = fmul(prod, d);
     }
     // block-wide inclusive prefix (sh_a) and suffix (sh_b) products of the per-thread products
@@ -293,7 +315,6 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
     __syncthreads();
 
     // back-substitution: inv_k = 1/d_k; barycentric sum  sum p_i w_i / (z - w_i)
-    ff::Fr invs[QE];
     ff::Fr acc = ff::Fr::zero();
     bool bad = false;
 #pragma unroll
@@ -302,14 +323,15 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
         const ff::Fr w = roots_brp[i];
         ff::Fr d = ff::sub(z, w);
         if (i == m) d = ff::Fr::one();
-        invs[k] = fmul(inv, pre[k]);
+        const ff::Fr inv_k = fmul(inv, get(k, i));
+        put(k, i, inv_k);
         inv = fmul(inv, d);
         bool ok;
         // the blob element stays canonical: a Montgomery product with one canonical operand is the canonical product,
         // so neither the elements nor the results below need a conversion multiplication
         const ff::Fr p = fr_load_be(bw + (size_t)i * 8, &ok);
         bad |= !ok;
-        acc = ff::add(acc, fmul(fmul(invs[k], w), p));
+        acc = ff::add(acc, fmul(fmul(inv_k, w), p));
     }
     if (bad) sh_bad = 1;
     sh_a[t] = acc;
@@ -347,10 +369,11 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
         bool ok;
         const ff::Fr p = fr_load_be(bw + (size_t)i * 8, &ok);
         const ff::Fr ymp = ff::sub(y, p);            // canonical
-        const ff::Fr qc = fmul(ymp, invs[k]);     // canonical x Montgomery -> canonical
-        if (m >= 0) col = ff::add(col, fmul(fmul(ff::neg(ymp), roots_brp[i]), invs[k]));
-#pragma unroll
-        for (int l = 0; l < 8; ++l) q_out[(blob * N + i) * 8 + l] = qc.v[l];
+        const ff::Fr inv_k = get(k, i);
+        const ff::Fr qc = fmul(ymp, inv_k);       // canonical x Montgomery -> canonical
+        if (m >= 0) col = ff::add(col, fmul(fmul(ff::neg(ymp), roots_brp[i]), inv_k));
+        qslot[2 * i] = make_uint4(qc.v[0], qc.v[1], qc.v[2], qc.v[3]);
+        qslot[2 * i + 1] = make_uint4(qc.v[4], qc.v[5], qc.v[6], qc.v[7]);
     }
     if (m >= 0) {
         sh_a[t] = col;
@@ -873,6 +896,7 @@ struct KzgAmdSettings {
     CoalesceQueue q_commit, q_blob_proof, q_proof;
     // measurement switches, read once when the settings object is created
     bool cfg_device_sha = getenv("KZGAMD_DEVICE_SHA") && atoi(getenv("KZGAMD_DEVICE_SHA")) != 0;
+    bool cfg_quotient_arrays = env_int("KZGAMD_QUOTIENT_ARRAYS", 0, 0, 1) != 0;
     size_t cfg_prove_chunk = (size_t)env_int("KZGAMD_PROVE_CHUNK", 0, 0, 1 << 20);
     bool cfg_wide_check = !(getenv("KZGAMD_WIDE_CHECK") && atoi(getenv("KZGAMD_WIDE_CHECK")) == 0);  // 0: single-lane tests
     size_t cfg_prove_first = (size_t)env_int("KZGAMD_PROVE_FIRST", 0, 0, 1 << 20);
@@ -1502,7 +1526,7 @@ void prove_enqueue(KzgAmdSettings* dev, size_t off, size_t n, hipStream_t stream
         hipLaunchKernelGGL(k_quotient_b, dim3((unsigned)(n * QS)), dim3(QT), 0, stream, scal, yv, dev->d_qscratch, bl, zv,
                            (const ff::Fr*)dev->d_brp_roots, n_inverse());
     } else {
-        hipLaunchKernelGGL(k_quotient, dim3((unsigned)n), dim3(QT), 0, stream, scal, yv, stat, bl, zv,
+        hipLaunchKernelGGL(dev->cfg_quotient_arrays ? k_quotient<true> : k_quotient<false>, dim3((unsigned)n), dim3(QT), 0, stream, scal, yv, stat, bl, zv,
                            (const ff::Fr*)dev->d_brp_roots, n_inverse());
     }
     if (evaluate_only) return;  // y = p(z) is all the caller wants (the field work of batched verification)
@@ -2384,7 +2408,7 @@ extern "C" C_KZG_RET kzgamd_compute_blob_kzg_proof_device(void* d_proofs, void* 
                            (const u32*)d_commitments, n);
         hipLaunchKernelGGL(k_check_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, stat,
                            (const unsigned char*)d_commitments, n);
-        hipLaunchKernelGGL(k_quotient, dim3((unsigned)n), dim3(QT), 0, st, scal, y, stat, (const u32*)d_blobs, (const u32*)z,
+        hipLaunchKernelGGL(dev->cfg_quotient_arrays ? k_quotient<true> : k_quotient<false>, dim3((unsigned)n), dim3(QT), 0, st, scal, y, stat, (const u32*)d_blobs, (const u32*)z,
                            (const ff::Fr*)dev->d_brp_roots, n_inverse());
         kzgamd::msm_lock(dev->msm);
         try {

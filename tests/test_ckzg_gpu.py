@@ -329,38 +329,6 @@ def test_vectors_compute_cells_and_kzg_proofs(kzg, settings, golden, blob_loader
     assert hashlib.sha256(bp[:128 * 48]).hexdigest() == golden["compute_cells_and_kzg_proofs"][-2]["output"]["proofs_sha256"]
 
 
-def test_cell_proofs_fk20_matches_vectors_and_the_direct_form(kzg, settings, golden, blob_loader, monkeypatch):
-    """The batch algorithm for cell proofs (FK20, kzg/src/das.rs:630-696: Toeplitz vectors, 64 transforms of 128,
-    128 MSMs of 64 points over x_ext_fft_columns, two G1 transforms) against the reference's vectors and against the
-    direct form (one fixed-base MSM per cell), which is what single blobs use."""
-    import hashlib
-
-    cases = [c for c in golden["compute_cells_and_kzg_proofs"] if c["output"] is not None]
-    blobs = b"".join(blob_loader(c["blob"]) for c in cases)
-    monkeypatch.setenv("KZGAMD_FK20", "1")
-    cells, proofs = kzg.compute_cells_and_kzg_proofs_batch(blobs, len(cases), settings)
-    for k, c in enumerate(cases):
-        assert hashlib.sha256(proofs[k * 6144:(k + 1) * 6144]).hexdigest() == c["output"]["proofs_sha256"], c["name"]
-        assert hashlib.sha256(cells[k * 262144:(k + 1) * 262144]).hexdigest() == c["output"]["cells_sha256"], c["name"]
-    # a single blob through FK20 as well
-    _, p1 = kzg.compute_cells_and_kzg_proofs(blob_loader(cases[3]["blob"]), settings, want_cells=False)
-    assert p1 == proofs[3 * 6144:4 * 6144]
-    # random blobs, batch of 70 (above the size from which FK20 is the default): FK20 == direct
-    rnd = random.Random(720)
-    n = 70
-    rb = bytearray(rnd.randbytes(n * BLOB))
-    for i in range(0, n * BLOB, 32):
-        rb[i] = 0
-    rb[5 * BLOB:6 * BLOB] = bytes(BLOB)  # the zero polynomial: every proof is the point at infinity
-    rb = bytes(rb)
-    monkeypatch.delenv("KZGAMD_FK20")
-    _, p_default = kzg.compute_cells_and_kzg_proofs_batch(rb, n, settings)
-    monkeypatch.setenv("KZGAMD_FK20", "0")
-    _, p_direct = kzg.compute_cells_and_kzg_proofs_batch(rb, n, settings)
-    assert p_default == p_direct
-    assert p_direct[5 * 6144:5 * 6144 + 48] == b"\xc0" + bytes(47)
-
-
 def test_batch_256_blobs_commit_and_prove(kzg, settings, oracle, oracle_settings, monkeypatch):
     # BASELINE configs[4] size: 256 blobs in one batched call; sampled blobs checked against the oracle,
     # all of them against the single-blob path through a digest of digests
@@ -409,23 +377,6 @@ def test_batch_256_blobs_commit_and_prove(kzg, settings, oracle, oracle_settings
         with pytest.raises(kzg.KzgAmdError):
             kzg.compute_blob_kzg_proof_batch(blobs, b"".join(badc), n, settings)
     assert kzg.compute_blob_kzg_proof_batch(blobs, b"".join(cms), n, settings) == proofs  # and recovers afterwards
-    # KZGAMD_DEVICE_SHA=1: the same call with the Fiat-Shamir hashes on the GPU and no host threads
-    monkeypatch.setenv("KZGAMD_DEVICE_SHA", "1")
-    assert kzg.compute_blob_kzg_proof_batch(blobs, b"".join(cms), n, settings) == proofs
-    zs2, ys2 = kzg.compute_challenges_and_evaluate_batch(blobs, b"".join(cms), n, settings)
-    monkeypatch.delenv("KZGAMD_DEVICE_SHA")
-    zs1, ys1 = kzg.compute_challenges_and_evaluate_batch(blobs, b"".join(cms), n, settings)
-    assert (zs1, ys1) == (zs2, ys2)
-    monkeypatch.setenv("KZGAMD_DEVICE_SHA", "1")
-    bad = bytearray(blobs)
-    bad[200 * BLOB + 64:200 * BLOB + 96] = b"\xff" * 32
-    with pytest.raises(kzg.KzgAmdError):
-        kzg.compute_blob_kzg_proof_batch(bytes(bad), b"".join(cms), n, settings)
-    badc = list(cms)
-    badc[130] = b"\x9f" + b"\xff" * 47
-    with pytest.raises(kzg.KzgAmdError):
-        kzg.compute_blob_kzg_proof_batch(blobs, b"".join(badc), n, settings)
-
 
 
 def test_concurrent_callers_share_one_settings_handle(kzg, settings, oracle, oracle_settings):

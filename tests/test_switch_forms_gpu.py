@@ -1,0 +1,101 @@
+"""Forms of the c-kzg paths that a settings object chooses by switch.  The switches are read ONCE, when the
+object is created, so every form gets its own object here — with 8 GB tables, and in a module of its own so that the
+137 + 43 + 77 GB of another module's default object are released before these are built."""
+import hashlib
+import os
+import random
+
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+BLOB = 131072
+SETUP = os.path.join(GOLDEN, "trusted_setup.txt")
+
+
+@pytest.fixture(scope="module")
+def forms(kzg):
+    """settings objects: default form / FK20 forced / direct cell proofs forced / device SHA-256 + array k_quotient"""
+    saved = {k: os.environ.get(k) for k in ("KZGAMD_FBW_MAX_GB", "KZGAMD_FK20", "KZGAMD_DEVICE_SHA", "KZGAMD_QUOTIENT_ARRAYS")}
+    made = {}
+    try:
+        os.environ["KZGAMD_FBW_MAX_GB"] = "8"
+        for name, env in (("default", {}), ("fk20", {"KZGAMD_FK20": "1"}), ("direct", {"KZGAMD_FK20": "0"}),
+                          ("device_sha", {"KZGAMD_DEVICE_SHA": "1", "KZGAMD_QUOTIENT_ARRAYS": "1"})):
+            for k, v in env.items():
+                os.environ[k] = v
+            made[name] = kzg.KZGSettings.from_file(SETUP)
+            for k in env:
+                del os.environ[k]
+        yield made
+    finally:
+        for s in made.values():
+            s.close()
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_cell_proofs_fk20_matches_vectors_and_the_direct_form(kzg, forms, golden, blob_loader):
+    """The batch algorithm for cell proofs (FK20, kzg/src/das.rs:630-696: Toeplitz vectors, 64 transforms of 128,
+    128 MSMs of 64 points over x_ext_fft_columns, two G1 transforms) against the reference's vectors and against the
+    direct form (one fixed-base MSM per cell), which is what single blobs use."""
+    cases = [c for c in golden["compute_cells_and_kzg_proofs"] if c["output"] is not None]
+    blobs = b"".join(blob_loader(c["blob"]) for c in cases)
+    cells, proofs = kzg.compute_cells_and_kzg_proofs_batch(blobs, len(cases), forms["fk20"])
+    for k, c in enumerate(cases):
+        assert hashlib.sha256(proofs[k * 6144:(k + 1) * 6144]).hexdigest() == c["output"]["proofs_sha256"], c["name"]
+        assert hashlib.sha256(cells[k * 262144:(k + 1) * 262144]).hexdigest() == c["output"]["cells_sha256"], c["name"]
+    assert kzg.compute_cells_and_kzg_proofs_batch(blobs, len(cases), forms["direct"]) == (cells, proofs)
+    # a single blob through FK20 as well
+    _, p1 = kzg.compute_cells_and_kzg_proofs(blob_loader(cases[3]["blob"]), forms["fk20"], want_cells=False)
+    assert p1 == proofs[3 * 6144:4 * 6144]
+    # random blobs, batch of 70 (above the size from which FK20 is the default): default == FK20 == direct
+    rnd = random.Random(720)
+    n = 70
+    rb = bytearray(rnd.randbytes(n * BLOB))
+    for i in range(0, n * BLOB, 32):
+        rb[i] = 0
+    rb[5 * BLOB:6 * BLOB] = bytes(BLOB)  # the zero polynomial: every proof is the point at infinity
+    rb = bytes(rb)
+    _, p_default = kzg.compute_cells_and_kzg_proofs_batch(rb, n, forms["default"])
+    _, p_fk20 = kzg.compute_cells_and_kzg_proofs_batch(rb, n, forms["fk20"])
+    _, p_direct = kzg.compute_cells_and_kzg_proofs_batch(rb, n, forms["direct"])
+    assert p_default == p_direct and p_fk20 == p_direct
+    assert p_direct[5 * 6144:5 * 6144 + 48] == b"\xc0" + bytes(47)
+
+
+def test_proof_batch_with_device_sha_and_array_quotient(kzg, forms):
+    """KZGAMD_DEVICE_SHA=1 (the Fiat-Shamir hashes of a host-buffer batch on the GPU, no host threads) and
+    KZGAMD_QUOTIENT_ARRAYS=1 (k_quotient with per-thread arrays instead of the output slots): the same proofs, challenges
+    and evaluations as the default object, and the same rejections."""
+    rnd = random.Random(257)
+    n = 256
+    blobs = bytearray(rnd.randbytes(n * BLOB))
+    for i in range(0, n * BLOB, 32):
+        blobs[i] = 0
+    blobs[7 * BLOB:8 * BLOB] = bytes(BLOB)
+    blobs = bytes(blobs)
+    s1, s2 = forms["default"], forms["device_sha"]
+    cms = kzg.blob_to_kzg_commitment_batch(blobs, n, s1)
+    assert kzg.blob_to_kzg_commitment_batch(blobs, n, s2) == cms
+    proofs = kzg.compute_blob_kzg_proof_batch(blobs, b"".join(cms), n, s1)
+    assert kzg.compute_blob_kzg_proof_batch(blobs, b"".join(cms), n, s2) == proofs
+    assert kzg.compute_challenges_and_evaluate_batch(blobs, b"".join(cms), n, s2) == \
+        kzg.compute_challenges_and_evaluate_batch(blobs, b"".join(cms), n, s1)
+    assert kzg.verify_blob_kzg_proof_batch([blobs[i * BLOB:(i + 1) * BLOB] for i in range(0, n, 37)], cms[::37], proofs[::37], s2)
+    bad = bytearray(blobs)
+    bad[200 * BLOB + 64:200 * BLOB + 96] = b"\xff" * 32
+    with pytest.raises(kzg.KzgAmdError):
+        kzg.compute_blob_kzg_proof_batch(bytes(bad), b"".join(cms), n, s2)
+    badc = list(cms)
+    badc[130] = b"\x9f" + b"\xff" * 47
+    with pytest.raises(kzg.KzgAmdError):
+        kzg.compute_blob_kzg_proof_batch(blobs, b"".join(badc), n, s2)
+    assert kzg.compute_blob_kzg_proof_batch(blobs, b"".join(cms), n, s2) == proofs  # and recovers afterwards
+    # a mid-sized batch (one workgroup per blob in k_quotient, a single chunk)
+    m = 40
+    assert kzg.compute_blob_kzg_proof_batch(blobs[:m * BLOB], b"".join(cms[:m]), m, s2) == proofs[:m]
