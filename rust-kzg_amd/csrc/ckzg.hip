@@ -690,6 +690,99 @@ __global__ void __launch_bounds__(64) k_decode_check_g1(AffPt* __restrict__ out,
     status[i] = !CHECK || affpt_in_g1(p) ? 0 : 2;
 }
 
+// The decode of k_decode_check_g1<false> with the square root limb-parallel, FOUR POINTS PER WAVE (one per DPP row of
+// fpw.hip.h).  y = (x^3 + 4)^((p+1)/4) is a chain of 380 squarings that nothing shortens: in one lane 570 multiplications
+// of ~1 us each (the plain square-and-multiply of g1io::pow_sat), here 4-bit windows — 14 table products, then 4
+// squarings + at most one product per nibble of the exponent, 95 nibbles — of one row-parallel multiplication step each.
+// Lane 0 of a row parses its point and computes x^3 + 4 before the chain, and checks the root, picks the sign and writes
+// the slot after it: the same single-lane code as g1io::uncompress on either side of the chain.
+__global__ void __launch_bounds__(64) k_decode_g1_wide(AffPt* __restrict__ out, int* __restrict__ status,
+                                                       const unsigned char* __restrict__ in, size_t n) {
+    __shared__ u32 sh_in[4][16], sh_out[4][16];
+    const int lane = threadIdx.x, row = lane >> 4, li = lane & 15;
+    const size_t i = (size_t)blockIdx.x * 4 + row;
+    const bool mine = li == 0 && i < n;
+    bool chain = false, sort = false;
+    fp28::Fe x = fp28::zero(), y2 = fp28::zero();
+    sh_in[row][li] = 0;
+    fpw::wave_sync();
+    if (mine) {
+        unsigned char buf[48];
+        for (int k = 0; k < 48; ++k) buf[k] = in[48 * i + k];
+        const bool compressed = (buf[0] >> 7) & 1, infinity = (buf[0] >> 6) & 1;
+        sort = (buf[0] >> 5) & 1;
+        buf[0] &= 0x1f;
+        const ff::Fp xs = g1io::be48_to_sat(buf);
+        int st = 1;  // not a valid encoding, unless ...
+        if (compressed && infinity) {
+            if (!sort && xs.is_zero()) {
+                AffPt o;
+                o.flags = 1;
+                o.pad[0] = o.pad[1] = o.pad[2] = 0;
+                o.x = fp28::zero();
+                o.y = fp28::zero();
+                out[i] = o;
+                st = 0;
+            }
+        } else if (compressed && !g1io::sat_geq_p(xs)) {
+            x = g1io::from_plain(xs);
+            fp28::Fe b4;
+#pragma unroll
+            for (int k = 0; k < 14; ++k) b4.v[k] = g1io::b4_392_l(k);
+            y2 = fp28::addn(fp28::mul(fp28::sqr(x), x), b4);  // x^3 + 4, < 4p
+#pragma unroll
+            for (int k = 0; k < 14; ++k) sh_in[row][k] = y2.v[k];
+            chain = true;
+        }
+        if (!chain) status[i] = st;
+    }
+    fpw::wave_sync();
+    // the chain (rows without a point run it on zero)
+    const fpw::Lane lc = fpw::lane_consts(lane);
+    const u32 a = sh_in[row][li];
+    u32 t[16];
+    t[0] = 0;
+    t[1] = a;
+#pragma unroll
+    for (int k = 2; k < 16; ++k) t[k] = fpw::wmul4(t[k - 1], a, lc);
+    auto nibble = [](int j) -> u32 { return (g1io::p_sqrt_exp_l(j >> 3) >> (4 * (j & 7))) & 15u; };
+    auto pick = [&](u32 d) -> u32 {
+        u32 v = t[1];
+#pragma unroll
+        for (int k = 2; k < 16; ++k) v = d == (u32)k ? t[k] : v;
+        return v;
+    };
+    u32 acc = pick(nibble(94));  // the top nibble of (p+1)/4 is not zero
+#pragma unroll 1
+    for (int j = 93; j >= 0; --j) {
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) acc = fpw::wmul4(acc, acc, lc);
+        const u32 d = nibble(j);
+        if (d) acc = fpw::wmul4(acc, pick(d), lc);
+    }
+    sh_out[row][li] = fpw::wnorm_full(acc, lc);
+    fpw::wave_sync();
+    if (mine && chain) {
+        fp28::Fe y;
+#pragma unroll
+        for (int k = 0; k < 14; ++k) y.v[k] = sh_out[row][k];
+        const fp28::Fe chk = fp28::sub<8>(fp28::sqr(y), y2);
+        if (!fp28::is_zero_mod_p(chk)) {
+            status[i] = 1;  // x^3 + 4 is not a square: no such point
+        } else {
+            y = fp28::canon(y);
+            if (g1io::is_lex_largest(g1io::to_plain(y)) != sort) y = fp28::canon(fp28::neg<2>(y));
+            AffPt o;
+            o.flags = 0;
+            o.pad[0] = o.pad[1] = o.pad[2] = 0;
+            o.x = fp28::canon(x);
+            o.y = y;
+            out[i] = o;
+            status[i] = 0;
+        }
+    }
+}
+
 // The membership test of affpt_in_g1 with ONE WAVE PER POINT (g1w: the limbs of a coordinate across the lanes of a DPP
 // row, the independent products of a point formula in the four rows): 2 x (63 doublings + 5 additions) of 3 / 4
 // multiplication steps each instead of ~1 000 single-lane multiplications — the test is a latency chain (1.1 ms in one
@@ -741,10 +834,11 @@ __global__ void __launch_bounds__(64) k_affpts_in_g1_wide(int* __restrict__ stat
 
 // decode + membership test of np compressed points: up to WIDE_CHECK_MAX points the test runs one wave per point
 constexpr size_t WIDE_CHECK_MAX = 4096;
+constexpr size_t WIDE_COMMIT_CHECK_MAX = 512;  // ... the commitments of a proof batch: up to this many
 void decode_check_enqueue(AffPt* d_pts, int* d_stat, const unsigned char* d_bytes, size_t np, hipStream_t st, bool wide) {
     const dim3 grid((unsigned)((np + 63) / 64));
     if (wide && np <= WIDE_CHECK_MAX) {
-        hipLaunchKernelGGL(k_decode_check_g1<false>, grid, dim3(64), 0, st, d_pts, d_stat, d_bytes, np);
+        hipLaunchKernelGGL(k_decode_g1_wide, dim3((unsigned)((np + 3) / 4)), dim3(64), 0, st, d_pts, d_stat, d_bytes, np);
         hipLaunchKernelGGL(k_affpts_in_g1_wide, dim3((unsigned)np), dim3(64), 0, st, d_stat, (const AffPt*)d_pts, np);
     } else {
         hipLaunchKernelGGL(k_decode_check_g1<true>, grid, dim3(64), 0, st, d_pts, d_stat, d_bytes, np);
@@ -963,6 +1057,7 @@ struct KzgAmdSettings {
     unsigned char* d_proofs = nullptr;
     size_t cap_cells = 0;
     int* d_cstatus = nullptr;
+    AffPt* d_cpts = nullptr;  // decoded commitments of a proof batch of <= WIDE_COMMIT_CHECK_MAX blobs (wide check)
     std::mutex mu;
     // staging for the host-buffer entry points
     unsigned char* d_blobs = nullptr;
@@ -1118,6 +1213,7 @@ struct KzgAmdSettings {
         if (d_roots8192) (void)hipFree(d_roots8192);
         release_cells();
         if (d_cstatus) (void)hipFree(d_cstatus);
+        if (d_cpts) (void)hipFree(d_cpts);
         if (stream2 && stream2 != stream) (void)hipStreamDestroy(stream2);
         if (msm) kzgamd::msm_destroy(msm);
         if (d_blobs) (void)hipFree(d_blobs);
@@ -1160,6 +1256,8 @@ struct KzgAmdSettings {
         if (d_commit) (void)hipFree(d_commit);
         if (d_cstatus) (void)hipFree(d_cstatus);
         d_cstatus = nullptr;
+        if (d_cpts) (void)hipFree(d_cpts);
+        d_cpts = nullptr;
         d_blobs = nullptr;
         d_scalars = nullptr;
         d_status = nullptr;
@@ -1176,6 +1274,7 @@ struct KzgAmdSettings {
         CK_HIP(hipMalloc(&d_y, nblobs * 32));
         CK_HIP(hipMalloc(&d_commit, nblobs * 48));
         CK_HIP(hipMalloc(&d_cstatus, nblobs * sizeof(int)));
+        CK_HIP(hipMalloc(&d_cpts, WIDE_COMMIT_CHECK_MAX * sizeof(AffPt)));
         cap_blobs = nblobs;
     }
 };
@@ -1627,8 +1726,18 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
                 CK_HIP(hipEventRecord(dev->ev_commit, dev->stream2));
             }
             CK_HIP(hipMemsetAsync(dev->d_cstatus, 0, n * sizeof(int), dev->stream2));
-            hipLaunchKernelGGL(k_check_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, dev->stream2,
-                               dev->d_cstatus, (const unsigned char*)dev->d_commit, n);
+            // up to 512 commitments: square root and membership test limb-parallel (0.3 + 0.25 ms instead of 1.7 ms of
+            // single-lane chain; a wave per point is ~9x the instructions of a lane per point, which a larger batch,
+            // whose MSM hides the chain anyway, should not pay)
+            if (n <= WIDE_COMMIT_CHECK_MAX && dev->cfg_wide_check) {
+                hipLaunchKernelGGL(k_decode_g1_wide, dim3((unsigned)((n + 3) / 4)), dim3(64), 0, dev->stream2, dev->d_cpts,
+                                   dev->d_cstatus, (const unsigned char*)dev->d_commit, n);
+                hipLaunchKernelGGL(k_affpts_in_g1_wide, dim3((unsigned)n), dim3(64), 0, dev->stream2, dev->d_cstatus,
+                                   (const AffPt*)dev->d_cpts, n);
+            } else {
+                hipLaunchKernelGGL(k_check_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, dev->stream2,
+                                   dev->d_cstatus, (const unsigned char*)dev->d_commit, n);
+            }
             // its result is fetched at the very end: a device-to-host copy into pageable memory blocks the calling
             // thread until the kernel is done (1.7 ms for 256 commitments), and nothing below depends on it
         }
