@@ -835,13 +835,19 @@ __global__ void __launch_bounds__(64) k_affpts_in_g1_wide(int* __restrict__ stat
 // decode + membership test of np compressed points: up to WIDE_CHECK_MAX points the test runs one wave per point
 constexpr size_t WIDE_CHECK_MAX = 4096;
 constexpr size_t WIDE_COMMIT_CHECK_MAX = 512;  // ... the commitments of a proof batch: up to this many
-void decode_check_enqueue(AffPt* d_pts, int* d_stat, const unsigned char* d_bytes, size_t np, hipStream_t st, bool wide) {
+// `decoded` (optional) is recorded when the slots are written — before the membership test in the two-kernel form, so a
+// consumer that only needs the points (the MSM of a verification call, whose result is thrown away if a test fails) can
+// start while the test still runs
+void decode_check_enqueue(AffPt* d_pts, int* d_stat, const unsigned char* d_bytes, size_t np, hipStream_t st, bool wide,
+                          hipEvent_t decoded = nullptr) {
     const dim3 grid((unsigned)((np + 63) / 64));
     if (wide && np <= WIDE_CHECK_MAX) {
         hipLaunchKernelGGL(k_decode_g1_wide, dim3((unsigned)((np + 3) / 4)), dim3(64), 0, st, d_pts, d_stat, d_bytes, np);
+        if (decoded) (void)hipEventRecord(decoded, st);
         hipLaunchKernelGGL(k_affpts_in_g1_wide, dim3((unsigned)np), dim3(64), 0, st, d_stat, (const AffPt*)d_pts, np);
     } else {
         hipLaunchKernelGGL(k_decode_check_g1<true>, grid, dim3(64), 0, st, d_pts, d_stat, d_bytes, np);
+        if (decoded) (void)hipEventRecord(decoded, st);
     }
 }
 
@@ -991,6 +997,7 @@ struct KzgAmdSettings {
     // measurement switches, read once when the settings object is created
     bool cfg_device_sha = getenv("KZGAMD_DEVICE_SHA") && atoi(getenv("KZGAMD_DEVICE_SHA")) != 0;
     bool cfg_quotient_arrays = env_int("KZGAMD_QUOTIENT_ARRAYS", 0, 0, 1) != 0;
+    size_t cfg_host_check_max = (size_t)env_int("KZGAMD_HOST_CHECK_MAX", 64, 0, 1 << 20);  // see HOST_CHECK_MAX
     size_t cfg_prove_chunk = (size_t)env_int("KZGAMD_PROVE_CHUNK", 0, 0, 1 << 20);
     bool cfg_wide_check = !(getenv("KZGAMD_WIDE_CHECK") && atoi(getenv("KZGAMD_WIDE_CHECK")) == 0);  // 0: single-lane tests
     size_t cfg_prove_first = (size_t)env_int("KZGAMD_PROVE_FIRST", 0, 0, 1 << 20);
@@ -1084,6 +1091,7 @@ struct KzgAmdSettings {
     unsigned char* d_vbytes = nullptr;
     AffPt* d_vpts = nullptr;
     int* d_vstat = nullptr;
+    hipEvent_t ev_decoded = nullptr;  // the points of a verification call are decoded (their membership test may still run)
     size_t vcap = 0;
     kzgamd::MsmContext* msm_verify = nullptr;
     void ensure_verify(size_t np) {
@@ -1188,6 +1196,7 @@ struct KzgAmdSettings {
         if (ev_commit) (void)hipEventDestroy(ev_commit);
         if (ev_cells) (void)hipEventDestroy(ev_cells);
         if (msm_verify) kzgamd::msm_destroy(msm_verify);
+        if (ev_decoded) (void)hipEventDestroy(ev_decoded);
         if (d_vbytes) (void)hipFree(d_vbytes);
         if (d_vpts) (void)hipFree(d_vpts);
         if (d_vstat) (void)hipFree(d_vstat);
@@ -1711,7 +1720,7 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
     // a CPU core than in one GPU lane); a batch: one lane each on a second stream.
     // (the device check is a 1.7 ms latency chain whatever the count; a host core takes ~0.2 ms per commitment with
     // 64-bit limbs, and the hashing pool does them in parallel while the GPU proves: up to 64 blobs the host wins)
-    const bool host_check = derive && n <= HOST_CHECK_MAX && !commitments_checked_elsewhere;
+    const bool host_check = derive && n <= dev->cfg_host_check_max && !commitments_checked_elsewhere;
     // KZGAMD_DEVICE_SHA=1: the Fiat-Shamir hashes of a host-buffer batch on the GPU too (k_challenge_sha256, one lane per
     // blob: 2050 serial compressions, ~8 ms however many blobs) and no host threads at all.  Measured against the host
     // pool: 256 blobs 22 k vs 50 k proofs/s, 1024 blobs 47 k vs 66 k, 4096 blobs 72 k vs 78 k — the kernel only pays when
@@ -2696,7 +2705,8 @@ void verify_g1_begin(const Bytes48* commitments, const Bytes48* proofs, size_t n
     CK_HIP(hipMemcpyAsync(dev->d_vbytes, dev->vstage.data(), dev->vstage.size(), hipMemcpyHostToDevice, st));
     CK_HIP(hipMemsetAsync(dev->d_vstat, 0, np * sizeof(int), st));
     CK_HIP(hipMemsetAsync(dev->d_vpts, 0, np * sizeof(AffPt), st));
-    decode_check_enqueue(dev->d_vpts, dev->d_vstat, (const unsigned char*)dev->d_vbytes, np, st, dev->cfg_wide_check);
+    if (!dev->ev_decoded) CK_HIP(hipEventCreateWithFlags(&dev->ev_decoded, hipEventDisableTiming));
+    decode_check_enqueue(dev->d_vpts, dev->d_vstat, (const unsigned char*)dev->d_vbytes, np, st, dev->cfg_wide_check, dev->ev_decoded);
     CK_HIP(hipGetLastError());
 }
 
@@ -2750,6 +2760,20 @@ void verify_g1_finish(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commi
         }
         sc[np + 2 * n] = ff::neg(sy);            // row 1: generator
     }
+    // The MSM starts as soon as the points are decoded, next to their membership test (0.25 ms on stream2): if a point
+    // fails it — or is no encoding at all: its slot stays zero — the sums below are garbage that nobody reads.
+    blst_p1 out[2];
+    if (scalars_ok) {
+        try {
+            CK_HIP(hipEventSynchronize(dev->ev_decoded));
+            if (!dev->msm_verify) dev->msm_verify = kzgamd::msm_create(dev->d_vpts, np, true, false, true);
+            else kzgamd::msm_reset_points(dev->msm_verify, dev->d_vpts, np);
+            kzgamd::msm_run_host(dev->msm_verify, out, sc.data(), np, 2);
+        } catch (...) {
+            (void)hipStreamSynchronize(st);  // nothing of this call stays in flight
+            throw;
+        }
+    }
     std::vector<int> stat(np);
     CK_HIP(hipMemcpyAsync(stat.data(), dev->d_vstat, np * sizeof(int), hipMemcpyDeviceToHost, st));
     CK_HIP(hipStreamSynchronize(st));
@@ -2757,10 +2781,6 @@ void verify_g1_finish(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commi
     for (size_t i = 0; i < np; ++i) CK_REQUIRE(stat[i] != 1, "Invalid G1 encoding");
     for (size_t i = 0; i < n; ++i) CK_REQUIRE(stat[i] == 0, "Invalid proof");
     for (size_t i = n; i < 2 * n; ++i) CK_REQUIRE(stat[i] == 0, "Invalid commitment");
-    if (!dev->msm_verify) dev->msm_verify = kzgamd::msm_create(dev->d_vpts, np, true, false, true);
-    else kzgamd::msm_reset_points(dev->msm_verify, dev->d_vpts, np);
-    blst_p1 out[2];
-    kzgamd::msm_run_host(dev->msm_verify, out, sc.data(), np, 2);
     *proof_lincomb = out[0];
     *rhs = out[1];
 }
@@ -3052,7 +3072,8 @@ void decode_points_begin(KzgAmdSettings* dev, const std::vector<uint8_t>& bytes,
     CK_HIP(hipMemcpyAsync(dev->d_vbytes, dev->vstage.data(), np * 48, hipMemcpyHostToDevice, st));
     CK_HIP(hipMemsetAsync(dev->d_vstat, 0, np * sizeof(int), st));
     CK_HIP(hipMemsetAsync(dev->d_vpts, 0, np * sizeof(AffPt), st));
-    decode_check_enqueue(dev->d_vpts, dev->d_vstat, (const unsigned char*)dev->d_vbytes, np, st, dev->cfg_wide_check);
+    if (!dev->ev_decoded) CK_HIP(hipEventCreateWithFlags(&dev->ev_decoded, hipEventDisableTiming));
+    decode_check_enqueue(dev->d_vpts, dev->d_vstat, (const unsigned char*)dev->d_vbytes, np, st, dev->cfg_wide_check, dev->ev_decoded);
     CK_HIP(hipGetLastError());
 }
 std::vector<int> decode_points_status(KzgAmdSettings* dev, size_t np) {
@@ -3180,19 +3201,24 @@ void verify_cells(bool* ok, const Bytes48* commitments_bytes, const uint64_t* ce
     }
     for (size_t k = 0; k < CELL_SIZE; ++k) interp[k] = ff::to_mont(interp[k]);  // the kernels work on canonical values
     for (size_t k = 0; k < CELL_SIZE; ++k) sc[np + n + m + k] = ff::neg(interp[k]);
+    // the MSM next to the membership test of its points, as in verify_g1_finish
+    blst_p1 out[2];
+    try {
+        std::lock_guard<std::mutex> lk(dev->mu);
+        kzgamd::DeviceGuard on_device(dev->device);
+        CK_HIP(on_device.err);
+        CK_HIP(hipEventSynchronize(dev->ev_decoded));
+        if (!dev->msm_verify) dev->msm_verify = kzgamd::msm_create(dev->d_vpts, np, true, false, true);
+        else kzgamd::msm_reset_points(dev->msm_verify, dev->d_vpts, np);
+        kzgamd::msm_run_host(dev->msm_verify, out, sc.data(), np, 2);
+    } catch (...) {
+        (void)decode_points_status(dev, np);  // nothing of this call stays in flight
+        throw;
+    }
     const std::vector<int> stat = decode_points_status(dev, np);
     for (size_t i = 0; i < np; ++i) CK_REQUIRE(stat[i] != 1, "Invalid G1 encoding");
     for (size_t i = 0; i < n; ++i) CK_REQUIRE(stat[i] == 0, "Proof is not valid");
     for (size_t i = n; i < n + m; ++i) CK_REQUIRE(stat[i] == 0, "Commitment is not valid");
-    blst_p1 out[2];
-    {
-        std::lock_guard<std::mutex> lk(dev->mu);
-        kzgamd::DeviceGuard on_device(dev->device);
-        CK_HIP(on_device.err);
-        if (!dev->msm_verify) dev->msm_verify = kzgamd::msm_create(dev->d_vpts, np, true, false, true);
-        else kzgamd::msm_reset_points(dev->msm_verify, dev->d_vpts, np);
-        kzgamd::msm_run_host(dev->msm_verify, out, sc.data(), np, 2);
-    }
     blst_p2 g2gen, g2s64;
     const kzgamd::pairing::G2Jac gen = kzgamd::pairing::g2_generator();
     memcpy(&g2gen, &gen, sizeof g2gen);
