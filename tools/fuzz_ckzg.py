@@ -73,6 +73,13 @@ while time.time() < t_end:
         ey = C.create_string_buffer(32)
         assert L.ocompute_kzg_proof(ep, ey, blobs[b], zs[b], C.byref(os_)) == 0
         assert ys[b] == ey.raw, ("evaluate", n, b, seed, cases)
+    # the verification entry points on what was just produced (decode + membership test + two-row MSM on the GPU, pairing on
+    # the host): the batch verifies, and does not with two proofs exchanged (unless they are equal)
+    assert kzg.verify_blob_kzg_proof_batch(blobs, cms, proofs, s), ("verify batch", n, seed, cases)
+    if n >= 2 and proofs[0] != proofs[1]:
+        swapped = [proofs[1], proofs[0]] + list(proofs[2:])
+        assert not kzg.verify_blob_kzg_proof_batch(blobs, cms, swapped, s), ("verify swapped", n, seed, cases)
+    assert kzg.verify_kzg_proof(cms[0], zs[0], ys[0], proofs[0], s), ("verify_kzg_proof", seed, cases)
     # compute_kzg_proof at chosen points: in the domain (even powers of the 8192-th root) and outside
     z = rnd.choice([pow(roots[1], 2 * rnd.randrange(4096), O.R), rnd.randrange(O.R), 0, 1, O.R - 1])
     zb = z.to_bytes(32, "big")
