@@ -1129,6 +1129,7 @@ struct KzgAmdSettings {
     }
     // EIP-7594 cell verification / recovery state, built on first use
     std::vector<uint8_t> mono64_bytes;  // g1_values_monomial[0..64) compressed (the interpolation-polynomial commitment)
+    AffPt* d_mono64 = nullptr;          // ... decoded and subgroup-checked once, as MSM slots
     ff::Fr* d_rec[4] = {nullptr, nullptr, nullptr, nullptr};  // recovery: four vectors of 8192 field elements
     u32* d_rec_in = nullptr;         // up to 128 cells as canonical limbs
     u32* d_rec_idx = nullptr;        // their cell indices
@@ -1150,7 +1151,7 @@ struct KzgAmdSettings {
         cap_vc = 0;
         const size_t cap = n < 128 ? 128 : n;
         CK_HIP(hipMalloc(&d_vc_cells, cap * CELL_SIZE * 32));
-        CK_HIP(hipMalloc(&d_vc_cols, cap * sizeof(u32)));
+        CK_HIP(hipMalloc(&d_vc_cols, (cap + 2 * CELLS_PER_BLOB + 1) * sizeof(u32)));
         CK_HIP(hipMalloc(&d_vc_pw, cap * sizeof(ff::Fr)));
         cap_vc = cap;
     }
@@ -1197,6 +1198,7 @@ struct KzgAmdSettings {
         if (ev_cells) (void)hipEventDestroy(ev_cells);
         if (msm_verify) kzgamd::msm_destroy(msm_verify);
         if (ev_decoded) (void)hipEventDestroy(ev_decoded);
+        if (d_mono64) (void)hipFree(d_mono64);
         if (d_vbytes) (void)hipFree(d_vbytes);
         if (d_vpts) (void)hipFree(d_vpts);
         if (d_vstat) (void)hipFree(d_vstat);
@@ -3062,16 +3064,19 @@ bool cells_to_limbs(std::vector<ff::Fr>& out, const Cell* cells, size_t ncells) 
 
 // decode `np` compressed G1 points on the GPU (stream2): AffPt slots in dev->d_vpts, per-point status in dev->d_vstat
 // (0 ok, 1 not an encoding of a curve point, 2 on the curve but outside G1).  Caller holds dev->vmu.
-void decode_points_begin(KzgAmdSettings* dev, const std::vector<uint8_t>& bytes, size_t np) {
+// `tail` (optional): `ntail` slots decoded and checked by an earlier call, appended behind the np decoded ones (status 0)
+void decode_points_begin(KzgAmdSettings* dev, const std::vector<uint8_t>& bytes, size_t np, const AffPt* tail = nullptr,
+                         size_t ntail = 0) {
     std::lock_guard<std::mutex> lk(dev->mu);
     kzgamd::DeviceGuard on_device(dev->device);
     CK_HIP(on_device.err);
-    dev->ensure_verify(np);
+    dev->ensure_verify(np + ntail);
     dev->vstage = bytes;
     hipStream_t st = dev->stream2;
     CK_HIP(hipMemcpyAsync(dev->d_vbytes, dev->vstage.data(), np * 48, hipMemcpyHostToDevice, st));
-    CK_HIP(hipMemsetAsync(dev->d_vstat, 0, np * sizeof(int), st));
+    CK_HIP(hipMemsetAsync(dev->d_vstat, 0, (np + ntail) * sizeof(int), st));
     CK_HIP(hipMemsetAsync(dev->d_vpts, 0, np * sizeof(AffPt), st));
+    if (ntail) CK_HIP(hipMemcpyAsync(dev->d_vpts + np, tail, ntail * sizeof(AffPt), hipMemcpyDeviceToDevice, st));
     if (!dev->ev_decoded) CK_HIP(hipEventCreateWithFlags(&dev->ev_decoded, hipEventDisableTiming));
     decode_check_enqueue(dev->d_vpts, dev->d_vstat, (const unsigned char*)dev->d_vbytes, np, st, dev->cfg_wide_check, dev->ev_decoded);
     CK_HIP(hipGetLastError());
@@ -3093,14 +3098,16 @@ std::vector<int> decode_points_status(KzgAmdSettings* dev, size_t np) {
 // elements canonical: the products and sums stay canonical; columns nobody asked about stay zero);
 // then 128 inverse transforms of 64 values (ntt.hip);
 // k_vcell_interp: interp[k] = sum_col v[col][k] * h_col^-k,  h_col^-k = roots_of_unity[(8192 - rbl7(col)) k mod 8192].
+// cols = [start of column 0 .. 128 in `order` (129 words) | order: the cells' indices grouped by column, ascending inside]
 __global__ void __launch_bounds__(256) k_vcell_agg(ff::Fr* __restrict__ agg, const u32* __restrict__ cells,
-                                                   const u32* __restrict__ cols, const ff::Fr* __restrict__ pw, size_t n) {
+                                                   const u32* __restrict__ cols, const ff::Fr* __restrict__ pw) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= CELLS_PER_EXT_BLOB * CELL_SIZE) return;
     const u32 col = t >> 6, f = t & 63u;
     ff::Fr acc = ff::Fr::zero();
-    for (size_t i = 0; i < n; ++i) {
-        if (cols[i] != col) continue;
+    const u32* order = cols + CELLS_PER_EXT_BLOB + 1;
+    for (u32 j = cols[col]; j < cols[col + 1]; ++j) {
+        const size_t i = order[j];
         ff::Fr c;
 #pragma unroll
         for (int k = 0; k < 8; ++k) c.v[k] = cells[(i * CELL_SIZE + f) * 8 + k];
@@ -3148,11 +3155,14 @@ void verify_cells(bool* ok, const Bytes48* commitments_bytes, const uint64_t* ce
         dev->mono64_bytes.resize(CELL_SIZE * 48);
         compress_on_host(dev->mono64_bytes.data(), cs->g1_values_monomial, CELL_SIZE);
     }
-    std::vector<uint8_t> stage(np * 48);
+    // the 64 setup points are decoded and tested by the first call of a settings object and kept as slots (d_mono64)
+    const bool have_mono = dev->d_mono64 != nullptr;
+    const size_t ndec = have_mono ? n + m : np;
+    std::vector<uint8_t> stage(ndec * 48);
     memcpy(stage.data(), proofs_bytes, n * 48);
     memcpy(stage.data() + n * 48, uniq.data(), m * 48);
-    memcpy(stage.data() + (n + m) * 48, dev->mono64_bytes.data(), CELL_SIZE * 48);
-    decode_points_begin(dev, stage, np);
+    if (!have_mono) memcpy(stage.data() + (n + m) * 48, dev->mono64_bytes.data(), CELL_SIZE * 48);
+    decode_points_begin(dev, stage, ndec, dev->d_mono64, have_mono ? CELL_SIZE : 0);
     // host, meanwhile (the decode + subgroup tests are 0.75 ms of GPU latency): the cells' field elements, ...
     std::vector<ff::Fr> cf;
     if (!cells_to_limbs(cf, cells, n)) {
@@ -3163,7 +3173,13 @@ void verify_cells(bool* ok, const Bytes48* commitments_bytes, const uint64_t* ce
     const ff::Fr r = cell_batch_challenge(uniq.data(), m, cidx.data(), cell_indices, cells, proofs_bytes, n);
     std::vector<ff::Fr> sc(2 * np, ff::Fr::zero());
     std::vector<ff::Fr> pws(n);
-    std::vector<u32> cols32(n);
+    std::vector<u32> cols32(CELLS_PER_EXT_BLOB + 1 + n, 0u);  // column starts, then the cells grouped by column (k_vcell_agg)
+    for (size_t i = 0; i < n; ++i) ++cols32[(size_t)cell_indices[i] + 1];
+    for (size_t c = 0; c < CELLS_PER_EXT_BLOB; ++c) cols32[c + 1] += cols32[c];
+    {
+        std::vector<u32> cursor(cols32.begin(), cols32.begin() + CELLS_PER_EXT_BLOB);
+        for (size_t i = 0; i < n; ++i) cols32[CELLS_PER_EXT_BLOB + 1 + cursor[(size_t)cell_indices[i]]++] = (u32)i;
+    }
     ff::Fr pw = ff::Fr::one();
     for (size_t i = 0; i < n; ++i) {
         const size_t col = (size_t)cell_indices[i];
@@ -3171,7 +3187,6 @@ void verify_cells(bool* ok, const Bytes48* commitments_bytes, const uint64_t* ce
         sc[np + i] = ff::mul(pw, roots[rbl7((u32)col) * CELL_SIZE]);                    // row 1: r^i * h_k^64 (:837-884)
         sc[np + n + cidx[i]] = ff::add(sc[np + n + cidx[i]], pw);                       // row 1: commitment weights (:698-743)
         pws[i] = pw;
-        cols32[i] = (u32)col;
         pw = ff::mul(pw, r);
     }
     // the aggregated interpolation polynomial (:778-835) on the GPU: k_vcell_agg, 128 inverse transforms of 64, k_vcell_interp
@@ -3188,10 +3203,10 @@ void verify_cells(bool* ok, const Bytes48* commitments_bytes, const uint64_t* ce
         }
         hipStream_t st = dev->stream;
         CK_HIP(hipMemcpyAsync(dev->d_vc_cells, cf.data(), n * CELL_SIZE * 32, hipMemcpyHostToDevice, st));
-        CK_HIP(hipMemcpyAsync(dev->d_vc_cols, cols32.data(), n * sizeof(u32), hipMemcpyHostToDevice, st));
+        CK_HIP(hipMemcpyAsync(dev->d_vc_cols, cols32.data(), cols32.size() * sizeof(u32), hipMemcpyHostToDevice, st));
         CK_HIP(hipMemcpyAsync(dev->d_vc_pw, pws.data(), n * sizeof(ff::Fr), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_vcell_agg, dim3((unsigned)(CELLS_PER_EXT_BLOB * CELL_SIZE / 256)), dim3(256), 0, st, dev->d_rec[0],
-                           (const u32*)dev->d_vc_cells, (const u32*)dev->d_vc_cols, (const ff::Fr*)dev->d_vc_pw, n);
+                           (const u32*)dev->d_vc_cells, (const u32*)dev->d_vc_cols, (const ff::Fr*)dev->d_vc_pw);
         if (kzgamd_ntt_fr_device(dev->ntt, dev->d_rec[1], dev->d_rec[0], CELL_SIZE, CELLS_PER_EXT_BLOB, 1, st) != 0)
             throw CkErr{C_KZG_ERROR, "ntt"};
         hipLaunchKernelGGL(k_vcell_interp, dim3((unsigned)CELL_SIZE), dim3((unsigned)CELLS_PER_EXT_BLOB), 0, st, dev->d_rec[2],
@@ -3219,6 +3234,19 @@ void verify_cells(bool* ok, const Bytes48* commitments_bytes, const uint64_t* ce
     for (size_t i = 0; i < np; ++i) CK_REQUIRE(stat[i] != 1, "Invalid G1 encoding");
     for (size_t i = 0; i < n; ++i) CK_REQUIRE(stat[i] == 0, "Proof is not valid");
     for (size_t i = n; i < n + m; ++i) CK_REQUIRE(stat[i] == 0, "Commitment is not valid");
+    if (!have_mono) {
+        bool mono_ok = true;
+        for (size_t i = n + m; i < np; ++i) mono_ok = mono_ok && stat[i] == 0;
+        if (mono_ok) {
+            std::lock_guard<std::mutex> lk(dev->mu);
+            kzgamd::DeviceGuard on_device(dev->device);
+            CK_HIP(on_device.err);
+            AffPt* keep = nullptr;
+            CK_HIP(hipMalloc(&keep, CELL_SIZE * sizeof(AffPt)));
+            if (hipMemcpy(keep, dev->d_vpts + n + m, CELL_SIZE * sizeof(AffPt), hipMemcpyDeviceToDevice) == hipSuccess) dev->d_mono64 = keep;
+            else (void)hipFree(keep);
+        }
+    }
     blst_p2 g2gen, g2s64;
     const kzgamd::pairing::G2Jac gen = kzgamd::pairing::g2_generator();
     memcpy(&g2gen, &gen, sizeof g2gen);
