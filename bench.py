@@ -682,7 +682,7 @@ def main():
                 raise RuntimeError("kzgamd_compute_cells_and_kzg_proofs_batch: %d" % rc)
 
         small = {}
-        for nn in (16, 64):
+        for nn in (1, 4, 8, 16, 64):  # 1 and 2 blobs: the direct form; from 3 blobs FK20
             cells_n(nn)
             t0 = time.perf_counter()
             cells_n(nn)

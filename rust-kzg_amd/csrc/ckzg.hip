@@ -226,7 +226,10 @@ class WorkerPool {
 };
 
 constexpr int QT = 512;            // threads per blob
-constexpr size_t FK20_MIN_BLOBS = 16;  // cell proofs by FK20 from this batch size (measured crossover: 25 ms either way)
+// cell proofs by FK20 from this batch size.  Re-measured after the G1 stages were rewritten (round 4, tools/time_cells.py,
+// one settings object per form): 1 / 2 / 3 / 4 / 8 / 16 blobs FK20 4.15 / 4.16 / 4.23 / 4.25 / 4.29 / 5.32 ms, direct form
+// 1.91 / 3.16 / 4.52 / 5.75 / 10.88 / 20.65 ms (round 3's crossover was 16 blobs at 25 ms either way)
+constexpr size_t FK20_MIN_BLOBS = 3;
 constexpr size_t PROVE_CHUNK = 64;  // blobs per pipeline stage of a large compute_blob_kzg_proof batch
 constexpr size_t COMMIT_CHUNK = 64;   // smallest pipeline stage of a blob_to_kzg_commitment batch (batches from twice this are pipelined)
 constexpr size_t QSPLIT_MAX = 16;  // up to this many blobs (a lane batch) run the multi-workgroup variant (k_quotient_a/b)
