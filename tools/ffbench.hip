@@ -304,6 +304,42 @@ __device__ __host__ inline ff28::Fp28 mul28_karatsuba(const ff28::Fp28& a, const
     return r;
 }
 
+// The same product with as much instruction-level parallelism as the data flow has: the 27 column sums of a*b on 27
+// independent chains, then the Montgomery reduction operand-wise — once m[k] is known its 13 products m[k]*p[j] go to 13
+// different columns at once, and the serial path is only  column k complete -> m[k] -> m[k]*p[1] into column k+1 -> carry.
+// (The product-scanning form keeps two chains per column.)  For kernels that run ONE wave per SIMD, where nothing else
+// fills the issue slots; costs 27 64-bit accumulators.
+__device__ __host__ inline ff28::Fp28 mul28_ilp(const ff28::Fp28& a, const ff28::Fp28& b) {
+    using namespace ff28;
+    typedef unsigned long long u64_;
+    u64_ col[2 * L - 1];
+#pragma unroll
+    for (int k = 0; k < 2 * L - 1; ++k) {
+        u64_ s = 0;
+#pragma unroll
+        for (int i = (k < L ? 0 : k - L + 1); i <= (k < L ? k : L - 1); ++i) s += (u64_)a.v[i] * b.v[k - i];
+        col[k] = s;
+    }
+    Fp28 r;
+    u64_ carry = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const u64_ t = col[k] + carry;
+        const u32 m = ((u32)t * P0INV) & MASK;
+#pragma unroll
+        for (int j = 1; j < L; ++j) col[k + j] += (u64_)m * p28(j);
+        carry = (t + (u64_)m * p28(0)) >> 28;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; ++k) {
+        const u64_ t = col[k] + carry;
+        r.v[k - L] = (u32)t & MASK;
+        carry = t >> 28;
+    }
+    r.v[L - 1] = (u32)carry;
+    return r;
+}
+
 template <int V>
 __global__ void __launch_bounds__(256) mul_kernel(const Fp* in, Fp* out, int iters) {
     int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -346,13 +382,21 @@ __global__ void __launch_bounds__(256) mul_kernel(const Fp* in, Fp* out, int ite
         }
         out[2 * tid] = ff28::to_sat(a);
         out[2 * tid + 1] = ff28::to_sat(b);
+    } else if (V == 5) {
+        ff28::Fp28 a = ff28::from_sat(x), b = ff28::from_sat(y);
+        for (int i = 0; i < iters; ++i) {
+            a = mul28_ilp(a, b);
+            b = mul28_ilp(b, a);
+        }
+        out[2 * tid] = ff28::to_sat(a);
+        out[2 * tid + 1] = ff28::to_sat(b);
     }
 }
 
 static void host_ref(const Fp* in, Fp* out, int n, int iters, int V) {
     for (int t = 0; t < n; ++t) {
         Fp x = in[2 * t], y = in[2 * t + 1];
-        if (V == 1 || V == 3 || V == 4) {
+        if (V == 1 || V == 3 || V == 4 || V == 5) {
             ff28::Fp28 a = ff28::from_sat(x), b = ff28::from_sat(y);
             for (int i = 0; i < iters; ++i) {
                 a = ff28::mul(a, b);
@@ -376,9 +420,10 @@ static void host_ref(const Fp* in, Fp* out, int n, int iters, int V) {
     }
 }
 
+// blocks = 2048: eight waves per SIMD (throughput); 256 / 512: ONE / TWO waves per SIMD — the latency of a dependent chain
 template <int V>
-static void run_mul(const char* name) {
-    const int blocks = 256 * 8, threads = 256, n = blocks * threads, iters = 200;
+static void run_mul(const char* name, int blocks = 256 * 8) {
+    const int threads = 256, n = blocks * threads, iters = 200;
     std::vector<Fp> h(2 * n), ho(2 * n), ref(2 * 64);
     unsigned long long s = 88172645463325252ull;
     for (auto& f : h) {
@@ -411,8 +456,8 @@ static void run_mul(const char* name) {
     for (int i = 0; i < 128; ++i)
         if (ref[i] != ho[i]) ++bad;
     double ops = (double)n * iters * 2;
-    printf("%-28s %8.3f ms  %8.2f G op/s   mismatches(vs host, 128 samples)=%d\n", name, ms, ops / (ms * 1e-3) * 1e-9,
-           bad);
+    printf("%-28s %4d blocks %8.3f ms  %8.2f G op/s  %7.1f ns per dependent product  mismatches(vs host, 128 samples)=%d\n", name,
+           blocks, ms, ops / (ms * 1e-3) * 1e-9, ms * 1e6 / (iters * 2), bad);
     CK(hipFree(din));
     CK(hipFree(dout));
 }
@@ -450,5 +495,11 @@ int main() {
     run_mul<4>("fp mul 14x28, Karatsuba (again)");
     run_mul<3>("fp mul 14x28, one chain (again)");
     run_mul<2>("fp add+sub 12x32");
+    run_mul<5>("fp mul 14x28, ILP form");
+    for (int rep = 0; rep < 2; ++rep)
+        for (int blocks : {256, 512}) {
+            run_mul<1>("fp mul 14x28 comba", blocks);
+            run_mul<5>("fp mul 14x28, ILP form", blocks);
+        }
     return 0;
 }
