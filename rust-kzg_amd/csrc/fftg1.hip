@@ -215,7 +215,7 @@ __device__ __forceinline__ bool dadd_body<1>(Xyzz& acc, const Xyzz& b, int) {
     const Fe ppp = mul(p, pp);
     const Fe q = mul(u, pp);
     const Fe x3 = sub<8>(sqr(rr_), addn(add(q, q), ppp));
-    acc.y = sub<4>(mul(rr_, sub<16>(q, x3)), mul(s, ppp));
+    acc.y = mul2_inline(rr_, sub<16>(q, x3), sub_lazy<8>(zero(), s), ppp);  // R*(Q - X3) - S*PPP, one reduction
     acc.x = x3;
     acc.zz = mul(mul(acc.zz, b.zz), pp);
     acc.zzz = mul(mul(acc.zzz, b.zzz), ppp);

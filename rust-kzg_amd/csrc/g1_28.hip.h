@@ -76,7 +76,8 @@ FF_HD void dbl(Xyzz& acc) {
     Fe m = sqr(acc.x);
     Fe m3 = addn(add(m, m), m);
     Fe x3 = sub<8>(sqr(m3), addn(s, s));
-    Fe y3 = sub<4>(mul(m3, sub<16>(s, x3)), mul(w, acc.y));
+    // Y3 = M*(S - X3) - W*Y as one two-product reduction, as in madd
+    Fe y3 = mul2_inline(m3, sub<16>(s, x3), w, sub_lazy<8>(zero(), acc.y));
     acc.x = x3;
     acc.y = y3;
     acc.zz = mul(acc.zz, v);
@@ -134,7 +135,7 @@ FF_HD bool dadd_unequal(Xyzz& acc, const Xyzz& b) {
     Fe ppp = mul(p, pp);
     Fe q = mul(u, pp);
     Fe x3 = sub<8>(sqr(r), addn(add(q, q), ppp));
-    Fe y3 = sub<4>(mul(r, sub<16>(q, x3)), mul(s, ppp));
+    Fe y3 = mul2_inline(r, sub<16>(q, x3), sub_lazy<8>(zero(), s), ppp);  // R*(Q - X3) - S*PPP, one reduction
     acc.x = x3;
     acc.y = y3;
     acc.zz = mul(mul(acc.zz, b.zz), pp);
@@ -163,7 +164,7 @@ FF_HD void dadd(Xyzz& acc, const Xyzz& b) {
     Fe ppp = mul(p, pp);
     Fe q = mul(u, pp);
     Fe x3 = sub<8>(sqr(r), addn(add(q, q), ppp));
-    Fe y3 = sub<4>(mul(r, sub<16>(q, x3)), mul(s, ppp));
+    Fe y3 = mul2_inline(r, sub<16>(q, x3), sub_lazy<8>(zero(), s), ppp);  // R*(Q - X3) - S*PPP, one reduction
     acc.x = x3;
     acc.y = y3;
     acc.zz = mul(mul(acc.zz, b.zz), pp);
