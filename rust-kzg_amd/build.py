@@ -75,31 +75,54 @@ def _obj_stale(src, obj):
     return False
 
 
-def build(force=False, verbose=False):
+def _compile_and_link(lib, tag, defines, force, verbose):
+    """Objects <source><tag>.o (parallel hipcc, rebuilt by their .d files) -> lib."""
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     for s in srcs:
-        o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        o = os.path.join(CSRC, s.replace(".hip", tag + ".o"))
         objs.append(o)
         if not force and not _obj_stale(os.path.join(CSRC, s), o):
             continue
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-MD", "-MF", o[:-2] + ".d", "-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + defines + ["-MD", "-MF", o[:-2] + ".d", "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, cwd=CSRC)))
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + s)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
-    subprocess.check_call(cmd, cwd=CSRC)
-    return LIB
+    if procs or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lpthread"]
+        subprocess.check_call(cmd, cwd=CSRC)
+    return lib
+
+
+def build(force=False, verbose=False):
+    """The product library.  KZGAMD_REBUILD=1 in the environment forces a full recompilation (what a fresh clone does)."""
+    force = force or os.environ.get("KZGAMD_REBUILD") == "1"
+    if not force and not _stale():
+        return LIB
+    return _compile_and_link(LIB, "", [], force, verbose)
+
+
+# The forced-rare-path flavour: the same sources with -DKZGAMD_FORCE_EXACT_TESTS, in which the cheap filter in front of
+# every exact "is this zero mod p" test (fp28::is_zero_mod_p, g1w::is_zero_mod_p: taken by 2.4e-7 of the values) is
+# compiled out, so the exact comparison — the code a rare value reaches, with its LDS exchanges and wave-local
+# synchronisation — runs on EVERY point addition of every kernel.  Results must be bit-identical to the product
+# library's; the GPU suite and the fuzzers run against both (tests/conftest.py).  Test infrastructure, never shipped.
+LIB_EXACT = os.path.join(CSRC, "libkzg_mi355x_exact.so")
+
+
+def build_exact(force=False, verbose=False):
+    force = force or os.environ.get("KZGAMD_REBUILD") == "1"
+    return _compile_and_link(LIB_EXACT, ".exact", ["-DKZGAMD_FORCE_EXACT_TESTS"], force, verbose)
 
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     if "--prefixed" in sys.argv:
         print(build_prefixed(verbose=True))
+    if "--exact" in sys.argv:
+        print(build_exact(force="--force" in sys.argv, verbose=True))

@@ -308,7 +308,12 @@ FF_HD Fe sqr(const Fe& a) { return sqr_inline(a); }
 FF_HD bool is_zero_mod_p(const Fe& a_in) {
     // the low 28 bits of limb 0 are the value mod 2^28 whether or not the limbs are normalized
     const u32 k = (a_in.v[0] * P0INV_POS) & MASK;
+    // -DKZGAMD_FORCE_EXACT_TESTS (build.py: libkzg_mi355x_exact.so, test infrastructure): no filter, every call runs
+    // the exact comparison below — the branch 2.4e-7 of the values take becomes the one every value takes.  For
+    // k >= 64 the comparison is against k*p >= 64p > a, so the answer is the same.
+#if !defined(KZGAMD_FORCE_EXACT_TESTS)
     if (k >= 64) return false;
+#endif
     Fe a = a_in;
     norm(a);
     u64 c = 0;

@@ -5,7 +5,8 @@
 // restate (pippenger_utils.rs:90-210), with the same exceptional cases
 // (infinity, P == Q -> double, P == -Q -> infinity).
 //
-// Value bounds carried between calls (see fp28.hip.h): X < 10p, Y < 6p, ZZ, ZZZ < 2p.
+// Value bounds carried between calls (see fp28.hip.h): X < 10p, Y < 6p, ZZ, ZZZ < 2p (dbl and dadd also take Y <= 8p:
+// a negated input; madd does not).
 #pragma once
 #include "fp28.hip.h"
 
@@ -76,8 +77,11 @@ FF_HD void dbl(Xyzz& acc) {
     Fe m = sqr(acc.x);
     Fe m3 = addn(add(m, m), m);
     Fe x3 = sub<8>(sqr(m3), addn(s, s));
-    // Y3 = M*(S - X3) - W*Y as one two-product reduction, as in madd
-    Fe y3 = mul2_inline(m3, sub<16>(s, x3), w, sub_lazy<8>(zero(), acc.y));
+    // Y3 = M*(S - X3) - W*Y as one two-product reduction, as in madd.  The pad is 16p, not 8p: the one-lane G1 stage
+    // doubles points whose Y is fp28::neg<8>(y) = 8p - y in (6p, 8p] (fftg1.hip: apply_half, negated table entries),
+    // and 8p - Y underflows its top limb once Y > 8p - 2^364.  16p - Y has limbs < 2^29: columns < 2^62, value
+    // product < 140 p^2 (tests/test_host_cpu.py::test_dbl_of_a_negated_point_with_a_tiny_y).
+    Fe y3 = mul2_inline(m3, sub<16>(s, x3), w, sub_lazy<16>(zero(), acc.y));
     acc.x = x3;
     acc.y = y3;
     acc.zz = mul(acc.zz, v);

@@ -27,11 +27,11 @@ def unhex(s):
     return bytes.fromhex(s[2:])
 
 
-def build_harness(tmp_path):
+def build_harness(tmp_path, kzg):
     exe = str(tmp_path / "c_abi_harness")
-    libdir = os.path.join(ROOT, "rust-kzg_amd", "csrc")
+    libdir = os.path.dirname(kzg.LIB_PATH)
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O1", "-I" + os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "c_abi_harness.c"), "-L" + libdir, "-lkzg_mi355x",
+                           os.path.join(ROOT, "tests", "c_abi_harness.c"), "-L" + libdir, "-l:" + os.path.basename(kzg.LIB_PATH),
                            "-Wl,-rpath," + libdir, "-o", exe])
     return exe
 
@@ -40,7 +40,7 @@ def test_header_is_c99_and_layout_matches_the_reference(tmp_path, kzg):
     """No GPU needed: the header compiles as strict C99 inside a real consumer, the consumer links against every
     symbol it uses, and the struct layouts are the reference's (kzg/src/eth/c_bindings.rs:16-113, 429-474)."""
     kzg.lib()  # the library must be built
-    exe = build_harness(tmp_path)
+    exe = build_harness(tmp_path, kzg)
     p = subprocess.run([exe, "layout"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert p.returncode == 0, p.stdout.decode()
     assert b"layout ok" in p.stdout
@@ -239,7 +239,7 @@ def write_records(path, oracle_settings):
 
 @pytest.mark.gpu
 def test_c_harness_replays_the_vectors(tmp_path, kzg, oracle_settings):
-    exe = build_harness(tmp_path)
+    exe = build_harness(tmp_path, kzg)
     rec = str(tmp_path / "records.bin")
     counts = write_records(rec, oracle_settings)
     # what the fixed-size signatures can express of the reference's vectors (the rest is rejected by its bindings)

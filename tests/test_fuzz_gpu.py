@@ -1,5 +1,9 @@
-"""The differential fuzzers of tools/ as part of the GPU suite: a fixed seed and a short time budget each
-(tools/fuzz_msm.py: MSM entry points vs the oracle; tools/fuzz_ckzg.py: c-kzg surface and NTT vs the oracle)."""
+"""The differential fuzzers of tools/ as part of the GPU suite: a fixed seed and a time budget each
+(tools/fuzz_msm.py: MSM entry points vs the oracle; tools/fuzz_ckzg.py: c-kzg surface and NTT vs the oracle;
+tools/fuzz_g1.py: the G1 transforms under every stage form and the FK20 cell proofs), against BOTH builds of the
+library (conftest.py: the product library and the forced-rare-path one; KZGAMD_LIB carries the choice to the tool).
+The only wrong result this code base ever shipped (round 3's four-wave block sum, once per 1e5 small batches) was found
+by fuzz_ckzg.py, so the budgets are minutes, not seconds; longer sessions are logged under profiles/."""
 import os
 import subprocess
 import sys
@@ -10,12 +14,18 @@ from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
+BUDGET = {"product": {"fuzz_msm.py": 120, "fuzz_ckzg.py": 120, "fuzz_g1.py": 30},
+          "exact": {"fuzz_msm.py": 45, "fuzz_ckzg.py": 45, "fuzz_g1.py": 30}}
 
-@pytest.mark.parametrize("tool,seed", [("fuzz_msm.py", 11), ("fuzz_ckzg.py", 12)])
-def test_differential_fuzz(tool, seed):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "25", str(seed)], stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, timeout=900, cwd=ROOT)
+
+@pytest.mark.parametrize("tool,seed", [("fuzz_msm.py", 11), ("fuzz_ckzg.py", 12), ("fuzz_g1.py", 13)])
+def test_differential_fuzz(kzg, tool, seed):
+    flavour = "exact" if kzg.LIB_PATH.endswith("_exact.so") else "product"
+    assert os.environ.get("KZGAMD_LIB") == kzg.LIB_PATH  # the tool loads the same build
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), str(BUDGET[flavour][tool]), str(seed)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200, cwd=ROOT)
     out = p.stdout.decode()
     assert p.returncode == 0 and "fuzz ok" in out, out[-3000:]
+    assert os.path.basename(kzg.LIB_PATH) in out, out[-500:]  # the tool reports which library it ran
     cases = int(out.split("fuzz ok:")[1].split()[0])
     assert cases >= 10, out[-500:]

@@ -289,3 +289,75 @@ def test_batched_binary_gcd_inverse_equals_the_bit_by_bit_one(tmp_path):
     out = subprocess.check_output([str(exe), "60000"]).decode()
     assert "Fr: 0 mismatches" in out and "Fp: 0 mismatches" in out, out
     assert out.count("fallbacks so far 0") == 2, out
+
+
+def test_dbl_of_a_negated_point_with_a_tiny_y(tmp_path):
+    """g1::dbl takes Y up to 8p: the one-lane G1 stage doubles points whose Y is fp28::neg<8>(y) (fftg1.hip: apply_half,
+    negated table entries).  With the 8p pad of round 4 the lazy 8p - Y underflowed its top limb whenever the
+    Montgomery y was below 8p mod 2^364 (about 9e-6 of all points): directed values with a zero / one top
+    limb, negated, doubled, against the same residue reduced below 2p first.  madd / dadd / dadd_unequal get the same
+    treatment on their own documented input bounds."""
+    import shutil
+    import subprocess
+
+    cxx = shutil.which("g++") or shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    src = tmp_path / "dblcheck.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstdint>
+#include "g1_28.hip.h"
+static uint64_t st = 0x9e3779b97f4a7c15ull;
+static uint32_t rnd() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 16); }
+using fp28::Fe;
+static Fe rfe(uint32_t top) { Fe r; for (int i = 0; i < 13; ++i) r.v[i] = rnd() & fp28::MASK; r.v[13] = top; return r; }
+static bool same(const Fe& a, const Fe& b) { return fp28::to_blst(a) == fp28::to_blst(b); }
+static bool same_pt(const g1::Xyzz& a, const g1::Xyzz& b) {  // same representation class: coordinates equal mod p
+    return same(a.x, b.x) && same(a.y, b.y) && same(a.zz, b.zz) && same(a.zzz, b.zzz);
+}
+int main() {
+    int bad = 0;
+    for (int it = 0; it < 30000; ++it) {
+        g1::Xyzz P;
+        P.x = rfe(rnd() % 0x1a011);
+        P.zz = rfe(rnd() % 0x1a011);
+        P.zzz = rfe(rnd() % 0x1a011);
+        Fe y = rfe(it % 3 == 0 ? 0 : (it % 3 == 1 ? 1 : rnd() % 0x1a011));
+        if (it == 5) y = fp28::zero();
+        if (it == 6) for (int i = 0; i < 13; ++i) y.v[i] = fp28::MASK;   // 2^364 - 1
+        g1::Xyzz A = P, B = P;
+        A.y = fp28::neg<8>(y);                            // 8p - y in (6p, 8p]
+        B.y = fp28::mul(fp28::neg<8>(y), fp28::one());    // the same residue, < 2p
+        g1::Xyzz A2 = A, B2 = B;
+        g1::dbl(A);
+        g1::dbl(B);
+        if (!same_pt(A, B)) ++bad;
+        // the additions with the (6p, 8p] operand on either side (formulas are identities in any field, so the
+        // operands need not be curve points)
+        g1::Xyzz Q;
+        Q.x = rfe(rnd() % 0x1a011); Q.y = rfe(rnd() % 0x1a011); Q.zz = rfe(rnd() % 0x1a011); Q.zzz = rfe(rnd() % 0x1a011);
+        g1::Xyzz C = A2, D = B2;
+        g1::dadd(C, Q);
+        g1::dadd(D, Q);
+        if (!same_pt(C, D)) ++bad;
+        C = Q; D = Q;
+        g1::dadd(C, A2);
+        g1::dadd(D, B2);
+        if (!same_pt(C, D)) ++bad;
+        C = Q; D = Q;
+        if (g1::dadd_unequal(C, A2) || g1::dadd_unequal(D, B2)) ++bad;
+        if (!same_pt(C, D)) ++bad;
+        // madd: accumulator Y below 6p (its documented bound), tiny top limbs included
+        g1::Xyzz E = P, F = P;
+        E.y = fp28::sub<4>(fp28::addn(y, y), fp28::zero());   // 2y + 4p < 6p
+        F.y = fp28::mul(E.y, fp28::one());
+        g1::madd(E, Q.x, Q.y);
+        g1::madd(F, Q.x, Q.y);
+        if (!same_pt(E, F)) ++bad;
+    }
+    printf("%d\n", bad);
+    return bad != 0;
+}
+''')
+    exe = tmp_path / "dblcheck"
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "rust-kzg_amd", "csrc"), "-x", "c++", str(src), "-o", str(exe)])
+    assert subprocess.check_output([str(exe)]).strip() == b"0"

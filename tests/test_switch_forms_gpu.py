@@ -99,3 +99,37 @@ def test_proof_batch_with_device_sha_and_array_quotient(kzg, forms):
     # a mid-sized batch (one workgroup per blob in k_quotient, a single chunk)
     m = 40
     assert kzg.compute_blob_kzg_proof_batch(blobs[:m * BLOB], b"".join(cms[:m]), m, s2) == proofs[:m]
+
+
+def test_one_lane_stage_at_production_scale(kzg, forms):
+    """The one-lane chain (k_g1_stage_chain<1>) is the form FK20 uses above 256 blobs and fft_g1 above 2^15 points:
+    1024 blobs are 131 072 half-butterflies per stage, 1.4 million chains of ~170 point operations in one call — enough
+    for a 1e-5-per-chain event to show several times (ADVICE round 4: g1::dbl's Y3 with an 8p pad on a negated,
+    tiny-y point did exactly that, 4.5e-6 per half-butterfly, while the suite only ever ran this form at 64 points).
+    Every proof against the same blobs in batches of 64 (the four-lane form: other kernels, other formulas' schedule),
+    which the vectors and the direct form pin."""
+    import ctypes as C
+
+    import numpy as np
+
+    n = 1024
+    rng = np.random.default_rng(1024)
+    arr = rng.integers(0, 256, size=(n * 4096, 32), dtype=np.uint8)
+    arr[:, 0] = 0
+    blobs = arr.tobytes()
+    L = kzg.lib()
+    s = forms["default"]
+    big = C.create_string_buffer(n * 6144)
+    assert L.kzgamd_compute_cells_and_kzg_proofs_batch(None, big, blobs, n, C.byref(s.c)) == 0
+    small = C.create_string_buffer(64 * 6144)
+    bad = []
+    for k in range(0, n, 64):
+        assert L.kzgamd_compute_cells_and_kzg_proofs_batch(None, small, blobs[k * BLOB:(k + 64) * BLOB], 64, C.byref(s.c)) == 0
+        if small.raw != big.raw[k * 6144:(k + 64) * 6144]:
+            bad += [k + j for j in range(64) if small.raw[j * 6144:(j + 1) * 6144] != big.raw[(k + j) * 6144:(k + j + 1) * 6144]]
+    assert not bad, bad
+    # and two of those batches through the direct form (one fixed-base MSM per cell; what the reference's vectors pin)
+    d = forms["direct"]
+    for k in (0, 960):
+        assert L.kzgamd_compute_cells_and_kzg_proofs_batch(None, small, blobs[k * BLOB:(k + 64) * BLOB], 64, C.byref(d.c)) == 0
+        assert small.raw == big.raw[k * 6144:(k + 64) * 6144], k

@@ -106,4 +106,4 @@ while time.time() < t_end:
         assert L.odas_fft_extension(C.byref(ofs), odds, data, nn) == 0
         assert bytes(fs.das_fft_extension(data, nn))[: 32 * nn] == bytes(odds), ("das", logn, seed, cases)
     cases += 1
-print("fuzz ok:", cases, "cases, seed", seed)
+print("fuzz ok:", cases, "cases, seed", seed, "library", os.path.basename(kzg.LIB_PATH))

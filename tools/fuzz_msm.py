@@ -112,4 +112,4 @@ while time.time() < t_end:
     C.memmove(C.byref(got), d_out.cpu().numpy().tobytes(), 144)
     assert compressed(got) == want, ("device variable-base", n, mode, smode, seed, cases)
     cases += 1
-print("fuzz ok:", cases, "cases, seed", seed)
+print("fuzz ok:", cases, "cases, seed", seed, "library", os.path.basename(kzg.LIB_PATH))
