@@ -21,6 +21,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1900,6 +1902,7 @@ struct MsmTuning {
     int fine_bits = 0;         // KZGAMD_FINE_BITS: width of the second sort level (0 = default)
     bool one_level_sort = false, tree_tail = false, flat_digits = false, direct_scatter = false, scatter_atomics = false;
     bool tile_v1 = false;      // KZGAMD_TILE_V1=1: k_tile_sums in its five-site form
+    bool combine = true;       // KZGAMD_NO_COMBINE=1: concurrent mult_pippenger_prepared calls queue on the mutex, one launch each
     static MsmTuning from_env() {
         MsmTuning t;
         auto num = [](const char* name) {
@@ -1922,6 +1925,7 @@ struct MsmTuning {
         t.direct_scatter = getenv("KZGAMD_DIRECT_SCATTER") != nullptr;
         t.scatter_atomics = getenv("KZGAMD_SCATTER_ATOMICS") != nullptr;
         t.tile_v1 = getenv("KZGAMD_TILE_V1") != nullptr;
+        t.combine = getenv("KZGAMD_NO_COMBINE") == nullptr;
         return t;
     }
 };
@@ -1971,7 +1975,39 @@ struct kzgamd::MsmContext {
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     static constexpr size_t EV_MAX = 4 * 512;
+    // Combining of concurrent host-buffer calls on ONE prepared handle.  The reference shares the handle between rayon
+    // workers (SpparkPrecomputation is Send + Sync, kzg/src/msm/sppark.rs:24-44; verify_blob_kzg_proof_batch calls the
+    // MSM from par_chunks, kzg/src/eip_4844.rs:781-805): callers of mult_pippenger_prepared queue a request; one of
+    // them at a time (the leader) takes everything queued with the same length, up to COMBINE_MAX requests, and runs
+    // it as ONE nbatch launch — the ~10 runtime operations of an invocation are paid per batch, not per call, and
+    // the GPU sees a few thousand waves instead of a few hundred.  A caller returns as soon as its own request is
+    // served; leadership passes to whoever is waiting.  Each caller copies its scalars into a page-locked slot on its
+    // own thread before it queues (truly asynchronous H2D copies; a copy from pageable memory goes through the
+    // runtime's staging path, which serialises concurrent callers).
+    struct HostCall {
+        void* out;
+        const void* scalars;
+        size_t npoints;
+        unsigned char* slot = nullptr;
+        bool done = false, failed = false;
+        HipErr err{hipSuccess, ""};
+    };
+    static constexpr size_t COMBINE_MAX = 32;
+    static constexpr int COMBINE_SLOTS = 48;
+    struct Combine {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<HostCall*> pending;
+        bool leader = false;
+        unsigned char* h_slots = nullptr;  // COMBINE_SLOTS x slot_bytes, page-locked
+        unsigned char* h_out = nullptr;    // COMBINE_MAX x 144, page-locked
+        size_t slot_bytes = 0;
+        bool pinned_failed = false;
+        std::vector<unsigned char*> free_slots;
+    } comb;
     ~MsmContext() {
+        if (comb.h_slots) (void)hipHostFree(comb.h_slots);
+        if (comb.h_out) (void)hipHostFree(comb.h_out);
         table.release();
         wide.release();
         ws.release();
@@ -2724,8 +2760,105 @@ int msm_get_profile(MsmContext* ctx, float* accum_ms, float* total_ms) {
     return cnt;
 }
 
+// one batch of the combiner: every request has the same length; fills done / failed of each
+static void msm_run_combined_batch(MsmContext* ctx, const std::vector<MsmContext::HostCall*>& batch) {
+    const size_t nb = batch.size(), np = batch[0]->npoints;
+    try {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        DeviceGuard on_device(ctx->device);
+        HIP_TRY(on_device.err);
+        ctx->ws.scalars.ensure(nb * np * 8 + 8);
+        ctx->ws.out.ensure(nb * 3 + 3);
+        if (!ctx->comb.h_out) HIP_TRY(hipHostMalloc((void**)&ctx->comb.h_out, MsmContext::COMBINE_MAX * 144, hipHostMallocDefault));
+        try {
+            for (size_t j = 0; j < nb; ++j)
+                HIP_TRY(hipMemcpyAsync(ctx->ws.scalars.p + j * np * 8, batch[j]->slot ? (const void*)batch[j]->slot : batch[j]->scalars,
+                                       np * 32, hipMemcpyHostToDevice, ctx->stream));
+            msm_enqueue(ctx, ctx->ws.out.p, ctx->ws.scalars.p, np, nb, 1, ctx->stream, OUT_JACOBIAN);
+            HIP_TRY(hipMemcpyAsync(ctx->comb.h_out, ctx->ws.out.p, nb * 144, hipMemcpyDeviceToHost, ctx->stream));
+        } catch (...) {
+            (void)hipStreamSynchronize(ctx->stream);  // whatever was enqueued still reads the callers' slots
+            throw;
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (size_t j = 0; j < nb; ++j) memcpy(batch[j]->out, ctx->comb.h_out + j * 144, 144);
+    } catch (const HipErr& e) {
+        for (auto* r : batch) {
+            r->failed = true;
+            r->err = e;
+        }
+    } catch (...) {
+        for (auto* r : batch) {
+            r->failed = true;
+            r->err = HipErr{hipErrorUnknown, "combined MSM batch failed"};
+        }
+    }
+}
+
+static void msm_run_host_combined(MsmContext* ctx, void* out, const void* scalars, size_t npoints) {
+    MsmContext::HostCall me{out, scalars, npoints};
+    auto& q = ctx->comb;
+    std::vector<MsmContext::HostCall*> batch;
+    batch.reserve(MsmContext::COMBINE_MAX);  // everything that can throw happens before the request is visible
+    std::unique_lock<std::mutex> lk(q.mu);
+    if (!q.h_slots && !q.pinned_failed) {
+        DeviceGuard on_device(ctx->device);
+        q.slot_bytes = ctx->n * 32;
+        if (on_device.err != hipSuccess ||
+            hipHostMalloc((void**)&q.h_slots, (size_t)MsmContext::COMBINE_SLOTS * q.slot_bytes, hipHostMallocPortable) != hipSuccess) {
+            q.h_slots = nullptr;
+            q.pinned_failed = true;
+            (void)hipGetLastError();
+        } else {
+            for (int i = MsmContext::COMBINE_SLOTS; i-- > 0;) q.free_slots.push_back(q.h_slots + (size_t)i * q.slot_bytes);
+        }
+    }
+    if (!q.free_slots.empty()) {
+        me.slot = q.free_slots.back();
+        q.free_slots.pop_back();
+        lk.unlock();
+        memcpy(me.slot, scalars, npoints * 32);
+        lk.lock();
+    }
+    q.pending.push_back(&me);
+    while (!me.done) {
+        if (!q.leader) {
+            q.leader = true;
+            while (!q.pending.empty() && !me.done) {
+                batch.clear();
+                const size_t np = q.pending.front()->npoints;
+                for (auto it = q.pending.begin(); it != q.pending.end() && batch.size() < MsmContext::COMBINE_MAX;) {
+                    if ((*it)->npoints == np) {
+                        batch.push_back(*it);
+                        it = q.pending.erase(it);
+                    } else {
+                        ++it;
+                    }
+                }
+                lk.unlock();
+                msm_run_combined_batch(ctx, batch);
+                lk.lock();
+                for (auto* r : batch) r->done = true;
+                q.cv.notify_all();
+            }
+            q.leader = false;
+            q.cv.notify_all();  // whoever still waits leads what is left
+        } else {
+            q.cv.wait(lk);
+        }
+    }
+    if (me.slot) q.free_slots.push_back(me.slot);
+    lk.unlock();
+    if (me.failed) throw me.err;
+}
+
 // host buffers in, host buffers out
 void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoints, size_t nbatch) {
+    if (npoints > ctx->n) throw HipErr{hipErrorInvalidValue, "npoints exceeds the prepared size"};
+    if (ctx->prepared && nbatch == 1 && npoints > 0 && ctx->tune.combine) {
+        msm_run_host_combined(ctx, out, scalars, npoints);
+        return;
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard on_device(ctx->device);
     HIP_TRY(on_device.err);
