@@ -104,8 +104,11 @@ def test_proof_batch_with_device_sha_and_array_quotient(kzg, forms):
 def test_one_lane_stage_at_production_scale(kzg, forms):
     """The one-lane chain (k_g1_stage_chain<1>) is the form FK20 uses above 256 blobs and fft_g1 above 2^15 points:
     1024 blobs are 131 072 half-butterflies per stage, 1.4 million chains of ~170 point operations in one call — enough
-    for a 1e-5-per-chain event to show several times (ADVICE round 4: g1::dbl's Y3 with an 8p pad on a negated,
-    tiny-y point did exactly that, 4.5e-6 per half-butterfly, while the suite only ever ran this form at 64 points).
+    for a 1e-5-per-chain event to show several times, where the suite only ever ran this form at 64 points.  (It is a
+    test of scale, not of round 4's g1::dbl pad bug: measured on the GPU, a library with the old 8p pad passes it — the Y
+    of a stage input is the output of a two-product reduction R*(Q - X3) + (8p - S)*PPP, whose (8p - S)*PPP / 2^392
+    term keeps it above 2^364, so tiny values reach the doubling only through raw inputs.  The directed host test
+    tests/test_host_cpu.py::test_dbl_of_a_negated_point_with_a_tiny_y is what pins that bug.)
     Every proof against the same blobs in batches of 64 (the four-lane form: other kernels, other formulas' schedule),
     which the vectors and the direct form pin."""
     import ctypes as C
