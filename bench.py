@@ -646,11 +646,21 @@ def main():
                 env = dict(os.environ, KZGAMD_FBW_MAX_GB="100", LD_LIBRARY_PATH=os.path.join(ROOT, "rust-kzg_amd", "csrc") + ":" + os.environ.get("LD_LIBRARY_PATH", "") + ":/opt/rocm/lib")
                 o16 = json.loads(subprocess.run([cb, SETUP, "0.8", "16"], stdout=subprocess.PIPE, env=env, timeout=120).stdout.decode().strip().splitlines()[-1])
                 o1 = json.loads(subprocess.run([cb, SETUP, "0.5", "1"], stdout=subprocess.PIPE, env=env, timeout=120).stdout.decode().strip().splitlines()[-1])
+                # B1 seam: the same threads on ONE prepared handle, mult_pippenger_prepared (what a Rust caller through
+                # the kzg:: traits reaches); with and without the combining of concurrent calls into one launch
+                env_nc = dict(env, KZGAMD_NO_COMBINE="1")
+                b16nc = json.loads(subprocess.run([cb, SETUP, "0.8", "16", "2"], stdout=subprocess.PIPE, env=env_nc, timeout=120).stdout.decode().strip().splitlines()[-1])
                 res["concurrent_callers"] = {
                     "threads_16": {"blob_to_kzg_commitment_per_s": o16.get("commit_threads_16"), "compute_blob_kzg_proof_per_s": o16.get("proof_threads_16")},
                     "threads_1": {"blob_to_kzg_commitment_per_s": o1.get("commit_threads_1"), "compute_blob_kzg_proof_per_s": o1.get("proof_threads_1")},
+                    "b1_prepared_threads_1": o1.get("b1_prepared_threads_1"),
+                    "b1_prepared_threads_16": o16.get("b1_prepared_threads_16"),
+                    "b1_prepared_threads_16_over_1": (o16.get("b1_prepared_threads_16") or 0) / max(o1.get("b1_prepared_threads_1") or 1, 1),
+                    "b1_prepared_threads_16_calls_not_combined": b16nc.get("b1_prepared_threads_16"),
+                    "b1_unit": "mult_pippenger_prepared calls/s (4096 scalars each) on one shared prepared handle",
                     "failed_or_different_from_the_serial_results": (o16.get("failed_or_different_from_the_serial_results", 0) or 0)
-                                                                   + (o1.get("failed_or_different_from_the_serial_results", 0) or 0),
+                                                                   + (o1.get("failed_or_different_from_the_serial_results", 0) or 0)
+                                                                   + (b16nc.get("failed_or_different_from_the_serial_results", 0) or 0),
                     "path": "native threads, one CKZGSettings, host buffers; calls are merged into batches on up to three lanes "
                             "(own process: its settings object is loaded next to this one); every result is compared with "
                             "the one a serial call gave"}

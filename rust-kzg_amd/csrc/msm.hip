@@ -21,6 +21,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -1903,6 +1904,7 @@ struct MsmTuning {
     bool one_level_sort = false, tree_tail = false, flat_digits = false, direct_scatter = false, scatter_atomics = false;
     bool tile_v1 = false;      // KZGAMD_TILE_V1=1: k_tile_sums in its five-site form
     bool combine = true;       // KZGAMD_NO_COMBINE=1: concurrent mult_pippenger_prepared calls queue on the mutex, one launch each
+    int combine_lanes = 2, combine_gather_min = 6, combine_gather_us = 60;  // KZGAMD_COMBINE_{LANES,GATHER_MIN,GATHER_US}
     static MsmTuning from_env() {
         MsmTuning t;
         auto num = [](const char* name) {
@@ -1926,6 +1928,9 @@ struct MsmTuning {
         t.scatter_atomics = getenv("KZGAMD_SCATTER_ATOMICS") != nullptr;
         t.tile_v1 = getenv("KZGAMD_TILE_V1") != nullptr;
         t.combine = getenv("KZGAMD_NO_COMBINE") == nullptr;
+        if (getenv("KZGAMD_COMBINE_LANES")) t.combine_lanes = num("KZGAMD_COMBINE_LANES") >= 2 ? 2 : 1;
+        if (getenv("KZGAMD_COMBINE_GATHER_MIN")) t.combine_gather_min = num("KZGAMD_COMBINE_GATHER_MIN");
+        if (getenv("KZGAMD_COMBINE_GATHER_US")) t.combine_gather_us = num("KZGAMD_COMBINE_GATHER_US");
         return t;
     }
 };
@@ -1994,20 +1999,36 @@ struct kzgamd::MsmContext {
     };
     static constexpr size_t COMBINE_MAX = 32;
     static constexpr int COMBINE_SLOTS = 48;
+    // Up to COMBINE_LANES batches are in flight at once, each on a lane of its own (stream, staging, and — through
+    // workspace_for(stream) — MSM workspace): the copies and launches of one batch are issued while the kernels of the
+    // previous one run.  The handle's mutex is held while a batch is enqueued, not while it is awaited.
+    static constexpr int COMBINE_LANES = 2;
+    struct CombineLane {
+        hipStream_t st = nullptr;
+        DevBuf<u32> scalars;
+        DevBuf<ff::Fp> out;
+        unsigned char* h_out = nullptr;  // COMBINE_MAX x 144, page-locked
+        bool busy = false;
+    };
     struct Combine {
         std::mutex mu;
         std::condition_variable cv;
         std::deque<HostCall*> pending;
-        bool leader = false;
+        int leaders = 0;
+        CombineLane lanes[COMBINE_LANES];
         unsigned char* h_slots = nullptr;  // COMBINE_SLOTS x slot_bytes, page-locked
-        unsigned char* h_out = nullptr;    // COMBINE_MAX x 144, page-locked
         size_t slot_bytes = 0;
         bool pinned_failed = false;
         std::vector<unsigned char*> free_slots;
     } comb;
     ~MsmContext() {
         if (comb.h_slots) (void)hipHostFree(comb.h_slots);
-        if (comb.h_out) (void)hipHostFree(comb.h_out);
+        for (auto& l : comb.lanes) {
+            if (l.h_out) (void)hipHostFree(l.h_out);
+            l.scalars.release();
+            l.out.release();
+            if (l.st) (void)hipStreamDestroy(l.st);
+        }
         table.release();
         wide.release();
         ws.release();
@@ -2760,28 +2781,31 @@ int msm_get_profile(MsmContext* ctx, float* accum_ms, float* total_ms) {
     return cnt;
 }
 
-// one batch of the combiner: every request has the same length; fills done / failed of each
-static void msm_run_combined_batch(MsmContext* ctx, const std::vector<MsmContext::HostCall*>& batch) {
+// one batch of the combiner on `lane`: every request has the same length; fills failed / err of each
+static void msm_run_combined_batch(MsmContext* ctx, MsmContext::CombineLane& lane, const std::vector<MsmContext::HostCall*>& batch) {
     const size_t nb = batch.size(), np = batch[0]->npoints;
     try {
-        std::lock_guard<std::mutex> lk(ctx->mu);
         DeviceGuard on_device(ctx->device);
         HIP_TRY(on_device.err);
-        ctx->ws.scalars.ensure(nb * np * 8 + 8);
-        ctx->ws.out.ensure(nb * 3 + 3);
-        if (!ctx->comb.h_out) HIP_TRY(hipHostMalloc((void**)&ctx->comb.h_out, MsmContext::COMBINE_MAX * 144, hipHostMallocDefault));
-        try {
-            for (size_t j = 0; j < nb; ++j)
-                HIP_TRY(hipMemcpyAsync(ctx->ws.scalars.p + j * np * 8, batch[j]->slot ? (const void*)batch[j]->slot : batch[j]->scalars,
-                                       np * 32, hipMemcpyHostToDevice, ctx->stream));
-            msm_enqueue(ctx, ctx->ws.out.p, ctx->ws.scalars.p, np, nb, 1, ctx->stream, OUT_JACOBIAN);
-            HIP_TRY(hipMemcpyAsync(ctx->comb.h_out, ctx->ws.out.p, nb * 144, hipMemcpyDeviceToHost, ctx->stream));
-        } catch (...) {
-            (void)hipStreamSynchronize(ctx->stream);  // whatever was enqueued still reads the callers' slots
-            throw;
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);  // enqueue only: the wait below runs beside the other lane's enqueue
+            if (!lane.st) HIP_TRY(hipStreamCreateWithFlags(&lane.st, hipStreamNonBlocking));
+            if (!lane.h_out) HIP_TRY(hipHostMalloc((void**)&lane.h_out, MsmContext::COMBINE_MAX * 144, hipHostMallocDefault));
+            lane.scalars.ensure(nb * np * 8 + 8);
+            lane.out.ensure(nb * 3 + 3);
+            try {
+                for (size_t j = 0; j < nb; ++j)
+                    HIP_TRY(hipMemcpyAsync(lane.scalars.p + j * np * 8, batch[j]->slot ? (const void*)batch[j]->slot : batch[j]->scalars,
+                                           np * 32, hipMemcpyHostToDevice, lane.st));
+                msm_enqueue(ctx, lane.out.p, lane.scalars.p, np, nb, 1, lane.st, OUT_JACOBIAN);
+                HIP_TRY(hipMemcpyAsync(lane.h_out, lane.out.p, nb * 144, hipMemcpyDeviceToHost, lane.st));
+            } catch (...) {
+                (void)hipStreamSynchronize(lane.st);  // whatever was enqueued still reads the callers' slots
+                throw;
+            }
         }
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (size_t j = 0; j < nb; ++j) memcpy(batch[j]->out, ctx->comb.h_out + j * 144, 144);
+        HIP_TRY(hipStreamSynchronize(lane.st));
+        for (size_t j = 0; j < nb; ++j) memcpy(batch[j]->out, lane.h_out + j * 144, 144);
     } catch (const HipErr& e) {
         for (auto* r : batch) {
             r->failed = true;
@@ -2821,10 +2845,28 @@ static void msm_run_host_combined(MsmContext* ctx, void* out, const void* scalar
         lk.lock();
     }
     q.pending.push_back(&me);
+    q.cv.notify_one();  // a leader gathering requests may have enough now
     while (!me.done) {
-        if (!q.leader) {
-            q.leader = true;
+        if (q.leaders < ctx->tune.combine_lanes && !q.pending.empty()) {
+            ++q.leaders;
+            MsmContext::CombineLane* lane = nullptr;
+            for (auto& l : q.lanes)
+                if (!l.busy) {
+                    lane = &l;
+                    break;
+                }
+            lane->busy = true;  // leaders <= lanes: one is free
             while (!q.pending.empty() && !me.done) {
+                // another batch is in flight: a short wait lets the callers it is about to release come back with their
+                // next request — larger batches, fewer invocations
+                if (q.leaders > 1 && q.pending.size() < (size_t)ctx->tune.combine_gather_min && ctx->tune.combine_gather_us > 0) {
+                    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(ctx->tune.combine_gather_us);
+                    while (q.pending.size() < (size_t)ctx->tune.combine_gather_min && !me.done &&
+                           q.cv.wait_until(lk, until) != std::cv_status::timeout) {
+                    }
+                    if (me.done) break;
+                    if (q.pending.empty()) continue;
+                }
                 batch.clear();
                 const size_t np = q.pending.front()->npoints;
                 for (auto it = q.pending.begin(); it != q.pending.end() && batch.size() < MsmContext::COMBINE_MAX;) {
@@ -2836,12 +2878,13 @@ static void msm_run_host_combined(MsmContext* ctx, void* out, const void* scalar
                     }
                 }
                 lk.unlock();
-                msm_run_combined_batch(ctx, batch);
+                msm_run_combined_batch(ctx, *lane, batch);
                 lk.lock();
                 for (auto* r : batch) r->done = true;
                 q.cv.notify_all();
             }
-            q.leader = false;
+            lane->busy = false;
+            --q.leaders;
             q.cv.notify_all();  // whoever still waits leads what is left
         } else {
             q.cv.wait(lk);

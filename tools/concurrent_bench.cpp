@@ -2,6 +2,7 @@
 // pattern (kzg/src/eip_4844.rs:781-805) without an interpreter lock in the way.
 // Build: g++ -O2 -std=c++17 tools/concurrent_bench.cpp -Iinclude -Lrust-kzg_amd/csrc -lkzg_mi355x -lpthread -o tools/concurrent_bench
 // Run:   LD_LIBRARY_PATH=rust-kzg_amd/csrc tools/concurrent_bench tests/golden/trusted_setup.txt [seconds]
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -12,6 +13,7 @@
 #include <vector>
 
 #include "kzg_mi355x.h"
+#include "../rust-kzg_amd/csrc/host_g1.h"  // host_p1_compress: results are compared as group elements
 
 int main(int argc, char** argv) {
     if (argc < 2) return 2;
@@ -38,6 +40,29 @@ int main(int argc, char** argv) {
     std::vector<KZGProof> pr(NB);
     for (int i = 0; i < NB; ++i)
         if (compute_blob_kzg_proof(&pr[i], &blobs[i], &cm[i], &s) != C_KZG_OK) return 4;
+    // B1: one prepared handle over the setup's Lagrange points, shared by the threads (what rust-kzg's g1_lincomb does
+    // with SpparkPrecomputation, kzg/src/msm/sppark.rs:24-44): mult_pippenger_prepared, 4096 Montgomery scalars per call
+    const size_t NP = 4096;
+    std::vector<blst_p1_affine> aff(NP);
+    for (size_t i = 0; i < NP; ++i) {
+        const blst_p1* P = reinterpret_cast<const blst_p1*>(&s.g1_values_lagrange_brp[i]);
+        aff[i].x = P->x;  // the setup's points are affine (Z = 1 in Montgomery form)
+        aff[i].y = P->y;
+    }
+    void* msm = prepare_msm(aff.data(), NP);
+    if (!msm) return 5;
+    std::vector<std::vector<blst_fr>> sc(NB, std::vector<blst_fr>(NP));
+    std::vector<std::array<uint8_t, 48>> want(NB);
+    for (int i = 0; i < NB; ++i) {
+        for (auto& x : sc[i]) {
+            for (int k = 0; k < 4; ++k) x.l[k] = rng();
+            x.l[3] &= 0x3fffffffffffffffull;  // below r: a valid Montgomery representative of some scalar
+        }
+        blst_p1 out;
+        RustError e = mult_pippenger_prepared(msm, &out, NP, sc[i].data());
+        if (e.code) return 6;
+        kzgamd::host_p1_compress(want[i].data(), &out);
+    }
     long errors = 0;  // failed calls + results that differ from the serial ones
     printf("{");
     bool first = true;
@@ -45,7 +70,7 @@ int main(int argc, char** argv) {
     if (argc > 3) Ts = {atoi(argv[3])};
     const int only = argc > 4 ? atoi(argv[4]) : -1;  // 0 = commitments only, 1 = proofs only
     for (int T : Ts) {
-        for (int what = 0; what < 2; ++what) {
+        for (int what = 0; what < 3; ++what) {
             if (only >= 0 && what != only) continue;
             std::atomic<bool> stop{false};
             std::atomic<long> total{0};
@@ -58,6 +83,20 @@ int main(int argc, char** argv) {
                     KZGProof p;
                     const int i = t % NB;
                     while (!stop.load(std::memory_order_relaxed)) {
+                        if (what == 2) {
+                            blst_p1 out;
+                            uint8_t got[48];
+                            RustError e = mult_pippenger_prepared(msm, &out, NP, sc[i].data());
+                            if (e.code) {
+                                free(e.message);
+                                bad.fetch_add(1);
+                            } else {
+                                kzgamd::host_p1_compress(got, &out);
+                                if (memcmp(got, want[i].data(), 48) != 0) bad.fetch_add(1);
+                            }
+                            ++n;
+                            continue;
+                        }
                         C_KZG_RET rc = what == 0 ? blob_to_kzg_commitment(&c, &blobs[i], &s)
                                                  : compute_blob_kzg_proof(&p, &blobs[i], &cm[i], &s);
                         if (rc != C_KZG_OK || memcmp(what == 0 ? c.bytes : p.bytes, what == 0 ? cm[i].bytes : pr[i].bytes, 48) != 0)
@@ -71,12 +110,13 @@ int main(int argc, char** argv) {
             stop.store(true);
             for (auto& x : th) x.join();
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            printf("%s\"%s_threads_%d\": %.0f", first ? "" : ", ", what == 0 ? "commit" : "proof", T, total.load() / dt);
+            printf("%s\"%s_threads_%d\": %.0f", first ? "" : ", ", what == 0 ? "commit" : what == 1 ? "proof" : "b1_prepared", T, total.load() / dt);
             first = false;
             errors += bad.load();
         }
     }
     printf(", \"failed_or_different_from_the_serial_results\": %ld}\n", errors);
+    free_msm(msm);
     free_trusted_setup(&s);
     return 0;
 }
