@@ -648,7 +648,7 @@ def main():
                 o1 = json.loads(subprocess.run([cb, SETUP, "0.5", "1"], stdout=subprocess.PIPE, env=env, timeout=120).stdout.decode().strip().splitlines()[-1])
                 # B1 seam: the same threads on ONE prepared handle, mult_pippenger_prepared (what a Rust caller through
                 # the kzg:: traits reaches); with and without the combining of concurrent calls into one launch
-                env_nc = dict(env, KZGAMD_NO_COMBINE="1")
+                env_nc = dict(env, KZGAMD_TUNING="combine=0")
                 b16nc = json.loads(subprocess.run([cb, SETUP, "0.8", "16", "2"], stdout=subprocess.PIPE, env=env_nc, timeout=120).stdout.decode().strip().splitlines()[-1])
                 res["concurrent_callers"] = {
                     "threads_16": {"blob_to_kzg_commitment_per_s": o16.get("commit_threads_16"), "compute_blob_kzg_proof_per_s": o16.get("proof_threads_16")},
@@ -786,7 +786,7 @@ def main():
             res["in_process_multi"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_extras:
-        # ---- what a smaller commitment table costs (KZGAMD_FBW_MAX_GB): device-resident commitments/s per HBM budget ----
+        # ---- what a smaller commitment table costs (KzgAmdConfig.table_budget_bytes): device-resident commitments/s per HBM budget ----
         rows = []
         dblobs = make_blobs(torch, 1024, 99, dev)
         dout = torch.zeros(1024 * 48, dtype=torch.uint8, device=dev)
@@ -794,9 +794,8 @@ def main():
         dscr = [torch.empty(1024 * BLOB, dtype=torch.uint8, device=dev) for _ in range(2)]
         sts = [torch.cuda.Stream(device=dev) for _ in range(2)]
         for gb in (10, 20, 40, 80, 160):
-            os.environ["KZGAMD_FBW_MAX_GB"] = str(gb)
             try:
-                sb = kzg.KZGSettings.from_file(SETUP)
+                sb = kzg.KZGSettings.from_file(SETUP, kzg.make_config(table_budget_gb=gb))
                 hi = kzg.PreparedMsm.info(type("H", (), {"handle": sb.msm_handle()})())
                 for st_ in sts:
                     sb.reserve(1024, st_.cuda_stream)
@@ -818,9 +817,8 @@ def main():
                 sb.close()
             except Exception as e:  # noqa: BLE001
                 rows.append({"budget_gb": gb, "error": repr(e)})
-        os.environ.pop("KZGAMD_FBW_MAX_GB", None)
         res["throughput_vs_table_budget"] = {"rows": rows, "path": "device-resident commitments, batches of 1024 on two streams, a "
-                                             "settings object per KZGAMD_FBW_MAX_GB value (the default budget is 160 GB)"}
+                                             "settings object per KzgAmdConfig.table_budget_bytes value (the default budget is 160 GB)"}
 
     if dist is not None:
         dist.barrier()

@@ -53,6 +53,25 @@ typedef struct { blst_fp x, y, z; } blst_p1;          /* Jacobian; infinity = Z 
 typedef struct { int code; char *message; } RustError;
 
 /* ------------------------------------------------------------------------------------------
+ * Configuration of a handle (new API; the reference's handles take none — its sppark context sizes itself).  Every
+ * creating entry point has an _ex form that takes one; NULL means the defaults, which is what the plain names pass.
+ * Values are read once, when the handle is created.  Set struct_size = sizeof(KzgAmdConfig) (kzgamd_config_init does).
+ * ------------------------------------------------------------------------------------------ */
+#define KZGAMD_NO_TABLES UINT64_MAX   /* table_budget_bytes: build no wide fixed-base table at all (bucket engine) */
+typedef struct {
+    uint32_t struct_size;          /* sizeof(KzgAmdConfig) of the caller's header */
+    int32_t device;                /* GPU ordinal the handle lives on; -1 = the calling thread's current device */
+    uint64_t table_budget_bytes;   /* HBM EACH fixed-base table of the handle may take (a settings object has up to three:
+                                    * commitments, cell proofs, FK20 columns; tables after the first are built at first
+                                    * use).  0 = default: 160 GB, capped by what is free less 12 GB of working room */
+    const char *tuning;            /* NULL, or "key=value;key=value": the measured switches (kzgamd_tuning_keys lists
+                                    * them).  An unknown key or a value out of range fails the call */
+} KzgAmdConfig;
+void kzgamd_config_init(KzgAmdConfig *cfg);   /* struct_size, device = -1, no budget, no tuning */
+/* the tuning keys, one per line: "name default lo hi meaning"; returns a static string */
+const char *kzgamd_tuning_keys(void);
+
+/* ------------------------------------------------------------------------------------------
  * B1 — GPU MSM plug-in.  Same three symbols `rust-kzg-blst` binds under feature `sppark`
  * (blst-sppark/src/lib.rs:8-62, defined today by blst-sppark/cuda/pippenger.cu:23-38).
  * Scalars are blst_fr IN MONTGOMERY FORM (blst/src/kzg_proofs.rs:47-48); out is Jacobian.
@@ -70,8 +89,20 @@ RustError mult_pippenger(blst_p1 *out, const blst_p1_affine points[], size_t npo
  * mult_pippenger_faster_inf(ctx,out,npoints,batches,scalars), arkworks3-sppark-wlc/src/lib.rs:24-42):
  * scalars is nbatch x npoints, out is nbatch points. */
 void free_msm(void *msm);
+void *kzgamd_prepare_msm_ex(const blst_p1_affine points[], size_t npoints, const KzgAmdConfig *cfg);
 RustError mult_pippenger_prepared_batch(void *msm, blst_p1 out[], size_t npoints, size_t nbatch,
                                         const blst_fr scalars[]);
+
+/* Matrix handle: `rows` independent base sets of `cols` points each in ONE table (points[r * cols + c]) — what the
+ * reference's precomputation holds for g1_lincomb_batch (BgmwTable.batch_points, kzg/src/msm/bgmw.rs:206-304; FK20's
+ * 128 columns of 64 points, kzg/src/das.rs:682-686) and multiplies in multiply_batch (bgmw.rs:306-380):
+ *   out[m * rows + r] = sum_c scalars[(m * rows + r) * cols + c] * points[r * cols + c],   m < nmat
+ * in one launch for all rows (and all nmat scalar matrices: nmat = 1 is G1LinComb::g1_lincomb_batch,
+ * kzg/src/lib.rs:156-181).  Scalars in Montgomery form, out Jacobian, as mult_pippenger_prepared.  The handle needs a
+ * wide table (NULL when none fits cfg's budget: rows * cols * 2^9 * 13 slots of 128 B at the least); free_msm frees it;
+ * thread-safe like every handle. */
+void *kzgamd_prepare_msm_matrix(const blst_p1_affine points[], size_t rows, size_t cols, const KzgAmdConfig *cfg);
+RustError kzgamd_mult_pippenger_matrix(void *msm, blst_p1 out[], const blst_fr scalars[], size_t nmat);
 
 /* Device-resident form used by the batched blob pipeline and bench.py: d_scalars / d_out are
  * device pointers, work is enqueued on `stream` (a hipStream_t, NULL = default stream) and NOT
@@ -92,7 +123,7 @@ int kzgamd_msm_device(void *msm);
 /* introspection for benches/tests: window bits, table rows, buckets of a handle */
 int kzgamd_msm_info(void *msm, int *window_bits, int *rows, size_t *nbuckets, size_t *npoints);
 /* non-zero if the handle holds the wide fixed-base table (rows x npoints x 2^(window_bits-1) affine multiples,
- * built when it fits KZGAMD_FBW_MAX_GB (default 160, capped by free HBM); 0 disables) and so runs the gather-and-add
+ * built when it fits the handle's table budget (KzgAmdConfig.table_budget_bytes; default 160 GB, capped by free HBM)) and so runs the gather-and-add
  * path: 1 = rows cover the 255-bit scalar (rows additions per scalar), 2 = GLV form, rows cover a 128-bit half
  * (2 x rows additions per scalar; chosen only when every base passed the r-torsion test at prepare time) */
 int kzgamd_msm_uses_wide_table(void *msm);
@@ -103,6 +134,7 @@ int kzgamd_msm_get_profile(void *msm, float *accum_ms, float *total_ms);
 /* Handle over DEVICE-resident bases (blst_p1_affine[npoints] in HBM); prepare != 0 builds the fixed-base
  * rows like prepare_msm, 0 gives the variable-base engine mult_pippenger uses. */
 void *kzgamd_msm_create_device(const void *d_points_affine, size_t npoints, int prepare);
+void *kzgamd_msm_create_device_ex(const void *d_points_affine, size_t npoints, int prepare, const KzgAmdConfig *cfg);
 /* bench/test utility: npoints distinct G1 points h_i*G (h_i from splitmix64(seed,i), 248 bits) written
  * as blst_p1_affine into device memory */
 RustError kzgamd_generate_points(void *d_out_affine, size_t npoints, uint64_t seed, void *stream);
@@ -118,6 +150,7 @@ RustError kzgamd_generate_points(void *d_out_affine, size_t npoints, uint64_t se
  *   negative: device error
  * ------------------------------------------------------------------------------------------ */
 void *kzgamd_ntt_new(unsigned scale);           /* FsFFTSettings::new(scale), blst/src/types/fft_settings.rs:30-58 */
+void *kzgamd_ntt_new_ex(unsigned scale, const KzgAmdConfig *cfg);
 void kzgamd_ntt_free(void *ctx);
 int ntt_fr(void *ctx, blst_fr *out, const blst_fr *in, size_t n, int inverse);
 int das_fft_extension(void *ctx, blst_fr *odds, const blst_fr *evens, size_t half_n);
@@ -283,6 +316,13 @@ C_KZG_RET compute_verify_cell_kzg_proof_batch_challenge(blst_fr *challenge_out, 
                                                         uint64_t num_commitments, const uint64_t *commitment_indices,
                                                         const uint64_t *cell_indices, const Cell *cells,
                                                         const Bytes48 *proofs_bytes, uint64_t num_cells);
+/* load_trusted_setup / load_trusted_setup_file with a configuration (device, table budget, tuning); same outputs and
+ * failures, plus C_KZG_BADARGS for a malformed configuration */
+C_KZG_RET kzgamd_load_trusted_setup_ex(CKZGSettings *out, const uint8_t *g1_monomial_bytes, uint64_t num_g1_monomial_bytes,
+                                       const uint8_t *g1_lagrange_bytes, uint64_t num_g1_lagrange_bytes,
+                                       const uint8_t *g2_monomial_bytes, uint64_t num_g2_monomial_bytes,
+                                       uint64_t precompute, const KzgAmdConfig *cfg);
+C_KZG_RET kzgamd_load_trusted_setup_file_ex(CKZGSettings *out, FILE *in, const KzgAmdConfig *cfg);
 /* the prepared-MSM handle behind a settings object (for kzgamd_msm_* calls) */
 void *kzgamd_settings_msm_handle(const CKZGSettings *s);
 /* the GPU a settings object lives on (-1 if unknown) */
@@ -296,7 +336,7 @@ C_KZG_RET kzgamd_settings_reserve(const CKZGSettings *s, size_t n, void *stream)
  * one Rust process that parallelises inside itself over groups of blobs (kzg/src/eip_4844.rs:770-816) around one shared
  * precomputation handle (kzg/src/msm/sppark.rs:24-44); its GPU path is single-device
  * (arkworks3-sppark-wlc/sppark/msm/pippenger.cuh:573-575).  Here: s[0..ndev) are settings objects loaded from the
- * same trusted setup, normally one per GPU (two on one GPU work too — e.g. under KZGAMD_FBW_MAX_GB — and are how the
+ * same trusted setup, normally one per GPU (two on one GPU work too — with a table budget that lets both fit — and are how the
  * path is tested on a one-GPU box).  Blob i of the batch goes to s[k] for the k with lo_k <= i < hi_k, contiguous slabs
  * whose sizes differ by at most one; one host thread per settings object drives that object's single-device pipeline;
  * results land in place in out[].  Nothing is exchanged between devices (no collective): blobs are independent and
@@ -310,6 +350,10 @@ int kzgamd_shard_range(size_t n, size_t parts, size_t k, size_t *lo, size_t *hi)
 /* one CKZGSettings per entry of devices[] (NULL = GPUs 0 .. ndev-1) from one setup file, loaded in parallel; all or
  * nothing: on failure every out[d] is left empty.  The caller's current device is left alone. */
 C_KZG_RET kzgamd_load_trusted_setup_file_multi(CKZGSettings out[], const int devices[], size_t ndev, FILE *in);
+/* the same with a configuration for every object (cfg->device is ignored: devices[] places them); two objects on one
+ * GPU need an explicit table_budget_bytes that lets both fit */
+C_KZG_RET kzgamd_load_trusted_setup_file_multi_ex(CKZGSettings out[], const int devices[], size_t ndev, FILE *in,
+                                                  const KzgAmdConfig *cfg);
 void kzgamd_free_trusted_setup_multi(CKZGSettings s[], size_t ndev);
 C_KZG_RET kzgamd_blob_to_kzg_commitment_batch_multi(KZGCommitment *out, const Blob *blobs, size_t n,
                                                     const CKZGSettings *const s[], size_t ndev);

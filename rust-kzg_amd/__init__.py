@@ -57,6 +57,9 @@ _lib = None
 
 # every symbol include/kzg_mi355x.h declares; tests check the library exports all of them
 EXPORTS = [
+    "kzgamd_config_init", "kzgamd_tuning_keys", "kzgamd_prepare_msm_ex", "kzgamd_prepare_msm_matrix", "kzgamd_mult_pippenger_matrix",
+    "kzgamd_msm_create_device_ex", "kzgamd_ntt_new_ex", "kzgamd_load_trusted_setup_ex", "kzgamd_load_trusted_setup_file_ex",
+    "kzgamd_load_trusted_setup_file_multi_ex",
     "prepare_msm", "mult_pippenger_prepared", "mult_pippenger", "free_msm", "mult_pippenger_prepared_batch",
     "kzgamd_msm_prepared_batch_device", "kzgamd_msm_info", "kzgamd_msm_uses_wide_table", "kzgamd_msm_set_profile", "kzgamd_msm_get_profile",
     "kzgamd_device_count", "kzgamd_version", "kzgamd_msm_create_device", "kzgamd_generate_points",
@@ -92,6 +95,44 @@ C_KZG_OK, C_KZG_BADARGS, C_KZG_ERROR, C_KZG_MALLOC = 0, 1, 2, 3
 BYTES_PER_BLOB = 131072
 
 
+class KzgAmdConfig(C.Structure):
+    """include/kzg_mi355x.h: the configuration every creating entry point's _ex form takes"""
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("table_budget_bytes", C.c_uint64), ("tuning", C.c_char_p)]
+
+
+NO_TABLES = (1 << 64) - 1
+
+
+def make_config(device=-1, table_budget_gb=None, tuning=None, no_tables=False):
+    """KzgAmdConfig for the `config=` arguments below.  table_budget_gb: HBM each fixed-base table may take (None = the
+    library's default); tuning: a dict or "key=value;key=value" string of the measured switches (tuning_keys())."""
+    cfg = KzgAmdConfig()
+    lib().kzgamd_config_init(C.byref(cfg))
+    cfg.device = device
+    if no_tables:
+        cfg.table_budget_bytes = NO_TABLES
+    elif table_budget_gb is not None:
+        cfg.table_budget_bytes = max(1, int(table_budget_gb * 1e9))
+    if isinstance(tuning, dict):
+        tuning = ";".join("%s=%d" % (k, int(v)) for k, v in tuning.items())
+    if tuning:
+        cfg.tuning = tuning.encode()
+    return cfg
+
+
+def _cfgp(config):
+    return C.byref(config) if config is not None else None
+
+
+def tuning_keys():
+    """{name: (default, lo, hi, meaning)} — the table of rust-kzg_amd/csrc/config.h"""
+    out = {}
+    for line in lib().kzgamd_tuning_keys().decode().splitlines():
+        name, d, lo, hi, what = line.split(" ", 4)
+        out[name] = (int(d), int(lo), int(hi), what)
+    return out
+
+
 def lib():
     """Load libkzg_mi355x.so; raises (loudly) when it has not been built."""
     global _lib
@@ -103,6 +144,20 @@ def lib():
     vp, sz = C.c_void_p, C.c_size_t
     L.prepare_msm.restype = vp
     L.prepare_msm.argtypes = [vp, sz]
+    cp = C.POINTER(KzgAmdConfig)
+    L.kzgamd_config_init.restype = None
+    L.kzgamd_config_init.argtypes = [cp]
+    L.kzgamd_tuning_keys.restype = C.c_char_p
+    L.kzgamd_prepare_msm_ex.restype = vp
+    L.kzgamd_prepare_msm_ex.argtypes = [vp, sz, cp]
+    L.kzgamd_prepare_msm_matrix.restype = vp
+    L.kzgamd_prepare_msm_matrix.argtypes = [vp, sz, sz, cp]
+    L.kzgamd_mult_pippenger_matrix.restype = RustError
+    L.kzgamd_mult_pippenger_matrix.argtypes = [vp, vp, vp, sz]
+    L.kzgamd_msm_create_device_ex.restype = vp
+    L.kzgamd_msm_create_device_ex.argtypes = [vp, sz, C.c_int, cp]
+    L.kzgamd_ntt_new_ex.restype = vp
+    L.kzgamd_ntt_new_ex.argtypes = [C.c_uint, cp]
     L.free_msm.restype = None
     L.free_msm.argtypes = [vp]
     L.mult_pippenger_prepared.restype = RustError
@@ -153,6 +208,13 @@ def lib():
                                      C.c_uint64]
     L.load_trusted_setup_file.restype = C.c_int
     L.load_trusted_setup_file.argtypes = [sp, vp]
+    L.kzgamd_load_trusted_setup_ex.restype = C.c_int
+    L.kzgamd_load_trusted_setup_ex.argtypes = [sp, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64,
+                                               C.c_uint64, cp]
+    L.kzgamd_load_trusted_setup_file_ex.restype = C.c_int
+    L.kzgamd_load_trusted_setup_file_ex.argtypes = [sp, vp, cp]
+    L.kzgamd_load_trusted_setup_file_multi_ex.restype = C.c_int
+    L.kzgamd_load_trusted_setup_file_multi_ex.argtypes = [vp, vp, sz, vp, cp]
     L.free_trusted_setup.restype = None
     L.free_trusted_setup.argtypes = [sp]
     L.kzgamd_compute_challenges_and_evaluate_batch.restype = C.c_int
@@ -250,9 +312,10 @@ def _addr(buf):
 class PreparedMsm:
     """Owning handle = the reference's SpparkPrecomputation.table (kzg/src/msm/sppark.rs:5-22)."""
 
-    def __init__(self, points, npoints):
+    def __init__(self, points, npoints, config=None):
         self.npoints = npoints
-        self.handle = lib().prepare_msm(_addr(points), npoints)
+        self.handle = lib().kzgamd_prepare_msm_ex(_addr(points), npoints, _cfgp(config)) if config is not None \
+            else lib().prepare_msm(_addr(points), npoints)
         if not self.handle:
             raise KzgAmdError("prepare_msm failed (no GPU, or bad arguments)")
 
@@ -276,9 +339,26 @@ class PreparedMsm:
             pass
 
 
-def prepare_multi_scalar_mult(points, npoints):
+def prepare_multi_scalar_mult(points, npoints, config=None):
     """blst-sppark/src/lib.rs:8-17.  points: ctypes array / buffer of blst_p1_affine."""
-    return PreparedMsm(points, npoints)
+    return PreparedMsm(points, npoints, config)
+
+
+class MatrixMsm(PreparedMsm):
+    """rows base sets of cols points in one table: the precomputation behind G1LinComb::g1_lincomb_batch
+    (kzg/src/lib.rs:156-181 -> BgmwTable::multiply_batch, kzg/src/msm/bgmw.rs:306-380).  points[r * cols + c]."""
+
+    def __init__(self, points, rows, cols, config=None):
+        self.rows, self.cols, self.npoints = rows, cols, rows * cols
+        self.handle = lib().kzgamd_prepare_msm_matrix(_addr(points), rows, cols, _cfgp(config))
+        if not self.handle:
+            raise KzgAmdError("kzgamd_prepare_msm_matrix failed (no GPU, bad arguments, or no wide table fits the budget)")
+
+    def multiply_batch(self, scalars, nmat=1):
+        """scalars: blst_fr[nmat * rows * cols] (Montgomery) -> (BlstP1 * (nmat * rows))"""
+        out = (BlstP1 * (nmat * self.rows))()
+        _check(lib().kzgamd_mult_pippenger_matrix(self.handle, out, _addr(scalars), nmat), "kzgamd_mult_pippenger_matrix")
+        return out
 
 
 def multi_scalar_mult_prepared(msm, scalars, npoints):
@@ -352,11 +432,13 @@ class KZGSettings:
         self.loaded = False
 
     @classmethod
-    def from_file(cls, path):
+    def from_file(cls, path, config=None):
         self = cls()
+        self._config = config  # keeps the tuning string alive for the duration of the call
         f = _fopen(path)
         try:
-            rc = lib().load_trusted_setup_file(C.byref(self.c), f)
+            rc = lib().kzgamd_load_trusted_setup_file_ex(C.byref(self.c), f, _cfgp(config)) if config is not None \
+                else lib().load_trusted_setup_file(C.byref(self.c), f)
         finally:
             _libc.fclose(f)
         if rc != C_KZG_OK:
@@ -365,10 +447,14 @@ class KZGSettings:
         return self
 
     @classmethod
-    def from_bytes(cls, g1_monomial, g1_lagrange, g2_monomial):
+    def from_bytes(cls, g1_monomial, g1_lagrange, g2_monomial, config=None):
         self = cls()
-        rc = lib().load_trusted_setup(C.byref(self.c), g1_monomial, len(g1_monomial), g1_lagrange, len(g1_lagrange),
-                                      g2_monomial, len(g2_monomial), 0)
+        if config is not None:
+            rc = lib().kzgamd_load_trusted_setup_ex(C.byref(self.c), g1_monomial, len(g1_monomial), g1_lagrange, len(g1_lagrange),
+                                                    g2_monomial, len(g2_monomial), 0, _cfgp(config))
+        else:
+            rc = lib().load_trusted_setup(C.byref(self.c), g1_monomial, len(g1_monomial), g1_lagrange, len(g1_lagrange),
+                                          g2_monomial, len(g2_monomial), 0)
         if rc != C_KZG_OK:
             raise KzgAmdError("load_trusted_setup: C_KZG_RET %d" % rc)
         self.loaded = True
@@ -455,9 +541,9 @@ def msm_get_profile(handle):
 class DeviceMsm(PreparedMsm):
     """Handle over device-resident bases (kzgamd_msm_create_device)."""
 
-    def __init__(self, d_points, npoints, prepare):
+    def __init__(self, d_points, npoints, prepare, config=None):
         self.npoints = npoints
-        self.handle = lib().kzgamd_msm_create_device(C.c_void_p(d_points), npoints, 1 if prepare else 0)
+        self.handle = lib().kzgamd_msm_create_device_ex(C.c_void_p(d_points), npoints, 1 if prepare else 0, _cfgp(config))
         if not self.handle:
             raise KzgAmdError("kzgamd_msm_create_device failed")
 
@@ -483,12 +569,12 @@ class FFTSettings:
     (blst/src/fft_fr.rs:156-165, blst/src/data_availability_sampling.rs:78-100).
     Errors are raised with the reference's messages."""
 
-    def __init__(self, scale):
+    def __init__(self, scale, config=None):
         if scale >= 32:
             raise KzgAmdError("Scale is expected to be within root of unity matrix row size")
         self.scale = scale
         self.max_width = 1 << scale
-        self.handle = lib().kzgamd_ntt_new(scale)
+        self.handle = lib().kzgamd_ntt_new_ex(scale, _cfgp(config)) if config is not None else lib().kzgamd_ntt_new(scale)
         if not self.handle:
             raise KzgAmdError("kzgamd_ntt_new failed (no GPU?)")
 
@@ -786,7 +872,7 @@ class MultiKZGSettings:
     the in-process multi-GPU path — contiguous slabs of blobs per settings object, one host thread each, inside the
     library.  Two entries may name the same GPU (how the path is tested on a one-GPU box)."""
 
-    def __init__(self, path, devices):
+    def __init__(self, path, devices, config=None):
         self.ndev = len(devices)
         self.devices = list(devices)
         self.arr = (CKZGSettings * self.ndev)()
@@ -794,7 +880,8 @@ class MultiKZGSettings:
         devs = (C.c_int * self.ndev)(*self.devices)
         f = _fopen(path)
         try:
-            rc = lib().kzgamd_load_trusted_setup_file_multi(self.arr, devs, self.ndev, f)
+            rc = lib().kzgamd_load_trusted_setup_file_multi_ex(self.arr, devs, self.ndev, f, _cfgp(config)) if config is not None \
+                else lib().kzgamd_load_trusted_setup_file_multi(self.arr, devs, self.ndev, f)
         finally:
             _libc.fclose(f)
         if rc != C_KZG_OK:

@@ -18,6 +18,7 @@
 
 #include "../../include/kzg_mi355x.h"
 #include "ckzg_internal.h"
+#include "config.h"
 #include "device_guard.h"
 #include "ff.hip.h"
 #include "fr29.hip.h"
@@ -241,7 +242,6 @@ constexpr int QE = (int)(N / QT);  // elements per thread (8), element index i =
 // the 4096 inversions are one Fermat inversion per blob via a block-wide product scan
 // (the reference's fr_batch_inv :882-914 is the same trick, serial).
 // Outputs: q as canonical little-endian scalars (ready for the MSM), y canonical.
-template <bool ARRAYS>
 __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* __restrict__ y_out, int* __restrict__ status,
                                                  const u32* __restrict__ blobs, const u32* __restrict__ z_be,
                                                  const ff::Fr* __restrict__ roots_brp, ff::Fr ninv) {
@@ -262,21 +262,15 @@ __global__ void __launch_bounds__(QT) k_quotient(u32* __restrict__ q_out, u32* _
     if (!zok && t == 0) sh_bad = 1;
 
     // The thread's QE prefix products, then its QE inverses, are kept in the element's own 32-byte slot of q_out until the
-    // quotient overwrites them (same lane, same address).  ARRAYS (KZGAMD_QUOTIENT_ARRAYS=1): as per-thread arrays, which
-    // are 536 bytes of scratch per lane — the loops are too large to unroll with the multiplications inlined, so the
-    // arrays are indexed dynamically.
+    // quotient overwrites them (same lane, same address).  (Per-thread arrays instead were 536 bytes of scratch per lane —
+    // the loops are too large to unroll with the multiplications inlined, so the arrays were indexed dynamically; removed
+    // in round 5.)
     uint4* qslot = reinterpret_cast<uint4*>(q_out + blob * (N * 8));
-    ff::Fr held[ARRAYS ? QE : 1];
-    auto put = [&](int k, int i, const ff::Fr& x) {
-        if (ARRAYS) {
-            held[ARRAYS ? k : 0] = x;
-            return;
-        }
+    auto put = [&](int, int i, const ff::Fr& x) {
         qslot[2 * i] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
         qslot[2 * i + 1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
     };
-    auto get = [&](int k, int i) {
-        if (ARRAYS) return held[ARRAYS ? k : 0];
+    auto get = [&](int, int i) {
         const uint4 lo = qslot[2 * i], hi = qslot[2 * i + 1];
         ff::Fr x;
         x.v[0] = lo.x, x.v[1] = lo.y, x.v[2] = lo.z, x.v[3] = lo.w;
@@ -988,25 +982,36 @@ struct KzgAmdSettings {
         std::condition_variable cv;
         std::deque<void*> pending;
         int leaders = 0;
+        int max_leaders = 3, gather_us = 60;  // tuning keys leaders / gather_min / gather_us (apply_options)
+        size_t gather_min = 6;
     };
-    static int env_int(const char* name, int dflt, int lo, int hi) {  // a measurement switch, clamped to [lo, hi]
-        const char* v = getenv(name);
-        if (!v) return dflt;
-        const long x = strtol(v, nullptr, 10);
-        return x < lo ? lo : (x > hi ? hi : (int)x);
-    }
-    static inline int MAX_LEADERS = env_int("KZGAMD_LEADERS", 3, 1, 64);  // read once, at load; never below one leader
+    // the tuning keys of config.h this layer reads, copied once when the settings object is created (apply_options;
+    // lanes take their parent's)
+    kzgamd::Options opt;
     CoalesceQueue q_commit, q_blob_proof, q_proof;
-    // measurement switches, read once when the settings object is created
-    bool cfg_device_sha = getenv("KZGAMD_DEVICE_SHA") && atoi(getenv("KZGAMD_DEVICE_SHA")) != 0;
-    bool cfg_quotient_arrays = env_int("KZGAMD_QUOTIENT_ARRAYS", 0, 0, 1) != 0;
-    size_t cfg_host_check_max = (size_t)env_int("KZGAMD_HOST_CHECK_MAX", 64, 0, 1 << 20);  // see HOST_CHECK_MAX
-    size_t cfg_prove_chunk = (size_t)env_int("KZGAMD_PROVE_CHUNK", 0, 0, 1 << 20);
-    bool cfg_wide_check = !(getenv("KZGAMD_WIDE_CHECK") && atoi(getenv("KZGAMD_WIDE_CHECK")) == 0);  // 0: single-lane tests
-    size_t cfg_prove_first = (size_t)env_int("KZGAMD_PROVE_FIRST", 0, 0, 1 << 20);
-    size_t cfg_commit_first = (size_t)env_int("KZGAMD_COMMIT_FIRST", 0, 0, 1 << 20);
-    size_t cfg_commit_chunk = (size_t)env_int("KZGAMD_COMMIT_CHUNK", 0, 0, 1 << 20);
-    int cfg_fk20 = getenv("KZGAMD_FK20") ? (atoi(getenv("KZGAMD_FK20")) != 0 ? 1 : 0) : -1;  // -1: by batch size
+    bool cfg_device_sha = false;
+    size_t cfg_host_check_max = 64;  // see HOST_CHECK_MAX
+    size_t cfg_prove_chunk = 0;
+    bool cfg_wide_check = true;      // false: single-lane tests
+    size_t cfg_prove_first = 0, cfg_commit_first = 0, cfg_commit_chunk = 0;
+    int cfg_fk20 = -1;               // -1: by batch size
+    void apply_options(const kzgamd::Options& o) {
+        using namespace kzgamd;
+        opt = o;
+        for (CoalesceQueue* q : {&q_commit, &q_blob_proof, &q_proof}) {
+            q->max_leaders = (int)o.t[T_LEADERS];
+            q->gather_min = (size_t)o.t[T_GATHER_MIN];
+            q->gather_us = (int)o.t[T_GATHER_US];
+        }
+        cfg_device_sha = o.t[T_DEVICE_SHA] != 0;
+        cfg_host_check_max = (size_t)o.t[T_HOST_CHECK_MAX];
+        cfg_prove_chunk = (size_t)o.t[T_PROVE_CHUNK];
+        cfg_wide_check = o.t[T_WIDE_CHECK] != 0;
+        cfg_prove_first = (size_t)o.t[T_PROVE_FIRST];
+        cfg_commit_first = (size_t)o.t[T_COMMIT_FIRST];
+        cfg_commit_chunk = (size_t)o.t[T_COMMIT_CHUNK];
+        cfg_fk20 = (int)o.t[T_FK20];
+    }
     bool is_lane = false;
     std::atomic<bool> busy{false};
     // page-locked staging for calls of up to LANE_MAX_BLOBS blobs: copies to and from it are truly asynchronous (a
@@ -1308,6 +1313,7 @@ KzgAmdSettings* lookup(const CKZGSettings* s) {
 // A lane of `parent`: own streams, staging and mutex; tables and engine handles borrowed (see KzgAmdSettings::lanes)
 KzgAmdSettings* make_lane(KzgAmdSettings* parent) {
     std::unique_ptr<KzgAmdSettings> ln(new KzgAmdSettings());
+    ln->apply_options(parent->opt);
     ln->is_lane = true;
     ln->device = parent->device;
     kzgamd::DeviceGuard on_device(parent->device);
@@ -1451,7 +1457,12 @@ void free_host_arrays(CKZGSettings* s) {
 
 // load_trusted_setup_rust (kzg/src/eip_4844.rs:1022-1086) with the G1 work on the device
 void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint8_t* g1_lag, size_t n1l,
-               const uint8_t* g2_mono, size_t n2) {
+               const uint8_t* g2_mono, size_t n2, const KzgAmdConfig* cfg) {
+    kzgamd::Options opt;
+    {
+        std::string err;
+        if (!kzgamd::Options::resolve(opt, cfg, &err)) throw CkErr{C_KZG_BADARGS, err};
+    }
     CK_REQUIRE(n1m / 48 == N && n1m % 48 == 0, "Invalid number of G1 points");
     CK_REQUIRE(n1l / 48 == N && n1l % 48 == 0, "Invalid number of G1 points");
     CK_REQUIRE(n2 / 96 == NUM_G2 && n2 % 96 == 0, "Invalid number of G2 points");
@@ -1464,11 +1475,16 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
         CK_REQUIRE(kzgamd::pairing::g2_uncompress(g2[i], g2_mono + 96 * i), "Failed to uncompress G2 point");
 
     auto* dev = new KzgAmdSettings();
+    dev->apply_options(opt);
     unsigned char* d_bytes = nullptr;
     AffPt* d_pts = nullptr;
     int* d_bad = nullptr;
     ff::Fp* d_p1 = nullptr;
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    kzgamd::DeviceGuard placed(opt.device >= 0 ? opt.device : cur_dev);  // the caller's device is restored on return
     try {
+        CK_HIP(placed.err);
         CK_HIP(hipGetDevice(&dev->device));
         CK_HIP(hipStreamCreateWithFlags(&dev->stream, hipStreamNonBlocking));
         // stream2 carries the long one-lane latency chains that nothing waits for until the end of a call (the
@@ -1506,7 +1522,8 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
 
         // fixed-base MSM table over the bit-reversed Lagrange points (FsKZGSettings::new ->
         // prepare_msm, blst/src/types/kzg_settings.rs:109-123)
-        dev->msm = kzgamd::msm_create(d_pts + N, N, true, true, true);
+        dev->opt.device = -1;  // dev->device names the GPU from here on
+        dev->msm = kzgamd::msm_create(d_pts + N, N, true, true, true, kzgamd::G1_TRUSTED, &dev->opt);
         CK_HIP(hipMalloc(&dev->d_monomial, N * sizeof(AffPt)));
         CK_HIP(hipMemcpy(dev->d_monomial, d_pts, N * sizeof(AffPt), hipMemcpyDeviceToDevice));
 
@@ -1552,7 +1569,7 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
                 const size_t start = N - CELL_SIZE - 1 - offset;
                 for (size_t i = 0; i + 1 < CELLS_PER_BLOB; ++i) xin[offset * K2 + i] = out->g1_values_monomial[start - i * CELL_SIZE];
             }
-            dev->ntt = kzgamd_ntt_new(13);
+            dev->ntt = kzgamd::ntt_create(13, dev->opt);
             if (!dev->ntt) throw CkErr{C_KZG_ERROR, "kzgamd_ntt_new failed"};
             if (kzgamd_fft_g1_batch(dev->ntt, xout.data(), xin.data(), K2, CELL_SIZE, 0) != 0) throw CkErr{C_KZG_ERROR, "fft_g1"};
             out->x_ext_fft_columns = leak_array<blst_p1*>(K2);
@@ -1639,7 +1656,7 @@ void prove_enqueue(KzgAmdSettings* dev, size_t off, size_t n, hipStream_t stream
         hipLaunchKernelGGL(k_quotient_b, dim3((unsigned)(n * QS)), dim3(QT), 0, stream, scal, yv, dev->d_qscratch, bl, zv,
                            (const ff::Fr*)dev->d_brp_roots, n_inverse());
     } else {
-        hipLaunchKernelGGL(dev->cfg_quotient_arrays ? k_quotient<true> : k_quotient<false>, dim3((unsigned)n), dim3(QT), 0, stream, scal, yv, stat, bl, zv,
+        hipLaunchKernelGGL(k_quotient, dim3((unsigned)n), dim3(QT), 0, stream, scal, yv, stat, bl, zv,
                            (const ff::Fr*)dev->d_brp_roots, n_inverse());
     }
     if (evaluate_only) return;  // y = p(z) is all the caller wants (the field work of batched verification)
@@ -2005,7 +2022,7 @@ void fk20_prepare(KzgAmdSettings* dev, const CKZGSettings* cs) {
         aff[2 * k] = hfp::mul(P[0], zi2);
         aff[2 * k + 1] = hfp::mul(P[1], hfp::mul(zi2, zi));
     }
-    dev->msm_xext = kzgamd::msm_create(aff.data(), total, false, true, false);
+    dev->msm_xext = kzgamd::msm_create(aff.data(), total, false, true, false, kzgamd::G1_TRUSTED, &dev->opt);
 }
 
 // The 128 cell proofs of n polynomials whose 4096 monomial coefficients are in dev->d_fr_b, compressed into
@@ -2088,7 +2105,7 @@ void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_
             fk20 = false;
         }
     }
-    if (proofs && !fk20 && !dev->msm_monomial) dev->msm_monomial = kzgamd::msm_create(dev->d_monomial, N, true, true, true);
+    if (proofs && !fk20 && !dev->msm_monomial) dev->msm_monomial = kzgamd::msm_create(dev->d_monomial, N, true, true, true, kzgamd::G1_TRUSTED, &dev->opt);
     dev->ensure(n);
     dev->ensure_cells(n);
     if (proofs && fk20) dev->ensure_fk20(n);
@@ -2191,21 +2208,30 @@ KzgAmdSettings* kzgamd::device_settings(const CKZGSettings* s) { return lookup(s
 
 // ---------------------------------------------------------------- C ABI (B3)
 
-extern "C" C_KZG_RET load_trusted_setup(CKZGSettings* out, const uint8_t* g1_monomial_bytes, uint64_t num_g1_monomial_bytes,
-                                        const uint8_t* g1_lagrange_bytes, uint64_t num_g1_lagrange_bytes,
-                                        const uint8_t* g2_monomial_bytes, uint64_t num_g2_monomial_bytes,
-                                        uint64_t precompute) {
+extern "C" C_KZG_RET kzgamd_load_trusted_setup_ex(CKZGSettings* out, const uint8_t* g1_monomial_bytes, uint64_t num_g1_monomial_bytes,
+                                                  const uint8_t* g1_lagrange_bytes, uint64_t num_g1_lagrange_bytes,
+                                                  const uint8_t* g2_monomial_bytes, uint64_t num_g2_monomial_bytes,
+                                                  uint64_t precompute, const KzgAmdConfig* cfg) {
     (void)precompute;
     if (!out) return C_KZG_BADARGS;
     zero_settings(out);
     if (!g1_monomial_bytes || !g1_lagrange_bytes || !g2_monomial_bytes) return C_KZG_BADARGS;
     return guarded([&] {
         load_impl(out, g1_monomial_bytes, num_g1_monomial_bytes, g1_lagrange_bytes, num_g1_lagrange_bytes, g2_monomial_bytes,
-                  num_g2_monomial_bytes);
+                  num_g2_monomial_bytes, cfg);
     });
 }
+extern "C" C_KZG_RET load_trusted_setup(CKZGSettings* out, const uint8_t* g1_monomial_bytes, uint64_t num_g1_monomial_bytes,
+                                        const uint8_t* g1_lagrange_bytes, uint64_t num_g1_lagrange_bytes,
+                                        const uint8_t* g2_monomial_bytes, uint64_t num_g2_monomial_bytes,
+                                        uint64_t precompute) {
+    return kzgamd_load_trusted_setup_ex(out, g1_monomial_bytes, num_g1_monomial_bytes, g1_lagrange_bytes, num_g1_lagrange_bytes,
+                                        g2_monomial_bytes, num_g2_monomial_bytes, precompute, nullptr);
+}
 
-extern "C" C_KZG_RET load_trusted_setup_file(CKZGSettings* out, FILE* in) {
+extern "C" C_KZG_RET load_trusted_setup_file(CKZGSettings* out, FILE* in) { return kzgamd_load_trusted_setup_file_ex(out, in, nullptr); }
+
+extern "C" C_KZG_RET kzgamd_load_trusted_setup_file_ex(CKZGSettings* out, FILE* in, const KzgAmdConfig* cfg) {
     if (!out) return C_KZG_BADARGS;
     zero_settings(out);
     if (!in) return C_KZG_BADARGS;
@@ -2215,7 +2241,7 @@ extern "C" C_KZG_RET load_trusted_setup_file(CKZGSettings* out, FILE* in) {
         buf.resize(len);
         std::vector<uint8_t> g1m, g1l, g2m;
         parse_setup_text(buf, g1m, g1l, g2m);
-        load_impl(out, g1m.data(), g1m.size(), g1l.data(), g1l.size(), g2m.data(), g2m.size());
+        load_impl(out, g1m.data(), g1m.size(), g1l.data(), g1l.size(), g2m.data(), g2m.size(), cfg);
     });
 }
 
@@ -2245,8 +2271,8 @@ namespace {
 // (run's implementation calls it), and whoever has not got to it by the end does it then.
 template <class Req, class Run>
 C_KZG_RET coalesced_call(KzgAmdSettings::CoalesceQueue& q, Req& me, Run&& run) {
-    static const size_t gather_min = (size_t)KzgAmdSettings::env_int("KZGAMD_GATHER_MIN", 6, 1, (int)KzgAmdSettings::LANE_MAX_BLOBS);
-    static const int gather_us = KzgAmdSettings::env_int("KZGAMD_GATHER_US", 60, 0, 100000);
+    const size_t gather_min = q.gather_min;
+    const int gather_us = q.gather_us;
     // everything that can allocate happens before the request is visible to other callers: nothing below throws
     std::vector<Req*> batch;
     std::unique_lock<std::mutex> lk(q.mu, std::defer_lock);
@@ -2260,7 +2286,7 @@ C_KZG_RET coalesced_call(KzgAmdSettings::CoalesceQueue& q, Req& me, Run&& run) {
     q.cv.notify_one();  // a leader gathering requests may have enough now
     bool idled = false;
     while (!me.done) {
-        if (q.leaders < KzgAmdSettings::MAX_LEADERS && !q.pending.empty()) {
+        if (q.leaders < q.max_leaders && !q.pending.empty()) {
             ++q.leaders;
             while (!q.pending.empty() && !me.done) {
                 // under load (other batches in flight) a short wait lets the callers that have just been served come
@@ -2531,7 +2557,7 @@ extern "C" C_KZG_RET kzgamd_compute_blob_kzg_proof_device(void* d_proofs, void* 
                            (const u32*)d_commitments, n);
         hipLaunchKernelGGL(k_check_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, stat,
                            (const unsigned char*)d_commitments, n);
-        hipLaunchKernelGGL(dev->cfg_quotient_arrays ? k_quotient<true> : k_quotient<false>, dim3((unsigned)n), dim3(QT), 0, st, scal, y, stat, (const u32*)d_blobs, (const u32*)z,
+        hipLaunchKernelGGL(k_quotient, dim3((unsigned)n), dim3(QT), 0, st, scal, y, stat, (const u32*)d_blobs, (const u32*)z,
                            (const ff::Fr*)dev->d_brp_roots, n_inverse());
         kzgamd::msm_lock(dev->msm);
         try {
@@ -2771,7 +2797,7 @@ void verify_g1_finish(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commi
     if (scalars_ok) {
         try {
             CK_HIP(hipEventSynchronize(dev->ev_decoded));
-            if (!dev->msm_verify) dev->msm_verify = kzgamd::msm_create(dev->d_vpts, np, true, false, true);
+            if (!dev->msm_verify) dev->msm_verify = kzgamd::msm_create(dev->d_vpts, np, true, false, true, kzgamd::G1_TRUSTED, &dev->opt);
             else kzgamd::msm_reset_points(dev->msm_verify, dev->d_vpts, np);
             kzgamd::msm_run_host(dev->msm_verify, out, sc.data(), np, 2);
         } catch (...) {
@@ -3226,7 +3252,7 @@ void verify_cells(bool* ok, const Bytes48* commitments_bytes, const uint64_t* ce
         kzgamd::DeviceGuard on_device(dev->device);
         CK_HIP(on_device.err);
         CK_HIP(hipEventSynchronize(dev->ev_decoded));
-        if (!dev->msm_verify) dev->msm_verify = kzgamd::msm_create(dev->d_vpts, np, true, false, true);
+        if (!dev->msm_verify) dev->msm_verify = kzgamd::msm_create(dev->d_vpts, np, true, false, true, kzgamd::G1_TRUSTED, &dev->opt);
         else kzgamd::msm_reset_points(dev->msm_verify, dev->d_vpts, np);
         kzgamd::msm_run_host(dev->msm_verify, out, sc.data(), np, 2);
     } catch (...) {
@@ -3346,7 +3372,7 @@ void recover_cells(Cell* recovered_cells, KZGProof* recovered_proofs, const uint
             CK_HIP(hipMalloc(&dev->d_roots8192, (2 * N + 1) * sizeof(ff::Fr)));
             CK_HIP(hipMemcpy(dev->d_roots8192, cs->roots_of_unity, (2 * N + 1) * sizeof(ff::Fr), hipMemcpyHostToDevice));
         }
-        if (!dev->msm_monomial) dev->msm_monomial = kzgamd::msm_create(dev->d_monomial, N, true, true, true);
+        if (!dev->msm_monomial) dev->msm_monomial = kzgamd::msm_create(dev->d_monomial, N, true, true, true, kzgamd::G1_TRUSTED, &dev->opt);
         dev->ensure_q(1);
         CK_HIP(hipMemcpyAsync(dev->d_fr_b, D, N * sizeof(ff::Fr), hipMemcpyDeviceToDevice, st));
         enqueue_cell_proofs(dev, 1, st, false);

@@ -33,6 +33,7 @@
 #include "g1w.hip.h"
 #include "glv.hip.h"
 #include "host_g1.h"
+#include "config.h"
 #include "device_guard.h"
 #include "msm_internal.h"
 
@@ -888,76 +889,11 @@ __global__ void __launch_bounds__(DIGIT_T) k_digit_sums(const Xyzz* __restrict__
 // 256 workgroups of eight waves at n = 2^20 (a chain of ~15 additions).  The (digit, value) cells that are left have
 // nb / 1024 values each: few enough additions for one wave per addition (k_digit_sums_wide, k_digit_bits_wide).
 constexpr int TILE_T = 512;  // two buckets per lane and phase: a full CU (two waves per SIMD) per tile
-__global__ void __launch_bounds__(TILE_T) k_tile_sums(const Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
-                                                      const unsigned char* __restrict__ heavy, Xyzz* __restrict__ dense,
-                                                      Xyzz* __restrict__ Gs, Xyzz* __restrict__ Cp, size_t nb, size_t nchunk,
-                                                      ChunkSel cs) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ts[];
-    Xyzz* sh = (Xyzz*)smem_ts;
-    const size_t ntiles = nb >> 10;
-    const size_t set = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
-    const size_t k0 = tile << 10;
-    const int t = threadIdx.x;
-    Xyzz acc;
-    {
-        // rows: lane t folds and adds buckets 32 r + 2 q, + 1 of the tile, r = t / 16, q = t % 16
-        const int r = t >> 4, q = t & 15;
-        const size_t kb = k0 + (size_t)(32 * r + 2 * q);
-        g1::set_inf(acc);
-#pragma unroll 1
-        for (int i = 0; i < 2; ++i) {
-            Xyzz v;
-            load_bucket(v, partials + set * (nb + nchunk), offsets + set * (nb + 1), heavy + set * nb, kb + i, nb, cs);
-            dense[set * nb + kb + i] = v;
-            g1::dadd(acc, v);
-        }
-        // the row tree runs q-major (slot 32 q + r) so that the lanes still adding at a level are the first
-        // 32 * stride of the workgroup: whole waves drop out level by level instead of all eight staying half empty
-        sh[32 * q + r] = acc;
-        __syncthreads();
-        acc = sh[t];
-#pragma unroll 1
-        for (int stride = 8; stride > 0; stride >>= 1) {
-            if (t < 32 * stride) {
-                Xyzz v = sh[t + 32 * stride];
-                g1::dadd(acc, v);
-                sh[t] = acc;
-            }
-            __syncthreads();
-        }
-        if (t < 32) Gs[set * (nb >> 5) + (k0 >> 5) + t] = acc;
-    }
-    __threadfence();  // the folded buckets this workgroup wrote are read back below by other lanes
-    __syncthreads();
-    {
-        // columns: lane t adds rows 2 rg, 2 rg + 1 of column c, c = t % 32, rg = t / 32
-        const int c = t & 31, rg = t >> 5;
-        g1::set_inf(acc);
-#pragma unroll 1
-        for (int i = 0; i < 2; ++i) {
-            Xyzz v = dense[set * nb + k0 + (size_t)(32 * (2 * rg + i) + c)];
-            g1::dadd(acc, v);
-        }
-        sh[t] = acc;
-        __syncthreads();
-#pragma unroll 1
-        for (int stride = 8; stride > 0; stride >>= 1) {
-            if (rg < stride) {
-                Xyzz v = sh[t + 32 * stride];
-                g1::dadd(acc, v);
-                sh[t] = acc;
-            }
-            __syncthreads();
-        }
-        if (rg == 0) Cp[(set * ntiles + tile) * 32 + c] = acc;
-    }
-}
-
-// The same sums with every addition at one of TWO inlined sites, each the body of a loop whose second operand comes from
+// Every addition is at one of TWO inlined sites, each the body of a loop whose second operand comes from
 // memory (the form that took the scratch out of the G1 stages): loop 1 folds the pieces of the lane's two
 // buckets, loop 2 is a ten-step schedule — the pair of buckets, four row-tree levels, the pair of rows, four column-tree
-// levels — in which a step only chooses where the operand comes from and where the sum goes.  k_tile_sums above has five
-// sites (each with its own never-taken doubling): 256 VGPRs, 86 of them spilled.
+// levels — in which a step only chooses where the operand comes from and where the sum goes.  (Round 3's form had five
+// sites, each with its own never-taken doubling: 256 VGPRs, 86 of them spilled; removed in round 5.)
 __global__ void __launch_bounds__(TILE_T) k_tile_sums_loop(const Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
                                                            const unsigned char* __restrict__ heavy, Xyzz* __restrict__ dense,
                                                            Xyzz* __restrict__ Gs, Xyzz* __restrict__ Cp, size_t nb,
@@ -1760,11 +1696,10 @@ __global__ void __launch_bounds__(128) k_gen_points(ff::Fp* __restrict__ out, si
 
 // ---------------------------------------------------------------- host side
 
-// HBM the wide table may take: KZGAMD_FBW_MAX_GB (default below), capped by what is free right now
-// (leaving room for the build scratch and the per-call workspaces)
-double fbw_budget_gb() {
-    double budget_gb = FBW_DEFAULT_GB;
-    if (const char* e = getenv("KZGAMD_FBW_MAX_GB")) budget_gb = atof(e);
+// HBM the wide table may take: the handle's configured budget (Options::table_budget_gb; < 0 = the default below),
+// capped by what is free right now (leaving room for the build scratch and the per-call workspaces)
+double fbw_budget_gb(double configured) {
+    double budget_gb = configured >= 0 ? configured : FBW_DEFAULT_GB;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         const double room = ((double)free_b - 12e9) / 1.05 / 1e9;
@@ -1777,8 +1712,8 @@ double fbw_budget_gb() {
 // fits the HBM budget.  Without the split a scalar costs rows = ceil(256/c) additions from a table of
 // rows * n * 2^(c-1) slots; with the GLV split (bases must be in the r-torsion subgroup) 2 * ceil(128/c) additions from
 // a table of ceil(128/c) * n * 2^(c-1) slots.  Returns 0 when nothing fits.
-int choose_wide_window(size_t n, bool glv_allowed, bool* use_glv) {
-    const double budget_gb = fbw_budget_gb();
+int choose_wide_window(size_t n, bool glv_allowed, bool* use_glv, double configured_gb) {
+    const double budget_gb = fbw_budget_gb(configured_gb);
     int best_c = 0, best_adds = 1 << 30;
     double best_gb = 0;
     bool best_glv = false;
@@ -1801,7 +1736,7 @@ int choose_wide_window(size_t n, bool glv_allowed, bool* use_glv) {
 int choose_window(size_t n, bool prepared, bool glv, int forced) {
     // minimise adds: prepared  n*ceil(256/c) + 3*2^(c-1);  unprepared  ceil(256/c) * (n + 3*2^(c-1));
     // unprepared with the GLV split: (128/c + 1) bucket sets fed by 2n half-scalars
-    // forced: KZGAMD_WINDOW / KZGAMD_WINDOW_PREPARED as read when the handle was created (0 = by size)
+    // forced: tuning keys window / window_prepared as read when the handle was created (0 = by size)
     if (forced >= 2 && forced <= 22) return forced;
     if (glv) {
         // measured on MI355X (tools/sweep_window.py, device-resident inputs): c = 16 wins from n = 2^15 up to at
@@ -1888,57 +1823,46 @@ struct Workspace {
 
 }  // namespace
 
-// The measurement switches of DESIGN.md §12, read from the environment ONCE, when a handle is created (an enqueue never
-// calls getenv); every variant computes the same result a different way.
+// The tuning keys of config.h this engine reads, copied ONCE when a handle is created (an enqueue never looks anything
+// up); every variant computes the same result a different way.
 struct MsmTuning {
-    int spl = 0;               // KZGAMD_SPL: scalars per lane of the wide-table path (0 = by batch size)
-    bool no_wide_tail = false; // KZGAMD_NO_WIDE_TAIL=1: single-lane instead of limb-parallel tails and folds
-    bool no_hybrid_fold = false;  // KZGAMD_NO_HYBRID_FOLD=1: two launches of k_blocksum for 5 .. 16 MSMs
-    int hybrid_max = 0;           // KZGAMD_HYBRID_MAX: MSMs per call folded by k_blocksum_hybrid (0 = BSH_MAX)
-    int wide_fold_max = 0;     // KZGAMD_WIDE_FOLD_MAX: MSMs per call folded limb-parallel (0 = WIDE_FOLD_MAX)
-    int spl1_max = 0;          // KZGAMD_SPL1_MAX: MSMs per call that get a lane per (scalar, half) (0 = 8)
-    int blocksum_threads = 0;  // KZGAMD_BLOCKSUM_THREADS: 64 / 128 / 256 (0 = by batch size)
-    int lgc = 0;               // KZGAMD_LGC: accumulation chunk (0 = by size)
-    int groups = 0;            // KZGAMD_GROUPS: window groups on their own streams (0 = one)
-    int fine_bits = 0;         // KZGAMD_FINE_BITS: width of the second sort level (0 = default)
+    int spl = 0, hybrid_max = 0, wide_fold_max = 0, spl1_max = 0, blocksum_threads = 0, lgc = 0, groups = 0, fine_bits = 0;
+    bool no_wide_tail = false, no_hybrid_fold = false;
     bool one_level_sort = false, tree_tail = false, flat_digits = false, direct_scatter = false, scatter_atomics = false;
-    bool tile_v1 = false;      // KZGAMD_TILE_V1=1: k_tile_sums in its five-site form
-    bool combine = true;       // KZGAMD_NO_COMBINE=1: concurrent mult_pippenger_prepared calls queue on the mutex, one launch each
-    int combine_lanes = 2, combine_gather_min = 6, combine_gather_us = 60;  // KZGAMD_COMBINE_{LANES,GATHER_MIN,GATHER_US}
-    static MsmTuning from_env() {
+    bool combine = true;
+    int combine_lanes = 2, combine_gather_min = 6, combine_gather_us = 60;
+    static MsmTuning from(const kzgamd::Options& o) {
+        using namespace kzgamd;
         MsmTuning t;
-        auto num = [](const char* name) {
-            const char* e = getenv(name);
-            return e ? atoi(e) : 0;
-        };
-        t.spl = num("KZGAMD_SPL") > 0 ? num("KZGAMD_SPL") : 0;
-        t.no_wide_tail = getenv("KZGAMD_NO_WIDE_TAIL") != nullptr;
-        t.no_hybrid_fold = getenv("KZGAMD_NO_HYBRID_FOLD") != nullptr;
-        t.hybrid_max = num("KZGAMD_HYBRID_MAX");
-        t.wide_fold_max = num("KZGAMD_WIDE_FOLD_MAX");
-        t.spl1_max = num("KZGAMD_SPL1_MAX");
-        t.blocksum_threads = num("KZGAMD_BLOCKSUM_THREADS");
-        t.lgc = num("KZGAMD_LGC");
-        t.groups = num("KZGAMD_GROUPS");
-        t.fine_bits = num("KZGAMD_FINE_BITS");
-        t.one_level_sort = getenv("KZGAMD_ONE_LEVEL_SORT") != nullptr;
-        t.tree_tail = getenv("KZGAMD_TREE_TAIL") != nullptr;
-        t.flat_digits = getenv("KZGAMD_FLAT_DIGITS") != nullptr;
-        t.direct_scatter = getenv("KZGAMD_DIRECT_SCATTER") != nullptr;
-        t.scatter_atomics = getenv("KZGAMD_SCATTER_ATOMICS") != nullptr;
-        t.tile_v1 = getenv("KZGAMD_TILE_V1") != nullptr;
-        t.combine = getenv("KZGAMD_NO_COMBINE") == nullptr;
-        if (getenv("KZGAMD_COMBINE_LANES")) t.combine_lanes = num("KZGAMD_COMBINE_LANES") >= 2 ? 2 : 1;
-        if (getenv("KZGAMD_COMBINE_GATHER_MIN")) t.combine_gather_min = num("KZGAMD_COMBINE_GATHER_MIN");
-        if (getenv("KZGAMD_COMBINE_GATHER_US")) t.combine_gather_us = num("KZGAMD_COMBINE_GATHER_US");
+        t.spl = (int)o.t[T_SPL];
+        t.no_wide_tail = o.t[T_NO_WIDE_TAIL] != 0;
+        t.no_hybrid_fold = o.t[T_NO_HYBRID_FOLD] != 0;
+        t.hybrid_max = (int)o.t[T_HYBRID_MAX];
+        t.wide_fold_max = (int)o.t[T_WIDE_FOLD_MAX];
+        t.spl1_max = (int)o.t[T_SPL1_MAX];
+        t.blocksum_threads = (int)o.t[T_BLOCKSUM_THREADS];
+        t.lgc = (int)o.t[T_LGC];
+        t.groups = (int)o.t[T_GROUPS];
+        t.fine_bits = (int)o.t[T_FINE_BITS];
+        t.one_level_sort = o.t[T_ONE_LEVEL_SORT] != 0;
+        t.tree_tail = o.t[T_TREE_TAIL] != 0;
+        t.flat_digits = o.t[T_FLAT_DIGITS] != 0;
+        t.direct_scatter = o.t[T_DIRECT_SCATTER] != 0;
+        t.scatter_atomics = o.t[T_SCATTER_ATOMICS] != 0;
+        t.combine = o.t[T_COMBINE] != 0;
+        t.combine_lanes = (int)o.t[T_COMBINE_LANES];
+        t.combine_gather_min = (int)o.t[T_COMBINE_GATHER_MIN];
+        t.combine_gather_us = (int)o.t[T_COMBINE_GATHER_US];
         return t;
     }
 };
 
 struct kzgamd::MsmContext {
     std::mutex mu;
-    MsmTuning tune = MsmTuning::from_env();
-    int window_forced = 0;  // KZGAMD_WINDOW (variable base) / KZGAMD_WINDOW_PREPARED at creation, 0 = by size
+    kzgamd::Options opt;
+    MsmTuning tune;
+    int window_forced = 0;  // tuning keys window (variable base) / window_prepared at creation, 0 = by size
+    size_t mat_rows = 0, mat_cols = 0;  // matrix handle (kzgamd_prepare_msm_matrix): rows base sets of cols points
     int device = 0;
     size_t n = 0;
     bool prepared = false;
@@ -2059,7 +1983,7 @@ static void require_device() {
 
 // Wide table: built tile by tile (chain of multiples as XYZZ -> batch-inverted affine slots).
 static void build_wide_table(MsmContext* ctx) {
-    const double budget_gb = fbw_budget_gb();
+    const double budget_gb = fbw_budget_gb(ctx->opt.table_budget_gb);
     const size_t mults = ctx->nb;  // 2^(c-1)
     const size_t nslots = (size_t)ctx->rows * ctx->n;
     const double gb = (double)nslots * (double)mults * sizeof(WidePt) / 1e9;
@@ -2090,15 +2014,29 @@ static void build_wide_table(MsmContext* ctx) {
 }
 
 // uploads points (host or device pointer), builds the fixed-base rows when `prepare`
-MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare, bool points_are_affpt, int g1_policy) {
+MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare, bool points_are_affpt, int g1_policy,
+                       const Options* opt) {
     require_device();
     auto* ctx = new MsmContext();
+    static const bool verbose = getenv("KZGAMD_VERBOSE") != nullptr;
     try {
+        if (opt) {
+            ctx->opt = *opt;
+        } else {
+            std::string err;
+            if (!Options::resolve(ctx->opt, nullptr, &err)) throw HipErr{hipErrorInvalidValue, "KZGAMD_TUNING does not parse"};
+        }
+        ctx->tune = MsmTuning::from(ctx->opt);
+        // the handle lives on opt.device when one is named; the caller's current device is restored on the way out
+        int cur_dev = 0;
+        HIP_TRY(hipGetDevice(&cur_dev));
+        DeviceGuard placed(ctx->opt.device >= 0 ? ctx->opt.device : cur_dev);
+        HIP_TRY(placed.err);
         HIP_TRY(hipGetDevice(&ctx->device));
         HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->n = n;
         ctx->prepared = prepare;
-        if (const char* e = getenv(prepare ? "KZGAMD_WINDOW_PREPARED" : "KZGAMD_WINDOW")) ctx->window_forced = atoi(e);
+        ctx->window_forced = (int)ctx->opt.t[prepare ? T_WINDOW_PREPARED : T_WINDOW];
         // The variable-base engine's GLV split (k = k1 + k2 x^2, second base psi(P) = [x^2]P) is an identity of the
         // r-torsion subgroup only, and the reference's G1::from_bytes accepts any curve point
         // (blst/src/types/g1.rs:65-87): the split is used when the caller vouches for the bases (internal callers
@@ -2109,16 +2047,15 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         // 4.57 / 9.7 / 16.8 ms against 3.51 / 6.5 / 13.1 ms for the GLV-split engine on the plain bases — the rows make
         // the gathers of the accumulation miss every cache (2 GB of table) and one set of 2^19 buckets costs the reduction
         // more than eight sets of 2^15 — so such a handle takes the variable-base shape when its bases pass
-        // the subgroup test.  KZGAMD_FIXED_AS_VARIABLE_MIN: log2 of the smallest such n (0 = never).
+        // the subgroup test.  Tuning key fixed_as_variable_min: log2 of the smallest such n (0 = never).
         bool as_variable = false;
         if (prepare && !ctx->window_forced && g1_policy != G1_NO_SPLIT) {
-            int lg = 19;
-            if (const char* e = getenv("KZGAMD_FIXED_AS_VARIABLE_MIN")) lg = atoi(e);
+            const int lg = (int)ctx->opt.t[T_FIXED_AS_VARIABLE_MIN];
             bool dummy;
-            as_variable = lg > 0 && lg < 40 && n >= ((size_t)1 << lg) && choose_wide_window(n, true, &dummy) == 0;
+            as_variable = lg > 0 && lg < 40 && n >= ((size_t)1 << lg) && choose_wide_window(n, true, &dummy, ctx->opt.table_budget_gb) == 0;
         }
         ctx->glv = (!prepare || as_variable) && g1_policy != G1_NO_SPLIT;
-        if (const char* e = getenv("KZGAMD_GLV")) ctx->glv = ctx->glv && atoi(e) != 0;
+        ctx->glv = ctx->glv && ctx->opt.t[T_GLV] != 0;
         if (!ctx->glv) as_variable = false;
         // the bases first (row 0 of the table; the variable-base engine appends the [x^2]P images)
         DevBuf<AffPt> row0;
@@ -2155,7 +2092,7 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         if (as_variable && ctx->glv) {
             prepare = false;
             ctx->prepared = false;
-            if (getenv("KZGAMD_VERBOSE"))
+            if (verbose)
                 fprintf(stderr, "kzg_mi355x: prepared handle over %zu points on GPU %d: no wide table fits, GLV-split bucket engine on the plain bases\n",
                         n, ctx->device);
         }
@@ -2165,12 +2102,11 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         int cw = 0;
         if (prepare && !ctx->window_forced) {
             bool dummy;
-            if (choose_wide_window(n, true, &dummy) != 0) {
+            if (choose_wide_window(n, true, &dummy, ctx->opt.table_budget_gb) != 0) {
                 // a wide table fits: its GLV form needs every base in the r-torsion subgroup (psi(P) = [x^2]P holds only
                 // there; FsG1::from_bytes does not check it, blst/src/types/g1.rs:65-87) — test the bases, once
                 bool in_g1 = false;
-                const char* e = getenv("KZGAMD_FBW_GLV");
-                if (!e || atoi(e) != 0) {
+                if (ctx->opt.t[T_FBW_GLV] != 0) {
                     DevBuf<int> bad;
                     bad.ensure(1);
                     HIP_TRY(hipMemsetAsync(bad.p, 0, sizeof(int), ctx->stream));
@@ -2182,7 +2118,7 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
                     bad.release();
                     in_g1 = nbad == 0;
                 }
-                cw = choose_wide_window(n, in_g1, &wide_glv);
+                cw = choose_wide_window(n, in_g1, &wide_glv, ctx->opt.table_budget_gb);
             }
         }
         if (cw) {
@@ -2208,7 +2144,7 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         staging.release();
         if (prepare) build_wide_table(ctx);
         if (ctx->fbw_glv && !ctx->fbw) throw HipErr{hipErrorOutOfMemory, "wide GLV table did not fit the HBM budget it was sized for"};
-        if (prepare && getenv("KZGAMD_VERBOSE")) {
+        if (prepare && verbose) {
             // the shape a handle ended up with depends on the HBM that was free: say so when asked
             const double gb = ctx->fbw ? (double)ctx->rows * (double)n * (double)ctx->nb * sizeof(WidePt) / 1e9 : 0.0;
             fprintf(stderr, "kzg_mi355x: prepared handle over %zu points on GPU %d: %s, %d-bit windows, %d rows, %s, %.1f GB, %d additions per scalar\n",
@@ -2494,7 +2430,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     // few sets of many buckets: the digit-decomposed reduction instead of the (A, M) tree (KZGAMD_TREE_TAIL=1: the tree)
     // measured (same box, tree vs digits): n = 2^14 (4096 buckets) 1.20 vs 1.35 ms, 2^16 1.53 vs 1.48, 2^20 4.53 vs 4.35, 2^22 14.67 vs 14.26
     const bool digit_tail = use_top && nb >= 16384 && !ctx->tune.tree_tail;
-    // the tiled form of the digit sums (k_tile_sums); KZGAMD_FLAT_DIGITS=1: one pass over the buckets per digit
+    // the tiled form of the digit sums (k_tile_sums_loop); tuning key flat_digits: one pass over the buckets per digit
     const bool tiled_digits = digit_tail && nb % 1024 == 0 && !ctx->tune.flat_digits;
     // shape of the tree (the same for every group: level 0 folds by the group size): k_top stride B + 2
     size_t top_stride = 0;
@@ -2647,7 +2583,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             if (tiled_digits) {
                 Xyzz* Gs = ws.lvlA[1].p + set0 * (nb >> 5);
                 Xyzz* Cp = ws.lvlM[1].p + set0 * (nb >> 5);
-                hipLaunchKernelGGL(ctx->tune.tile_v1 ? k_tile_sums : k_tile_sums_loop, dim3((unsigned)(ns * (nb >> 10))),
+                hipLaunchKernelGGL(k_tile_sums_loop, dim3((unsigned)(ns * (nb >> 10))),
                                    dim3(TILE_T), TILE_T * sizeof(Xyzz), st, (const Xyzz*)buckets, (const u32*)offsets,
                                    (const unsigned char*)heavy, dense, Gs, Cp, nb, nchunk, csel);
                 if (wide_tail) {
@@ -2896,9 +2832,9 @@ static void msm_run_host_combined(MsmContext* ctx, void* out, const void* scalar
 }
 
 // host buffers in, host buffers out
-void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoints, size_t nbatch) {
-    if (npoints > ctx->n) throw HipErr{hipErrorInvalidValue, "npoints exceeds the prepared size"};
-    if (ctx->prepared && nbatch == 1 && npoints > 0 && ctx->tune.combine) {
+void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoints, size_t nbatch, size_t nseg) {
+    if (npoints * (nseg ? nseg : 1) > ctx->n) throw HipErr{hipErrorInvalidValue, "npoints exceeds the prepared size"};
+    if (ctx->prepared && nbatch == 1 && npoints > 0 && ctx->tune.combine && !nseg) {
         msm_run_host_combined(ctx, out, scalars, npoints);
         return;
     }
@@ -2933,7 +2869,7 @@ void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoint
         }
         return;
     }
-    msm_enqueue(ctx, ctx->ws.out.p, ctx->ws.scalars.p, npoints, nbatch, 1, ctx->stream, OUT_JACOBIAN);
+    msm_enqueue(ctx, ctx->ws.out.p, ctx->ws.scalars.p, npoints, nbatch, 1, ctx->stream, OUT_JACOBIAN, false, nseg);
     HIP_TRY(hipMemcpyAsync(out, ctx->ws.out.p, nbatch * 144, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
 }
@@ -2955,16 +2891,73 @@ static RustError guarded(F&& f) {
     }
 }
 
-extern "C" void* prepare_msm(const blst_p1_affine points[], size_t npoints) {
+// a handle from the C ABI: NULL (with a line on stderr) on any failure, a malformed configuration included
+template <class F>
+static void* create_guarded(const char* who, const KzgAmdConfig* cfg, F&& make) {
     try {
-        if (!points || npoints == 0) return nullptr;
-        return kzgamd::msm_create(points, npoints, false, true, false, kzgamd::G1_CHECK);
+        kzgamd::Options opt;
+        std::string err;
+        if (!kzgamd::Options::resolve(opt, cfg, &err)) {
+            fprintf(stderr, "kzg_mi355x: %s: %s\n", who, err.c_str());
+            return nullptr;
+        }
+        return make(opt);
     } catch (const HipErr& e) {
-        fprintf(stderr, "kzg_mi355x: prepare_msm failed: %s: %s\n", e.what, hipGetErrorString(e.e));
+        fprintf(stderr, "kzg_mi355x: %s failed: %s: %s\n", who, e.what, hipGetErrorString(e.e));
         return nullptr;
     } catch (...) {
         return nullptr;
     }
+}
+
+extern "C" void kzgamd_config_init(KzgAmdConfig* cfg) {
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = (uint32_t)sizeof *cfg;
+    cfg->device = -1;
+}
+
+extern "C" const char* kzgamd_tuning_keys(void) {
+    static const std::string text = [] {
+        std::string s;
+        const kzgamd::TuneKey* k = kzgamd::tune_keys();
+        for (int i = 0; i < kzgamd::T_COUNT; ++i)
+            s += std::string(k[i].name) + " " + std::to_string(k[i].dflt) + " " + std::to_string(k[i].lo) + " " +
+                 std::to_string(k[i].hi) + " " + k[i].what + "\n";
+        return s;
+    }();
+    return text.c_str();
+}
+
+extern "C" void* kzgamd_prepare_msm_ex(const blst_p1_affine points[], size_t npoints, const KzgAmdConfig* cfg) {
+    if (!points || npoints == 0) return nullptr;
+    return create_guarded("prepare_msm", cfg, [&](const kzgamd::Options& opt) {
+        return kzgamd::msm_create(points, npoints, false, true, false, kzgamd::G1_CHECK, &opt);
+    });
+}
+extern "C" void* prepare_msm(const blst_p1_affine points[], size_t npoints) { return kzgamd_prepare_msm_ex(points, npoints, nullptr); }
+
+// rows base sets of cols points in one wide table; see include/kzg_mi355x.h
+extern "C" void* kzgamd_prepare_msm_matrix(const blst_p1_affine points[], size_t rows, size_t cols, const KzgAmdConfig* cfg) {
+    if (!points || rows == 0 || cols == 0) return nullptr;
+    return create_guarded("kzgamd_prepare_msm_matrix", cfg, [&](const kzgamd::Options& opt) -> void* {
+        MsmContext* ctx = kzgamd::msm_create(points, rows * cols, false, true, false, kzgamd::G1_CHECK, &opt);
+        if (!ctx->fbw) {
+            kzgamd::msm_destroy(ctx);
+            fprintf(stderr, "kzg_mi355x: kzgamd_prepare_msm_matrix: no wide table fits the budget (%zu x %zu points)\n", rows, cols);
+            return nullptr;
+        }
+        ctx->mat_rows = rows;
+        ctx->mat_cols = cols;
+        return ctx;
+    });
+}
+
+extern "C" RustError kzgamd_mult_pippenger_matrix(void* msm, blst_p1 out[], const blst_fr scalars[], size_t nmat) {
+    if (!msm || !out || !scalars) return make_error(1, "kzgamd_mult_pippenger_matrix: null handle, output or scalars");
+    MsmContext* ctx = (MsmContext*)msm;
+    if (!ctx->mat_rows) return make_error(1, "kzgamd_mult_pippenger_matrix: not a matrix handle");
+    return guarded([&] { kzgamd::msm_run_host(ctx, out, scalars, ctx->mat_cols, nmat * ctx->mat_rows, ctx->mat_rows); });
 }
 
 extern "C" void free_msm(void* msm) {
@@ -3077,16 +3070,14 @@ extern "C" RustError kzgamd_generate_points(void* d_out_affine, size_t n, uint64
 }
 
 // device-resident bases: prepare != 0 builds the fixed-base rows (like prepare_msm)
+extern "C" void* kzgamd_msm_create_device_ex(const void* d_points_affine, size_t npoints, int prepare, const KzgAmdConfig* cfg) {
+    if (!d_points_affine || npoints == 0) return nullptr;
+    return create_guarded("kzgamd_msm_create_device", cfg, [&](const kzgamd::Options& opt) {
+        return kzgamd::msm_create(d_points_affine, npoints, true, prepare != 0, false, kzgamd::G1_CHECK, &opt);
+    });
+}
 extern "C" void* kzgamd_msm_create_device(const void* d_points_affine, size_t npoints, int prepare) {
-    try {
-        if (!d_points_affine || npoints == 0) return nullptr;
-        return kzgamd::msm_create(d_points_affine, npoints, true, prepare != 0, false, kzgamd::G1_CHECK);
-    } catch (const HipErr& e) {
-        fprintf(stderr, "kzg_mi355x: kzgamd_msm_create_device failed: %s: %s\n", e.what, hipGetErrorString(e.e));
-        return nullptr;
-    } catch (...) {
-        return nullptr;
-    }
+    return kzgamd_msm_create_device_ex(d_points_affine, npoints, prepare, nullptr);
 }
 
 // sum of n Jacobian points on the host: the combine step of a large MSM sharded over several GPUs (each rank's

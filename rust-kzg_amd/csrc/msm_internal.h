@@ -13,8 +13,10 @@ enum { OUT_JACOBIAN = 0, OUT_COMPRESSED = 1, OUT_WINDOWS = 2, OUT_XYZZ = 3 };
 // at creation and fall back to the unsplit engine if one fails, G1_NO_SPLIT = never split.
 enum { G1_TRUSTED = 0, G1_CHECK = 1, G1_NO_SPLIT = 2 };
 // points: blst_p1_affine[n] (host or device) or g1::AffPt[n] (device); prepare = build fixed-base rows
+// opt: the handle's configuration (config.h); nullptr = defaults and environment
+struct Options;
 MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool prepare, bool points_are_affpt,
-                       int g1_policy = G1_TRUSTED);
+                       int g1_policy = G1_TRUSTED, const Options* opt = nullptr);
 void msm_destroy(MsmContext* ctx);
 // variable-base handle (prepare == false) over new device-resident AffPt bases: same as destroying it and creating
 // another, without the stream, the allocations and their synchronisations
@@ -31,7 +33,7 @@ bool msm_private_workspace(MsmContext* ctx, hipStream_t stream);
 // 48-byte compressed form of `count` g1::Xyzz points (device pointers)
 void g1_compress_xyzz(void* d_out48, const void* d_xyzz, size_t count, hipStream_t stream);
 int msm_device(MsmContext* ctx);
-void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoints, size_t nbatch);
+void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoints, size_t nbatch, size_t nseg = 0);
 void msm_lock(MsmContext* ctx);
 void msm_unlock(MsmContext* ctx);
 // per-kernel timing of the last enqueue (events on the launch stream); ms < 0 when disabled

@@ -77,6 +77,11 @@ extern "C" int kzgamd_shard_range(size_t n, size_t parts, size_t k, size_t* lo, 
 }
 
 extern "C" C_KZG_RET kzgamd_load_trusted_setup_file_multi(CKZGSettings out[], const int devices[], size_t ndev, FILE* in) {
+    return kzgamd_load_trusted_setup_file_multi_ex(out, devices, ndev, in, nullptr);
+}
+
+extern "C" C_KZG_RET kzgamd_load_trusted_setup_file_multi_ex(CKZGSettings out[], const int devices[], size_t ndev, FILE* in,
+                                                             const KzgAmdConfig* cfg) {
     if (!out) return C_KZG_BADARGS;
     for (size_t d = 0; d < ndev; ++d) memset(&out[d], 0, sizeof out[d]);
     if (!in || ndev == 0) return C_KZG_BADARGS;
@@ -91,15 +96,20 @@ extern "C" C_KZG_RET kzgamd_load_trusted_setup_file_multi(CKZGSettings out[], co
     if (len == 0) return C_KZG_BADARGS;
     // one loader thread per device: decompression, table build (0.8 s) and the first-use state run side by side
     const C_KZG_RET rc = fan_out(ndev, [&](size_t d) -> C_KZG_RET {
-        const int before = kzgamd_get_device();
-        if (kzgamd_set_device(devices ? devices[d] : (int)d) != 0) return C_KZG_BADARGS;
+        // the caller's configuration (budget per table, tuning) with the device of this entry
+        KzgAmdConfig mine;
+        kzgamd_config_init(&mine);
+        if (cfg) {
+            if (cfg->struct_size != sizeof mine) return C_KZG_BADARGS;
+            mine = *cfg;
+        }
+        mine.device = devices ? devices[d] : (int)d;
         FILE* f = fmemopen(text.data(), len, "r");
         C_KZG_RET r = C_KZG_MALLOC;
         if (f) {
-            r = load_trusted_setup_file(&out[d], f);
+            r = kzgamd_load_trusted_setup_file_ex(&out[d], f, &mine);
             fclose(f);
         }
-        if (before >= 0) (void)kzgamd_set_device(before);  // thread 0 is the caller's thread
         return r;
     });
     if (rc != C_KZG_OK)

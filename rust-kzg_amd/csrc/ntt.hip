@@ -25,6 +25,7 @@
 #include "ckzg_internal.h"
 #include "ff.hip.h"
 #include "fr29.hip.h"
+#include "config.h"
 #include "device_guard.h"
 #include "ntt_internal.h"
 #include "ntt_plan.h"
@@ -156,8 +157,8 @@ struct TileGeo {
 // One round of a pass on the four elements of a thread.  FIRST: the elements come from global memory (and, for a
 // transform's first pass, stages 0 and 1 multiply by w^0 = 1 at position 0: no multiplication); LAST: they go back
 // to it.  V: how a butterfly multiplies — 1 = subtractive Montgomery steps on one accumulator chain
-// (fr29::mul_signed), 2 = the same left to the compiler's re-association, 0 = round 2's additive multiplier
-// (measurement variants, KZGAMD_NTT_VARIANT at kzgamd_ntt_new; all three give the same bits).
+// (fr29::mul_signed), the only form launched; 2 = the same left to the compiler's re-association and 0 = round 2's
+// additive multiplier were measured and lost (profiles/NOTES.md), and are instantiated by tools/ only.
 template <int KIND, int V, bool FIRST, bool LAST, bool DAS = false>
 __device__ __forceinline__ void ntt_round(u32* sh, Fr* __restrict__ out, const Fr* __restrict__ in, const PassParams& P,
                                           const TileGeo<KIND>& G, int r, const uint2 te) {
@@ -392,14 +393,9 @@ void launch_pass(NttCtx* ctx, int kind, int T, Fr* d_out, const Fr* d_in, PassPa
     P.tab = (const uint2*)pd.d_tab;
     const size_t lds = (size_t)TILE * sizeof(u32) * fr29::L;
 #define KZG_LAUNCH(K, V) hipLaunchKernelGGL((k_ntt_pass<K, V>), dim3(grid), dim3(NT), lds, stream, d_out, d_in, P)
-#define KZG_LAUNCH_V(K)                      \
-    if (ctx->variant == 0) KZG_LAUNCH(K, 0); \
-    else if (ctx->variant == 1) KZG_LAUNCH(K, 1); \
-    else KZG_LAUNCH(K, 2)
+#define KZG_LAUNCH_V(K) KZG_LAUNCH(K, 1)
     if (kind == PLAN_DAS) {
-        if (ctx->variant == 0) hipLaunchKernelGGL(k_das_fused<0>, dim3(grid), dim3(NT), lds, stream, d_out, d_in, P);
-        else if (ctx->variant == 1) hipLaunchKernelGGL(k_das_fused<1>, dim3(grid), dim3(NT), lds, stream, d_out, d_in, P);
-        else hipLaunchKernelGGL(k_das_fused<2>, dim3(grid), dim3(NT), lds, stream, d_out, d_in, P);
+        hipLaunchKernelGGL(k_das_fused<1>, dim3(grid), dim3(NT), lds, stream, d_out, d_in, P);
     } else if (kind == KIND_A1) {
         KZG_LAUNCH_V(KIND_A1);
     } else if (kind == KIND_A2) {
@@ -461,7 +457,19 @@ void ntt_enqueue(NttCtx* ctx, Fr* d_out, const Fr* d_in, size_t n, size_t nbatch
 
 }  // namespace
 
-extern "C" void* kzgamd_ntt_new(unsigned scale) {
+extern "C" void* kzgamd_ntt_new(unsigned scale) { return kzgamd_ntt_new_ex(scale, nullptr); }
+
+extern "C" void* kzgamd_ntt_new_ex(unsigned scale, const KzgAmdConfig* cfg) {
+    kzgamd::Options opt;
+    std::string err;
+    if (!kzgamd::Options::resolve(opt, cfg, &err)) {
+        fprintf(stderr, "kzg_mi355x: kzgamd_ntt_new: %s\n", err.c_str());
+        return nullptr;
+    }
+    return kzgamd::ntt_create(scale, opt);
+}
+
+void* kzgamd::ntt_create(unsigned scale, const kzgamd::Options& opt) {
     if (scale >= 32) return nullptr;  // "Scale is expected to be within root of unity matrix row size"
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -470,20 +478,17 @@ extern "C" void* kzgamd_ntt_new(unsigned scale) {
     }
     auto* ctx = new NttCtx();
     try {
+        int cur_dev = 0;
+        NTT_TRY(hipGetDevice(&cur_dev));
+        kzgamd::DeviceGuard placed(opt.device >= 0 ? opt.device : cur_dev);  // the caller's device is restored on return
+        NTT_TRY(placed.err);
         NTT_TRY(hipGetDevice(&ctx->device));
         NTT_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->scale = scale;
         ctx->W = (size_t)1 << scale;
-        if (const char* v = getenv("KZGAMD_NTT_VARIANT")) ctx->variant = atoi(v);
-        auto env_size = [](const char* name, size_t& out) {
-            if (const char* v = getenv(name)) {
-                const long x = strtol(v, nullptr, 10);
-                out = x < 0 ? 0 : (size_t)x;
-            }
-        };
-        env_size("KZGAMD_G1_WIDE_MAX", ctx->g1_wide_max);
-        env_size("KZGAMD_G1_QUAD_MAX", ctx->g1_quad_max);
-        env_size("KZGAMD_G1_PAIR_MAX", ctx->g1_pair_max);
+        ctx->g1_wide_max = (size_t)opt.t[kzgamd::T_G1_WIDE_MAX];
+        ctx->g1_quad_max = (size_t)opt.t[kzgamd::T_G1_QUAD_MAX];
+        ctx->g1_pair_max = (size_t)opt.t[kzgamd::T_G1_PAIR_MAX];
         kzgamd::expand_roots(ctx->roots, scale);
         // device twiddles in the 2^261 domain, w*2^261 = (w*2^256) * 2^5, already sliced into the 9 x 29-bit limbs
         // the butterflies multiply with (36 bytes per root instead of 32, ~27 instructions less per butterfly)

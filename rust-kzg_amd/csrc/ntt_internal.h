@@ -28,7 +28,6 @@ struct NttCtx {
     using Fr = ff::Fr;
     std::map<int, NttPlanDev> plans;  // key = kind * 16 + T (kind 3: fused DAS plans); filled by kzgamd_ntt_new, read-only afterwards
     int device = 0;
-    int variant = 1;  // butterfly multiplier of the Fr kernels (ntt.hip), read from KZGAMD_NTT_VARIANT at creation
     unsigned scale = 0;
     size_t W = 0;
     void* d_roots = nullptr;  // W + 1 twiddles in the 2^261 domain as 9 x 29-bit limbs (Fr transforms), natural order
@@ -44,7 +43,7 @@ struct NttCtx {
     size_t cap_g1 = 0, cap_tab = 0;
     // G1 stages (fftg1.hip) by their number of half-butterflies: up to g1_wide_max a wave each (limb-parallel), up to
     // g1_quad_max four lanes each, up to g1_pair_max two lanes each, one lane each above
-    // (KZGAMD_G1_WIDE_MAX / _QUAD_MAX / _PAIR_MAX, read at creation; 0 disables a form)
+    // (tuning keys g1_wide_max / g1_quad_max / g1_pair_max, read at creation; 0 disables a form)
     size_t g1_wide_max = 4096, g1_quad_max = 16384, g1_pair_max = 32768;
 
     ~NttCtx() {
@@ -74,6 +73,9 @@ struct NttCtx {
 };
 
 namespace kzgamd {
+struct Options;
+// ntt.hip: what kzgamd_ntt_new_ex calls once the configuration is resolved (config.h); NULL on failure
+void* ntt_create(unsigned scale, const Options& opt);
 // fftg1.hip: G1 transforms of device-resident g1::Xyzz data, see there
 void* fftg1_device(NttCtx* ctx, void* data_xyzz, void* scratch_xyzz, size_t n, size_t nbatch, int inverse, hipStream_t st,
                    bool scale_inverse = true);

@@ -37,9 +37,10 @@ enum {
     OP_LOAD_BYTES = 16,  /* g1 monomial, g1 lagrange, g2 monomial, blob | commitment  (load_trusted_setup, byte form) */
     OP_COMMIT_BATCH = 17,/* blobs | commitments (batch, and batch_multi over two settings objects) */
     OP_PROOF_BATCH = 18, /* blobs, commitments | proofs */
-    OP_G1_SUM = 19       /* blst_p1[] | 48-byte compressed sum */
+    OP_G1_SUM = 19,      /* blst_p1[] | 48-byte compressed sum */
+    OP_MATRIX = 20       /* blst_p1_affine[rows*cols], {rows, cols, nmat} (u64), blst_fr[nmat*rows*cols] | nmat*rows compressed sums */
 };
-#define MAX_OP 20
+#define MAX_OP 21
 #define MAX_FIELDS 8
 
 typedef struct {
@@ -199,18 +200,48 @@ static int run(const char *setup_path, const char *records_path) {
     field_t fl[MAX_FIELDS];
     long rec = 0;
     int have_s2 = 0;
+    KzgAmdConfig cfg;
 
     if (kzgamd_device_count() < 1) {
         fprintf(stderr, "c_abi_harness: no GPU visible; the library has no CPU fallback\n");
         return 3;
     }
+    /* two settings objects live side by side on the one GPU: 40 GB per table each, through the configuration */
+    kzgamd_config_init(&cfg);
+    cfg.table_budget_bytes = 40000000000ull;
     f = fopen(setup_path, "r");
     if (!f) return 2;
-    if (load_trusted_setup_file(&s, f) != C_KZG_OK) {
-        fprintf(stderr, "load_trusted_setup_file failed\n");
+    if (kzgamd_load_trusted_setup_file_ex(&s, f, &cfg) != C_KZG_OK) {
+        fprintf(stderr, "kzgamd_load_trusted_setup_file_ex failed\n");
         return 2;
     }
     fclose(f);
+    {   /* a malformed configuration is refused: unknown tuning key, value out of range, wrong struct size */
+        KzgAmdConfig bad = cfg;
+        CKZGSettings sb;
+        bad.tuning = "no_such_key=1";
+        f = fopen(setup_path, "r");
+        if (!f || kzgamd_load_trusted_setup_file_ex(&sb, f, &bad) != C_KZG_BADARGS || sb.g1_values_lagrange_brp != NULL) {
+            fprintf(stderr, "an unknown tuning key was accepted\n");
+            return 2;
+        }
+        fclose(f);
+        bad.tuning = "spl=99";
+        if (kzgamd_ntt_new_ex(4, &bad) != NULL) {
+            fprintf(stderr, "an out-of-range tuning value was accepted\n");
+            return 2;
+        }
+        bad = cfg;
+        bad.struct_size = 3;
+        if (kzgamd_ntt_new_ex(4, &bad) != NULL) {
+            fprintf(stderr, "a truncated KzgAmdConfig was accepted\n");
+            return 2;
+        }
+        if (strstr(kzgamd_tuning_keys(), "g1_wide_max 4096 ") == NULL) {
+            fprintf(stderr, "kzgamd_tuning_keys does not list g1_wide_max\n");
+            return 2;
+        }
+    }
     if (!s.roots_of_unity || !s.g1_values_lagrange_brp || !s.g2_values_monomial || !s.x_ext_fft_columns || s.tables) {
         fprintf(stderr, "CKZGSettings not populated as the reference's\n");
         return 2;
@@ -402,8 +433,8 @@ static int run(const char *setup_path, const char *records_path) {
         }
         case OP_LOAD_BYTES: {
             KZGCommitment c;
-            C_KZG_RET rc = load_trusted_setup(&s2, fl[0].p, fl[0].len, fl[1].p, fl[1].len, fl[2].p, fl[2].len, 0);
-            check(op, rc == C_KZG_OK, "load_trusted_setup", rec);
+            C_KZG_RET rc = kzgamd_load_trusted_setup_ex(&s2, fl[0].p, fl[0].len, fl[1].p, fl[1].len, fl[2].p, fl[2].len, 0, &cfg);
+            check(op, rc == C_KZG_OK, "kzgamd_load_trusted_setup_ex", rec);
             if (rc == C_KZG_OK) {
                 int wb = 0, rows = 0, wide = 0;
                 have_s2 = 1;
@@ -452,6 +483,34 @@ static int run(const char *setup_path, const char *records_path) {
             blst_p1 sum;
             kzgamd_g1_sum(&sum, (const blst_p1 *)fl[0].p, (size_t)(fl[0].len / sizeof(blst_p1)));
             check(op, p1_equals_compressed(&sum, ex->p), "kzgamd_g1_sum", rec);
+            break;
+        }
+        case OP_MATRIX: {
+            /* the table behind g1_lincomb_batch (kzg/src/lib.rs:156-181, kzg/src/msm/bgmw.rs:306-380) */
+            const uint64_t *dims = (const uint64_t *)fl[1].p;
+            const size_t rows = (size_t)dims[0], cols = (size_t)dims[1], nmat = (size_t)dims[2];
+            KzgAmdConfig mc;
+            void *h;
+            blst_p1 *out = (blst_p1 *)malloc(nmat * rows * sizeof(blst_p1));
+            RustError e;
+            size_t k;
+            int good;
+            kzgamd_config_init(&mc);
+            mc.table_budget_bytes = 4000000000ull;
+            h = kzgamd_prepare_msm_matrix((const blst_p1_affine *)fl[0].p, rows, cols, &mc);
+            check(op, h != NULL, "kzgamd_prepare_msm_matrix", rec);
+            if (h) {
+                e = kzgamd_mult_pippenger_matrix(h, out, (const blst_fr *)fl[2].p, nmat);
+                good = e.code == 0;
+                for (k = 0; good && k < nmat * rows; ++k) good = p1_equals_compressed(&out[k], ex->p + 48 * k);
+                check(op, good, "kzgamd_mult_pippenger_matrix", rec);
+                /* a plain prepared handle is not a matrix handle */
+                e = kzgamd_mult_pippenger_matrix(kzgamd_settings_msm_handle(&s), out, (const blst_fr *)fl[2].p, 1);
+                check(op, e.code != 0, "matrix call on a plain handle is refused", rec);
+                free(e.message);
+                free_msm(h);
+            }
+            free(out);
             break;
         }
         default:

@@ -20,7 +20,7 @@ BLOB = 131072
 CELL = 2048
 (OP_COMMIT, OP_PROOF, OP_BLOB_PROOF, OP_VERIFY, OP_VERIFY_BLOB, OP_VERIFY_BATCH, OP_CELLS, OP_RECOVER, OP_VERIFY_CELLS,
  OP_CELL_CHALLENGE, OP_NTT, OP_DAS, OP_MSM, OP_FFT_G1, OP_CHALLENGE, OP_LOAD_BYTES, OP_COMMIT_BATCH, OP_PROOF_BATCH,
- OP_G1_SUM) = range(1, 20)
+ OP_G1_SUM, OP_MATRIX) = range(1, 21)
 
 
 def unhex(s):
@@ -215,6 +215,23 @@ def write_records(path, oracle_settings):
         L.og1_add_or_dbl(C.byref(total), C.byref(total), C.byref(jac[i]))
     r.add(OP_G1_SUM, bytes(jac), compressed(total))
 
+    # matrix handle: 64 rows of 64 of the setup's Lagrange points, two scalar matrices (short, zero and full-size scalars)
+    rows, cols, nmat = 64, 64, 2
+    mpts = oracle_settings.g1_lagrange_brp
+    vals = [rnd.randrange(O.R) for _ in range(nmat * rows * cols)]
+    vals[0], vals[1], vals[cols] = 0, O.R - 1, 1
+    vals[5 * cols:6 * cols] = [0] * cols  # a row that sums to infinity
+    msc = O.fr_array(vals)
+    sums = b""
+    for m in range(nmat):
+        for rr_ in range(rows):
+            want = O.G1()
+            base = (O.G1Affine * cols).from_address(C.addressof(mpts.contents) + rr_ * cols * 96)
+            sub = (O.Fr * cols).from_buffer(msc, (m * rows + rr_) * cols * 32)
+            L.omsm_affine(C.byref(want), base, sub, cols)
+            sums += compressed(want)
+    r.add(OP_MATRIX, C.string_at(mpts, rows * cols * 96), u64s([rows, cols, nmat]), bytes(msc), sums)
+
     # batch forms (single settings object, and the in-library multi-GPU form over two objects)
     blobs = []
     for _ in range(21):
@@ -246,9 +263,9 @@ def test_c_harness_replays_the_vectors(tmp_path, kzg, oracle_settings):
     assert (counts[OP_COMMIT], counts[OP_PROOF], counts[OP_BLOB_PROOF], counts[OP_CHALLENGE]) == (9, 48, 11, 9)
     assert (counts[OP_VERIFY], counts[OP_VERIFY_BLOB], counts[OP_VERIFY_BATCH]) == (114, 23, 15)
     assert (counts[OP_CELLS], counts[OP_RECOVER], counts[OP_VERIFY_CELLS], counts[OP_CELL_CHALLENGE]) == (9, 14, 22, 10)
-    env = dict(os.environ, KZGAMD_FBW_MAX_GB="40")  # two settings objects live side by side on the one GPU
+    # (its two settings objects live side by side on the one GPU: the harness gives each 40 GB per table through KzgAmdConfig)
     p = subprocess.run([exe, "run", os.path.join(GOLDEN, "trusted_setup.txt"), rec], stdout=subprocess.PIPE,
-                       stderr=subprocess.STDOUT, timeout=1500, env=env)
+                       stderr=subprocess.STDOUT, timeout=1500)
     out = p.stdout.decode()
     assert p.returncode == 0, out[-4000:]
     assert "0 failures" in out

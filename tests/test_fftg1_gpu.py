@@ -10,19 +10,19 @@ import oracle_ffi as O
 pytestmark = pytest.mark.gpu
 
 # The four forms of a stage (fftg1.hip): a wave / four lanes / two lanes / one lane per half-butterfly.  They are chosen
-# by grid size; the switches (read when the handle is created) force one of them for every size so that each is
-# checked against the oracle on the same cases.
-FORMS = {"by_size": {}, "wave": {"KZGAMD_G1_WIDE_MAX": "1000000"},
-         "four_lanes": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "1000000"},
-         "two_lanes": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "0", "KZGAMD_G1_PAIR_MAX": "1000000"},
-         "one_lane": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "0", "KZGAMD_G1_PAIR_MAX": "0"}}
+# by grid size; the tuning keys (read when the handle is created, KzgAmdConfig.tuning) force one of them for every size
+# so that each is checked against the oracle on the same cases.
+FORMS = {"by_size": {}, "wave": {"g1_wide_max": 1000000},
+         "four_lanes": {"g1_wide_max": 0, "g1_quad_max": 1000000},
+         "two_lanes": {"g1_wide_max": 0, "g1_quad_max": 0, "g1_pair_max": 1000000},
+         "one_lane": {"g1_wide_max": 0, "g1_quad_max": 0, "g1_pair_max": 0}}
 
 
 @pytest.fixture(params=list(FORMS))
-def form(request, monkeypatch):
-    for k, v in FORMS[request.param].items():
-        monkeypatch.setenv(k, v)
-    return request.param
+def form(request, kzg):
+    """the KzgAmdConfig that forces the form (None for the by-size default)"""
+    t = FORMS[request.param]
+    return kzg.make_config(tuning=t) if t else None
 
 
 def make_data(L, n):
@@ -64,7 +64,7 @@ def test_fft_g1_matches_oracle(kzg, oracle, logn, form):
     L = oracle.lib()
     scale = max(logn, 1)
     n = 1 << logn
-    fs = kzg.FFTSettings(scale)
+    fs = kzg.FFTSettings(scale, form)
     ofs = O.FFTSettings()
     assert L.offt_settings_new(C.byref(ofs), scale) == 0
     data = make_data(L, n)
@@ -84,7 +84,7 @@ def test_fft_g1_exceptional_inputs(kzg, oracle, form):
     """all points equal (every first-stage butterfly doubles / cancels), all infinity, P and -P pairs"""
     L = oracle.lib()
     n = 16
-    fs = kzg.FFTSettings(4)
+    fs = kzg.FFTSettings(4, form)
     ofs = O.FFTSettings()
     assert L.offt_settings_new(C.byref(ofs), 4) == 0
     g = O.G1()
@@ -140,7 +140,7 @@ def test_fft_g1_stride_and_batch(kzg, oracle, form):
     L = oracle.lib()
     n = 1 << 9
     data = random_points(L, n, 42)
-    fs1, fs2 = kzg.FFTSettings(9), kzg.FFTSettings(12)
+    fs1, fs2 = kzg.FFTSettings(9, form), kzg.FFTSettings(12, form)
     a = fs1.fft_g1(data, n)
     b = fs2.fft_g1(data, n)
     assert compressed(L, a, n) == compressed(L, b, n)

@@ -336,7 +336,7 @@ def test_msm_2p20_matches_oracle(oracle, kzg):
     sc[::10] = 0       # 10 % zero scalars
     d_sc = sc.cuda()
     d_out = torch.zeros(144, dtype=torch.uint8, device="cuda")
-    h = kzg.DeviceMsm(d_pts.data_ptr(), n, False)
+    h = kzg.DeviceMsm(d_pts.data_ptr(), n, False, kzg.make_config(tuning=tuning))
     kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr(), n, 1, False, stream)
     torch.cuda.synchronize()
     got = O.G1()
@@ -385,16 +385,15 @@ def test_msm_2p22_split_property(oracle, kzg, logn):
     assert compressed(L, exp) == compressed(L, outs[3])
 
 
-def test_prepared_bucket_path_without_wide_table(oracle, kzg, monkeypatch):
+def test_prepared_bucket_path_without_wide_table(oracle, kzg):
     """A prepared handle whose wide table does not fit (here: disabled) runs the fixed-base-rows bucket engine:
     one bucket set per MSM, single call and batch, skewed and edge scalars."""
     L = oracle.lib()
-    monkeypatch.setenv("KZGAMD_FBW_MAX_GB", "0")
     rnd = random.Random(15)
     n = 700
     pts = gen_points(L, n, rnd)
     pts[13] = O.G1Affine()
-    h = kzg.prepare_multi_scalar_mult(pts, n)
+    h = kzg.prepare_multi_scalar_mult(pts, n, kzg.make_config(no_tables=True))
     assert not h.info()["wide_table"] and h.info()["rows"] > 1
     vals = [rnd.randrange(O.R) for _ in range(n)]
     vals[0], vals[1], vals[2] = 0, O.R - 1, 1
@@ -411,13 +410,11 @@ def test_prepared_bucket_path_without_wide_table(oracle, kzg, monkeypatch):
 
 
 @pytest.mark.parametrize("outside", [False, True])
-def test_large_prepared_handle_takes_the_variable_base_shape(oracle, kzg, monkeypatch, outside):
+def test_large_prepared_handle_takes_the_variable_base_shape(oracle, kzg, outside):
     """A prepared handle too large for a wide table (here: the threshold lowered to 2^9 points, the table disabled) runs the
     GLV-split engine on the plain bases instead of table rows — unless a base fails the subgroup test, then it keeps
     the rows.  Same results either way, single call and batch."""
     L = oracle.lib()
-    monkeypatch.setenv("KZGAMD_FBW_MAX_GB", "0")
-    monkeypatch.setenv("KZGAMD_FIXED_AS_VARIABLE_MIN", "9")
     rnd = random.Random(16)
     n = 700
     pts = gen_points(L, n, rnd)
@@ -425,7 +422,7 @@ def test_large_prepared_handle_takes_the_variable_base_shape(oracle, kzg, monkey
     if outside:
         x, y = curve_points_outside_g1(1, 5)[0]
         pts[7].x, pts[7].y = O.fp_from_int(x), O.fp_from_int(y)
-    h = kzg.prepare_multi_scalar_mult(pts, n)
+    h = kzg.prepare_multi_scalar_mult(pts, n, kzg.make_config(no_tables=True, tuning={"fixed_as_variable_min": 9}))
     info = h.info()
     assert not info["wide_table"]
     assert (info["rows"] > 1) == outside, info
@@ -443,28 +440,24 @@ def test_large_prepared_handle_takes_the_variable_base_shape(oracle, kzg, monkey
     h.close()
 
 
-@pytest.mark.parametrize("env", [{"KZGAMD_FBW_MAX_GB": "2.0"}, {"KZGAMD_FBW_MAX_GB": "0.6"}, {"KZGAMD_FBW_MAX_GB": "0.3"},
-                                 {"KZGAMD_FBW_MAX_GB": "0.1"}, {"KZGAMD_FBW_MAX_GB": "2.0", "KZGAMD_FBW_GLV": "0"},
-                                 {"KZGAMD_FBW_MAX_GB": "0.3", "KZGAMD_FBW_GLV": "0"}])
-def test_wide_table_every_window_shape(oracle, kzg, monkeypatch, env):
+@pytest.mark.parametrize("budget_gb,glv", [(2.0, True), (0.6, True), (0.3, True), (0.1, True), (2.0, False), (0.3, False)])
+def test_wide_table_every_window_shape(oracle, kzg, budget_gb, glv):
     """The wide table under shrinking budgets: each budget picks another (window, rows, GLV / plain) shape — among them
     window counts that are not a multiple of four (the selector rows are padded) — and every shape gives the oracle's
     result, single call and batch."""
     L = oracle.lib()
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     rnd = random.Random(151)
     n = 96
     pts = gen_points(L, n, rnd)
     pts[5] = O.G1Affine()
-    h = kzg.prepare_multi_scalar_mult(pts, n)
+    h = kzg.prepare_multi_scalar_mult(pts, n, kzg.make_config(table_budget_gb=budget_gb, tuning=None if glv else {"fbw_glv": 0}))
     info = h.info()
     assert info["wide_table"], info
     # n = 96: 2.0 GB -> GLV c=15 (9 windows), 0.6 -> GLV c=13 (10), 0.3 -> GLV c=12 (11), 0.1 -> GLV c=10 (13);
     # without the split 2.0 -> c=14 (19 windows), 0.3 -> c=10 (26)
-    want = {("2.0", None): 9, ("0.6", None): 10, ("0.3", None): 11, ("0.1", None): 13, ("2.0", "0"): 19, ("0.3", "0"): 26}
-    assert info["rows"] == want[(env["KZGAMD_FBW_MAX_GB"], env.get("KZGAMD_FBW_GLV"))], info
-    assert info["wide_glv"] == (env.get("KZGAMD_FBW_GLV") != "0")
+    want = {(2.0, True): 9, (0.6, True): 10, (0.3, True): 11, (0.1, True): 13, (2.0, False): 19, (0.3, False): 26}
+    assert info["rows"] == want[(budget_gb, glv)], info
+    assert info["wide_glv"] == glv
     vals = [rnd.randrange(O.R) for _ in range(n)]
     vals[0], vals[1], vals[2] = 0, O.R - 1, 1
     batches = [vals, [rnd.randrange(1 << 130) for _ in range(n)], [O.R - 1 - rnd.randrange(1 << 20) for _ in range(n)],
@@ -510,22 +503,16 @@ def test_variable_base_device_handle_batched(oracle, kzg, nbatch):
     h.close()
 
 
-@pytest.mark.parametrize("env", [{}, {"KZGAMD_GROUPS": "2"}, {"KZGAMD_ONE_LEVEL_SORT": "1"},
-                                 {"KZGAMD_GROUPS": "3", "KZGAMD_ONE_LEVEL_SORT": "1"}, {"KZGAMD_NO_WIDE_TAIL": "1"},
-                                 {"KZGAMD_TREE_TAIL": "1"}, {"KZGAMD_TREE_TAIL": "1", "KZGAMD_GROUPS": "2"},
-                                 {"KZGAMD_FINE_BITS": "9"}, {"KZGAMD_FINE_BITS": "10", "KZGAMD_LGC": "3"},
-                                 {"KZGAMD_LGC": "7"}, {"KZGAMD_FLAT_DIGITS": "1"},
-                                 {"KZGAMD_FLAT_DIGITS": "1", "KZGAMD_NO_WIDE_TAIL": "1"}, {"KZGAMD_DIRECT_SCATTER": "1"}, {"KZGAMD_SCATTER_ATOMICS": "1"},
-                                 {"KZGAMD_NO_WIDE_TAIL": "1", "KZGAMD_FINE_BITS": "8"}, {"KZGAMD_TILE_V1": "1"},
-                                 {"KZGAMD_TILE_V1": "1", "KZGAMD_LGC": "3"}, {"KZGAMD_LGC": "4"}])
-def test_variable_base_engine_variants(oracle, kzg, monkeypatch, env):
+@pytest.mark.parametrize("tuning", [{}, {"groups": 2}, {"one_level_sort": 1}, {"groups": 3, "one_level_sort": 1}, {"no_wide_tail": 1},
+                                    {"tree_tail": 1}, {"tree_tail": 1, "groups": 2}, {"fine_bits": 9}, {"fine_bits": 10, "lgc": 3},
+                                    {"lgc": 7}, {"flat_digits": 1}, {"flat_digits": 1, "no_wide_tail": 1}, {"direct_scatter": 1},
+                                    {"scatter_atomics": 1}, {"no_wide_tail": 1, "fine_bits": 8}, {"lgc": 3}, {"lgc": 4}])
+def test_variable_base_engine_variants(oracle, kzg, tuning):
     """Every selectable shape of the variable-base engine (two-level / one-level sort, window groups on their own
     streams, limb-parallel / single-lane tails, digit-decomposed / tree bucket reduction) on the same 40 000-point MSM
     with a skewed scalar distribution."""
     import torch
 
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
     L = oracle.lib()
     n = 40000
     stream = torch.cuda.current_stream().cuda_stream
@@ -539,7 +526,7 @@ def test_variable_base_engine_variants(oracle, kzg, monkeypatch, env):
     sc[1::50, 8:] = 0      # short scalars
     d_sc = sc.cuda()
     d_out = torch.zeros(144, dtype=torch.uint8, device="cuda")
-    h = kzg.DeviceMsm(d_pts.data_ptr(), n, False)
+    h = kzg.DeviceMsm(d_pts.data_ptr(), n, False, kzg.make_config(tuning=tuning))
     kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr(), n, 1, False, stream)
     torch.cuda.synchronize()
     got = O.G1()

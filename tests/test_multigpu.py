@@ -283,12 +283,12 @@ def _random_blobs(seed, n):
     return blobs
 
 
-def _in_process_multi(kzg, oracle, oracle_settings, devices):
+def _in_process_multi(kzg, oracle, oracle_settings, devices, config=None):
     import ctypes as C
     import random
 
     L = oracle.lib()
-    ms = kzg.MultiKZGSettings(SETUP, devices)
+    ms = kzg.MultiKZGSettings(SETUP, devices, config)
     try:
         assert ms.settings_devices() == list(devices)
         assert kzg.get_device() == 0  # loading on other devices left the caller's device alone
@@ -366,11 +366,10 @@ def _in_process_multi(kzg, oracle, oracle_settings, devices):
 
 
 @pytest.mark.gpu
-def test_in_process_multi_two_settings_objects_on_gpu0(kzg, oracle, oracle_settings, monkeypatch):
-    # the in-library multi-GPU path on the hardware there is: two settings objects on GPU 0 (table budget capped so
-    # that both fit), every result against the oracle
-    monkeypatch.setenv("KZGAMD_FBW_MAX_GB", "40")
-    _in_process_multi(kzg, oracle, oracle_settings, [0, 0])
+def test_in_process_multi_two_settings_objects_on_gpu0(kzg, oracle, oracle_settings):
+    # the in-library multi-GPU path on the hardware there is: two settings objects on GPU 0 (40 GB per table through
+    # KzgAmdConfig.table_budget_bytes so that both fit — no environment variable), every result against the oracle
+    _in_process_multi(kzg, oracle, oracle_settings, [0, 0], kzg.make_config(table_budget_gb=40))
 
 
 @pytest.mark.gpu

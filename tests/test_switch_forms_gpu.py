@@ -1,6 +1,7 @@
-"""Forms of the c-kzg paths that a settings object chooses by switch.  The switches are read ONCE, when the
-object is created, so every form gets its own object here — with 8 GB tables, and in a module of its own so that the
-137 + 43 + 77 GB of another module's default object are released before these are built."""
+"""Forms of the c-kzg paths that a settings object chooses by tuning key.  The keys are read ONCE, when the
+object is created (KzgAmdConfig.tuning), so every form gets its own object here — with 8 GB tables (KzgAmdConfig.
+table_budget_bytes), and in a module of its own so that the 137 + 43 + 77 GB of another module's default object are
+released before these are built."""
 import hashlib
 import os
 import random
@@ -16,27 +17,16 @@ SETUP = os.path.join(GOLDEN, "trusted_setup.txt")
 
 @pytest.fixture(scope="module")
 def forms(kzg):
-    """settings objects: default form / FK20 forced / direct cell proofs forced / device SHA-256 + array k_quotient"""
-    saved = {k: os.environ.get(k) for k in ("KZGAMD_FBW_MAX_GB", "KZGAMD_FK20", "KZGAMD_DEVICE_SHA", "KZGAMD_QUOTIENT_ARRAYS")}
+    """settings objects: default form / FK20 forced / direct cell proofs forced / device SHA-256; each with 8 GB per
+    table through its KzgAmdConfig — four objects side by side on one GPU, no environment variable involved"""
     made = {}
     try:
-        os.environ["KZGAMD_FBW_MAX_GB"] = "8"
-        for name, env in (("default", {}), ("fk20", {"KZGAMD_FK20": "1"}), ("direct", {"KZGAMD_FK20": "0"}),
-                          ("device_sha", {"KZGAMD_DEVICE_SHA": "1", "KZGAMD_QUOTIENT_ARRAYS": "1"})):
-            for k, v in env.items():
-                os.environ[k] = v
-            made[name] = kzg.KZGSettings.from_file(SETUP)
-            for k in env:
-                del os.environ[k]
+        for name, tuning in (("default", None), ("fk20", {"fk20": 1}), ("direct", {"fk20": 0}), ("device_sha", {"device_sha": 1})):
+            made[name] = kzg.KZGSettings.from_file(SETUP, kzg.make_config(table_budget_gb=8, tuning=tuning))
         yield made
     finally:
         for s in made.values():
             s.close()
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def test_cell_proofs_fk20_matches_vectors_and_the_direct_form(kzg, forms, golden, blob_loader):
@@ -68,10 +58,9 @@ def test_cell_proofs_fk20_matches_vectors_and_the_direct_form(kzg, forms, golden
     assert p_direct[5 * 6144:5 * 6144 + 48] == b"\xc0" + bytes(47)
 
 
-def test_proof_batch_with_device_sha_and_array_quotient(kzg, forms):
-    """KZGAMD_DEVICE_SHA=1 (the Fiat-Shamir hashes of a host-buffer batch on the GPU, no host threads) and
-    KZGAMD_QUOTIENT_ARRAYS=1 (k_quotient with per-thread arrays instead of the output slots): the same proofs, challenges
-    and evaluations as the default object, and the same rejections."""
+def test_proof_batch_with_device_sha(kzg, forms):
+    """Tuning key device_sha=1 (the Fiat-Shamir hashes of a host-buffer batch on the GPU, no host threads): the same
+    proofs, challenges and evaluations as the default object, and the same rejections."""
     rnd = random.Random(257)
     n = 256
     blobs = bytearray(rnd.randbytes(n * BLOB))

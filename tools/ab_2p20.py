@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of one 2^20 variable-base MSM under two environments, alternating in one process (box-to-box and run-to-run
-noise is larger than most of the differences of interest):  python tools/ab_2p20.py KZGAMD_FLAT_DIGITS=1 [logn]"""
+noise is larger than most of the differences of interest):  python tools/ab_2p20.py flat_digits=1 [logn]"""
 import os
 import sys
 
@@ -10,7 +10,7 @@ import torch
 from conftest import load_package
 
 kzg = load_package()
-var = sys.argv[1] if len(sys.argv) > 1 else "KZGAMD_FLAT_DIGITS=1"
+var = sys.argv[1] if len(sys.argv) > 1 else "flat_digits=1"
 logn = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 k, v = var.split("=")
 dev = torch.device("cuda", 0)
@@ -24,12 +24,9 @@ g.manual_seed(2)
 sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g, device=dev)
 sc[:, 31] &= 0x3F
 out = torch.zeros(144, dtype=torch.uint8, device=dev)
-# the switches are read when a handle is created: one handle per environment, both alive, used alternately
-os.environ.pop(k, None)
+# the tuning keys are read when a handle is created: one handle per configuration, both alive, used alternately
 handles = {"default": kzg.DeviceMsm(pts.data_ptr(), n, False)}
-os.environ[k] = v
-handles[var] = kzg.DeviceMsm(pts.data_ptr(), n, False)
-os.environ.pop(k, None)
+handles[var] = kzg.DeviceMsm(pts.data_ptr(), n, False, kzg.make_config(tuning={k: int(v)}))
 
 
 def run(h):

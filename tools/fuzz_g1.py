@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzz of the G1 transforms (fftg1.hip): fft_g1 / kzgamd_fft_g1_batch against the CPU oracle on random
 sizes, batches, directions and inputs (random points, infinities, repeats, negations), under every stage form
-(KZGAMD_G1_{WIDE,QUAD,PAIR}_MAX forced per handle); and the FK20 cell proofs of batches of every form against the
+(tuning keys g1_{wide,quad,pair}_max forced per handle through KzgAmdConfig); and the FK20 cell proofs of batches of every form against the
 single-blob entry point (the direct form: one fixed-base MSM per cell).
 Not part of the test suite:  python tools/fuzz_g1.py [seconds] [seed]"""
 import ctypes as C
@@ -21,17 +21,15 @@ L = O.lib()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rnd = random.Random(seed)
-FORMS = {"by_size": {}, "wave": {"KZGAMD_G1_WIDE_MAX": "100000000"},
-         "four": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "100000000"},
-         "two": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "0", "KZGAMD_G1_PAIR_MAX": "100000000"},
-         "one": {"KZGAMD_G1_WIDE_MAX": "0", "KZGAMD_G1_QUAD_MAX": "0", "KZGAMD_G1_PAIR_MAX": "0"}}
-KEYS = ("KZGAMD_G1_WIDE_MAX", "KZGAMD_G1_QUAD_MAX", "KZGAMD_G1_PAIR_MAX")
+FORMS = {"by_size": {}, "wave": {"g1_wide_max": 100000000},
+         "four": {"g1_wide_max": 0, "g1_quad_max": 100000000},
+         "two": {"g1_wide_max": 0, "g1_quad_max": 0, "g1_pair_max": 100000000},
+         "one": {"g1_wide_max": 0, "g1_quad_max": 0, "g1_pair_max": 0}}
 
 
 def with_form(name):
-    for k in KEYS:
-        os.environ.pop(k, None)
-    os.environ.update(FORMS[name])
+    """the KzgAmdConfig that forces the form (None: by size)"""
+    return kzg.make_config(tuning=FORMS[name]) if FORMS[name] else None
 
 
 g = O.G1()
@@ -85,12 +83,12 @@ cases = bad = 0
 t_end = time.time() + budget * 0.6
 while time.time() < t_end:
     form = rnd.choice(list(FORMS))
-    with_form(form)
+    cfg = with_form(form)
     logn = rnd.choice([0, 1, 2, 3, 4, 5, 6, 7, 8])
     n = 1 << logn
     nbatch = rnd.choice([1, 1, 2, 3, 5])
     scale = rnd.choice([max(logn, 1), max(logn, 1) + 2])
-    fs = kzg.FFTSettings(scale)
+    fs = kzg.FFTSettings(scale, cfg)
     ofs = O.FFTSettings()
     assert L.offt_settings_new(C.byref(ofs), scale) == 0
     inverse = rnd.random() < 0.5
@@ -118,8 +116,7 @@ first = True
 while time.time() < t_end or first:
     first = False
     form = rnd.choice(list(FORMS))
-    with_form(form)
-    s = kzg.KZGSettings.from_file(eb.SETUP)
+    s = kzg.KZGSettings.from_file(eb.SETUP, with_form(form))
     n = rnd.choice([16, 17, 33, 64, 70, 130, 200])
     blobs = bytearray(rnd.randbytes(n * BLOB))
     for i in range(0, n * BLOB, 32):

@@ -1,5 +1,5 @@
 """One MSM of 2^logn points on the bucket engine, four calls on one handle (for rocprofv3): prof_2p20.py [logn] [fixed]
-(fixed: a prepared handle — table rows 2^(c j) P, one bucket set; KZGAMD_WINDOW_PREPARED picks c)"""
+(fixed: a prepared handle — table rows 2^(c j) P, one bucket set; tuning key window_prepared picks c)"""
 import importlib.util, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for spl in 0 4; do
-KZGAMD_SPL=$spl rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$spl -o x -- python $R/tools/time_g1.py --only-cells 4096,16384,32768 > /tmp/log_$spl.txt 2>&1
+KZGAMD_TUNING="spl=$spl" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$spl -o x -- python $R/tools/time_g1.py --only-cells 4096,16384,32768 > /tmp/log_$spl.txt 2>&1
 echo "== SPL=$spl"; grep "n=256" /tmp/log_$spl.txt
 python3 - <<PY
 import csv, glob, collections

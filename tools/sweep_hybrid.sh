@@ -2,7 +2,7 @@
 # KZGAMD_HYBRID_MAX (largest batch k_blocksum_hybrid takes), KZGAMD_WIDE_FOLD_MAX (largest batch k_wide_fold64 takes;
 # negative: never)
 export KZGAMD_FBW_MAX_GB=100
-for cfg in "KZGAMD_WIDE_FOLD_MAX=1" "KZGAMD_WIDE_FOLD_MAX=-1" "KZGAMD_WIDE_FOLD_MAX=4 KZGAMD_HYBRID_MAX=16"; do
+for cfg in "KZGAMD_TUNING=wide_fold_max=1" "KZGAMD_TUNING=wide_fold_max=-1" "KZGAMD_TUNING=wide_fold_max=4;hybrid_max=16"; do
   echo "== $cfg"
   env $cfg python tools/time_batches.py 2>&1 | grep "n="
 done

@@ -14,7 +14,7 @@ sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=g); sc[:, 31] &
 out = torch.zeros(144, dtype=torch.uint8, device=dev)
 for prep in (1, 0):
     for c in ([13, 14, 15, 16, 17, 18, 20] if prep else [13, 15, 16, 17, 18, 19]):
-        os.environ["KZGAMD_WINDOW_PREPARED" if prep else "KZGAMD_WINDOW"] = str(c)
+        os.environ["KZGAMD_TUNING"] = ("window_prepared=%d" if prep else "window=%d") % c
         h = kzg.DeviceMsm(pts.data_ptr(), n, bool(prep))
         f = lambda: kzg.msm_prepared_batch_device(h, out.data_ptr(), sc.data_ptr(), n, 1, False, stream)
         f(); torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Window sweep for the variable-base engine: for each n, time the MSM for every KZGAMD_WINDOW candidate.
+"""Window sweep for the variable-base engine: for each n, time the MSM for every `window` candidate (KZGAMD_TUNING).
 Run on an MI355X:  python tools/sweep_window.py [logn ...]"""
 import json
 import os
@@ -28,7 +28,7 @@ for logn in logns:
     n = 1 << logn
     row = {}
     for c in range(max(4, logn - 8), min(22, logn + 1)):
-        os.environ["KZGAMD_WINDOW"] = str(c)
+        os.environ["KZGAMD_TUNING"] = "window=%d" % c
         h = kzg.DeviceMsm(pts.data_ptr(), n, False)
         fn = lambda: kzg.msm_prepared_batch_device(h, out.data_ptr(), sc.data_ptr(), n, 1, False, stream)
         fn()
@@ -45,5 +45,5 @@ for logn in logns:
         h.close()
     res[logn] = row
     print(logn, row, flush=True)
-os.environ.pop("KZGAMD_WINDOW", None)
+os.environ.pop("KZGAMD_TUNING", None)
 print(json.dumps(res))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""compute_cells_and_kzg_proofs: FK20 (KZGAMD_FK20=1) against the direct form (=0), proofs only, host buffers."""
+"""compute_cells_and_kzg_proofs: FK20 (tuning key fk20=1) against the direct form (=0), proofs only, host buffers."""
 import os
 import random
 import sys
@@ -21,10 +21,9 @@ for i in range(0, nmax * BLOB, 32):
     blobs[i] = 0
 blobs = bytes(blobs)
 rows = {}
-# KZGAMD_FK20 is read when a settings object is created: one object per form, one after the other (each builds its tables)
+# the key is read when a settings object is created: one object per form, one after the other (each builds its tables)
 for mode in ("1", "0"):
-    os.environ["KZGAMD_FK20"] = mode
-    s = kzg.KZGSettings.from_file(eb.SETUP)
+    s = kzg.KZGSettings.from_file(eb.SETUP, kzg.make_config(tuning={"fk20": int(mode)}))
     for n in sorted({m for m in sizes if m <= nmax}):
         if mode == "0" and n > 256:
             continue  # the direct form needs 16 MB of quotient vectors per blob

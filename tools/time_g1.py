@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""G1 transforms: the stage forms by grid size (KZGAMD_G1_WIDE_MAX,_QUAD_MAX,_PAIR_MAX; default) against the single-lane ones (0,0,0), for the FK20
+"""G1 transforms: the stage forms by grid size (tuning keys g1_wide_max, g1_quad_max, g1_pair_max; default) against the single-lane ones (0,0,0), for the FK20
 cell proofs of 16 ... 256 blobs and for fft_g1 of 2^7 ... 2^15 points.  Every proof / point of the two variants is
 compared.  usage: time_g1.py [wide_max,quad_max,pair_max ...]"""
 import ctypes as C
@@ -47,7 +47,7 @@ MONO = distinct_points(1 << 15)
 ref = {}
 for v in variants:
     parts = v.split(",")
-    os.environ["KZGAMD_G1_WIDE_MAX"], os.environ["KZGAMD_G1_QUAD_MAX"], os.environ["KZGAMD_G1_PAIR_MAX"] = parts[:3]
+    os.environ["KZGAMD_TUNING"] = "g1_wide_max=%s;g1_quad_max=%s;g1_pair_max=%s" % tuple(parts[:3])
     s = kzg.KZGSettings.from_file(eb.SETUP)
     for n in (() if ONLY_FFT else SIZES):
         proofs = C.create_string_buffer(n * 128 * 48)

@@ -46,8 +46,8 @@ for logn in logns:
     ref = bytes(o.cpu().numpy()); h.close()
     print("2^%d variable-base  c=%d  %.3f ms" % (logn, 16, ms), flush=True)
     for w in windows:
-        if w: os.environ["KZGAMD_WINDOW_PREPARED"] = str(w)
-        else: os.environ.pop("KZGAMD_WINDOW_PREPARED", None)
+        if w: os.environ["KZGAMD_TUNING"] = "window_prepared=%d" % w
+        else: os.environ.pop("KZGAMD_TUNING", None)
         import time
         t0 = time.perf_counter()
         h = kzg.DeviceMsm(pts.data_ptr(), n, True)

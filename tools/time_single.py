@@ -16,7 +16,7 @@ for name, fn in (("commit", lambda: kzg.blob_to_kzg_commitment(b, s)), ("blob pr
     t0 = time.perf_counter()
     for _ in range(50):
         fn()
-    print("%-10s %.3f ms" % (name, (time.perf_counter() - t0) / 50 * 1e3), os.environ.get("KZGAMD_WSPLIT", "default"))
+    print("%-10s %.3f ms" % (name, (time.perf_counter() - t0) / 50 * 1e3), os.environ.get("KZGAMD_TUNING", "default"))
 s.close()
 # verification: field work / G1 combinations on the GPU, one pairing check on the host
 s = kzg.KZGSettings.from_file(eb.SETUP)

@@ -29,4 +29,4 @@ for name, sc in cases.items():
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); fn(); b.record(); torch.cuda.synchronize()
         ts.append(a.elapsed_time(b))
-    print("%-16s %8.3f ms" % (name, min(ts)), os.environ.get("KZGAMD_ONE_LEVEL_SORT", ""), flush=True)
+    print("%-16s %8.3f ms" % (name, min(ts)), os.environ.get("KZGAMD_TUNING", ""), flush=True)

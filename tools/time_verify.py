@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ms per verify_blob_kzg_proof_batch (64 blobs) and verify_cell_kzg_proof_batch (128 cells of one blob) call, host
-buffers; KZGAMD_WIDE_CHECK=0 runs the single-lane membership tests instead of the wave-per-point ones."""
+buffers; KZGAMD_TUNING=wide_check=0 runs the single-lane membership tests instead of the wave-per-point ones."""
 import os
 import sys
 import time
