@@ -36,6 +36,31 @@ BLOB = 131072
 N = 4096
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK = 1024 * 2.4e9 / 4               # 1024 SIMDs x one wave64 VALU instruction per 4 cycles at the nominal 2.4 GHz
+VALU_PEAK_MODEL = ("1 wave64 instruction / SIMD / 4 cycles at 2.4 GHz: the issue rate tools/ffbench.hip measures for "
+                   "v_mad_u64_u32-class instructions (profiles/r03_ffbench.log: 4.2-5.7 wall cycles per instruction for every "
+                   "three-operand or 64-bit opcode; 2.9-3.0 for two-operand 32-bit ones)")
+# MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction issues over 2 cycles (the FP32 vector rate, 157.3 TFLOP/s)
+VALU_PEAK_GUIDE_NOMINAL = 1024 * 2.4e9 / 2
+ISA_HISTOGRAM = os.path.join(ROOT, "profiles", "r05_isa_histogram.json")  # tools/isa_histogram.py
+
+
+def opcode_weighted_peak(kernel_substr):
+    """VALU wave-instructions/s the chip can issue for THIS kernel's opcode mix: the static class counts of the kernel
+    (tools/isa_histogram.py) weighted with the issue cycles per class tools/ffbench.hip measured; None without the file"""
+    try:
+        with open(ISA_HISTOGRAM) as f:
+            h = json.load(f)
+    except (OSError, ValueError):
+        return None
+    for name, k in h["kernels"].items():
+        if kernel_substr in name and k.get("mean_issue_cycles_per_valu_instruction"):
+            mean = k["mean_issue_cycles_per_valu_instruction"]
+            return {"peak": 1024 * 2.4e9 / mean, "mean_issue_cycles_per_instruction": mean, "classes": k["classes"],
+                    "class_issue_cycles": k["class_issue_cycles"], "kernel_symbol": name,
+                    "source": "profiles/r05_isa_histogram.json (static opcode classes of the kernel) x profiles/r03_ffbench.log "
+                              "(measured wall cycles per wave-instruction per class at the nominal 2.4 GHz)"}
+    return None
+
 ALG_BYTES_PER_COMMIT = 128 * N             # SURVEY §8(d): 96 B point + 32 B scalar per pair
 ALG_ADDS_PER_COMMIT = 20 * N + 8192        # SURVEY §8(d): BGMW count for the fixed-base 4096 case
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
@@ -430,6 +455,11 @@ def main():
         wave_instr = pk["SQ_INSTS_VALU"] / pk_batch * B
         res["valu"] = {"bound": "VALU issue", "kernel": kern, "achieved": wave_instr / (own_ms * 1e-3), "peak": VALU_PEAK,
                        "unit": "VALU wave-instructions/s", "frac": wave_instr / (own_ms * 1e-3) / VALU_PEAK,
+                       "peak_model": VALU_PEAK_MODEL,
+                       "peak_guide_nominal": VALU_PEAK_GUIDE_NOMINAL,
+                       "frac_vs_guide_nominal": wave_instr / (own_ms * 1e-3) / VALU_PEAK_GUIDE_NOMINAL,
+                       "opcode_weighted": (lambda ow: None if ow is None else dict(ow, frac=wave_instr / (own_ms * 1e-3) / ow["peak"]))(
+                           opcode_weighted_peak("k_fbw_accumILi8ELb%d" % (1 if info["wide_glv"] else 0))),  # every SPL >= 2 has the same mix
                        "kernel_ms_alone": own_ms, "valu_instructions_per_mixed_add": wave_instr * 64 / (B * N * info["adds_per_scalar"]),
                        "busy_frac_at_sustained_clock": pk.get("valu_busy_frac"),
                        "sustained_clock_ghz": pk.get("effective_clock_ghz"),
@@ -572,6 +602,7 @@ def main():
                 "valu": None if not winstr else {
                     "bound": "VALU issue", "achieved": winstr / (ms * 1e-3), "peak": VALU_PEAK, "unit": "VALU wave-instructions/s",
                     "frac": winstr / (ms * 1e-3) / VALU_PEAK, "wave_instructions_per_call": winstr,
+                    "peak_model": VALU_PEAK_MODEL, "frac_vs_guide_nominal": winstr / (ms * 1e-3) / VALU_PEAK_GUIDE_NOMINAL,
                     "instructions_per_butterfly": winstr * 64 / muls,
                     "floor_us_at_nominal_clock": winstr / VALU_PEAK * 1e6,
                     "busy_frac_at_sustained_clock": pk.get("valu_busy_frac"), "scratch_bytes_per_lane": pk.get("scratch", 0),

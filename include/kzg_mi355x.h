@@ -103,6 +103,14 @@ RustError mult_pippenger_prepared_batch(void *msm, blst_p1 out[], size_t npoints
  * thread-safe like every handle. */
 void *kzgamd_prepare_msm_matrix(const blst_p1_affine points[], size_t rows, size_t cols, const KzgAmdConfig *cfg);
 RustError kzgamd_mult_pippenger_matrix(void *msm, blst_p1 out[], const blst_fr scalars[], size_t nmat);
+/* The matrix as a part of an existing handle (any handle of prepare_msm / kzgamd_settings_msm_handle): the reference's
+ * PrecomputationTable is ONE object built from (points, matrix) (precompute(), kzg/src/msm/bgmw.rs:206-304) and the sppark
+ * flavour of it has room for one pointer (kzg/src/msm/sppark.rs:5-22) — after this call kzgamd_mult_pippenger_matrix on
+ * `msm` multiplies by the attached matrix, mult_pippenger_prepared by its own points as before; free_msm frees both.
+ * cfg: the matrix table's budget and tuning (its device is the handle's). */
+/* rows and columns of the matrix a handle holds or has attached; 1 when it has none */
+int kzgamd_msm_matrix_shape(void *msm, size_t *rows, size_t *cols);
+RustError kzgamd_msm_attach_matrix(void *msm, const blst_p1_affine points[], size_t rows, size_t cols, const KzgAmdConfig *cfg);
 
 /* Device-resident form used by the batched blob pipeline and bench.py: d_scalars / d_out are
  * device pointers, work is enqueued on `stream` (a hipStream_t, NULL = default stream) and NOT

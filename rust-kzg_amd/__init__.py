@@ -57,7 +57,7 @@ _lib = None
 
 # every symbol include/kzg_mi355x.h declares; tests check the library exports all of them
 EXPORTS = [
-    "kzgamd_config_init", "kzgamd_tuning_keys", "kzgamd_prepare_msm_ex", "kzgamd_prepare_msm_matrix", "kzgamd_mult_pippenger_matrix",
+    "kzgamd_config_init", "kzgamd_tuning_keys", "kzgamd_msm_attach_matrix", "kzgamd_msm_matrix_shape", "kzgamd_prepare_msm_ex", "kzgamd_prepare_msm_matrix", "kzgamd_mult_pippenger_matrix",
     "kzgamd_msm_create_device_ex", "kzgamd_ntt_new_ex", "kzgamd_load_trusted_setup_ex", "kzgamd_load_trusted_setup_file_ex",
     "kzgamd_load_trusted_setup_file_multi_ex",
     "prepare_msm", "mult_pippenger_prepared", "mult_pippenger", "free_msm", "mult_pippenger_prepared_batch",
@@ -152,6 +152,10 @@ def lib():
     L.kzgamd_prepare_msm_ex.argtypes = [vp, sz, cp]
     L.kzgamd_prepare_msm_matrix.restype = vp
     L.kzgamd_prepare_msm_matrix.argtypes = [vp, sz, sz, cp]
+    L.kzgamd_msm_matrix_shape.restype = C.c_int
+    L.kzgamd_msm_matrix_shape.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+    L.kzgamd_msm_attach_matrix.restype = RustError
+    L.kzgamd_msm_attach_matrix.argtypes = [vp, vp, sz, sz, cp]
     L.kzgamd_mult_pippenger_matrix.restype = RustError
     L.kzgamd_mult_pippenger_matrix.argtypes = [vp, vp, vp, sz]
     L.kzgamd_msm_create_device_ex.restype = vp
@@ -319,6 +323,17 @@ class PreparedMsm:
         if not self.handle:
             raise KzgAmdError("prepare_msm failed (no GPU, or bad arguments)")
 
+    def attach_matrix(self, points, rows, cols, config=None):
+        """kzgamd_msm_attach_matrix: this handle also answers multiply_batch (the reference's precompute(points, matrix))"""
+        _check(lib().kzgamd_msm_attach_matrix(self.handle, _addr(points), rows, cols, _cfgp(config)), "kzgamd_msm_attach_matrix")
+        self.rows, self.cols = rows, cols
+
+    def multiply_batch(self, scalars, nmat=1):
+        """scalars: blst_fr[nmat * rows * cols] (Montgomery) -> (BlstP1 * (nmat * rows)); needs a matrix (attach_matrix / MatrixMsm)"""
+        out = (BlstP1 * (nmat * self.rows))()
+        _check(lib().kzgamd_mult_pippenger_matrix(self.handle, out, _addr(scalars), nmat), "kzgamd_mult_pippenger_matrix")
+        return out
+
     def info(self):
         c, rows, nb, n = C.c_int(), C.c_int(), C.c_size_t(), C.c_size_t()
         lib().kzgamd_msm_info(self.handle, C.byref(c), C.byref(rows), C.byref(nb), C.byref(n))
@@ -354,11 +369,6 @@ class MatrixMsm(PreparedMsm):
         if not self.handle:
             raise KzgAmdError("kzgamd_prepare_msm_matrix failed (no GPU, bad arguments, or no wide table fits the budget)")
 
-    def multiply_batch(self, scalars, nmat=1):
-        """scalars: blst_fr[nmat * rows * cols] (Montgomery) -> (BlstP1 * (nmat * rows))"""
-        out = (BlstP1 * (nmat * self.rows))()
-        _check(lib().kzgamd_mult_pippenger_matrix(self.handle, out, _addr(scalars), nmat), "kzgamd_mult_pippenger_matrix")
-        return out
 
 
 def multi_scalar_mult_prepared(msm, scalars, npoints):
@@ -473,6 +483,14 @@ class KZGSettings:
 
     def g1_lagrange_brp(self):
         return (BlstP1 * 4096).from_address(self.c.g1_values_lagrange_brp)
+
+    def g1_lagrange_affine(self):
+        """the same points as blst_p1_affine (a loaded setup's points have Z = 1: x and y are the affine coordinates)"""
+        jac = self.g1_lagrange_brp()
+        aff = (BlstP1Affine * 4096)()
+        for i in range(4096):
+            aff[i].x, aff[i].y = jac[i].x, jac[i].y
+        return aff
 
     def close(self):
         if self.loaded:

@@ -15,6 +15,9 @@ struct DeviceGuard {
         if (err == hipSuccess && prev != dev) {
             err = hipSetDevice(dev);
             changed = err == hipSuccess;
+            // a refused device is reported through `err` only: the runtime's sticky last-error must not fail the
+            // next, unrelated call's hipGetLastError() check
+            if (!changed) (void)hipGetLastError();
         }
     }
     ~DeviceGuard() {

@@ -1863,6 +1863,7 @@ struct kzgamd::MsmContext {
     MsmTuning tune;
     int window_forced = 0;  // tuning keys window (variable base) / window_prepared at creation, 0 = by size
     size_t mat_rows = 0, mat_cols = 0;  // matrix handle (kzgamd_prepare_msm_matrix): rows base sets of cols points
+    MsmContext* matrix = nullptr;       // kzgamd_msm_attach_matrix: a matrix handle owned by this one
     int device = 0;
     size_t n = 0;
     bool prepared = false;
@@ -1946,6 +1947,7 @@ struct kzgamd::MsmContext {
         std::vector<unsigned char*> free_slots;
     } comb;
     ~MsmContext() {
+        delete matrix;
         if (comb.h_slots) (void)hipHostFree(comb.h_slots);
         for (auto& l : comb.lanes) {
             if (l.h_out) (void)hipHostFree(l.h_out);
@@ -2953,9 +2955,38 @@ extern "C" void* kzgamd_prepare_msm_matrix(const blst_p1_affine points[], size_t
     });
 }
 
+// the same table as a part of an existing handle: what one PrecomputationTable of the reference holds (points AND
+// matrix, kzg/src/msm/bgmw.rs:206-304), behind the single pointer SpparkPrecomputation has room for
+extern "C" RustError kzgamd_msm_attach_matrix(void* msm, const blst_p1_affine points[], size_t rows, size_t cols,
+                                              const KzgAmdConfig* cfg) {
+    if (!msm || !points || rows == 0 || cols == 0) return make_error(1, "kzgamd_msm_attach_matrix: bad arguments");
+    MsmContext* ctx = (MsmContext*)msm;
+    KzgAmdConfig inherited;
+    kzgamd_config_init(&inherited);
+    if (cfg) inherited = *cfg;
+    inherited.device = ctx->device;  // the matrix lives where its handle lives
+    void* m = kzgamd_prepare_msm_matrix(points, rows, cols, &inherited);
+    if (!m) return make_error(1, "kzgamd_msm_attach_matrix: the matrix handle could not be built (see stderr)");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    kzgamd::DeviceGuard on_device(ctx->device);
+    delete ctx->matrix;
+    ctx->matrix = (MsmContext*)m;
+    return ok_error();
+}
+
+extern "C" int kzgamd_msm_matrix_shape(void* msm, size_t* rows, size_t* cols) {
+    MsmContext* ctx = (MsmContext*)msm;
+    if (ctx && !ctx->mat_rows && ctx->matrix) ctx = ctx->matrix;
+    if (!ctx || !ctx->mat_rows) return 1;
+    if (rows) *rows = ctx->mat_rows;
+    if (cols) *cols = ctx->mat_cols;
+    return 0;
+}
+
 extern "C" RustError kzgamd_mult_pippenger_matrix(void* msm, blst_p1 out[], const blst_fr scalars[], size_t nmat) {
     if (!msm || !out || !scalars) return make_error(1, "kzgamd_mult_pippenger_matrix: null handle, output or scalars");
     MsmContext* ctx = (MsmContext*)msm;
+    if (!ctx->mat_rows && ctx->matrix) ctx = ctx->matrix;
     if (!ctx->mat_rows) return make_error(1, "kzgamd_mult_pippenger_matrix: not a matrix handle");
     return guarded([&] { kzgamd::msm_run_host(ctx, out, scalars, ctx->mat_cols, nmat * ctx->mat_rows, ctx->mat_rows); });
 }

@@ -206,26 +206,39 @@ impl G1LinComb<FsFr, FsFp, MiG1Affine, MiG1ProjAddAffine> for MiG1 {
         out
     }
 
-    /// Batched form (kzg/src/lib.rs:159-181).  Its only caller is `compute_fk20_proofs` (kzg/src/das.rs:682-686),
-    /// which passes the 128 rows of `x_ext_fft_columns` TOGETHER WITH the settings' precomputation — and the table
-    /// `MiKZGSettings::new` builds is over `g1_values_lagrange_brp`, not over those rows.  The reference's own backends
-    /// only use a table here when it was built from the matrix (`precompute(points, matrix)`); this backend has no
-    /// such table, so the precomputation is ignored and every row is a variable-base MSM over ITS points.
-    /// (`compute_cells_and_kzg_proofs` through the C-ABI runs FK20 on the device with a table over the columns —
-    /// rust-kzg_amd/csrc/ckzg.hip `fk20_prepare` — and is the fast path.)
+    /// Batched form (kzg/src/lib.rs:159-181).  Its one caller is `compute_fk20_proofs` (kzg/src/das.rs:682-686),
+    /// which passes the 128 rows of `x_ext_fft_columns` together with the settings' precomputation.  As in the
+    /// reference (`precomputation.multiply_batch(scalars)`, kzg/src/msm/bgmw.rs:306-380) the table is the one
+    /// `MiKZGSettings::new` built from those rows (`kzgamd_msm_attach_matrix`): all rows in ONE launch of the device's
+    /// wide-table path (`kzgamd_mult_pippenger_matrix`).  Without a table — or when the matrix did not fit the HBM
+    /// budget and was not attached — every row is a variable-base MSM over its points, like the trait's default.
     fn g1_lincomb_batch(
         points: &[Vec<Self>],
         scalars: &[Vec<FsFr>],
-        _precomputation: Option<&MiPrecomputation>,
+        precomputation: Option<&MiPrecomputation>,
     ) -> Result<Vec<Self>, String> {
         if points.len() != scalars.len() {
             return Err("Invalid batch size".into());
         }
-        let mut result = Vec::with_capacity(points.len());
         for (p, s) in points.iter().zip(scalars.iter()) {
             if p.len() != s.len() {
                 return Err("Invalid point count length".into());
             }
+        }
+        if let Some(table) = precomputation {
+            let rows = scalars.len();
+            let cols = scalars.first().map_or(0, |r| r.len());
+            if rows > 0 && cols > 0 && scalars.iter().all(|r| r.len() == cols) {
+                let flat: Vec<FsFr> = scalars.iter().flat_map(|r| r.iter().copied()).collect();
+                let flat_raw = unsafe { core::slice::from_raw_parts(flat.as_ptr() as *const blst_fr, flat.len()) };
+                // Err: no matrix attached to this handle (or another shape): fall through to the row-by-row form
+                if let Ok(sums) = unsafe { sys::msm_matrix_raw(table.table, flat_raw, rows) } {
+                    return Ok(sums.into_iter().map(MiG1::from_blst).collect());
+                }
+            }
+        }
+        let mut result = Vec::with_capacity(points.len());
+        for (p, s) in points.iter().zip(scalars.iter()) {
             result.push(Self::g1_lincomb(p, s, p.len(), None));
         }
         Ok(result)

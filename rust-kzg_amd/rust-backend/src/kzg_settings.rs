@@ -25,22 +25,34 @@ pub struct MiKZGSettings {
     pub g1_values_monomial: Vec<MiG1>,
     pub g1_values_lagrange_brp: Vec<MiG1>,
     pub g2_values_monomial: Vec<FsG2>,
-    /// device-resident fixed-base table over `g1_values_lagrange_brp` (`prepare_msm`)
+    /// device-resident fixed-base tables behind ONE handle: over `g1_values_lagrange_brp` (`prepare_msm`, what
+    /// `g1_lincomb` multiplies by) and over the rows of `x_ext_fft_columns` (`kzgamd_msm_attach_matrix`, what
+    /// `g1_lincomb_batch` multiplies by) — the reference's `precompute(points, matrix)`
     pub precomputation: Option<Arc<MiPrecomputation>>,
     pub x_ext_fft_columns: Vec<Vec<MiG1>>,
     pub cell_size: usize,
 }
 
-fn prepare(points: &[MiG1]) -> Option<Arc<MiPrecomputation>> {
+fn prepare(points: &[MiG1], matrix: &[Vec<MiG1>]) -> Option<Arc<MiPrecomputation>> {
     let mut affines: Vec<MiG1Affine> = alloc::vec![MiG1Affine::default(); points.len()];
     MiG1Affine::into_affines_loc(&mut affines, points);
     let raw = unsafe { core::slice::from_raw_parts(affines.as_ptr() as *const blst_p1_affine, affines.len()) };
     let handle = sys::prepare_raw(raw);
     if handle.is_null() {
-        None
-    } else {
-        Some(Arc::new(MiPrecomputation::from_ptr(handle)))
+        return None;
     }
+    // the matrix rows, flattened row-major (every row has the same length: cell_size)
+    let rows = matrix.len();
+    let cols = matrix.first().map_or(0, |r| r.len());
+    if rows > 0 && cols > 0 && matrix.iter().all(|r| r.len() == cols) {
+        let flat: Vec<MiG1> = matrix.iter().flat_map(|r| r.iter().copied()).collect();
+        let mut flat_aff: Vec<MiG1Affine> = alloc::vec![MiG1Affine::default(); flat.len()];
+        MiG1Affine::into_affines_loc(&mut flat_aff, &flat);
+        let flat_raw = unsafe { core::slice::from_raw_parts(flat_aff.as_ptr() as *const blst_p1_affine, flat_aff.len()) };
+        // a matrix that does not fit the HBM budget is not an error: g1_lincomb_batch then runs row by row
+        let _ = unsafe { sys::attach_matrix_raw(handle, flat_raw, rows, cols, None) };
+    }
+    Some(Arc::new(MiPrecomputation::from_ptr(handle)))
 }
 
 impl KZGSettings<FsFr, MiG1, FsG2, MiFFTSettings, FsPoly, FsFp, MiG1Affine, MiG1ProjAddAffine> for MiKZGSettings {
@@ -75,12 +87,13 @@ impl KZGSettings<FsFr, MiG1, FsG2, MiFFTSettings, FsPoly, FsFp, MiG1Affine, MiG1
                 x_ext_fft_columns[row][offset] = value;
             }
         }
+        let precomputation = prepare(g1_lagrange_brp, &x_ext_fft_columns);
         Ok(Self {
             g1_values_monomial: g1_monomial.to_vec(),
             g1_values_lagrange_brp: g1_lagrange_brp.to_vec(),
             g2_values_monomial: g2_monomial.to_vec(),
             fs: fft_settings.clone(),
-            precomputation: prepare(g1_lagrange_brp),
+            precomputation,
             x_ext_fft_columns,
             cell_size,
         })

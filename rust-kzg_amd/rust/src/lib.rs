@@ -15,7 +15,34 @@ pub struct RustError {
     pub message: *mut c_char,
 }
 
+/// `KzgAmdConfig` of include/kzg_mi355x.h: device, HBM budget per fixed-base table, tuning string.
+#[repr(C)]
+pub struct KzgAmdConfig {
+    pub struct_size: u32,
+    pub device: i32,
+    pub table_budget_bytes: u64,
+    pub tuning: *const c_char,
+}
+
+impl Default for KzgAmdConfig {
+    fn default() -> Self {
+        let mut cfg = core::mem::MaybeUninit::<KzgAmdConfig>::uninit();
+        unsafe {
+            kzgamd_config_init(cfg.as_mut_ptr());
+            cfg.assume_init()
+        }
+    }
+}
+
 extern "C" {
+    fn kzgamd_config_init(cfg: *mut KzgAmdConfig);
+    fn kzgamd_prepare_msm_ex(points: *const blst_p1_affine, npoints: usize, cfg: *const KzgAmdConfig) -> *mut c_void;
+    fn kzgamd_prepare_msm_matrix(points: *const blst_p1_affine, rows: usize, cols: usize, cfg: *const KzgAmdConfig) -> *mut c_void;
+    fn kzgamd_msm_attach_matrix(msm: *mut c_void, points: *const blst_p1_affine, rows: usize, cols: usize,
+                                cfg: *const KzgAmdConfig) -> RustError;
+    fn kzgamd_mult_pippenger_matrix(msm: *mut c_void, out: *mut blst_p1, scalars: *const blst_fr, nmat: usize) -> RustError;
+    fn kzgamd_msm_matrix_shape(msm: *mut c_void, rows: *mut usize, cols: *mut usize) -> c_int;
+    fn kzgamd_ntt_new_ex(scale: u32, cfg: *const KzgAmdConfig) -> *mut c_void;
     fn prepare_msm(points: *const blst_p1_affine, npoints: usize) -> *mut c_void;
     fn free_msm(msm: *mut c_void);
     fn mult_pippenger_prepared(msm: *mut c_void, out: *mut blst_p1, npoints: usize, scalars: *const blst_fr) -> RustError;
@@ -120,6 +147,52 @@ pub unsafe fn msm_prepared_batch_raw(handle: *mut c_void, scalars: &[blst_fr], n
     Ok(out)
 }
 
+/// The matrix of `precompute(points, matrix)` (kzg/src/msm/bgmw.rs:206-304) attached to a handle of [`prepare_raw`]:
+/// `rows` base sets of `cols` points, row-major.  One pointer then serves `g1_lincomb` and `g1_lincomb_batch`.
+///
+/// # Safety
+/// `handle` must come from [`prepare_raw`] and not have been freed.
+pub unsafe fn attach_matrix_raw(handle: *mut c_void, points: &[blst_p1_affine], rows: usize, cols: usize,
+                                cfg: Option<&KzgAmdConfig>) -> Result<(), String> {
+    if rows == 0 || cols == 0 || points.len() != rows * cols {
+        return Err("bad matrix shape".into());
+    }
+    let cfg_ptr = cfg.map_or(core::ptr::null(), |c| c as *const KzgAmdConfig);
+    check(kzgamd_msm_attach_matrix(handle, points.as_ptr(), rows, cols, cfg_ptr), "kzgamd_msm_attach_matrix")
+}
+
+/// `multiply_batch` (kzg/src/msm/bgmw.rs:306-380) on the attached matrix: `scalars` is rows x cols, row-major;
+/// one launch for all rows.
+///
+/// # Safety
+/// `handle` must carry a matrix ([`attach_matrix_raw`]) of `rows` rows.
+pub unsafe fn msm_matrix_raw(handle: *mut c_void, scalars: &[blst_fr], rows: usize) -> Result<Vec<blst_p1>, String> {
+    let (mut hr, mut hc) = (0usize, 0usize);
+    if kzgamd_msm_matrix_shape(handle, &mut hr, &mut hc) != 0 {
+        return Err("no matrix attached to this handle".into());
+    }
+    if rows != hr || scalars.len() != hr * hc {
+        return Err("bad matrix shape".into());
+    }
+    let mut out = vec![blst_p1::default(); rows];
+    check(kzgamd_mult_pippenger_matrix(handle, out.as_mut_ptr(), scalars.as_ptr(), 1), "kzgamd_mult_pippenger_matrix")?;
+    Ok(out)
+}
+
+/// A stand-alone matrix handle (`kzgamd_prepare_msm_matrix`); release with [`free_raw`].
+pub fn prepare_matrix_raw(points: &[blst_p1_affine], rows: usize, cols: usize, cfg: Option<&KzgAmdConfig>) -> *mut c_void {
+    if rows == 0 || cols == 0 || points.len() != rows * cols {
+        return core::ptr::null_mut();
+    }
+    let cfg_ptr = cfg.map_or(core::ptr::null(), |c| c as *const KzgAmdConfig);
+    unsafe { kzgamd_prepare_msm_matrix(points.as_ptr(), rows, cols, cfg_ptr) }
+}
+
+/// [`prepare_raw`] with a configuration (device, table budget, tuning).
+pub fn prepare_raw_with(points: &[blst_p1_affine], cfg: &KzgAmdConfig) -> *mut c_void {
+    unsafe { kzgamd_prepare_msm_ex(points.as_ptr(), points.len(), cfg) }
+}
+
 /// `prepare_multi_scalar_mult` of blst-sppark/src/lib.rs:8-17: the handle is leaked into the settings object like
 /// the reference's (release it with [`free_raw`] when the settings go away).
 pub fn prepare_raw(points: &[blst_p1_affine]) -> *mut c_void {
@@ -166,6 +239,18 @@ impl GpuNtt {
         let ctx = unsafe { kzgamd_ntt_new(scale as u32) };
         if ctx.is_null() {
             return Err("kzgamd_ntt_new failed (no gfx950 device?)".into());
+        }
+        Ok(Self { ctx })
+    }
+
+    /// the same on a chosen device / with tuning keys (`KzgAmdConfig`)
+    pub fn with_config(scale: usize, cfg: &KzgAmdConfig) -> Result<Self, String> {
+        if scale >= 32 {
+            return Err(String::from("Scale is expected to be within root of unity matrix row size"));
+        }
+        let ctx = unsafe { kzgamd_ntt_new_ex(scale as u32, cfg) };
+        if ctx.is_null() {
+            return Err("kzgamd_ntt_new_ex failed (no gfx950 device, or a malformed configuration)".into());
         }
         Ok(Self { ctx })
     }

@@ -77,6 +77,18 @@ def test_matrix_handle_fk20_shape_against_the_oracle_and_separate_calls(kzg, ora
     with pytest.raises(kzg.KzgAmdError):   # a matrix call on a plain prepared handle
         kzg._check(kzg.lib().kzgamd_mult_pippenger_matrix(s.msm_handle(), out, sc, 1), "matrix")
     h.close()
+    # the matrix as a part of the Lagrange-points handle (one PrecomputationTable = points + matrix in the reference):
+    # the same handle then answers both g1_lincomb and g1_lincomb_batch
+    both = kzg.prepare_multi_scalar_mult(s.g1_lagrange_affine(), 4096, kzg.make_config(table_budget_gb=8))
+    both.attach_matrix(aff, rows, cols, kzg.make_config(table_budget_gb=16))
+    got = both.multiply_batch(sc, 1)
+    assert [compressed(L, got[k]) for k in range(rows)] == want[:rows]
+    lag = s.g1_lagrange_affine()
+    sc4096 = O.fr_array([rnd.randrange(O.R) for _ in range(4096)])
+    exp = O.G1()
+    L.omsm_affine(C.byref(exp), C.cast(lag, C.POINTER(O.G1Affine)), sc4096, 4096)
+    assert compressed(L, kzg.multi_scalar_mult_prepared(both, sc4096, 4096)) == compressed(L, exp)
+    both.close()
     s.close()
 
 

@@ -361,3 +361,79 @@ int main() {
     exe = tmp_path / "dblcheck"
     subprocess.check_call([cxx, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "rust-kzg_amd", "csrc"), "-x", "c++", str(src), "-o", str(exe)])
     assert subprocess.check_output([str(exe)]).strip() == b"0"
+
+
+def _c_prototypes():
+    """{name: [parameter declarations]} of every function include/kzg_mi355x.h declares"""
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"^\s*#.*$", "", src, flags=re.M)
+    protos = {}
+    for m in re.finditer(r"^[A-Za-z_][\w\s\*]*?\b([a-z_][a-z0-9_]*)\s*\(([^;{]*?)\)\s*;", src, flags=re.M | re.S):
+        args = " ".join(m.group(2).split())
+        protos[m.group(1)] = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+    return protos
+
+
+def _rust_externs(path):
+    """{name: [parameter declarations]} of every fn inside an extern "C" block of a Rust source"""
+    src = open(path).read()
+    src = re.sub(r"//.*$", "", src, flags=re.M)
+    out = {}
+    for block in re.finditer(r'extern\s+"C"\s*\{(.*?)\n\s*\}', src, flags=re.S):
+        body = block.group(1)
+        for m in re.finditer(r"(#\[link_name\s*=\s*\"(\w+)\"\]\s*)?(?:pub\s+)?fn\s+(\w+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", body, flags=re.S):
+            args = " ".join(m.group(4).split())
+            out[m.group(2) or m.group(3)] = [a.strip() for a in args.split(",") if a.strip()]
+    return out
+
+
+def test_rust_sys_crate_declares_what_the_header_declares():
+    """The Rust side of the boundary cannot be compiled in this image (no cargo): at least every `extern "C"` item of the
+    sys crate (rust-kzg_amd/rust/src/lib.rs) must name a function of include/kzg_mi355x.h with the same number of
+    parameters, pointer parameters where the header has pointers and integers where it has integers, and its #[repr(C)]
+    mirror of KzgAmdConfig must have the header's fields in the header's order."""
+    protos = _c_prototypes()
+    rs = os.path.join(ROOT, "rust-kzg_amd", "rust", "src", "lib.rs")
+    ext = _rust_externs(rs)
+    assert len(ext) >= 40, sorted(ext)
+    for must in ("prepare_msm", "mult_pippenger_prepared", "mult_pippenger", "ntt_fr", "das_fft_extension", "fft_g1",
+                 "kzgamd_msm_attach_matrix", "kzgamd_mult_pippenger_matrix", "kzgamd_config_init", "blob_to_kzg_commitment",
+                 "compute_cells_and_kzg_proofs", "kzgamd_load_trusted_setup_file_multi"):
+        assert must in ext, must
+    for name, rargs in ext.items():
+        if name == "free":  # libc
+            continue
+        assert name in protos, "Rust declares %s, the header does not" % name
+        cargs = protos[name]
+        assert len(rargs) == len(cargs), (name, rargs, cargs)
+        for ra, ca in zip(rargs, cargs):
+            c_is_ptr = "*" in ca or "[" in ca
+            r_is_ptr = "*const" in ra or "*mut" in ra or "&" in ra
+            assert c_is_ptr == r_is_ptr, (name, ra, ca)
+            if not c_is_ptr:
+                rt = ra.split(":")[1].strip()
+                if "size_t" in ca:
+                    assert rt == "usize", (name, ra, ca)
+                elif "uint64_t" in ca:
+                    assert rt == "u64", (name, ra, ca)
+                elif re.search(r"\bunsigned\b", ca):
+                    assert rt == "u32", (name, ra, ca)
+                elif re.search(r"\bint\b", ca):
+                    assert rt in ("c_int", "core::ffi::c_int"), (name, ra, ca)
+    # KzgAmdConfig
+    hdr = open(HEADER).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    end = hdr.index("} KzgAmdConfig;")
+    c_fields = hdr[hdr.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
+    c_names = [re.search(r"(\w+)\s*$", d.strip()).group(1) for d in c_fields.split(";") if d.strip()]
+    src = open(rs).read()
+    r_fields = re.search(r"#\[repr\(C\)\]\s*pub struct KzgAmdConfig \{(.*?)\}", src, flags=re.S).group(1)
+    r_decl = [(m.group(1), m.group(2).strip()) for m in re.finditer(r"pub (\w+):\s*([^,]+),", r_fields)]
+    assert [n for n, _ in r_decl] == c_names == ["struct_size", "device", "table_budget_bytes", "tuning"]
+    assert [t for _, t in r_decl] == ["u32", "i32", "u64", "*const c_char"]
+    # and the backend crate only calls what the sys crate offers
+    sys_fns = set(re.findall(r"pub (?:unsafe )?fn (\w+)", src))
+    for fn in ("g1.rs", "kzg_settings.rs", "fft_settings.rs"):
+        used = set(re.findall(r"sys::(\w+)\(", open(os.path.join(ROOT, "rust-kzg_amd", "rust-backend", "src", fn)).read()))
+        assert used <= sys_fns, (fn, used - sys_fns)
