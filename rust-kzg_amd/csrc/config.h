@@ -22,7 +22,7 @@ enum TuneId {
     // wide-table (fixed-base) path of the MSM
     T_SPL, T_NO_WIDE_TAIL, T_NO_HYBRID_FOLD, T_HYBRID_MAX, T_WIDE_FOLD_MAX, T_SPL1_MAX, T_BLOCKSUM_THREADS,
     // bucket engine
-    T_LGC, T_GROUPS, T_FINE_BITS, T_ONE_LEVEL_SORT, T_TREE_TAIL, T_FLAT_DIGITS, T_DIRECT_SCATTER, T_SCATTER_ATOMICS,
+    T_LGC, T_GROUPS, T_TAIL_PIECES, T_FINE_BITS, T_ONE_LEVEL_SORT, T_TREE_TAIL, T_FLAT_DIGITS, T_DIRECT_SCATTER, T_SCATTER_ATOMICS,
     // shape of a handle
     T_WINDOW, T_WINDOW_PREPARED, T_FIXED_AS_VARIABLE_MIN, T_GLV, T_FBW_GLV,
     // concurrent host-buffer callers of one prepared handle (B1)
@@ -52,6 +52,7 @@ inline const TuneKey* tune_keys() {
         {"blocksum_threads", 0, 0, 256, "threads of k_blocksum: 64 / 128 / 256 (0 = by batch size)"},
         {"lgc", 0, 0, 16, "log2 of the accumulation chunk of the bucket engine (0 = by size)"},
         {"groups", 0, 0, 4, "window groups of the bucket engine on their own streams (0 = one)"},
+        {"tail_pieces", 0, 0, 4, "a single large MSM accumulates its window sets in this many pieces, the reduction of a piece beside the accumulation of the next (0, 1 = one piece; measured: nothing gained)"},
         {"fine_bits", 0, 0, 16, "width of the second sort level (0 = default)"},
         {"one_level_sort", 0, 0, 1, "1: the one-level sort at every size (it is the form small bucket counts take anyway)"},
         {"tree_tail", 0, 0, 1, "1: the tree reduction at every size (the form of fewer than 16384 buckets)"},

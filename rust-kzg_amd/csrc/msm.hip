@@ -733,13 +733,15 @@ __global__ void __launch_bounds__(256) k_accum(const u32* __restrict__ offsets, 
 constexpr u32 HSEG = 1024;
 __global__ void __launch_bounds__(64) k_heavy(Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
                                               const u32* __restrict__ heavy_list, const u32* __restrict__ nheavy,
-                                              u32 heavy_cap, size_t nb, size_t nchunk, u32 step, u32 span, ChunkSel cs) {
+                                              u32 heavy_cap, size_t nb, size_t nchunk, u32 step, u32 span, ChunkSel cs,
+                                              u32 set_lo, u32 set_hi) {
     __shared__ Xyzz sh[64];
     u32 cnt = *nheavy;
     if (cnt > heavy_cap) cnt = heavy_cap;
     const int lane = threadIdx.x;
     for (u32 idx = blockIdx.x; idx < cnt; idx += gridDim.x) {
         const size_t set = heavy_list[2 * idx], bk = heavy_list[2 * idx + 1];
+        if (set < set_lo || set >= set_hi) continue;  // the sets of this launch's piece (workgroup-uniform)
         const u32* off = offsets + set * (nb + 1);
         Xyzz* pz = partials + set * (nb + nchunk) + bk;
         const int lgc = eff_lgc(off[nb], cs);
@@ -1831,6 +1833,7 @@ struct MsmTuning {
     bool one_level_sort = false, tree_tail = false, flat_digits = false, direct_scatter = false, scatter_atomics = false;
     bool combine = true;
     int combine_lanes = 2, combine_gather_min = 6, combine_gather_us = 60;
+    int tail_pieces = 0;
     static MsmTuning from(const kzgamd::Options& o) {
         using namespace kzgamd;
         MsmTuning t;
@@ -1853,6 +1856,7 @@ struct MsmTuning {
         t.combine_lanes = (int)o.t[T_COMBINE_LANES];
         t.combine_gather_min = (int)o.t[T_COMBINE_GATHER_MIN];
         t.combine_gather_us = (int)o.t[T_COMBINE_GATHER_US];
+        t.tail_pieces = (int)o.t[T_TAIL_PIECES];
         return t;
     }
 };
@@ -2564,34 +2568,49 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             HIP_TRY(hipEventRecord(ctx->ev_dig[g], st));
             if (g > 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_acc[g - 1], 0));
         }
-        if (pev) HIP_TRY(hipEventRecord(pev[1], st));
-        hipLaunchKernelGGL(k_accum, dim3((unsigned)((ns * nchunk + 255) / 256)), dim3(256), 0, st, (const u32*)offsets,
-                           (const u32*)(ws.sorted.p + set0 * set_cap), (const AffPt*)ctx->table.p, buckets, nb, ns, set_cap,
-                           nchunk, csel);
-        if (pev) HIP_TRY(hipEventRecord(pev[2], st));
-        if (G > 1) HIP_TRY(hipEventRecord(ctx->ev_acc[g], st));
+        // One PIECE of this group's sets: accumulation on `ast`, everything after it (heavy buckets, bucket reduction,
+        // window sums) on `tst`.  With tst != ast the tail of a piece runs beside the accumulation of the next one: the
+        // reductions are latency chains on a fraction of the chip (0.7 ms of 3.4 at n = 2^20), the accumulation is VALU
+        // throughput — tuning key tail_pieces.
+        auto run_piece = [&](size_t ps0, size_t pns, int piece, hipStream_t ast, hipStream_t tst) {
+        // lanes per set so that THIS launch's sets fill the chip (every kernel below derives the chunk length from it)
+        const ChunkSel pcs{csel.lo, csel.hi, pns == ns ? csel.target : (u32)(118000 / pns)};
+        // (offsets, buckets, heavy are this GROUP's arrays: k_heavy's list indexes sets within the group)
+        const u32* p_off = offsets + (ps0 - set0) * (nb + 1);
+        Xyzz* p_buckets = buckets + (ps0 - set0) * (nb + nchunk);
+        const unsigned char* p_heavy = heavy + (ps0 - set0) * nb;
+        hipLaunchKernelGGL(k_accum, dim3((unsigned)((pns * nchunk + 255) / 256)), dim3(256), 0, ast, p_off,
+                           (const u32*)(ws.sorted.p + ps0 * set_cap), (const AffPt*)ctx->table.p, p_buckets, nb, pns, set_cap,
+                           nchunk, pcs);
+        if (tst != ast) {
+            HIP_TRY(hipEventRecord(ctx->ev_acc[piece], ast));
+            HIP_TRY(hipStreamWaitEvent(tst, ctx->ev_acc[piece], 0));
+        } else if (G > 1) {
+            HIP_TRY(hipEventRecord(ctx->ev_acc[g], ast));  // the next group's accumulation may start
+        }
+        hipStream_t st = tst;
         hipLaunchKernelGGL(k_heavy, dim3(256, 64), dim3(64), 0, st, buckets, (const u32*)offsets, (const u32*)heavy_list,
-                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, 1u, HSEG, csel);
+                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, 1u, HSEG, pcs, (u32)(ps0 - set0), (u32)(ps0 - set0 + pns));
         hipLaunchKernelGGL(k_heavy, dim3(1024, 1), dim3(64), 0, st, buckets, (const u32*)offsets, (const u32*)heavy_list,
-                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, HSEG, 0u, csel);
+                           (const u32*)nheavy, (u32)heavy_cap, nb, nchunk, HSEG, 0u, pcs, (u32)(ps0 - set0), (u32)(ps0 - set0 + pns));
         if (digit_tail) {
             // few sets: digit-decomposed reduction (k_digit_sums / k_digit_bits), then the Horner over the bit sums
             int logNb = 0;
             while (((size_t)1 << logNb) < nb) ++logNb;
             const int J = (logNb + DIGIT_BITS - 1) / DIGIT_BITS;
-            Xyzz* S = ws.lvlA[0].p + set0 * (size_t)(J * 32);
-            Xyzz* top = ws.top.p + set0 * top_stride;
-            Xyzz* dense = ws.dense.p + set0 * nb;
+            Xyzz* S = ws.lvlA[0].p + ps0 * (size_t)(J * 32);
+            Xyzz* top = ws.top.p + ps0 * top_stride;
+            Xyzz* dense = ws.dense.p + ps0 * nb;
             if (tiled_digits) {
-                Xyzz* Gs = ws.lvlA[1].p + set0 * (nb >> 5);
-                Xyzz* Cp = ws.lvlM[1].p + set0 * (nb >> 5);
-                hipLaunchKernelGGL(k_tile_sums_loop, dim3((unsigned)(ns * (nb >> 10))),
-                                   dim3(TILE_T), TILE_T * sizeof(Xyzz), st, (const Xyzz*)buckets, (const u32*)offsets,
-                                   (const unsigned char*)heavy, dense, Gs, Cp, nb, nchunk, csel);
+                Xyzz* Gs = ws.lvlA[1].p + ps0 * (nb >> 5);
+                Xyzz* Cp = ws.lvlM[1].p + ps0 * (nb >> 5);
+                hipLaunchKernelGGL(k_tile_sums_loop, dim3((unsigned)(pns * (nb >> 10))),
+                                   dim3(TILE_T), TILE_T * sizeof(Xyzz), st, (const Xyzz*)p_buckets, p_off,
+                                   p_heavy, dense, Gs, Cp, nb, nchunk, pcs);
                 if (wide_tail) {
-                    // cells of this group: [0, ns * J * 32) digit sums, then ns * (logNb + 2) bit sums
-                    const size_t c1 = ns * (size_t)(J * 32), c2 = ns * (size_t)(logNb + 2);
-                    const size_t cbase = set0 * (size_t)(J * 32 + logNb + 2);
+                    // cells of this group: [0, pns * J * 32) digit sums, then pns * (logNb + 2) bit sums
+                    const size_t c1 = pns * (size_t)(J * 32), c2 = pns * (size_t)(logNb + 2);
+                    const size_t cbase = ps0 * (size_t)(J * 32 + logNb + 2);
                     u32* cnt = ws.wcount.p + cbase;
                     Xyzz* part = ws.wpart.p + cbase * WSPLIT;  // WSPLIT >= WSPLIT_S slots per cell
                     HIP_TRY(hipMemsetAsync(cnt, 0, (c1 + c2) * sizeof(u32), st));
@@ -2600,38 +2619,34 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                     hipLaunchKernelGGL(k_digit_bits_wide, dim3((unsigned)(c2 * WSPLIT)), dim3(64), 0, st, (const Xyzz*)S, top,
                                        part + c1 * WSPLIT, cnt + c1, logNb, J);
                 } else {
-                    hipLaunchKernelGGL(k_digit_sums2, dim3((unsigned)(ns * (size_t)(J * 32))), dim3(64), 0, st, (const Xyzz*)Gs,
+                    hipLaunchKernelGGL(k_digit_sums2, dim3((unsigned)(pns * (size_t)(J * 32))), dim3(64), 0, st, (const Xyzz*)Gs,
                                        (const Xyzz*)Cp, S, nb, logNb, J);
                 }
             } else {
-                hipLaunchKernelGGL(k_fold_buckets, dim3((unsigned)((ns * nb + 127) / 128)), dim3(128), 0, st,
-                                   (const Xyzz*)buckets, (const u32*)offsets, (const unsigned char*)heavy, dense, nb, ns, nchunk,
-                                   csel);
-                hipLaunchKernelGGL(k_digit_sums, dim3((unsigned)(ns * (size_t)(J * 32))), dim3(DIGIT_T), DIGIT_T * sizeof(Xyzz),
+                hipLaunchKernelGGL(k_fold_buckets, dim3((unsigned)((pns * nb + 127) / 128)), dim3(128), 0, st,
+                                   (const Xyzz*)p_buckets, p_off, p_heavy, dense, nb, pns, nchunk,
+                                   pcs);
+                hipLaunchKernelGGL(k_digit_sums, dim3((unsigned)(pns * (size_t)(J * 32))), dim3(DIGIT_T), DIGIT_T * sizeof(Xyzz),
                                    st, (const Xyzz*)dense, S, nb, logNb, J);
             }
             if (!(tiled_digits && wide_tail))
-                hipLaunchKernelGGL(k_digit_bits, dim3((unsigned)(ns * (size_t)(logNb + 2))), dim3(64), 0, st, (const Xyzz*)S,
+                hipLaunchKernelGGL(k_digit_bits, dim3((unsigned)(pns * (size_t)(logNb + 2))), dim3(64), 0, st, (const Xyzz*)S,
                                    top, logNb, J);
             if (wide_tail)
-                hipLaunchKernelGGL(k_winsum_wide, dim3((unsigned)ns), dim3(64), 0, st, (const Xyzz*)top, ws.win.p + set0,
+                hipLaunchKernelGGL(k_winsum_wide, dim3((unsigned)pns), dim3(64), 0, st, (const Xyzz*)top, ws.win.p + ps0,
                                    logNb, 0);
             else
-                hipLaunchKernelGGL(k_winsum, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, st, (const Xyzz*)top,
-                                   ws.win.p + set0, ns, logNb, 0);
+                hipLaunchKernelGGL(k_winsum, dim3((unsigned)((pns + 63) / 64)), dim3(64), 0, st, (const Xyzz*)top,
+                                   ws.win.p + ps0, pns, logNb, 0);
             finA = nullptr;
             finM = ws.win.p;
-            if (G > 1) {
-                HIP_TRY(hipEventRecord(ctx->ev_done[g], st));
-                HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done[g], 0));
-            }
-            continue;
+            return;
         }
         // bucket-reduction tree: GRP-ary levels while they are throughput work (nb -> nb/GRP -> ...), then the
         // B + 2 concurrent plain sums of k_top and the short per-window Horner of k_winsum
         size_t nin = nb;
         int logS = 0, lvl = 0;
-        const Xyzz *inA = buckets, *inM = nullptr;
+        const Xyzz *inA = p_buckets, *inM = nullptr;
         do {
             // level 0 also folds each bucket's pieces (entries/chunk + 1 of them): keep >= ~128k lanes in flight
             int grp = GRP, lg = 3;
@@ -2641,14 +2656,14 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                     --lg;
                 }
             const size_t nout = (nin + grp - 1) / grp;
-            Xyzz *oA = ws.lvlA[lvl & 1].p + set0 * nout, *oM = ws.lvlM[lvl & 1].p + set0 * nout;
-            const unsigned grid = (unsigned)((ns * nout + 127) / 128);
+            Xyzz *oA = ws.lvlA[lvl & 1].p + ps0 * nout, *oM = ws.lvlM[lvl & 1].p + ps0 * nout;
+            const unsigned grid = (unsigned)((pns * nout + 127) / 128);
             if (lvl == 0)
-                hipLaunchKernelGGL(k_level<true>, dim3(grid), dim3(128), 0, st, inA, inM, oA, oM, nin, ns, logS,
-                                   (const u32*)offsets, (const unsigned char*)heavy, nb, nchunk, grp, csel);
+                hipLaunchKernelGGL(k_level<true>, dim3(grid), dim3(128), 0, st, inA, inM, oA, oM, nin, pns, logS,
+                                   (const u32*)offsets, p_heavy, nb, nchunk, grp, pcs);
             else
-                hipLaunchKernelGGL(k_level<false>, dim3(grid), dim3(128), 0, st, inA, inM, oA, oM, nin, ns, logS,
-                                   (const u32*)nullptr, (const unsigned char*)nullptr, nb, nchunk, grp, csel);
+                hipLaunchKernelGGL(k_level<false>, dim3(grid), dim3(128), 0, st, inA, inM, oA, oM, nin, pns, logS,
+                                   (const u32*)nullptr, (const unsigned char*)nullptr, nb, nchunk, grp, pcs);
             inA = oA;
             inM = oM;
             nin = nout;
@@ -2658,15 +2673,15 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         if (use_top) {
             int B = 0;
             while (((size_t)1 << B) < nin) ++B;
-            Xyzz* top = ws.top.p + set0 * top_stride;
-            hipLaunchKernelGGL(k_top, dim3((unsigned)(ns * (size_t)(B + 2))), dim3(TOPT), TOPT * sizeof(Xyzz), st, inA, inM,
+            Xyzz* top = ws.top.p + ps0 * top_stride;
+            hipLaunchKernelGGL(k_top, dim3((unsigned)(pns * (size_t)(B + 2))), dim3(TOPT), TOPT * sizeof(Xyzz), st, inA, inM,
                                top, nin, B);
             if (wide_tail)
-                hipLaunchKernelGGL(k_winsum_wide, dim3((unsigned)ns), dim3(64), 0, st, (const Xyzz*)top, ws.win.p + set0, B,
+                hipLaunchKernelGGL(k_winsum_wide, dim3((unsigned)pns), dim3(64), 0, st, (const Xyzz*)top, ws.win.p + ps0, B,
                                    logS);
             else
-                hipLaunchKernelGGL(k_winsum, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, st, (const Xyzz*)top,
-                                   ws.win.p + set0, ns, B, logS);
+                hipLaunchKernelGGL(k_winsum, dim3((unsigned)((pns + 63) / 64)), dim3(64), 0, st, (const Xyzz*)top,
+                                   ws.win.p + ps0, pns, B, logS);
             finA = nullptr;
             finM = ws.win.p;
         } else {
@@ -2674,9 +2689,42 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             finA = ws.lvlA[(lvl - 1) & 1].p;
             finM = ws.lvlM[(lvl - 1) & 1].p;
         }
-        if (G > 1) {
-            HIP_TRY(hipEventRecord(ctx->ev_done[g], st));
-            HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done[g], 0));
+            };
+        {
+            // pieces: only for one group of few large sets (a single large MSM) in the digit-tail form
+            int pieces = 1;
+            // Measured (tools/time_pieces.py, profiles/NOTES.md): n = 2^20 in 1 / 2 / 3 / 4 pieces 3.50 / 3.54 / 4.00 / 3.92 ms.
+            // The side tail does run inside the next accumulation (the trace shows it there, three times slower than
+            // alone, the accumulation none the slower), but two accumulation launches with the shorter chunks a piece needs
+            // to fill the chip cost 0.25 ms more than one, and the LAST piece's tail — latency chains that do not shrink
+            // with the number of sets — stays exposed.  One piece is the default; the key stays for the measurement.
+            if (G == 1 && nbatch == 1 && digit_tail && tiled_digits && wide_tail && ns >= 4 && ctx->tune.tail_pieces > 1) {
+                pieces = ctx->tune.tail_pieces;
+                if (pieces > MsmContext::MAXG) pieces = MsmContext::MAXG;
+                if ((size_t)pieces > ns) pieces = (int)ns;
+            }
+            if (pev) HIP_TRY(hipEventRecord(pev[1], st));
+            size_t done = 0;
+            for (int p = 0; p < pieces; ++p) {
+                const size_t pns = (ns - done) / (size_t)(pieces - p);
+                hipStream_t tst = st;
+                if (p + 1 < pieces) {  // the last piece's tail stays on the launch stream
+                    if (!ctx->aux[p]) HIP_TRY(hipStreamCreateWithFlags(&ctx->aux[p], hipStreamNonBlocking));
+                    if (!ctx->ev_acc[p]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_acc[p], hipEventDisableTiming));
+                    if (!ctx->ev_done[p]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done[p], hipEventDisableTiming));
+                    tst = ctx->aux[p];
+                }
+                run_piece(set0 + done, pns, p, st, tst);
+                if (tst != st) HIP_TRY(hipEventRecord(ctx->ev_done[p], tst));
+                done += pns;
+            }
+            // the launch stream joins the side tails only now: a wait placed earlier would hold the next piece's accumulation
+            for (int p = 0; p + 1 < pieces; ++p) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done[p], 0));
+            if (pev) HIP_TRY(hipEventRecord(pev[2], st));
+            if (G > 1) {
+                HIP_TRY(hipEventRecord(ctx->ev_done[g], st));
+                HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done[g], 0));
+            }
         }
     }
     if (wide_tail && !ctx->prepared && out_mode == OUT_JACOBIAN && nwin > 1) {

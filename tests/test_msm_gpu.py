@@ -335,17 +335,21 @@ def test_msm_2p20_matches_oracle(oracle, kzg):
     sc[:, 31] &= 0x3F  # canonical little-endian scalars < 2^254
     sc[::10] = 0       # 10 % zero scalars
     d_sc = sc.cuda()
-    d_out = torch.zeros(144, dtype=torch.uint8, device="cuda")
-    h = kzg.DeviceMsm(d_pts.data_ptr(), n, False, kzg.make_config(tuning=tuning))
-    kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr(), n, 1, False, stream)
-    torch.cuda.synchronize()
-    got = O.G1()
-    C.memmove(C.byref(got), d_out.cpu().numpy().tobytes(), 144)
     pts = (O.G1Affine * n).from_buffer_copy(d_pts.cpu().numpy().tobytes())
     exp = O.G1()
     L.omsm_tiling_pippenger(C.byref(exp), pts, sc.numpy().tobytes(), n)
-    assert compressed(L, got) == compressed(L, exp)
-    h.close()
+    # the accumulation in one piece (the default), and in two, three, four pieces whose reductions run beside the
+    # accumulation of the next piece (tuning key tail_pieces): the same sum
+    for pieces in (0, 2, 3, 4):
+        d_out = torch.zeros(144, dtype=torch.uint8, device="cuda")
+        h = kzg.DeviceMsm(d_pts.data_ptr(), n, False, kzg.make_config(tuning={"tail_pieces": pieces}))
+        for _ in range(2):  # the second call reuses the streams and events of the first
+            kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr(), n, 1, False, stream)
+            torch.cuda.synchronize()
+            got = O.G1()
+            C.memmove(C.byref(got), d_out.cpu().numpy().tobytes(), 144)
+            assert compressed(L, got) == compressed(L, exp), pieces
+        h.close()
 
 
 @pytest.mark.parametrize("logn", [22, 23, 24])
