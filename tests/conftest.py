@@ -72,11 +72,14 @@ def oracle_settings(oracle, trusted_setup_text):
 FLAVOURS = {"product": "libkzg_mi355x.so", "exact": "libkzg_mi355x_exact.so"}
 
 
-def load_package(flavour="product"):
+def load_package(flavour=None):
     """import rust-kzg_amd/ (hyphenated directory) under the module name rust_kzg_amd (rust_kzg_amd_exact for the
-    forced-rare-path build)"""
+    forced-rare-path build).  flavour None (tools, helper processes): whatever KZGAMD_LIB names, else the product library."""
     import importlib.util
 
+    if flavour is None and os.environ.get("KZGAMD_LIB"):
+        flavour = next((k for k, v in FLAVOURS.items() if os.environ["KZGAMD_LIB"].endswith("/" + v)), "custom")
+    flavour = flavour or "product"
     name = "rust_kzg_amd" if flavour == "product" else "rust_kzg_amd_" + flavour
     if name in sys.modules:
         return sys.modules[name]
@@ -94,7 +97,8 @@ def load_package(flavour="product"):
     mod = importlib.util.module_from_spec(spec)
     sys.modules[name] = mod
     saved = os.environ.get("KZGAMD_LIB")
-    os.environ["KZGAMD_LIB"] = os.path.join(ROOT, "rust-kzg_amd", "csrc", FLAVOURS[flavour])
+    if flavour != "custom":
+        os.environ["KZGAMD_LIB"] = os.path.join(ROOT, "rust-kzg_amd", "csrc", FLAVOURS[flavour])
     try:
         spec.loader.exec_module(mod)
     finally:
