@@ -44,11 +44,11 @@ VALU_PEAK_GUIDE_NOMINAL = 1024 * 2.4e9 / 2
 ISA_HISTOGRAM = os.path.join(ROOT, "profiles", "r05_isa_histogram.json")  # tools/isa_histogram.py
 
 
-def opcode_weighted_peak(kernel_substr):
+def opcode_weighted_peak(kernel_substr, path=None):
     """VALU wave-instructions/s the chip can issue for THIS kernel's opcode mix: the static class counts of the kernel
     (tools/isa_histogram.py) weighted with the issue cycles per class tools/ffbench.hip measured; None without the file"""
     try:
-        with open(ISA_HISTOGRAM) as f:
+        with open(path or ISA_HISTOGRAM) as f:
             h = json.load(f)
     except (OSError, ValueError):
         return None
@@ -57,14 +57,14 @@ def opcode_weighted_peak(kernel_substr):
             mean = k["mean_issue_cycles_per_valu_instruction"]
             return {"peak": 1024 * 2.4e9 / mean, "mean_issue_cycles_per_instruction": mean, "classes": k["classes"],
                     "class_issue_cycles": k["class_issue_cycles"], "kernel_symbol": name,
-                    "source": "profiles/r05_isa_histogram.json (static opcode classes of the kernel) x profiles/r03_ffbench.log "
+                    "source": os.path.relpath(path or ISA_HISTOGRAM, ROOT) + " (static opcode classes of the kernel) x profiles/r03_ffbench.log "
                               "(measured wall cycles per wave-instruction per class at the nominal 2.4 GHz)"}
     return None
 
 ALG_BYTES_PER_COMMIT = 128 * N             # 96 B point + 32 B scalar per pair
 ALG_ADDS_PER_COMMIT = 20 * N + 8192        # BGMW count for the fixed-base 4096 case
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
-PMC_FALLBACK = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
+PMC_FALLBACK = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
 CSRC = os.path.join(ROOT, "rust-kzg_amd", "csrc")
 # the sources a kernel family is compiled from: counters collected from another text of these files are not printed
 KERNEL_SOURCES = {
@@ -423,6 +423,11 @@ def main():
         "streams": NS,
         "devices": devices,
     }
+    # what a scaling run can check by itself: the ranks that took part in the barrier / max-over-ranks / all-gather, as
+    # torch.distributed sees them under the nccl (= RCCL) backend; 1 and "none" for a single process
+    res["rccl_ranks"] = dist.get_world_size() if dist is not None else 1
+    res["dist_backend"] = dist.get_backend() if dist is not None else "none"
+    res["distinct_devices"] = len({(d.get("device"), d.get("name")) for d in devices}) if dist is None else len({d.get("device") for d in devices})
     if gather_ms is not None:
         res["result_allgather_ms"] = gather_ms
     pm, pm_src, pm_valid = pmc_summary()
@@ -484,6 +489,22 @@ def main():
             b.record()
             torch.cuda.synchronize()
             ts.append(a.elapsed_time(b))
+        return min(ts)
+
+    def ev_time_back_to_back(fn, k=16, reps=3):
+        """ms per call of k calls enqueued back to back between two events (min over reps): a single-call event pair also
+        times the launch gap in front of the kernel (~5 us), which a caller that keeps the stream busy never sees"""
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(k):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) / k)
         return min(ts)
 
     # ---- blob proofs, device-resident pipeline (every rank; weak scaling like the headline) ----------------------
@@ -576,6 +597,7 @@ def main():
             b = torch.empty_like(a)
             ms = ev_time(lambda: fs.fft_fr_device(b.data_ptr(), a.data_ptr(), n, nb, False, stream), reps=9)
             ms_inv = ev_time(lambda: fs.fft_fr_device(b.data_ptr(), a.data_ptr(), n, nb, True, stream), reps=9)
+            ms_b2b = ev_time_back_to_back(lambda: fs.fft_fr_device(b.data_ptr(), a.data_ptr(), n, nb, False, stream))
             # DAS extension of the half-size lists (BASELINE configs[3]: "fft_fr + DAS extension"): two half-size transforms
             h = n // 2
             t = torch.empty(nb * h * 8, dtype=torch.int32, device=dev)
@@ -586,7 +608,7 @@ def main():
             pk = npm.get(key) or {}
             winstr = pk.get("SQ_INSTS_VALU")
             ntt[key] = {
-                "ms": ms, "ms_inverse": ms_inv, "transforms_per_s": nb / (ms * 1e-3), "fr_mul_per_s": muls / (ms * 1e-3),
+                "ms": ms, "ms_inverse": ms_inv, "ms_back_to_back": ms_b2b, "transforms_per_s": nb / (ms * 1e-3), "fr_mul_per_s": muls / (ms * 1e-3),
                 "das_extension": {"half_n": h, "lists": nb, "ms": ms_das, "algorithmic_bytes": 2 * 64 * h * nb,
                                   "achieved_GBps": 2 * 64 * h * nb / (ms_das * 1e-3) / 1e9,
                                   "path": "kzgamd_das_fft_extension_device: inverse + forward transform of half_n points, the "
@@ -603,6 +625,8 @@ def main():
                     "bound": "VALU issue", "achieved": winstr / (ms * 1e-3), "peak": VALU_PEAK, "unit": "VALU wave-instructions/s",
                     "frac": winstr / (ms * 1e-3) / VALU_PEAK, "wave_instructions_per_call": winstr,
                     "peak_model": VALU_PEAK_MODEL, "frac_vs_guide_nominal": winstr / (ms * 1e-3) / VALU_PEAK_GUIDE_NOMINAL,
+                    "opcode_weighted": (lambda ow: None if ow is None else dict(ow, frac=winstr / (ms * 1e-3) / ow["peak"]))(
+                        opcode_weighted_peak("k_ntt_passILi%d" % (0 if n <= 4096 else 2), os.path.join(ROOT, "profiles", "r05_isa_histogram_ntt.json"))),
                     "instructions_per_butterfly": winstr * 64 / muls,
                     "floor_us_at_nominal_clock": winstr / VALU_PEAK * 1e6,
                     "busy_frac_at_sustained_clock": pk.get("valu_busy_frac"), "scratch_bytes_per_lane": pk.get("scratch", 0),

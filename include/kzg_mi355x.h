@@ -358,6 +358,12 @@ int kzgamd_shard_range(size_t n, size_t parts, size_t k, size_t *lo, size_t *hi)
 /* one CKZGSettings per entry of devices[] (NULL = GPUs 0 .. ndev-1) from one setup file, loaded in parallel; all or
  * nothing: on failure every out[d] is left empty.  The caller's current device is left alone. */
 C_KZG_RET kzgamd_load_trusted_setup_file_multi(CKZGSettings out[], const int devices[], size_t ndev, FILE *in);
+/* Page-locks (hipHostRegister, portable across devices) / releases a caller's buffer: copies between it and any device
+ * are then direct DMA instead of passing through the runtime's staging of pageable memory (one CPU pass over the data
+ * per device less — with several GPUs fed from one process that staging shares the host's memory bandwidth).  Optional:
+ * every entry point takes pageable buffers.  0 ok, 1 failed (nothing changed). */
+int kzgamd_pin_host_buffer(void *p, size_t bytes);
+int kzgamd_unpin_host_buffer(void *p);
 /* the same with a configuration for every object (cfg->device is ignored: devices[] places them); two objects on one
  * GPU need an explicit table_budget_bytes that lets both fit */
 C_KZG_RET kzgamd_load_trusted_setup_file_multi_ex(CKZGSettings out[], const int devices[], size_t ndev, FILE *in,

@@ -57,7 +57,7 @@ _lib = None
 
 # every symbol include/kzg_mi355x.h declares; tests check the library exports all of them
 EXPORTS = [
-    "kzgamd_config_init", "kzgamd_tuning_keys", "kzgamd_msm_attach_matrix", "kzgamd_msm_matrix_shape", "kzgamd_prepare_msm_ex", "kzgamd_prepare_msm_matrix", "kzgamd_mult_pippenger_matrix",
+    "kzgamd_config_init", "kzgamd_tuning_keys", "kzgamd_msm_attach_matrix", "kzgamd_msm_matrix_shape", "kzgamd_pin_host_buffer", "kzgamd_unpin_host_buffer", "kzgamd_prepare_msm_ex", "kzgamd_prepare_msm_matrix", "kzgamd_mult_pippenger_matrix",
     "kzgamd_msm_create_device_ex", "kzgamd_ntt_new_ex", "kzgamd_load_trusted_setup_ex", "kzgamd_load_trusted_setup_file_ex",
     "kzgamd_load_trusted_setup_file_multi_ex",
     "prepare_msm", "mult_pippenger_prepared", "mult_pippenger", "free_msm", "mult_pippenger_prepared_batch",
@@ -152,6 +152,10 @@ def lib():
     L.kzgamd_prepare_msm_ex.argtypes = [vp, sz, cp]
     L.kzgamd_prepare_msm_matrix.restype = vp
     L.kzgamd_prepare_msm_matrix.argtypes = [vp, sz, sz, cp]
+    L.kzgamd_pin_host_buffer.restype = C.c_int
+    L.kzgamd_pin_host_buffer.argtypes = [vp, sz]
+    L.kzgamd_unpin_host_buffer.restype = C.c_int
+    L.kzgamd_unpin_host_buffer.argtypes = [vp]
     L.kzgamd_msm_matrix_shape.restype = C.c_int
     L.kzgamd_msm_matrix_shape.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
     L.kzgamd_msm_attach_matrix.restype = RustError

@@ -2135,16 +2135,24 @@ void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_
         if (!dev->ev_cells) CK_HIP(hipEventCreateWithFlags(&dev->ev_cells, hipEventDisableTiming));
         CK_HIP(hipEventRecord(dev->ev_cells, st));
     }
-    if (proofs) enqueue_cell_proofs(dev, n, st, fk20);
-    if (side_copy) {
-        CK_HIP(hipStreamWaitEvent(dev->stream2, dev->ev_cells, 0));
-        CK_HIP(hipMemcpyAsync(cells, dev->d_fr_ext, n * 2 * N * 32, hipMemcpyDeviceToHost, dev->stream2));
-    } else if (cells) {
-        CK_HIP(hipMemcpyAsync(cells, dev->d_fr_ext, n * 2 * N * 32, hipMemcpyDeviceToHost, st));
-    }
-    if (proofs) CK_HIP(hipMemcpyAsync(proofs, dev->d_proofs, n * 128 * 48, hipMemcpyDeviceToHost, st));
     std::vector<int> status(n);
-    CK_HIP(hipMemcpyAsync(status.data(), dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, st));
+    try {
+        if (proofs) enqueue_cell_proofs(dev, n, st, fk20);
+        if (side_copy) {
+            CK_HIP(hipStreamWaitEvent(dev->stream2, dev->ev_cells, 0));
+            CK_HIP(hipMemcpyAsync(cells, dev->d_fr_ext, n * 2 * N * 32, hipMemcpyDeviceToHost, dev->stream2));
+        } else if (cells) {
+            CK_HIP(hipMemcpyAsync(cells, dev->d_fr_ext, n * 2 * N * 32, hipMemcpyDeviceToHost, st));
+        }
+        if (proofs) CK_HIP(hipMemcpyAsync(proofs, dev->d_proofs, n * 128 * 48, hipMemcpyDeviceToHost, st));
+        CK_HIP(hipMemcpyAsync(status.data(), dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, st));
+    } catch (...) {
+        // a copy into the caller's `cells` / `proofs` (or into `status`) may be in flight on either stream: nothing of it
+        // may outlive this call
+        (void)hipStreamSynchronize(st);
+        if (side_copy) (void)hipStreamSynchronize(dev->stream2);
+        throw;
+    }
     const hipError_t e1 = hipStreamSynchronize(st);
     if (side_copy) CK_HIP(hipStreamSynchronize(dev->stream2));  // also on the way out of a failure: `cells` is the caller's
     CK_HIP(e1);

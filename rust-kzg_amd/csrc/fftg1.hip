@@ -322,8 +322,18 @@ __device__ __forceinline__ void run_chain(Xyzz& acc, bool mul, u32 k0, u32 k1, u
                                           bool publish, int tail_steps, Tail&& tail, int r) {
     if (mul && r == 0) slots[0] = acc;
     const int last = TAB_STEPS + MAIN_STEPS + tail_steps;
+    // A wave none of whose lanes multiplies (stage 0: unit twiddles only; the j = 0 butterflies; points at infinity) has
+    // nothing to do in the 167 table and window steps: it publishes its (unchanged) operand and goes to the tail.
+    int first = 0;
+    if (__ballot(mul) == 0) {
+        if (publish) {
+            if (r == 0) slots[(size_t)SLOT_HALF * stride] = acc;
+            __threadfence_block();
+        }
+        first = TAB_STEPS + MAIN_STEPS;
+    }
 #pragma unroll 1
-    for (int step = 0; step < last; ++step) {
+    for (int step = first; step < last; ++step) {
         const bool in_tab = step < TAB_STEPS, in_tail = step >= TAB_STEPS + MAIN_STEPS;
         if (step == TAB_STEPS && mul) g1::set_inf(acc);  // the windows start from infinity; P is in slot 0
         bool want_dbl = false, need_dbl = false;

@@ -5,9 +5,11 @@
 // This is the shape of the reference's own callers: ONE process that parallelises inside itself over groups of blobs
 // (kzg/src/eip_4844.rs:770-816, rayon par_chunks), sharing one precomputation handle (kzg/src/msm/sppark.rs:24-44);
 // its GPU path is single-device (arkworks3-sppark-wlc/sppark/msm/pippenger.cuh:573-575).  Here the groups are the
-// devices.  Host-only code: everything goes through the single-device entry points of include/kzg_mi355x.h.
+// devices.  Host-only code: everything goes through the single-device entry points of include/kzg_mi355x.h (the one
+// HIP call is hipHostRegister in kzgamd_pin_host_buffer).
 #include "../../include/kzg_mi355x.h"
 
+#include <hip/hip_runtime.h>  // kzgamd_pin_host_buffer only: everything else goes through the entry points
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -115,6 +117,23 @@ extern "C" C_KZG_RET kzgamd_load_trusted_setup_file_multi_ex(CKZGSettings out[],
     if (rc != C_KZG_OK)
         for (size_t d = 0; d < ndev; ++d) free_trusted_setup(&out[d]);  // all or nothing (free of an empty object is a no-op)
     return rc;
+}
+
+// Page-lock a caller's buffer (blobs, commitments, results) so that the batch entry points' copies to and from it are
+// true DMA on every device instead of going through the runtime's staging of pageable memory — one CPU pass over the data
+// less per device.  On one GPU the runtime's pageable path (≈ 45 GB/s) is not the limit (profiles/NOTES.md §9); with eight
+// devices fed from one process the staging copies of eight host threads share the host's memory bandwidth.
+extern "C" int kzgamd_pin_host_buffer(void* p, size_t bytes) {
+    if (!p || !bytes) return 1;
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess ? 0 : 1;
+}
+extern "C" int kzgamd_unpin_host_buffer(void* p) {
+    if (!p) return 1;
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess ? 0 : 1;
 }
 
 extern "C" void kzgamd_free_trusted_setup_multi(CKZGSettings s[], size_t ndev) {

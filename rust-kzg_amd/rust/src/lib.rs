@@ -348,6 +348,8 @@ pub mod ckzg {
         pub fn kzgamd_verify_blob_kzg_proof_batch_multi(ok: *mut bool, blobs: *const Blob, commitments: *const Bytes48,
                                                         proofs: *const Bytes48, n: usize, s: *const *const CKZGSettings,
                                                         ndev: usize) -> CKzgRet;
+        pub fn kzgamd_pin_host_buffer(p: *mut core::ffi::c_void, bytes: usize) -> core::ffi::c_int;
+        pub fn kzgamd_unpin_host_buffer(p: *mut core::ffi::c_void) -> core::ffi::c_int;
         pub fn kzgamd_device_count() -> core::ffi::c_int;
         /// the slab [lo, hi) the `_multi` entry points give settings object `k` of `parts` for a batch of `n`
         pub fn kzgamd_shard_range(n: usize, parts: usize, k: usize, lo: *mut usize, hi: *mut usize) -> core::ffi::c_int;

@@ -306,6 +306,23 @@ def _in_process_multi(kzg, oracle, oracle_settings, devices, config=None):
             joined = b"".join(blobs[:n])
             assert ms.commit_batch(joined, n) == want_c[:n], n
             assert ms.proof_batch(joined, b"".join(want_c[:n]), n) == want_p[:n], n
+        # page-locked caller buffers (kzgamd_pin_host_buffer: the copies of every slab are direct DMA): the same results
+        pinned_in = C.create_string_buffer(b"".join(blobs), 37 * 131072)
+        pinned_out = C.create_string_buffer(37 * 48)
+        lib = kzg.lib()
+        assert lib.kzgamd_pin_host_buffer(pinned_in, len(pinned_in)) == 0
+        assert lib.kzgamd_pin_host_buffer(pinned_out, len(pinned_out)) == 0
+        try:
+            assert lib.kzgamd_blob_to_kzg_commitment_batch_multi(pinned_out, pinned_in, 37, ms.ptrs, ms.ndev) == 0
+            assert pinned_out.raw == b"".join(want_c)
+            C.memset(pinned_out, 0, len(pinned_out))
+            assert lib.kzgamd_compute_blob_kzg_proof_batch_multi(pinned_out, pinned_in, b"".join(want_c), 37, ms.ptrs, ms.ndev) == 0
+            assert pinned_out.raw == b"".join(want_p)
+        finally:
+            assert lib.kzgamd_unpin_host_buffer(pinned_in) == 0
+            assert lib.kzgamd_unpin_host_buffer(pinned_out) == 0
+        assert lib.kzgamd_unpin_host_buffer(pinned_out) == 1  # not registered any more
+        assert lib.kzgamd_pin_host_buffer(None, 16) == 1
         # a blob with an element >= r in the SECOND slab fails the call like the reference (BadArgs)
         bad = bytearray(blobs[30])
         bad[64:96] = bytes.fromhex("73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001")

@@ -4,7 +4,7 @@
 #   3. kernel trace + stats and PMC passes of the NTT kernels (tools/ntt_bench.py)
 #   4. kernel trace of one 2^20 MSM (tools/prof_2p20.py)
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 mkdir -p $R/gpurun_out
 timeout 1500 python $R/bench.py > $R/gpurun_out/bench_final.json 2> $R/gpurun_out/bench_final.err; tail -2 $R/gpurun_out/bench_final.err
 cd /tmp && export TMPDIR=/tmp
