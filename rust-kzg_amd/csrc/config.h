@@ -1,5 +1,5 @@
 // Configuration of a handle: what the caller passes in a KzgAmdConfig (include/kzg_mi355x.h) resolved into the values
-// the engines read.  One table holds every tuning key of the library (name, default, range, meaning) — DESIGN.md §12 is
+// the engines read.  One table holds every tuning key of the library (name, default, range, meaning) — DESIGN.md §9 is
 // generated from the same list (kzgamd_tuning_keys) — and the only environment variables the library itself reads are
 //   KZGAMD_TUNING       "key=value;key=value": the same string a caller puts in KzgAmdConfig.tuning (measurement tools)
 //   KZGAMD_FBW_MAX_GB   table budget per fixed-base table, when the caller passed none

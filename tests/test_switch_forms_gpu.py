@@ -1,4 +1,4 @@
-"""Forms of the c-kzg paths that a settings object chooses by tuning key (DESIGN.md §12).  The keys are read ONCE, when the
+"""Forms of the c-kzg paths that a settings object chooses by tuning key (DESIGN.md §9).  The keys are read ONCE, when the
 object is created (KzgAmdConfig.tuning), so every form gets its own object here — with 8 GB tables (KzgAmdConfig.
 table_budget_bytes), and in a module of its own so that the 137 + 43 + 77 GB of another module's default object are
 released before these are built."""
