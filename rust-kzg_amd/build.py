@@ -6,8 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libkzg_mi355x.so")
-SOURCES = ["msm.hip", "ckzg.hip", "ntt.hip", "fftg1.hip", "multi.hip"]
-HEADERS = ["ff.hip.h", "fp28.hip.h", "g1_28.hip.h", "g1_io.hip.h", "msm_internal.h", "ckzg_internal.h", "sha256.h", "host_g1.h", "host_pairing.h", "host_fp64.h", "ff28.hip.h", "fr29.hip.h", "ntt_internal.h", "device_guard.h", "fpw.hip.h", "g1w.hip.h", "glv.hip.h", "ntt_plan.h",
+SOURCES = ["msm.hip", "ckzg.hip", "ckzg_verify.hip", "ckzg_7594.hip", "ntt.hip", "fftg1.hip", "multi.hip"]
+HEADERS = ["ff.hip.h", "fp28.hip.h", "g1_28.hip.h", "g1_io.hip.h", "msm_internal.h", "ckzg_internal.h", "sha256.h", "host_g1.h", "host_pairing.h", "host_fp64.h", "ff28.hip.h", "fr29.hip.h", "ntt_internal.h", "device_guard.h", "fpw.hip.h", "g1w.hip.h", "glv.hip.h", "ntt_plan.h", "ckzg_shared.h", "config.h",
            os.path.join("..", "..", "include", "kzg_mi355x.h")]
 
 

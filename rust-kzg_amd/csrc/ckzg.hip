@@ -5,61 +5,9 @@
 // roots) hangs off a registry keyed by the settings' g1_values_lagrange_brp pointer —
 // the same trick the reference uses for its precomputation tables
 // (PrecomputationTableManager, kzg/src/eip_4844.rs:64-146).
-#include <hip/hip_runtime.h>
-#include <chrono>
-#include <stdint.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/kzg_mi355x.h"
-#include "ckzg_internal.h"
-#include "config.h"
-#include "device_guard.h"
-#include "ff.hip.h"
-#include "fr29.hip.h"
-#include "g1_io.hip.h"
-#include "g1w.hip.h"
-#include "host_g1.h"
-#include "host_pairing.h"
-#include "msm_internal.h"
-#include "ntt_internal.h"
-#include "sha256.h"
-#include <atomic>
-#include <condition_variable>
-#include <deque>
-#include <functional>
-#include <memory>
-#include <thread>
-
-using ff::u32;
-using ff::u64;
-using g1::AffPt;
+#include "ckzg_shared.h"
 
 namespace {
-
-struct CkErr {
-    C_KZG_RET rc;
-    std::string what;
-};
-#define CK_HIP(x)                                                                         \
-    do {                                                                                  \
-        hipError_t _e = (x);                                                              \
-        if (_e != hipSuccess) throw CkErr{C_KZG_ERROR, std::string(#x) + ": " + hipGetErrorString(_e)}; \
-    } while (0)
-#define CK_REQUIRE(cond, msg)                      \
-    do {                                           \
-        if (!(cond)) throw CkErr{C_KZG_BADARGS, msg}; \
-    } while (0)
-
-constexpr size_t N = FIELD_ELEMENTS_PER_BLOB;
-constexpr size_t NUM_G2 = 65;
-constexpr size_t CELL_SIZE = 64;                 // FIELD_ELEMENTS_PER_CELL
-constexpr size_t CELLS_PER_BLOB = N / CELL_SIZE;  // 64; the extended blob has 128 cells
 
 // ---------------------------------------------------------------- kernels
 
@@ -148,93 +96,6 @@ __global__ void __launch_bounds__(256) k_gather_blobs(uint4* __restrict__ out, B
     out[t] = reinterpret_cast<const uint4*>(blobs.p[t / PER])[t % PER];
 }
 
-// ---- Fr helpers for the proving kernel (Montgomery, 8 x u32) ----
-__device__ __forceinline__ ff::Fr fr_load_be(const u32* __restrict__ w8, bool* ok) {
-    // 32 big-endian bytes -> canonical limbs; *ok = value < r
-    ff::Fr a;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a.v[k] = __builtin_bswap32(w8[7 - k]);
-    u64 borrow = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        u64 d = (u64)a.v[k] - ff::FrParams::p(k) - borrow;
-        borrow = (d >> 32) & 1;
-    }
-    *ok = borrow != 0;
-    return a;
-}
-// Montgomery inverse by binary Euclid (ff.hip.h); 0 -> 0 like blst_fr_eucl_inverse
-__device__ ff::Fr fr_inverse(const ff::Fr& a) { return ff::inverse_bgcd(a); }
-// ff::mul on blst_fr values through the 29-bit multiplier of the NTT (fr29::mul_blst: the same result in about half
-// the instructions); the quotient kernels below are a stream of such products
-__device__ __forceinline__ ff::Fr fmul(const ff::Fr& a, const ff::Fr& b) { return fr29::mul_blst(a, b); }
-
-// Host worker threads for the per-blob SHA-256 challenges of a batch, kept alive between calls: spawning 16
-// threads costs ~0.4 ms, a tenth of a 256-blob proof call.
-class WorkerPool {
-  public:
-    explicit WorkerPool(unsigned n) {
-        for (unsigned w = 0; w < n; ++w) th_.emplace_back([this, w] { loop(w); });
-    }
-    ~WorkerPool() {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto& t : th_) t.join();
-    }
-    unsigned size() const { return (unsigned)th_.size(); }
-    // runs fn(w) for w = 0 .. active-1 on the pool and returns when all are done
-    void run(unsigned active, const std::function<void(unsigned)>& fn) {
-        std::unique_lock<std::mutex> lk(m_);
-        job_ = &fn;
-        active_ = active;
-        pending_ = (unsigned)th_.size();
-        ++gen_;
-        cv_.notify_all();
-        done_.wait(lk, [this] { return pending_ == 0; });
-        job_ = nullptr;
-    }
-
-  private:
-    void loop(unsigned w) {
-        unsigned seen = 0;
-        for (;;) {
-            const std::function<void(unsigned)>* job;
-            unsigned active;
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
-                if (stop_) return;
-                seen = gen_;
-                job = job_;
-                active = active_;
-            }
-            if (w < active) (*job)(w);
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                if (--pending_ == 0) done_.notify_all();
-            }
-        }
-    }
-    std::vector<std::thread> th_;
-    std::mutex m_;
-    std::condition_variable cv_, done_;
-    const std::function<void(unsigned)>* job_ = nullptr;
-    unsigned active_ = 0, pending_ = 0, gen_ = 0;
-    bool stop_ = false;
-};
-
-constexpr int QT = 512;            // threads per blob
-// cell proofs by FK20 from this batch size.  Re-measured after the G1 stages were rewritten (round 4, tools/time_cells.py,
-// one settings object per form): 1 / 2 / 3 / 4 / 8 / 16 blobs FK20 4.15 / 4.16 / 4.23 / 4.25 / 4.29 / 5.32 ms, direct form
-// 1.91 / 3.16 / 4.52 / 5.75 / 10.88 / 20.65 ms (round 3's crossover was 16 blobs at 25 ms either way)
-constexpr size_t FK20_MIN_BLOBS = 3;
-constexpr size_t PROVE_CHUNK = 64;  // blobs per pipeline stage of a large compute_blob_kzg_proof batch
-constexpr size_t COMMIT_CHUNK = 64;   // smallest pipeline stage of a blob_to_kzg_commitment batch (batches from twice this are pipelined)
-constexpr size_t QSPLIT_MAX = 16;  // up to this many blobs (a lane batch) run the multi-workgroup variant (k_quotient_a/b)
-constexpr int QE = (int)(N / QT);  // elements per thread (8), element index i = k*QT + t
 
 // compute_kzg_proof_rust up to the MSM (kzg/src/eip_4844.rs:437-510): y = p(z) by the barycentric
 // formula (evaluate_polynomial_in_evaluation_form :954-1003) and the quotient polynomial in
@@ -829,14 +690,13 @@ __global__ void __launch_bounds__(64) k_affpts_in_g1_wide(int* __restrict__ stat
     if (!ok && lane == 0) status[i] = 2;
 }
 
-// decode + membership test of np compressed points: up to WIDE_CHECK_MAX points the test runs one wave per point
-constexpr size_t WIDE_CHECK_MAX = 4096;
-constexpr size_t WIDE_COMMIT_CHECK_MAX = 512;  // ... the commitments of a proof batch: up to this many
+}  // namespace
+namespace ckz {
 // `decoded` (optional) is recorded when the slots are written — before the membership test in the two-kernel form, so a
 // consumer that only needs the points (the MSM of a verification call, whose result is thrown away if a test fails) can
 // start while the test still runs
 void decode_check_enqueue(AffPt* d_pts, int* d_stat, const unsigned char* d_bytes, size_t np, hipStream_t st, bool wide,
-                          hipEvent_t decoded = nullptr) {
+                          hipEvent_t decoded) {
     const dim3 grid((unsigned)((np + 63) / 64));
     if (wide && np <= WIDE_CHECK_MAX) {
         hipLaunchKernelGGL(k_decode_g1_wide, dim3((unsigned)((np + 3) / 4)), dim3(64), 0, st, d_pts, d_stat, d_bytes, np);
@@ -847,6 +707,8 @@ void decode_check_enqueue(AffPt* d_pts, int* d_stat, const unsigned char* d_byte
         if (decoded) (void)hipEventRecord(decoded, st);
     }
 }
+}  // namespace ckz
+namespace {
 
 // commitment bytes -> status: 0 ok (valid encoding, and infinity or in the r-torsion subgroup), 1 bad
 // (FsG1::from_bytes + `!is_inf && !is_valid`, kzg/src/eip_4844.rs:556-558,577)
@@ -861,448 +723,12 @@ __global__ void __launch_bounds__(64) k_check_commitments(int* __restrict__ stat
 }
 
 
-// ---------------- EIP-7594 cells + cell proofs ----------------
-__device__ __forceinline__ u32 brev32(u32 v, int bits) { return __builtin_bitreverse32(v) >> (32 - bits); }
-
-// blob bytes -> Montgomery Fr in bit-reversed order (blob_to_polynomial + reverse_bit_order of
-// poly_lagrange_to_monomial, kzg/src/das.rs:618-629); status = 1 when an element is >= r
-__global__ void __launch_bounds__(256) k_blob_to_fr_brp(ff::Fr* __restrict__ out, int* __restrict__ status,
-                                                        const u32* __restrict__ blobs, size_t nblobs) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblobs * N) return;
-    const size_t b = t / N, i = t % N;
-    bool ok;
-    ff::Fr v = fr_load_be(blobs + (b * N + brev32((u32)i, 12)) * 8, &ok);
-    if (!ok) status[b] = 1;
-    out[t] = ff::to_mont(v);
-}
-
-// monomial coefficients (4096) -> zero-extended 8192 (das.rs:260-261)
-__global__ void __launch_bounds__(256) k_zero_extend(ff::Fr* __restrict__ ext, const ff::Fr* __restrict__ mono, size_t nblobs) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblobs * 2 * N) return;
-    const size_t b = t / (2 * N), i = t % (2 * N);
-    ext[t] = i < N ? mono[b * N + i] : ff::Fr::zero();
-}
-
-// evaluations on the 8192 domain -> cells: bit-reversed order, 32-byte big-endian (das.rs:267-275)
-__global__ void __launch_bounds__(256) k_cells_out(u32* __restrict__ cells, const ff::Fr* __restrict__ ev, size_t nblobs) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblobs * 2 * N) return;
-    const size_t b = t / (2 * N), f = t % (2 * N);
-    ff::Fr v = ff::from_mont(ev[b * 2 * N + brev32((u32)f, 13)]);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) cells[t * 8 + k] = __builtin_bswap32(v.v[7 - k]);
-}
-
-// Quotient coefficients of the 128 cell proofs: q_k = p div (X^64 - a_k), a_k = w_128^brp7(k).
-// The reference reaches the same commitments through FK20 (Toeplitz FFTs + fft_g1, kzg/src/das.rs:660-696);
-// with the 4096-point wide table a proof is simply one more fixed-base MSM, so the division recurrence
-//   q_j = p_{j+64} + a_k * q_{j+64}
-// is run per (cell, residue class mod 64) and the 128 scalar vectors go to the MSM engine.
-__global__ void __launch_bounds__(64) k_cell_quotients(u32* __restrict__ q_out, const ff::Fr* __restrict__ mono,
-                                                       const ff::Fr* __restrict__ roots8192, size_t nblobs) {
-    const size_t b = blockIdx.x / 128, k = blockIdx.x % 128;
-    const int r = threadIdx.x;  // residue class
-    const ff::Fr a = roots8192[64 * brev32((u32)k, 7)];
-    const ff::Fr* p = mono + b * N;
-    u32* q = q_out + (b * 128 + k) * N * 8;
-    ff::Fr acc = ff::Fr::zero();
-    // j = r + 64*t ; top quotient index is N - 65
-#pragma unroll 1
-    for (int t = 63; t >= 0; --t) {
-        const int j = r + 64 * t;
-        ff::Fr v;
-        if (t == 63) {
-            v = ff::Fr::zero();  // q_j = 0 for j >= N - 64
-        } else {
-            acc = ff::add(p[j + 64], ff::mul(a, acc));
-            v = acc;
-        }
-        ff::Fr c = ff::from_mont(v);
-#pragma unroll
-        for (int l = 0; l < 8; ++l) q[(size_t)j * 8 + l] = c.v[l];
-    }
-}
-
-}  // namespace
-
-// ---------------------------------------------------------------- settings object
-struct KzgAmdSettings {
-    int device = 0;
-    kzgamd::MsmContext* msm = nullptr;  // prepared over g1_lagrange_brp
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // commitment validation runs beside the proving pipeline
-    // EIP-7594 state, built on first use
-    AffPt* d_monomial = nullptr;              // g1_values_monomial as table slots
-    kzgamd::MsmContext* msm_monomial = nullptr;
-    kzgamd::MsmContext* msm_xext = nullptr;  // FK20: the 128 columns of 64 points of x_ext_fft_columns, one wide table
-    ff::Fr *d_fk_a = nullptr, *d_fk_b = nullptr;  // FK20: n x 64 x 128 Toeplitz vectors / their transforms
-    g1::Xyzz *d_fk_h = nullptr, *d_fk_h2 = nullptr;  // FK20: n x 128 points, and the transform scratch
-    size_t cap_fk = 0, cap_q = 0;
-    void ensure_fk20(size_t nblobs) {
-        if (nblobs <= cap_fk) return;
-        release_fk20();
-        CK_HIP(hipMalloc(&d_fk_a, nblobs * 8192 * sizeof(ff::Fr)));
-        CK_HIP(hipMalloc(&d_fk_b, nblobs * 8192 * sizeof(ff::Fr)));
-        CK_HIP(hipMalloc(&d_fk_h, nblobs * 128 * sizeof(g1::Xyzz)));
-        CK_HIP(hipMalloc(&d_fk_h2, nblobs * 128 * sizeof(g1::Xyzz)));
-        cap_fk = nblobs;
-    }
-    void release_fk20() {
-        if (d_fk_a) (void)hipFree(d_fk_a);
-        if (d_fk_b) (void)hipFree(d_fk_b);
-        if (d_fk_h) (void)hipFree(d_fk_h);
-        if (d_fk_h2) (void)hipFree(d_fk_h2);
-        d_fk_a = d_fk_b = nullptr;
-        d_fk_h = d_fk_h2 = nullptr;
-        cap_fk = 0;
-    }
-    void ensure_q(size_t nblobs) {  // the 128 quotient vectors per blob of the direct cell-proof path (16 MB per blob)
-        if (nblobs <= cap_q) return;
-        if (d_q) (void)hipFree(d_q);
-        d_q = nullptr;
-        cap_q = 0;
-        CK_HIP(hipMalloc(&d_q, nblobs * 128 * N * 32));
-        cap_q = nblobs;
-    }
-    // Lanes: the reference's callers share one settings object between rayon workers (kzg/src/eip_4844.rs:781-805).
-    // A host-buffer call of a few blobs takes the first idle lane — a settings object of its own for everything a call
-    // mutates (streams, staging buffers, mutex) that BORROWS the tables and engine handles of its parent — so that up to
-    // MAX_LANES + 1 small calls are in flight on the GPU at once (their kernels are a few hundred waves each) instead
-    // of queueing on one mutex.  Lane objects are created on demand and live as long as the parent.
-    static constexpr size_t LANE_MAX_BLOBS = 16;
-    static constexpr int MAX_LANES = 15;
-    // Coalescing of concurrent single-blob calls (one queue per entry point): callers push a request; up to
-    // MAX_LEADERS of them at a time take everything queued (up to LANE_MAX_BLOBS requests) and run it as ONE batch on a
-    // lane, so that the ~10 runtime operations of a pipeline invocation (each of them takes a device-wide lock inside
-    // the HIP runtime: ~100 us of serialised host time per invocation) are paid per batch, not per call.
-    struct CoalesceQueue {
-        std::mutex mu;
-        std::condition_variable cv;
-        std::deque<void*> pending;
-        int leaders = 0;
-        int max_leaders = 3, gather_us = 60;  // tuning keys leaders / gather_min / gather_us (apply_options)
-        size_t gather_min = 6;
-    };
-    // the tuning keys of config.h this layer reads, copied once when the settings object is created (apply_options;
-    // lanes take their parent's)
-    kzgamd::Options opt;
-    CoalesceQueue q_commit, q_blob_proof, q_proof;
-    bool cfg_device_sha = false;
-    size_t cfg_host_check_max = 64;  // see HOST_CHECK_MAX
-    size_t cfg_prove_chunk = 0;
-    bool cfg_wide_check = true;      // false: single-lane tests
-    size_t cfg_prove_first = 0, cfg_commit_first = 0, cfg_commit_chunk = 0;
-    int cfg_fk20 = -1;               // -1: by batch size
-    void apply_options(const kzgamd::Options& o) {
-        using namespace kzgamd;
-        opt = o;
-        for (CoalesceQueue* q : {&q_commit, &q_blob_proof, &q_proof}) {
-            q->max_leaders = (int)o.t[T_LEADERS];
-            q->gather_min = (size_t)o.t[T_GATHER_MIN];
-            q->gather_us = (int)o.t[T_GATHER_US];
-        }
-        cfg_device_sha = o.t[T_DEVICE_SHA] != 0;
-        cfg_host_check_max = (size_t)o.t[T_HOST_CHECK_MAX];
-        cfg_prove_chunk = (size_t)o.t[T_PROVE_CHUNK];
-        cfg_wide_check = o.t[T_WIDE_CHECK] != 0;
-        cfg_prove_first = (size_t)o.t[T_PROVE_FIRST];
-        cfg_commit_first = (size_t)o.t[T_COMMIT_FIRST];
-        cfg_commit_chunk = (size_t)o.t[T_COMMIT_CHUNK];
-        cfg_fk20 = (int)o.t[T_FK20];
-    }
-    bool is_lane = false;
-    std::atomic<bool> busy{false};
-    // page-locked staging for calls of up to LANE_MAX_BLOBS blobs: copies to and from it are truly asynchronous (a
-    // copy from / to the caller's pageable memory goes through the runtime's own staging path, which serialises
-    // concurrent callers)
-    unsigned char* h_in = nullptr;   // LANE_MAX_BLOBS blobs
-    unsigned char* h_res = nullptr;  // per blob: 144 B result + 32 B y + 4 B status + 4 B commitment status
-    void ensure_pinned() {
-        if (h_in) return;
-        CK_HIP(hipHostMalloc((void**)&h_in, LANE_MAX_BLOBS * BYTES_PER_BLOB, hipHostMallocDefault));
-        CK_HIP(hipHostMalloc((void**)&h_res, LANE_MAX_BLOBS * 256, hipHostMallocDefault));
-    }
-    // Page-locked blob slots for the callers of the coalesced entry points: a caller copies its blob into a slot on its
-    // own thread (in parallel with the other callers) before it queues its request; the batch's kernels read the
-    // slots in place.  The pool belongs to the root settings object; a caller that finds it empty leaves the copy
-    // to the leader (the lane's own staging).
-    struct PinnedSlots {
-        static constexpr int NSLOTS = 48;
-        std::mutex mu;
-        unsigned char* base = nullptr;
-        bool failed = false;
-        std::vector<unsigned char*> free_;
-        unsigned char* acquire(int device) {
-            std::lock_guard<std::mutex> lk(mu);
-            if (!base && !failed) {
-                kzgamd::DeviceGuard on_device(device);
-                if (on_device.err != hipSuccess ||
-                    hipHostMalloc((void**)&base, (size_t)NSLOTS * BYTES_PER_BLOB, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
-                    base = nullptr;
-                    failed = true;
-                    (void)hipGetLastError();
-                } else {
-                    for (int i = NSLOTS; i-- > 0;) free_.push_back(base + (size_t)i * BYTES_PER_BLOB);
-                }
-            }
-            if (free_.empty()) return nullptr;
-            unsigned char* p = free_.back();
-            free_.pop_back();
-            return p;
-        }
-        void release(unsigned char* p) {
-            if (!p) return;
-            std::lock_guard<std::mutex> lk(mu);
-            free_.push_back(p);
-        }
-        ~PinnedSlots() {
-            if (base) (void)hipHostFree(base);
-        }
-    } slots;
-    std::mutex lanes_mu;
-    std::vector<std::unique_ptr<KzgAmdSettings>> lanes;
-    std::atomic<unsigned> lane_rr{0};
-    void* ntt = nullptr;                      // kzgamd_ntt_new(13)
-    ff::Fr* d_roots8192 = nullptr;            // roots_of_unity[0..=8192], Montgomery
-    ff::Fr *d_fr_a = nullptr, *d_fr_b = nullptr, *d_fr_ext = nullptr;  // 4096, 4096, 8192 per blob
-    u32* d_cells = nullptr;
-    u32* d_q = nullptr;                       // 128 x 4096 x 8 per blob
-    unsigned char* d_proofs = nullptr;
-    size_t cap_cells = 0;
-    int* d_cstatus = nullptr;
-    AffPt* d_cpts = nullptr;  // decoded commitments of a proof batch of <= WIDE_COMMIT_CHECK_MAX blobs (wide check)
-    std::mutex mu;
-    // staging for the host-buffer entry points
-    unsigned char* d_blobs = nullptr;
-    u32* d_scalars = nullptr;
-    int* d_status = nullptr;
-    unsigned char* d_out = nullptr;
-    u32* d_z = nullptr;              // n x 32 B big-endian evaluation points
-    u32* d_y = nullptr;              // n x 8 u32 canonical y
-    unsigned char* d_commit = nullptr;  // n x 48 B
-    unsigned char* d_qscratch = nullptr;  // k_quotient_a/b scratch for up to QSPLIT_MAX blobs
-    size_t cap_blobs = 0;
-    std::unique_ptr<WorkerPool> pool;  // created by the first batched proof call
-    // extra streams for the chunk pipeline of large proof batches (created on first use); chunk k runs on
-    // pipe_stream(k), `stream` waits for all of them in pipe_join()
-    static constexpr int NPIPE = 4;
-    hipStream_t pipe[NPIPE] = {};
-    hipEvent_t pipe_ev[NPIPE] = {};
-    hipEvent_t ev_commit = nullptr;  // the commitments of a proof batch are on the device (recorded on stream2)
-    hipEvent_t ev_cells = nullptr;   // the cells of a cells-and-proofs call are ready (recorded on stream; stream2 copies them out)
-    // batched verification: staging for [proofs | commitments | G] and the variable-base handle over them, kept
-    // between calls (a fresh handle per call cost 1.7 ms of stream / allocation / free round trips)
-    std::mutex vmu;                 // one batched verification at a time per settings object (its staging buffers)
-    std::vector<uint8_t> vstage;    // host staging of the 2n + 1 compressed points (must outlive the async copy)
-    unsigned char* d_vbytes = nullptr;
-    AffPt* d_vpts = nullptr;
-    int* d_vstat = nullptr;
-    hipEvent_t ev_decoded = nullptr;  // the points of a verification call are decoded (their membership test may still run)
-    size_t vcap = 0;
-    kzgamd::MsmContext* msm_verify = nullptr;
-    void ensure_verify(size_t np) {
-        if (np <= vcap) return;
-        if (d_vbytes) (void)hipFree(d_vbytes);
-        if (d_vpts) (void)hipFree(d_vpts);
-        if (d_vstat) (void)hipFree(d_vstat);
-        d_vbytes = nullptr;
-        d_vpts = nullptr;
-        d_vstat = nullptr;
-        vcap = 0;
-        const size_t cap = np < 257 ? 257 : np;
-        CK_HIP(hipMalloc(&d_vbytes, cap * 48));
-        CK_HIP(hipMalloc(&d_vpts, cap * sizeof(AffPt)));
-        CK_HIP(hipMalloc(&d_vstat, cap * sizeof(int)));
-        vcap = cap;
-    }
-    hipStream_t pipe_stream(size_t k) {
-        const int j = (int)(k % NPIPE);
-        if (!pipe[j]) {
-            if (hipStreamCreateWithFlags(&pipe[j], hipStreamNonBlocking) != hipSuccess) {
-                pipe[j] = nullptr;
-                return stream;
-            }
-            (void)hipEventCreateWithFlags(&pipe_ev[j], hipEventDisableTiming);
-        }
-        return pipe[j];
-    }
-    void pipe_join() {
-        for (int j = 0; j < NPIPE; ++j)
-            if (pipe[j] && pipe_ev[j]) {
-                (void)hipEventRecord(pipe_ev[j], pipe[j]);
-                (void)hipStreamWaitEvent(stream, pipe_ev[j], 0);
-            }
-    }
-    // EIP-7594 cell verification / recovery state, built on first use
-    std::vector<uint8_t> mono64_bytes;  // g1_values_monomial[0..64) compressed (the interpolation-polynomial commitment)
-    AffPt* d_mono64 = nullptr;          // ... decoded and subgroup-checked once, as MSM slots
-    ff::Fr* d_rec[4] = {nullptr, nullptr, nullptr, nullptr};  // recovery: four vectors of 8192 field elements
-    u32* d_rec_in = nullptr;         // up to 128 cells as canonical limbs
-    u32* d_rec_idx = nullptr;        // their cell indices
-    ff::Fr* d_pow7 = nullptr;        // 7^i and 7^-i, i < 8192 (coset shifts, das.rs:463-491)
-    ff::Fr* d_pow7inv = nullptr;
-    bool fk20_unavailable = false;   // the FK20 table could not be built (no HBM left): batches use the direct form
-    // verify_cell_kzg_proof_batch: the cells (canonical limbs), their columns and the powers of r, for k_vcell_agg
-    u32* d_vc_cells = nullptr;
-    u32* d_vc_cols = nullptr;
-    ff::Fr* d_vc_pw = nullptr;
-    size_t cap_vc = 0;
-    void ensure_vcells(size_t n) {
-        if (n <= cap_vc) return;
-        if (d_vc_cells) (void)hipFree(d_vc_cells);
-        if (d_vc_cols) (void)hipFree(d_vc_cols);
-        if (d_vc_pw) (void)hipFree(d_vc_pw);
-        d_vc_cells = d_vc_cols = nullptr;
-        d_vc_pw = nullptr;
-        cap_vc = 0;
-        const size_t cap = n < 128 ? 128 : n;
-        CK_HIP(hipMalloc(&d_vc_cells, cap * CELL_SIZE * 32));
-        CK_HIP(hipMalloc(&d_vc_cols, (cap + 2 * CELLS_PER_BLOB + 1) * sizeof(u32)));
-        CK_HIP(hipMalloc(&d_vc_pw, cap * sizeof(ff::Fr)));
-        cap_vc = cap;
-    }
-    void ensure_recover() {
-        if (d_rec[0]) return;
-        for (int k = 0; k < 4; ++k) CK_HIP(hipMalloc(&d_rec[k], 2 * N * sizeof(ff::Fr)));
-        CK_HIP(hipMalloc(&d_rec_in, 2 * N * 32));
-        CK_HIP(hipMalloc(&d_rec_idx, 128 * sizeof(u32)));
-        CK_HIP(hipMalloc(&d_pow7, 2 * N * sizeof(ff::Fr)));
-        CK_HIP(hipMalloc(&d_pow7inv, 2 * N * sizeof(ff::Fr)));
-        std::vector<ff::Fr> p(2 * N), q(2 * N);
-        ff::Fr seven = ff::Fr::zero();
-        seven.v[0] = 7;
-        seven = ff::to_mont(seven);
-        const ff::Fr inv7 = ff::inverse_bgcd(seven);
-        p[0] = q[0] = ff::Fr::one();
-        for (size_t i = 1; i < 2 * N; ++i) {
-            p[i] = ff::mul(p[i - 1], seven);
-            q[i] = ff::mul(q[i - 1], inv7);
-        }
-        CK_HIP(hipMemcpy(d_pow7, p.data(), p.size() * sizeof(ff::Fr), hipMemcpyHostToDevice));
-        CK_HIP(hipMemcpy(d_pow7inv, q.data(), q.size() * sizeof(ff::Fr), hipMemcpyHostToDevice));
-    }
-    std::vector<kzgamd::pairing::G2Jac> g2_monomial;  // [tau^i]G2, i < 65 (host; the pairing checks use [1])
-    std::vector<ff::Fr> brp_roots;  // brp_roots_of_unity[0..8192) (host copy, Montgomery)
-    ff::Fr* d_brp_roots = nullptr;  // first 4096 = the blob evaluation domain
-    ~KzgAmdSettings() {
-        lanes.clear();  // before the handles they borrow go away
-        if (h_in) (void)hipHostFree(h_in);
-        if (h_res) (void)hipHostFree(h_res);
-        if (is_lane) {
-            msm = nullptr;
-            msm_monomial = msm_xext = nullptr;
-            d_monomial = nullptr;
-            d_brp_roots = nullptr;
-            ntt = nullptr;
-            d_roots8192 = nullptr;
-        }
-        if (d_z) (void)hipFree(d_z);
-        if (d_y) (void)hipFree(d_y);
-        if (d_commit) (void)hipFree(d_commit);
-        if (d_qscratch) (void)hipFree(d_qscratch);
-        if (ev_commit) (void)hipEventDestroy(ev_commit);
-        if (ev_cells) (void)hipEventDestroy(ev_cells);
-        if (msm_verify) kzgamd::msm_destroy(msm_verify);
-        if (ev_decoded) (void)hipEventDestroy(ev_decoded);
-        if (d_mono64) (void)hipFree(d_mono64);
-        if (d_vbytes) (void)hipFree(d_vbytes);
-        if (d_vpts) (void)hipFree(d_vpts);
-        if (d_vstat) (void)hipFree(d_vstat);
-        for (int j = 0; j < NPIPE; ++j) {
-            if (pipe_ev[j]) (void)hipEventDestroy(pipe_ev[j]);
-            if (pipe[j]) (void)hipStreamDestroy(pipe[j]);
-        }
-        if (d_brp_roots) (void)hipFree(d_brp_roots);
-        for (int k = 0; k < 4; ++k)
-            if (d_rec[k]) (void)hipFree(d_rec[k]);
-        if (d_vc_cells) (void)hipFree(d_vc_cells);
-        if (d_vc_cols) (void)hipFree(d_vc_cols);
-        if (d_vc_pw) (void)hipFree(d_vc_pw);
-        if (d_rec_in) (void)hipFree(d_rec_in);
-        if (d_rec_idx) (void)hipFree(d_rec_idx);
-        if (d_pow7) (void)hipFree(d_pow7);
-        if (d_pow7inv) (void)hipFree(d_pow7inv);
-        if (d_monomial) (void)hipFree(d_monomial);
-        if (msm_monomial) kzgamd::msm_destroy(msm_monomial);
-        if (msm_xext) kzgamd::msm_destroy(msm_xext);
-        release_fk20();
-        if (ntt) kzgamd_ntt_free(ntt);
-        if (d_roots8192) (void)hipFree(d_roots8192);
-        release_cells();
-        if (d_cstatus) (void)hipFree(d_cstatus);
-        if (d_cpts) (void)hipFree(d_cpts);
-        if (stream2 && stream2 != stream) (void)hipStreamDestroy(stream2);
-        if (msm) kzgamd::msm_destroy(msm);
-        if (d_blobs) (void)hipFree(d_blobs);
-        if (d_scalars) (void)hipFree(d_scalars);
-        if (d_status) (void)hipFree(d_status);
-        if (d_out) (void)hipFree(d_out);
-        if (stream) (void)hipStreamDestroy(stream);
-    }
-    void release_cells() {
-        if (d_fr_a) (void)hipFree(d_fr_a);
-        if (d_fr_b) (void)hipFree(d_fr_b);
-        if (d_fr_ext) (void)hipFree(d_fr_ext);
-        if (d_cells) (void)hipFree(d_cells);
-        if (d_q) (void)hipFree(d_q);
-        if (d_proofs) (void)hipFree(d_proofs);
-        d_fr_a = d_fr_b = d_fr_ext = nullptr;
-        d_cells = d_q = nullptr;
-        d_proofs = nullptr;
-        cap_cells = 0;
-        cap_q = 0;
-    }
-    void ensure_cells(size_t nblobs) {
-        if (nblobs <= cap_cells) return;
-        release_cells();
-        CK_HIP(hipMalloc(&d_fr_a, nblobs * N * 32));
-        CK_HIP(hipMalloc(&d_fr_b, nblobs * N * 32));
-        CK_HIP(hipMalloc(&d_fr_ext, nblobs * 2 * N * 32));
-        CK_HIP(hipMalloc(&d_cells, nblobs * 2 * N * 32));
-        CK_HIP(hipMalloc(&d_proofs, nblobs * 128 * 48));
-        cap_cells = nblobs;
-    }
-    void ensure(size_t nblobs) {
-        if (nblobs <= cap_blobs) return;
-        if (d_blobs) (void)hipFree(d_blobs);
-        if (d_scalars) (void)hipFree(d_scalars);
-        if (d_status) (void)hipFree(d_status);
-        if (d_out) (void)hipFree(d_out);
-        if (d_z) (void)hipFree(d_z);
-        if (d_y) (void)hipFree(d_y);
-        if (d_commit) (void)hipFree(d_commit);
-        if (d_cstatus) (void)hipFree(d_cstatus);
-        d_cstatus = nullptr;
-        if (d_cpts) (void)hipFree(d_cpts);
-        d_cpts = nullptr;
-        d_blobs = nullptr;
-        d_scalars = nullptr;
-        d_status = nullptr;
-        d_out = nullptr;
-        d_z = nullptr;
-        d_y = nullptr;
-        d_commit = nullptr;
-        cap_blobs = 0;
-        CK_HIP(hipMalloc(&d_blobs, nblobs * BYTES_PER_BLOB));
-        CK_HIP(hipMalloc(&d_scalars, nblobs * BYTES_PER_BLOB));
-        CK_HIP(hipMalloc(&d_status, nblobs * sizeof(int)));
-        CK_HIP(hipMalloc(&d_out, nblobs * 144));  // 48-byte compressed results, or Jacobian for the small-batch path
-        CK_HIP(hipMalloc(&d_z, nblobs * 32));
-        CK_HIP(hipMalloc(&d_y, nblobs * 32));
-        CK_HIP(hipMalloc(&d_commit, nblobs * 48));
-        CK_HIP(hipMalloc(&d_cstatus, nblobs * sizeof(int)));
-        CK_HIP(hipMalloc(&d_cpts, WIDE_COMMIT_CHECK_MAX * sizeof(AffPt)));
-        cap_blobs = nblobs;
-    }
-};
-
-namespace {
 
 std::mutex g_registry_mu;
 std::map<const void*, KzgAmdSettings*> g_registry;
 
+}  // namespace
+namespace ckz {
 KzgAmdSettings* lookup(const CKZGSettings* s) {
     if (!s || !s->g1_values_lagrange_brp) return nullptr;
     std::lock_guard<std::mutex> lk(g_registry_mu);
@@ -1340,52 +766,8 @@ KzgAmdSettings* make_lane(KzgAmdSettings* parent) {
     parent->lanes.push_back(std::move(ln));
     return parent->lanes.back().get();
 }
-
-// The settings object a small host-buffer call runs on: the parent if idle, else an idle lane, else a new lane, else
-// (all MAX_LANES busy) one of them in turn — its mutex queues the call.  Released by the destructor.
-struct LaneRef {
-    KzgAmdSettings* use = nullptr;
-    bool flagged = false;
-    LaneRef(KzgAmdSettings* dev, size_t nblobs) {
-        use = dev;
-        if (nblobs > KzgAmdSettings::LANE_MAX_BLOBS) {
-            // large batches: the parent's own pipeline, one at a time (its mutex); marked busy so that small calls go
-            // to the lanes meanwhile
-            flagged = !dev->busy.exchange(true);
-            return;
-        }
-        // small calls run on lanes (their streams have MSM workspaces of their own: no cross-stream events per enqueue);
-        // the parent stays free for large batches
-        bool expect = false;
-        std::lock_guard<std::mutex> lk(dev->lanes_mu);
-        for (auto& ln : dev->lanes) {
-            expect = false;
-            if (ln->busy.compare_exchange_strong(expect, true)) {
-                use = ln.get();
-                flagged = true;
-                return;
-            }
-        }
-        if ((int)dev->lanes.size() < KzgAmdSettings::MAX_LANES) {
-            use = make_lane(dev);  // created busy
-            flagged = true;
-            return;
-        }
-        use = dev->lanes[dev->lane_rr.fetch_add(1) % dev->lanes.size()].get();
-    }
-    ~LaneRef() {
-        if (flagged) use->busy.store(false);
-    }
-    LaneRef(const LaneRef&) = delete;
-    LaneRef& operator=(const LaneRef&) = delete;
-};
-
-size_t reverse_bits(size_t v, unsigned bits) {
-    size_t r = 0;
-    for (unsigned b = 0; b < bits; ++b)
-        if (v & ((size_t)1 << b)) r |= (size_t)1 << (bits - 1 - b);
-    return r;
-}
+}  // namespace ckz
+namespace {
 
 // ---- trusted setup text (kzg/src/eip_4844.rs:151-228) ----
 bool is_ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
@@ -1599,13 +981,11 @@ void load_impl(CKZGSettings* out, const uint8_t* g1_mono, size_t n1m, const uint
 // A compressed result costs the GPU a field inversion in one lane (~0.15 ms of latency whatever the batch); for a
 // handful of results the host-buffer entry points fetch Jacobian points instead and compress them on the host
 // (~20 us each): a single blob_to_kzg_commitment call 0.71 -> 0.5 ms.
-// batches up to this size leave the device as Jacobian points and are compressed on the host with one inversion
-// (host_p1_compress_batch): k_final's one-lane inversion is 0.25 ms of latency, worth paying only when a block of 64
-// points shares it
-constexpr size_t HOST_COMPRESS_MAX = 16;
-constexpr size_t HOST_CHECK_MAX = 64;  // commitments of a proof batch validated on the host's cores up to this many
-
+}  // namespace
+namespace ckz {
 void compress_on_host(uint8_t* out48, const blst_p1* jac, size_t n) { kzgamd::host_p1_compress_batch(out48, jac, n); }
+}  // namespace ckz
+namespace {
 
 void commit_enqueue(KzgAmdSettings* dev, void* d_out, int* d_status, const void* d_blobs, u32* d_scalars, size_t n,
                     hipStream_t stream, int out_mode = kzgamd::OUT_COMPRESSED, const BlobPtrs* ptrs = nullptr) {
@@ -1710,6 +1090,8 @@ void fr_limbs_to_be32(uint8_t out[32], const u32 limbs[8]) {
     }
 }
 
+}  // namespace
+namespace ckz {
 bool host_blob_valid(const uint8_t* blob) {
     for (size_t i = 0; i < N; ++i) {
         const uint8_t* e = blob + 32 * i;
@@ -1721,12 +1103,16 @@ bool host_blob_valid(const uint8_t* blob) {
     }
     return true;
 }
+}  // namespace ckz
+namespace {
 
+}  // namespace
+namespace ckz {
 // proofs for n (blob, z) pairs; z_src = explicit evaluation points or nullptr to derive them
 // from the commitments (compute_blob_kzg_proof)
 // proofs == nullptr: evaluation only (zs_out receives the derived challenges)
 void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32* zs, const Bytes48* commitments, size_t n,
-                 KzgAmdSettings* dev, Bytes32* zs_out = nullptr, bool commitments_checked_elsewhere = false) {
+                 KzgAmdSettings* dev, Bytes32* zs_out, bool commitments_checked_elsewhere) {
     std::lock_guard<std::mutex> lk(dev->mu);
     kzgamd::DeviceGuard on_device(dev->device);
     CK_HIP(on_device.err);
@@ -1956,259 +1342,9 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
     if (ys)
         for (size_t i = 0; i < n; ++i) fr_limbs_to_be32(ys[i].bytes, &ylimbs[8 * i]);
 }
+}  // namespace ckz
+namespace {
 
-
-// ---------------- FK20 cell proofs (compute_fk20_proofs, kzg/src/das.rs:630-696) for batches ----------------
-// toeplitz_coeffs_stride for every (blob, offset i < 64): a 128-vector with p[4095 - i] at 0 and p[4095 - i - 64 j] at
-// 128 - j, j = 1 .. 62 (the circulant embedding of the Toeplitz matrix of every 64th coefficient)
-__global__ void __launch_bounds__(256) k_fk20_toeplitz(ff::Fr* __restrict__ out, const ff::Fr* __restrict__ mono, size_t nblobs) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblobs * 64 * 128) return;
-    const size_t b = t >> 13;
-    const u32 i = (u32)(t >> 7) & 63, idx = (u32)t & 127;
-    const ff::Fr* p = mono + b * N;
-    ff::Fr v = ff::Fr::zero();
-    if (idx == 0) v = p[N - 1 - i];
-    else if (idx >= 66) v = p[N - 1 - i - 64 * (128 - idx)];
-    out[t] = v;
-}
-// coeffs[blob][j][i] = transform_i[j] / 128: the scalars of column j next to each other (the MSM's layout), with the
-// 1/128 of the inverse G1 transform that follows folded in (a field multiplication here instead of a scalar
-// multiplication per point there)
-__global__ void __launch_bounds__(256) k_fk20_transpose(ff::Fr* __restrict__ out, const ff::Fr* __restrict__ in, size_t nblobs,
-                                                        ff::Fr inv128) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblobs * 128 * 64) return;
-    const size_t b = t >> 13;
-    const u32 j = (u32)(t >> 6) & 127, i = (u32)t & 63;
-    out[t] = ff::mul(in[(b * 64 + i) * 128 + j], inv128);
-}
-// h[64 .. 128) = identity (das.rs:688-691)
-__global__ void __launch_bounds__(256) k_fk20_zero_upper(g1::Xyzz* __restrict__ h, size_t nblobs) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblobs * 64) return;
-    g1::set_inf(h[(t >> 6) * 128 + 64 + (t & 63)]);
-}
-// reverse_bit_order of the 128 proofs of a blob (das.rs:288)
-__global__ void __launch_bounds__(256) k_fk20_brp(g1::Xyzz* __restrict__ out, const g1::Xyzz* __restrict__ in, size_t nblobs) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nblobs * 128) return;
-    out[t] = in[(t & ~(size_t)127) | (__builtin_bitreverse32((u32)t & 127u) >> 25)];
-}
-
-// the fixed-base handle over the 128 x 64 points of x_ext_fft_columns (column-major: base j * 64 + i)
-void fk20_prepare(KzgAmdSettings* dev, const CKZGSettings* cs) {
-    if (dev->msm_xext) return;
-    const size_t K2 = 2 * CELLS_PER_BLOB, total = K2 * CELL_SIZE;
-    std::vector<ff::Fp> aff(2 * total);  // blst_p1_affine: x, y
-    std::vector<ff::Fp> pre(total);
-    // Montgomery's trick over the Z coordinates (the columns hold no point at infinity for a valid setup; a zero Z
-    // is skipped and its point written as (0, 0), blst's affine infinity)
-    ff::Fp run = ff::Fp::one();
-    for (size_t k = 0; k < total; ++k) {
-        const ff::Fp* P = reinterpret_cast<const ff::Fp*>(&cs->x_ext_fft_columns[k / CELL_SIZE][k % CELL_SIZE]);
-        pre[k] = run;
-        if (!P[2].is_zero()) run = hfp::mul(run, P[2]);
-    }
-    ff::Fp inv = ff::inverse_bgcd(run);
-    for (size_t k = total; k-- > 0;) {
-        const ff::Fp* P = reinterpret_cast<const ff::Fp*>(&cs->x_ext_fft_columns[k / CELL_SIZE][k % CELL_SIZE]);
-        if (P[2].is_zero()) {
-            aff[2 * k] = aff[2 * k + 1] = ff::Fp::zero();
-            continue;
-        }
-        const ff::Fp zi = hfp::mul(inv, pre[k]), zi2 = hfp::sqr(zi);
-        inv = hfp::mul(inv, P[2]);
-        aff[2 * k] = hfp::mul(P[0], zi2);
-        aff[2 * k + 1] = hfp::mul(P[1], hfp::mul(zi2, zi));
-    }
-    dev->msm_xext = kzgamd::msm_create(aff.data(), total, false, true, false, kzgamd::G1_TRUSTED, &dev->opt);
-}
-
-// The 128 cell proofs of n polynomials whose 4096 monomial coefficients are in dev->d_fr_b, compressed into
-// dev->d_proofs (compute_fk20_proofs + reverse_bit_order, kzg/src/das.rs:280-288, 630-696): enqueue only.
-// The caller has prepared the handle its `fk20` choice needs and the buffers (ensure_fk20 / ensure_q).
-void enqueue_cell_proofs(KzgAmdSettings* dev, size_t n, hipStream_t st, bool fk20) {
-    if (fk20) {
-        const size_t nv = n * 64 * 128;
-        hipLaunchKernelGGL(k_fk20_toeplitz, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, dev->d_fk_a,
-                           (const ff::Fr*)dev->d_fr_b, n);
-        if (kzgamd_ntt_fr_device(dev->ntt, dev->d_fk_b, dev->d_fk_a, 128, 64 * n, 0, st) != 0) throw CkErr{C_KZG_ERROR, "ntt"};
-        ff::Fr k128 = ff::Fr::zero();
-        k128.v[0] = 128;
-        const ff::Fr inv128 = ff::inverse_bgcd(ff::to_mont(k128));  // Montgomery form of 1/128
-        hipLaunchKernelGGL(k_fk20_transpose, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, st, dev->d_fk_a,
-                           (const ff::Fr*)dev->d_fk_b, n, inv128);
-        // h_ext_fft[blob][j] = sum_i coeffs[j][i] * x_ext_fft_columns[j][i]: 128 n MSMs of 64 points, column j of the table
-        kzgamd::msm_lock(dev->msm_xext);
-        try {
-            kzgamd::msm_enqueue(dev->msm_xext, dev->d_fk_h, dev->d_fk_a, CELL_SIZE, n * 128, 1, st, kzgamd::OUT_XYZZ, false, 128);
-        } catch (...) {
-            kzgamd::msm_unlock(dev->msm_xext);
-            throw;
-        }
-        kzgamd::msm_unlock(dev->msm_xext);
-        // h = ifft_g1(h_ext_fft), upper half cleared, proofs = fft_g1(h), bit-reversed, compressed
-        g1::Xyzz* h = (g1::Xyzz*)kzgamd::fftg1_device((NttCtx*)dev->ntt, dev->d_fk_h, dev->d_fk_h2, 128, n, 1, st, false);
-        if (!h) throw CkErr{C_KZG_ERROR, "fft_g1"};
-        g1::Xyzz* other = h == dev->d_fk_h ? dev->d_fk_h2 : dev->d_fk_h;
-        hipLaunchKernelGGL(k_fk20_zero_upper, dim3((unsigned)((n * 64 + 255) / 256)), dim3(256), 0, st, h, n);
-        g1::Xyzz* pr = (g1::Xyzz*)kzgamd::fftg1_device((NttCtx*)dev->ntt, h, other, 128, n, 0, st);
-        if (!pr) throw CkErr{C_KZG_ERROR, "fft_g1"};
-        g1::Xyzz* fin = pr == h ? other : h;
-        hipLaunchKernelGGL(k_fk20_brp, dim3((unsigned)((n * 128 + 255) / 256)), dim3(256), 0, st, fin, (const g1::Xyzz*)pr, n);
-        kzgamd::g1_compress_xyzz(dev->d_proofs, fin, n * 128, st);
-    } else {
-        hipLaunchKernelGGL(k_cell_quotients, dim3((unsigned)(n * 128)), dim3(64), 0, st, dev->d_q, (const ff::Fr*)dev->d_fr_b,
-                           (const ff::Fr*)dev->d_roots8192, n);
-        kzgamd::msm_lock(dev->msm_monomial);
-        try {
-            kzgamd::msm_enqueue(dev->msm_monomial, dev->d_proofs, dev->d_q, N, n * 128, 0, st, kzgamd::OUT_COMPRESSED);
-        } catch (...) {
-            kzgamd::msm_unlock(dev->msm_monomial);
-            throw;
-        }
-        kzgamd::msm_unlock(dev->msm_monomial);
-    }
-}
-
-// compute_cells_and_kzg_proofs (kzg/src/das.rs:244-292) for n blobs; cells / proofs may be null (not both)
-void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_t n, const CKZGSettings* cs,
-                      KzgAmdSettings* dev) {
-    std::lock_guard<std::mutex> lk(dev->mu);
-    kzgamd::DeviceGuard on_device(dev->device);
-    CK_HIP(on_device.err);
-    if (!dev->d_roots8192) {
-        CK_HIP(hipMalloc(&dev->d_roots8192, (2 * N + 1) * sizeof(ff::Fr)));
-        CK_HIP(hipMemcpy(dev->d_roots8192, cs->roots_of_unity, (2 * N + 1) * sizeof(ff::Fr), hipMemcpyHostToDevice));
-    }
-    // Cell proofs: FK20 for batches (the reference's algorithm: 64 transforms of 128 scalars, 128 MSMs of 64 points
-    // over x_ext_fft_columns, two G1 transforms of 128 points — ~25x fewer point additions than 128 MSMs of 4096, but
-    // the G1 transforms are 14 serial stages of a 128-bit scalar multiplication each: tens of ms of latency whatever
-    // the batch).  A few blobs: the direct form, one more fixed-base MSM per cell over the monomial table.
-    // KZGAMD_FK20 = 0 / 1 forces one or the other.
-    bool fk20 = proofs && n >= FK20_MIN_BLOBS;
-    if (dev->cfg_fk20 >= 0) fk20 = proofs && dev->cfg_fk20 != 0;
-    if (dev->fk20_unavailable) fk20 = false;
-    if (proofs && fk20) {
-        // no HBM left for the FK20 table (creation throws, or succeeds without a wide table): the direct form computes
-        // the same proofs; the useless handle is dropped and the choice remembered
-        try {
-            fk20_prepare(dev, cs);
-        } catch (...) {
-            dev->fk20_unavailable = true;
-        }
-        if (!dev->fk20_unavailable && !kzgamd::msm_has_wide_table(dev->msm_xext)) dev->fk20_unavailable = true;
-        if (dev->fk20_unavailable) {
-            if (dev->msm_xext) kzgamd::msm_destroy(dev->msm_xext);
-            dev->msm_xext = nullptr;
-            fk20 = false;
-        }
-    }
-    if (proofs && !fk20 && !dev->msm_monomial) dev->msm_monomial = kzgamd::msm_create(dev->d_monomial, N, true, true, true, kzgamd::G1_TRUSTED, &dev->opt);
-    dev->ensure(n);
-    dev->ensure_cells(n);
-    if (proofs && fk20) dev->ensure_fk20(n);
-    if (proofs && !fk20) dev->ensure_q(n);
-    hipStream_t st = dev->stream;
-    CK_HIP(hipMemcpyAsync(dev->d_blobs, blobs, n * BYTES_PER_BLOB, hipMemcpyHostToDevice, st));
-    CK_HIP(hipMemsetAsync(dev->d_status, 0, n * sizeof(int), st));
-    hipLaunchKernelGGL(k_blob_to_fr_brp, dim3((unsigned)((n * N + 255) / 256)), dim3(256), 0, st, dev->d_fr_a, dev->d_status,
-                       (const u32*)dev->d_blobs, n);
-    // poly_lagrange_to_monomial: inverse NTT of the bit-reversed evaluations
-    if (kzgamd_ntt_fr_device(dev->ntt, dev->d_fr_b, dev->d_fr_a, N, n, 1, st) != 0) throw CkErr{C_KZG_ERROR, "ntt"};
-    if (cells) {
-        hipLaunchKernelGGL(k_zero_extend, dim3((unsigned)((n * 2 * N + 255) / 256)), dim3(256), 0, st, dev->d_fr_ext,
-                           (const ff::Fr*)dev->d_fr_b, n);
-        // d_fr_a is free again only for n*N elements; the 8192-point result needs its own buffer: reuse d_cells
-        // as scratch for the transform output, then convert in place through d_fr_ext
-        ff::Fr* ev = reinterpret_cast<ff::Fr*>(dev->d_cells);
-        if (kzgamd_ntt_fr_device(dev->ntt, ev, dev->d_fr_ext, 2 * N, n, 0, st) != 0) throw CkErr{C_KZG_ERROR, "ntt"};
-        hipLaunchKernelGGL(k_cells_out, dim3((unsigned)((n * 2 * N + 255) / 256)), dim3(256), 0, st,
-                           reinterpret_cast<u32*>(dev->d_fr_ext), (const ff::Fr*)ev, n);
-        // fetched below, after the proof kernels are enqueued: a copy into pageable memory blocks this thread
-    }
-    // The cells (256 KiB per blob) go back on the second stream while the proof kernels run on the first: the copy
-    // engine is idle during FK20 (256 blobs: 67 MB, ~2.5 ms that used to follow the proofs on the same stream).
-    const bool side_copy = cells && proofs && dev->stream2 && dev->stream2 != st;
-    if (side_copy) {
-        if (!dev->ev_cells) CK_HIP(hipEventCreateWithFlags(&dev->ev_cells, hipEventDisableTiming));
-        CK_HIP(hipEventRecord(dev->ev_cells, st));
-    }
-    std::vector<int> status(n);
-    try {
-        if (proofs) enqueue_cell_proofs(dev, n, st, fk20);
-        if (side_copy) {
-            CK_HIP(hipStreamWaitEvent(dev->stream2, dev->ev_cells, 0));
-            CK_HIP(hipMemcpyAsync(cells, dev->d_fr_ext, n * 2 * N * 32, hipMemcpyDeviceToHost, dev->stream2));
-        } else if (cells) {
-            CK_HIP(hipMemcpyAsync(cells, dev->d_fr_ext, n * 2 * N * 32, hipMemcpyDeviceToHost, st));
-        }
-        if (proofs) CK_HIP(hipMemcpyAsync(proofs, dev->d_proofs, n * 128 * 48, hipMemcpyDeviceToHost, st));
-        CK_HIP(hipMemcpyAsync(status.data(), dev->d_status, n * sizeof(int), hipMemcpyDeviceToHost, st));
-    } catch (...) {
-        // a copy into the caller's `cells` / `proofs` (or into `status`) may be in flight on either stream: nothing of it
-        // may outlive this call
-        (void)hipStreamSynchronize(st);
-        if (side_copy) (void)hipStreamSynchronize(dev->stream2);
-        throw;
-    }
-    const hipError_t e1 = hipStreamSynchronize(st);
-    if (side_copy) CK_HIP(hipStreamSynchronize(dev->stream2));  // also on the way out of a failure: `cells` is the caller's
-    CK_HIP(e1);
-    for (size_t i = 0; i < n; ++i) CK_REQUIRE(status[i] == 0, "Invalid scalar");
-}
-
-
-// ---------------- EIP-7594 recovery (kzg/src/das.rs:101-243, 566-657) ----------------
-// provided cells (canonical little-endian limbs, already checked < r on the host) -> the 8192 evaluations in
-// bit-reversed order, Montgomery form, missing positions and the reference's "null" sentinel as zero
-// (recover_cells: `if cells_brp[i].is_null() { zero }`, das.rs:611-617; Fr::null() = from_u64_arr([u64::MAX; 4]),
-// blst/src/types/fr.rs:36-38 — a provided element equal to it is dropped by the reference too).  drop_null is false
-// when all 128 cells are given: the reference then skips recover_cells (das.rs:172-181) and hands the values as they
-// are to poly_lagrange_to_monomial (:186-188), the sentinel value included.
-__global__ void __launch_bounds__(256) k_rec_scatter(ff::Fr* __restrict__ ev_brp, const u32* __restrict__ limbs,
-                                                     const u32* __restrict__ cell_idx, size_t ncells, bool drop_null) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ncells * CELL_SIZE) return;
-    const u32 c = cell_idx[t >> 6], j = (u32)t & 63;
-    ff::Fr v;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v.v[k] = limbs[t * 8 + k];
-    v = ff::to_mont(v);
-    ff::Fr nul;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) nul.v[k] = 0xffffffffu;
-    nul = ff::to_mont(nul);  // from_u64_arr reduces: (2^256 - 1) mod r in Montgomery form
-    if (drop_null && v == nul) v = ff::Fr::zero();
-    ev_brp[brev32(c * (u32)CELL_SIZE + j, 13)] = v;
-}
-__global__ void __launch_bounds__(256) k_fr_mul(ff::Fr* __restrict__ out, const ff::Fr* __restrict__ a, const ff::Fr* __restrict__ b,
-                                                size_t n) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) out[t] = fr29::mul_blst(a[t], b[t]);
-}
-// 1 / x per element (batch_inverse of the vanishing polynomial over the coset, das.rs:628-630: never zero there)
-__global__ void __launch_bounds__(64) k_fr_inverse(ff::Fr* __restrict__ data, size_t n) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n) data[t] = ff::inverse_bgcd(data[t]);
-}
-
-template <class F>
-C_KZG_RET guarded(F&& f) {
-    try {
-        f();
-        return C_KZG_OK;
-    } catch (const CkErr& e) {
-        static const bool debug = getenv("KZGAMD_DEBUG") != nullptr;
-        if (debug) fprintf(stderr, "kzg_mi355x: %s\n", e.what.c_str());
-        return e.rc == C_KZG_MALLOC ? C_KZG_MALLOC : C_KZG_BADARGS;  // the reference maps every failure to BadArgs
-    } catch (const std::bad_alloc&) {
-        return C_KZG_MALLOC;
-    } catch (...) {
-        return C_KZG_BADARGS;
-    }
-}
 
 }  // namespace
 
@@ -2702,786 +1838,6 @@ extern "C" C_KZG_RET kzgamd_compute_challenges_and_evaluate_batch(Bytes32* zs_ou
     });
 }
 
-namespace {
-
-bool fr_from_be32_checked(ff::Fr& out, const uint8_t* in) {  // FsFr::from_bytes: canonical limbs, false if >= r
-    for (int i = 0; i < 8; ++i) {
-        const uint8_t* q = in + (7 - i) * 4;
-        out.v[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
-    }
-    u64 borrow = 0;
-    for (int k = 0; k < 8; ++k) {
-        u64 d = (u64)out.v[k] - ff::FrParams::p(k) - borrow;
-        borrow = (d >> 32) & 1;
-    }
-    return borrow != 0;
-}
-
-// verify_kzg_proof_batch (kzg/src/eip_4844.rs:380-435) up to the pairing.  Host: the Fiat-Shamir scalar r
-// (compute_r_powers, :328-378) and the three scalar vectors; GPU: decoding + subgroup checks of the 2n points
-// (validate_batched_input, :721-734) and the linear combinations — as ONE two-row MSM over [proofs | commitments | G]:
-//     row 0:  r^i           0      0                 -> proof_lincomb
-//     row 1:  r^i z_i       r^i    -sum r^i y_i      -> rhs  ( = sum r^i (C_i - [y_i]G) + sum r^i z_i proof_i )
-// Batched verification, G1 half, in two steps so that the decode + subgroup check of the 2n points (a 1.7 ms latency
-// chain on its own stream) runs under whatever the caller does in between — the challenges and evaluations of
-// verify_blob_kzg_proof_batch.  The caller holds dev->vmu from begin to finish.
-void verify_g1_begin(const Bytes48* commitments, const Bytes48* proofs, size_t n, KzgAmdSettings* dev) {
-    std::lock_guard<std::mutex> lk(dev->mu);
-    kzgamd::DeviceGuard on_device(dev->device);
-    CK_HIP(on_device.err);
-    const size_t np = 2 * n + 1;
-    dev->ensure_verify(np);
-    // device: [proofs | commitments | generator], decoded and checked
-    dev->vstage.resize(np * 48);
-    memcpy(dev->vstage.data(), proofs, n * 48);
-    memcpy(dev->vstage.data() + n * 48, commitments, n * 48);
-    static const uint8_t G1_GENERATOR_COMPRESSED[48] = {
-        0x97, 0xf1, 0xd3, 0xa7, 0x31, 0x97, 0xd7, 0x94, 0x26, 0x95, 0x63, 0x8c, 0x4f, 0xa9, 0xac, 0x0f,
-        0xc3, 0x68, 0x8c, 0x4f, 0x97, 0x74, 0xb9, 0x05, 0xa1, 0x4e, 0x3a, 0x3f, 0x17, 0x1b, 0xac, 0x58,
-        0x6c, 0x55, 0xe8, 0x3f, 0xf9, 0x7a, 0x1a, 0xef, 0xfb, 0x3a, 0xf0, 0x0a, 0xdb, 0x22, 0xc6, 0xbb};
-    memcpy(dev->vstage.data() + 2 * n * 48, G1_GENERATOR_COMPRESSED, 48);
-    hipStream_t st = dev->stream2;
-    CK_HIP(hipMemcpyAsync(dev->d_vbytes, dev->vstage.data(), dev->vstage.size(), hipMemcpyHostToDevice, st));
-    CK_HIP(hipMemsetAsync(dev->d_vstat, 0, np * sizeof(int), st));
-    CK_HIP(hipMemsetAsync(dev->d_vpts, 0, np * sizeof(AffPt), st));
-    if (!dev->ev_decoded) CK_HIP(hipEventCreateWithFlags(&dev->ev_decoded, hipEventDisableTiming));
-    decode_check_enqueue(dev->d_vpts, dev->d_vstat, (const unsigned char*)dev->d_vbytes, np, st, dev->cfg_wide_check, dev->ev_decoded);
-    CK_HIP(hipGetLastError());
-}
-
-void verify_g1_finish(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commitments, const Bytes32* zs, const Bytes32* ys,
-                      const Bytes48* proofs, size_t n, KzgAmdSettings* dev) {
-    std::vector<ff::Fr> z(n), y(n);
-    bool scalars_ok = true;
-    for (size_t i = 0; i < n; ++i) {
-        scalars_ok = scalars_ok && fr_from_be32_checked(z[i], zs[i].bytes) && fr_from_be32_checked(y[i], ys[i].bytes);
-        z[i] = ff::to_mont(z[i]);
-        y[i] = ff::to_mont(y[i]);
-    }
-    std::lock_guard<std::mutex> lk(dev->mu);
-    kzgamd::DeviceGuard on_device(dev->device);
-    CK_HIP(on_device.err);
-    const size_t np = 2 * n + 1;
-    hipStream_t st = dev->stream2;
-    // host, meanwhile: r = hash_to_bls_field(sha256(domain | 4096 | n | (C_i | z_i | y_i | proof_i)...)), powers of r
-    std::vector<ff::Fr> sc(2 * np, ff::Fr::zero());
-    {
-        kzgamd::Sha256 h;
-        uint8_t head[32] = {0};
-        memcpy(head, "RCKZGBATCH___V1_", 16);
-        const uint64_t nfe = N, nn = n;
-        for (int i = 0; i < 8; ++i) {
-            head[16 + 7 - i] = (uint8_t)(nfe >> (8 * i));
-            head[24 + 7 - i] = (uint8_t)(nn >> (8 * i));
-        }
-        h.update(head, 32);
-        for (size_t i = 0; i < n; ++i) {
-            h.update(commitments[i].bytes, 48);
-            h.update(zs[i].bytes, 32);
-            h.update(ys[i].bytes, 32);
-            h.update(proofs[i].bytes, 48);
-        }
-        uint8_t digest[32];
-        h.finish(digest);
-        ff::Fr v;
-        for (int i = 0; i < 8; ++i) {
-            const uint8_t* q = digest + (7 - i) * 4;
-            v.v[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
-        }
-        const ff::Fr r = ff::mul(v, ff::Fr::r2());  // Montgomery form of (v mod r)
-        ff::Fr pw = ff::Fr::one(), sy = ff::Fr::zero();
-        for (size_t i = 0; i < n; ++i) {
-            sc[i] = pw;                          // row 0: proofs
-            sc[np + i] = ff::mul(pw, z[i]);      // row 1: proofs
-            sc[np + n + i] = pw;                 // row 1: commitments
-            sy = ff::add(sy, ff::mul(pw, y[i]));
-            pw = ff::mul(pw, r);
-        }
-        sc[np + 2 * n] = ff::neg(sy);            // row 1: generator
-    }
-    // The MSM starts as soon as the points are decoded, next to their membership test (0.25 ms on stream2): if a point
-    // fails it — or is no encoding at all: its slot stays zero — the sums below are garbage that nobody reads.
-    blst_p1 out[2];
-    if (scalars_ok) {
-        try {
-            CK_HIP(hipEventSynchronize(dev->ev_decoded));
-            if (!dev->msm_verify) dev->msm_verify = kzgamd::msm_create(dev->d_vpts, np, true, false, true, kzgamd::G1_TRUSTED, &dev->opt);
-            else kzgamd::msm_reset_points(dev->msm_verify, dev->d_vpts, np);
-            kzgamd::msm_run_host(dev->msm_verify, out, sc.data(), np, 2);
-        } catch (...) {
-            (void)hipStreamSynchronize(st);  // nothing of this call stays in flight
-            throw;
-        }
-    }
-    std::vector<int> stat(np);
-    CK_HIP(hipMemcpyAsync(stat.data(), dev->d_vstat, np * sizeof(int), hipMemcpyDeviceToHost, st));
-    CK_HIP(hipStreamSynchronize(st));
-    CK_REQUIRE(scalars_ok, "Invalid scalar");
-    for (size_t i = 0; i < np; ++i) CK_REQUIRE(stat[i] != 1, "Invalid G1 encoding");
-    for (size_t i = 0; i < n; ++i) CK_REQUIRE(stat[i] == 0, "Invalid proof");
-    for (size_t i = n; i < 2 * n; ++i) CK_REQUIRE(stat[i] == 0, "Invalid commitment");
-    *proof_lincomb = out[0];
-    *rhs = out[1];
-}
-
-void verify_batch_g1(blst_p1* proof_lincomb, blst_p1* rhs, const Bytes48* commitments, const Bytes32* zs, const Bytes32* ys,
-                     const Bytes48* proofs, size_t n, KzgAmdSettings* dev) {
-    std::lock_guard<std::mutex> vlk(dev->vmu);
-    // (the scalars are validated before anything is launched, as before)
-    for (size_t i = 0; i < n; ++i) {
-        ff::Fr t;
-        CK_REQUIRE(fr_from_be32_checked(t, zs[i].bytes) && fr_from_be32_checked(t, ys[i].bytes), "Invalid scalar");
-    }
-    verify_g1_begin(commitments, proofs, n, dev);
-    verify_g1_finish(proof_lincomb, rhs, commitments, zs, ys, proofs, n, dev);
-}
-
-}  // namespace
-
-extern "C" C_KZG_RET kzgamd_verify_kzg_proof_batch_g1(blst_p1* proof_lincomb_out, blst_p1* rhs_out, const Bytes48* commitments,
-                                                      const Bytes32* zs, const Bytes32* ys, const Bytes48* proofs, size_t n,
-                                                      const CKZGSettings* s) {
-    if (!proof_lincomb_out || !rhs_out) return C_KZG_BADARGS;
-    KzgAmdSettings* dev = lookup(s);
-    if (!dev) return C_KZG_BADARGS;
-    if (n == 0) {
-        memset(proof_lincomb_out, 0, sizeof *proof_lincomb_out);
-        memset(rhs_out, 0, sizeof *rhs_out);
-        return C_KZG_OK;
-    }
-    if (!commitments || !zs || !ys || !proofs) return C_KZG_BADARGS;
-    return guarded([&] { verify_batch_g1(proof_lincomb_out, rhs_out, commitments, zs, ys, proofs, n, dev); });
-}
-
-// verify_blob_kzg_proof_batch (kzg/src/eip_4844.rs:736-832) up to the pairing: challenges + evaluations on the GPU
-// (:690-719), then the G1 half above.  The caller finishes with  e(proof_lincomb, [tau]G2) == e(rhs, G2).
-extern "C" C_KZG_RET kzgamd_verify_blob_kzg_proof_batch_g1(blst_p1* proof_lincomb_out, blst_p1* rhs_out, const Blob* blobs,
-                                                           const Bytes48* commitments, const Bytes48* proofs, size_t n,
-                                                           const CKZGSettings* s) {
-    if (!proof_lincomb_out || !rhs_out) return C_KZG_BADARGS;
-    KzgAmdSettings* dev = lookup(s);
-    if (!dev) return C_KZG_BADARGS;
-    if (n == 0) {
-        memset(proof_lincomb_out, 0, sizeof *proof_lincomb_out);
-        memset(rhs_out, 0, sizeof *rhs_out);
-        return C_KZG_OK;
-    }
-    if (!blobs || !commitments || !proofs) return C_KZG_BADARGS;
-    return guarded([&] {
-        std::vector<Bytes32> zs(n), ys(n);
-        std::lock_guard<std::mutex> vlk(dev->vmu);
-        verify_g1_begin(commitments, proofs, n, dev);  // decode + subgroup check run under the evaluations
-        try {
-            prove_batch(nullptr, ys.data(), blobs, nullptr, commitments, n, dev, zs.data(), true);
-        } catch (...) {
-            (void)hipStreamSynchronize(dev->stream2);
-            throw;
-        }
-        verify_g1_finish(proof_lincomb_out, rhs_out, commitments, zs.data(), ys.data(), proofs, n, dev);
-    });
-}
-
-namespace {
-
-// check_proof_single (blst/src/types/kzg_settings.rs:178-196) on decoded, validated inputs.  The reference tests
-//     e(C - [y]G, G2) == e(proof, [tau]G2 - [z]G2);
-// with the [z] moved to the G1 side (bilinearity; the proof is a checked r-torsion point) the same statement is
-//     e(C - [y]G + [z]proof, G2) == e(proof, [tau]G2),
-// which pairs with the two fixed G2 points of the setup only: their line tables are cached (host_pairing.h), and the
-// G2 scalar multiplication becomes a G1 one.  One pairing-product check on the host (the reference keeps the pairing
-// on the CPU too).
-bool check_proof_single(const blst_p1& commitment, const blst_p1& proof, const ff::Fr& z_plain, const ff::Fr& y_plain,
-                        KzgAmdSettings* dev) {
-    using namespace kzgamd::pairing;
-    kzgamd::HostJac g;
-    {
-        const uint64_t GX[6] = {0x5cb38790fd530c16ull, 0x7817fc679976fff5ull, 0x154f95c7143ba1c1ull,
-                                0xf0ae6acdf3d0e747ull, 0xedce6ecc21dbf440ull, 0x120177419e0bfb75ull};
-        const uint64_t GY[6] = {0xbaac93d50ce72271ull, 0x8c22631a7918fd8eull, 0xdd595f13570725ceull,
-                                0x51ac582950405194ull, 0x0e1c8c3fad0059c0ull, 0x0bbc3efc5008a26aull};
-        for (int k = 0; k < 6; ++k) {
-            g.x.v[2 * k] = (u32)GX[k];
-            g.x.v[2 * k + 1] = (u32)(GX[k] >> 32);
-            g.y.v[2 * k] = (u32)GY[k];
-            g.y.v[2 * k + 1] = (u32)(GY[k] >> 32);
-        }
-        g.z = ff::Fp::one();
-    }
-    g.y = hfp::neg(g.y);  // -G
-    kzgamd::HostJac pi;
-    memcpy(&pi, &proof, sizeof pi);
-    // [z]proof - [y]G: one joint double-and-add over the 255 bits
-    kzgamd::HostJac acc;
-    acc.x = acc.y = acc.z = ff::Fp::zero();
-    for (int bit = 254; bit >= 0; --bit) {
-        acc = kzgamd::host_jac_dbl(acc);
-        if ((y_plain.v[bit >> 5] >> (bit & 31)) & 1) acc = kzgamd::host_jac_add(acc, g);
-        if ((z_plain.v[bit >> 5] >> (bit & 31)) & 1) acc = kzgamd::host_jac_add(acc, pi);
-    }
-    kzgamd::HostJac c;
-    memcpy(&c, &commitment, sizeof c);
-    const kzgamd::HostJac lhs = kzgamd::host_jac_add(c, acc);
-    blst_p1 a1;
-    memcpy(&a1, &lhs, sizeof a1);
-    const G2Jac g2gen = g2_generator();
-    blst_p2 a2, b2;
-    memcpy(&a2, &g2gen, sizeof a2);
-    memcpy(&b2, &dev->g2_monomial[1], sizeof b2);
-    return pairings_verify(&a1, &a2, &proof, &b2);
-}
-
-// FsG1::from_bytes + the is_inf / is_valid test of verify_kzg_proof_rust (kzg/src/eip_4844.rs:603-608)
-void decode_valid_g1(blst_p1& out, const uint8_t* bytes, const char* what) {
-    CK_REQUIRE(kzgamd::host_p1_uncompress(&out, bytes), std::string("Invalid ") + what);
-    CK_REQUIRE(kzgamd::host_p1_in_g1(&out), std::string("Invalid ") + what);
-}
-
-}  // namespace
-
-// blst/src/eip_4844.rs:383-405 -> verify_kzg_proof_raw (kzg/src/eip_4844.rs:613-637)
-extern "C" C_KZG_RET verify_kzg_proof(bool* ok, const Bytes48* commitment_bytes, const Bytes32* z_bytes, const Bytes32* y_bytes,
-                                      const Bytes48* proof_bytes, const CKZGSettings* s) {
-    if (!ok || !commitment_bytes || !z_bytes || !y_bytes || !proof_bytes) return C_KZG_BADARGS;
-    KzgAmdSettings* dev = lookup(s);
-    if (!dev) return C_KZG_BADARGS;
-    return guarded([&] {
-        blst_p1 c, pr;
-        ff::Fr z, y;
-        CK_REQUIRE(kzgamd::host_p1_uncompress(&c, commitment_bytes->bytes), "Invalid commitment");
-        CK_REQUIRE(fr_from_be32_checked(z, z_bytes->bytes), "Invalid scalar");
-        CK_REQUIRE(fr_from_be32_checked(y, y_bytes->bytes), "Invalid scalar");
-        CK_REQUIRE(kzgamd::host_p1_uncompress(&pr, proof_bytes->bytes), "Invalid proof");
-        CK_REQUIRE(kzgamd::host_p1_in_g1(&c), "Invalid commitment");
-        CK_REQUIRE(kzgamd::host_p1_in_g1(&pr), "Invalid proof");
-        *ok = check_proof_single(c, pr, z, y, dev);
-    });
-}
-
-// blst/src/eip_4844.rs:410-430 -> verify_blob_kzg_proof_raw (kzg/src/eip_4844.rs:667-688): challenge and evaluation
-// on the GPU, one pairing check on the host
-extern "C" C_KZG_RET verify_blob_kzg_proof(bool* ok, const Blob* blob, const Bytes48* commitment_bytes,
-                                           const Bytes48* proof_bytes, const CKZGSettings* s) {
-    if (!ok || !blob || !commitment_bytes || !proof_bytes) return C_KZG_BADARGS;
-    KzgAmdSettings* dev = lookup(s);
-    if (!dev) return C_KZG_BADARGS;
-    return guarded([&] {
-        blst_p1 c, pr;
-        CK_REQUIRE(host_blob_valid(blob->bytes), "Invalid scalar");           // bytes_to_blob
-        // the two points are decoded and subgroup-checked (0.3 ms of one core each) on two helper threads while this
-        // one hashes the challenge and the GPU evaluates the polynomial
-        bool c_ok = false, pr_ok = false;
-        std::thread tc, tp;
-        struct Joiner {  // declared before the threads start: an exception (also out of the second thread's creation)
-            std::thread &a, &b;  // must not leave a joinable thread behind
-            ~Joiner() {
-                if (a.joinable()) a.join();
-                if (b.joinable()) b.join();
-            }
-        } joiner{tc, tp};
-        tc = std::thread([&] {
-            c_ok = kzgamd::host_p1_uncompress(&c, commitment_bytes->bytes) && kzgamd::host_p1_in_g1(&c);  // infinity passes
-        });
-        tp = std::thread([&] {
-            pr_ok = kzgamd::host_p1_uncompress(&pr, proof_bytes->bytes) && kzgamd::host_p1_in_g1(&pr);
-        });
-        Bytes32 zb, yb;
-        {
-            LaneRef lane(dev, 1);
-            prove_batch(nullptr, &yb, blob, nullptr, commitment_bytes, 1, lane.use, &zb, true);
-        }
-        tc.join();
-        tp.join();
-        CK_REQUIRE(c_ok, "Invalid commitment");
-        CK_REQUIRE(pr_ok, "Invalid proof");
-        ff::Fr z, y;
-        CK_REQUIRE(fr_from_be32_checked(z, zb.bytes) && fr_from_be32_checked(y, yb.bytes), "Invalid scalar");
-        *ok = check_proof_single(c, pr, z, y, dev);
-    });
-}
-
-// blst/src/eip_4844.rs:435-471 -> verify_blob_kzg_proof_batch_raw (kzg/src/eip_4844.rs:736-866): n == 0 is true,
-// n == 1 the single verification, otherwise challenges, evaluations and the three linear combinations on the GPU
-// and ONE pairing check e(sum r^i proof_i, [tau]G2) == e(rhs, G2) on the host
-extern "C" C_KZG_RET verify_blob_kzg_proof_batch(bool* ok, const Blob* blobs, const Bytes48* commitments_bytes,
-                                                 const Bytes48* proofs_bytes, size_t n, const CKZGSettings* s) {
-    if (!ok) return C_KZG_BADARGS;
-    *ok = false;
-    KzgAmdSettings* dev = lookup(s);
-    if (!dev) return C_KZG_BADARGS;
-    if (n == 0) {
-        *ok = true;
-        return C_KZG_OK;
-    }
-    if (!blobs || !commitments_bytes || !proofs_bytes) return C_KZG_BADARGS;
-    if (n == 1) return verify_blob_kzg_proof(ok, blobs, commitments_bytes, proofs_bytes, s);
-    return guarded([&] {
-        blst_p1 pl, rhs;
-        std::vector<Bytes32> zs(n), ys(n);
-        {
-            std::lock_guard<std::mutex> vlk(dev->vmu);
-            verify_g1_begin(commitments_bytes, proofs_bytes, n, dev);  // decode + subgroup check run under the evaluations
-            try {
-                prove_batch(nullptr, ys.data(), blobs, nullptr, commitments_bytes, n, dev, zs.data(), true);
-            } catch (...) {
-                (void)hipStreamSynchronize(dev->stream2);  // the decode kernel reads dev->vstage's device copy: drain it
-                throw;
-            }
-            verify_g1_finish(&pl, &rhs, commitments_bytes, zs.data(), ys.data(), proofs_bytes, n, dev);
-        }
-        blst_p2 g2gen, g2tau;
-        const kzgamd::pairing::G2Jac gen = kzgamd::pairing::g2_generator();
-        memcpy(&g2gen, &gen, sizeof g2gen);
-        memcpy(&g2tau, &dev->g2_monomial[1], sizeof g2tau);
-        *ok = kzgamd::pairing::pairings_verify(&pl, &g2tau, &rhs, &g2gen);
-    });
-}
-
-
-// ================================================================ EIP-7594: cell verification and recovery
-namespace {
-
-constexpr size_t CELLS_PER_EXT_BLOB = 2 * CELLS_PER_BLOB;  // 128
-constexpr size_t BYTES_PER_CELL = CELL_SIZE * 32;
-
-inline u32 rbl7(u32 i) {  // CELL_INDICES_RBL (das.rs:87-96): reverse_bits_limited(128, i)
-    u32 r = 0;
-    for (int b = 0; b < 7; ++b)
-        if (i & (1u << b)) r |= 1u << (6 - b);
-    return r;
-}
-
-inline void put_u64_be(uint8_t* p, uint64_t v) {
-    for (int i = 0; i < 8; ++i) p[7 - i] = (uint8_t)(v >> (8 * i));
-}
-
-// hash_to_bls_field (kzg/src/eip_4844.rs:916-918): 32 big-endian bytes reduced mod r, Montgomery form
-inline ff::Fr hash_to_fr(const uint8_t digest[32]) {
-    ff::Fr v;
-    for (int i = 0; i < 8; ++i) {
-        const uint8_t* q = digest + (7 - i) * 4;
-        v.v[i] = ((u32)q[0] << 24) | ((u32)q[1] << 16) | ((u32)q[2] << 8) | (u32)q[3];
-    }
-    return ff::mul(v, ff::Fr::r2());
-}
-
-// compute_verify_cell_kzg_proof_batch_challenge (kzg/src/das.rs:391-452) on the caller's bytes: FsG1::to_bytes /
-// FsFr::to_bytes of a decoded, valid input are the input bytes themselves
-ff::Fr cell_batch_challenge(const Bytes48* commitments, size_t ncommit, const uint64_t* commitment_indices,
-                            const uint64_t* cell_indices, const Cell* cells, const Bytes48* proofs, size_t ncells) {
-    kzgamd::Sha256 h;
-    uint8_t head[48];
-    memcpy(head, "RCKZGCBATCH__V1_", 16);
-    put_u64_be(head + 16, N);
-    put_u64_be(head + 24, CELL_SIZE);
-    put_u64_be(head + 32, ncommit);
-    put_u64_be(head + 40, ncells);
-    h.update(head, 48);
-    for (size_t i = 0; i < ncommit; ++i) h.update(commitments[i].bytes, 48);
-    for (size_t i = 0; i < ncells; ++i) {
-        uint8_t ix[16];
-        put_u64_be(ix, commitment_indices[i]);
-        put_u64_be(ix + 8, cell_indices[i]);
-        h.update(ix, 16);
-        h.update(cells[i].bytes, BYTES_PER_CELL);
-        h.update(proofs[i].bytes, 48);
-    }
-    uint8_t digest[32];
-    h.finish(digest);
-    return hash_to_fr(digest);
-}
-
-// cells -> field elements (FsFr::from_bytes per element, c_bindings.rs:225-233): canonical limbs, false if any >= r
-bool cells_to_limbs(std::vector<ff::Fr>& out, const Cell* cells, size_t ncells) {
-    out.resize(ncells * CELL_SIZE);
-    bool ok = true;
-    for (size_t i = 0; i < ncells; ++i)
-        for (size_t j = 0; j < CELL_SIZE; ++j) ok = fr_from_be32_checked(out[i * CELL_SIZE + j], cells[i].bytes + 32 * j) && ok;
-    return ok;
-}
-
-// decode `np` compressed G1 points on the GPU (stream2): AffPt slots in dev->d_vpts, per-point status in dev->d_vstat
-// (0 ok, 1 not an encoding of a curve point, 2 on the curve but outside G1).  Caller holds dev->vmu.
-// `tail` (optional): `ntail` slots decoded and checked by an earlier call, appended behind the np decoded ones (status 0)
-void decode_points_begin(KzgAmdSettings* dev, const std::vector<uint8_t>& bytes, size_t np, const AffPt* tail = nullptr,
-                         size_t ntail = 0) {
-    std::lock_guard<std::mutex> lk(dev->mu);
-    kzgamd::DeviceGuard on_device(dev->device);
-    CK_HIP(on_device.err);
-    dev->ensure_verify(np + ntail);
-    dev->vstage = bytes;
-    hipStream_t st = dev->stream2;
-    CK_HIP(hipMemcpyAsync(dev->d_vbytes, dev->vstage.data(), np * 48, hipMemcpyHostToDevice, st));
-    CK_HIP(hipMemsetAsync(dev->d_vstat, 0, (np + ntail) * sizeof(int), st));
-    CK_HIP(hipMemsetAsync(dev->d_vpts, 0, np * sizeof(AffPt), st));
-    if (ntail) CK_HIP(hipMemcpyAsync(dev->d_vpts + np, tail, ntail * sizeof(AffPt), hipMemcpyDeviceToDevice, st));
-    if (!dev->ev_decoded) CK_HIP(hipEventCreateWithFlags(&dev->ev_decoded, hipEventDisableTiming));
-    decode_check_enqueue(dev->d_vpts, dev->d_vstat, (const unsigned char*)dev->d_vbytes, np, st, dev->cfg_wide_check, dev->ev_decoded);
-    CK_HIP(hipGetLastError());
-}
-std::vector<int> decode_points_status(KzgAmdSettings* dev, size_t np) {
-    std::lock_guard<std::mutex> lk(dev->mu);
-    kzgamd::DeviceGuard on_device(dev->device);
-    CK_HIP(on_device.err);
-    std::vector<int> stat(np);
-    CK_HIP(hipMemcpyAsync(stat.data(), dev->d_vstat, np * sizeof(int), hipMemcpyDeviceToHost, dev->stream2));
-    CK_HIP(hipStreamSynchronize(dev->stream2));
-    return stat;
-}
-
-// The aggregated interpolation polynomial of verify_cell_kzg_proof_batch
-// (compute_commitment_to_aggregated_interpolation_poly, kzg/src/das.rs:778-835) on the GPU — on the host its ~50 000
-// field multiplications were three quarters of a 128-cell call.
-// k_vcell_agg: agg[col][brp6(f)] = sum over the cells i of column col of r^i * cell_i[f]  (r^i Montgomery, the cell
-// elements canonical: the products and sums stay canonical; columns nobody asked about stay zero);
-// then 128 inverse transforms of 64 values (ntt.hip);
-// k_vcell_interp: interp[k] = sum_col v[col][k] * h_col^-k,  h_col^-k = roots_of_unity[(8192 - rbl7(col)) k mod 8192].
-// cols = [start of column 0 .. 128 in `order` (129 words) | order: the cells' indices grouped by column, ascending inside]
-__global__ void __launch_bounds__(256) k_vcell_agg(ff::Fr* __restrict__ agg, const u32* __restrict__ cells,
-                                                   const u32* __restrict__ cols, const ff::Fr* __restrict__ pw) {
-    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= CELLS_PER_EXT_BLOB * CELL_SIZE) return;
-    const u32 col = t >> 6, f = t & 63u;
-    ff::Fr acc = ff::Fr::zero();
-    const u32* order = cols + CELLS_PER_EXT_BLOB + 1;
-    for (u32 j = cols[col]; j < cols[col + 1]; ++j) {
-        const size_t i = order[j];
-        ff::Fr c;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) c.v[k] = cells[(i * CELL_SIZE + f) * 8 + k];
-        acc = ff::add(acc, fmul(pw[i], c));
-    }
-    agg[col * CELL_SIZE + (__builtin_bitreverse32(f) >> 26)] = acc;
-}
-__global__ void __launch_bounds__(128) k_vcell_interp(ff::Fr* __restrict__ out, const ff::Fr* __restrict__ v,
-                                                      const ff::Fr* __restrict__ roots8192) {
-    __shared__ ff::Fr sh[CELLS_PER_EXT_BLOB];
-    const u32 k = blockIdx.x, col = threadIdx.x;
-    const u32 rbl = __builtin_bitreverse32(col) >> 25;  // CELL_INDICES_RBL (das.rs:87-96)
-    const u32 idx = ((2u * (u32)N - rbl) * k) & (2u * (u32)N - 1u);
-    sh[col] = fmul(roots8192[idx], v[col * CELL_SIZE + k]);  // Montgomery x canonical -> canonical
-    __syncthreads();
-    for (u32 off = CELLS_PER_EXT_BLOB / 2; off > 0; off >>= 1) {
-        if (col < off) sh[col] = ff::add(sh[col], sh[col + off]);
-        __syncthreads();
-    }
-    if (col == 0) out[k] = sh[0];
-}
-
-// verify_cell_kzg_proof_batch (kzg/src/das.rs:294-389).  Host: parsing, the Fiat-Shamir scalar, the powers of r.
-// GPU: the aggregated interpolation polynomial (k_vcell_agg, <= 128 inverse transforms of 64 values, k_vcell_interp;
-// compute_commitment_to_aggregated_interpolation_poly, :778-835), decoding + subgroup checks of proofs and commitments, and every linear
-// combination as ONE two-row MSM over [proofs | unique commitments | g1_monomial[0..64)]:
-//     row 0:  r^i             0          0        -> proof_lincomb
-//     row 1:  r^i h_k(i)^64   weight_j   -I_k     -> sum_j w_j C_j - [I(s)] + sum_i r^i h^64 proof_i
-// then one pairing check e(row 1, G2) == e(row 0, [s^64]G2) on the host.
-void verify_cells(bool* ok, const Bytes48* commitments_bytes, const uint64_t* cell_indices, const Cell* cells,
-                  const Bytes48* proofs_bytes, size_t n, const CKZGSettings* cs, KzgAmdSettings* dev) {
-    for (size_t i = 0; i < n; ++i) CK_REQUIRE(cell_indices[i] < CELLS_PER_EXT_BLOB, "Invalid cell index");
-    // deduplicate_with_indices (das.rs:57-76): first occurrences, in order
-    std::vector<Bytes48> uniq;
-    std::vector<uint64_t> cidx(n);
-    for (size_t i = 0; i < n; ++i) {
-        size_t j = 0;
-        while (j < uniq.size() && memcmp(uniq[j].bytes, commitments_bytes[i].bytes, 48) != 0) ++j;
-        if (j == uniq.size()) uniq.push_back(commitments_bytes[i]);
-        cidx[i] = j;
-    }
-    const size_t m = uniq.size(), np = n + m + CELL_SIZE;
-    std::lock_guard<std::mutex> vlk(dev->vmu);
-    if (dev->mono64_bytes.empty()) {
-        dev->mono64_bytes.resize(CELL_SIZE * 48);
-        compress_on_host(dev->mono64_bytes.data(), cs->g1_values_monomial, CELL_SIZE);
-    }
-    // the 64 setup points are decoded and tested by the first call of a settings object and kept as slots (d_mono64)
-    const bool have_mono = dev->d_mono64 != nullptr;
-    const size_t ndec = have_mono ? n + m : np;
-    std::vector<uint8_t> stage(ndec * 48);
-    memcpy(stage.data(), proofs_bytes, n * 48);
-    memcpy(stage.data() + n * 48, uniq.data(), m * 48);
-    if (!have_mono) memcpy(stage.data() + (n + m) * 48, dev->mono64_bytes.data(), CELL_SIZE * 48);
-    decode_points_begin(dev, stage, ndec, dev->d_mono64, have_mono ? CELL_SIZE : 0);
-    // host, meanwhile (the decode + subgroup tests are 0.75 ms of GPU latency): the cells' field elements, ...
-    std::vector<ff::Fr> cf;
-    if (!cells_to_limbs(cf, cells, n)) {
-        (void)decode_points_status(dev, np);  // nothing of this call stays in flight
-        throw CkErr{C_KZG_BADARGS, "Invalid scalar"};
-    }
-    const ff::Fr* roots = reinterpret_cast<const ff::Fr*>(cs->roots_of_unity);
-    const ff::Fr r = cell_batch_challenge(uniq.data(), m, cidx.data(), cell_indices, cells, proofs_bytes, n);
-    std::vector<ff::Fr> sc(2 * np, ff::Fr::zero());
-    std::vector<ff::Fr> pws(n);
-    std::vector<u32> cols32(CELLS_PER_EXT_BLOB + 1 + n, 0u);  // column starts, then the cells grouped by column (k_vcell_agg)
-    for (size_t i = 0; i < n; ++i) ++cols32[(size_t)cell_indices[i] + 1];
-    for (size_t c = 0; c < CELLS_PER_EXT_BLOB; ++c) cols32[c + 1] += cols32[c];
-    {
-        std::vector<u32> cursor(cols32.begin(), cols32.begin() + CELLS_PER_EXT_BLOB);
-        for (size_t i = 0; i < n; ++i) cols32[CELLS_PER_EXT_BLOB + 1 + cursor[(size_t)cell_indices[i]]++] = (u32)i;
-    }
-    ff::Fr pw = ff::Fr::one();
-    for (size_t i = 0; i < n; ++i) {
-        const size_t col = (size_t)cell_indices[i];
-        sc[i] = pw;                                                                     // row 0: proofs
-        sc[np + i] = ff::mul(pw, roots[rbl7((u32)col) * CELL_SIZE]);                    // row 1: r^i * h_k^64 (:837-884)
-        sc[np + n + cidx[i]] = ff::add(sc[np + n + cidx[i]], pw);                       // row 1: commitment weights (:698-743)
-        pws[i] = pw;
-        pw = ff::mul(pw, r);
-    }
-    // the aggregated interpolation polynomial (:778-835) on the GPU: k_vcell_agg, 128 inverse transforms of 64, k_vcell_interp
-    std::vector<ff::Fr> interp(CELL_SIZE);
-    {
-        std::lock_guard<std::mutex> lk(dev->mu);
-        kzgamd::DeviceGuard on_device(dev->device);
-        CK_HIP(on_device.err);
-        dev->ensure_recover();
-        dev->ensure_vcells(n);
-        if (!dev->d_roots8192) {
-            CK_HIP(hipMalloc(&dev->d_roots8192, (2 * N + 1) * sizeof(ff::Fr)));
-            CK_HIP(hipMemcpy(dev->d_roots8192, cs->roots_of_unity, (2 * N + 1) * sizeof(ff::Fr), hipMemcpyHostToDevice));
-        }
-        hipStream_t st = dev->stream;
-        CK_HIP(hipMemcpyAsync(dev->d_vc_cells, cf.data(), n * CELL_SIZE * 32, hipMemcpyHostToDevice, st));
-        CK_HIP(hipMemcpyAsync(dev->d_vc_cols, cols32.data(), cols32.size() * sizeof(u32), hipMemcpyHostToDevice, st));
-        CK_HIP(hipMemcpyAsync(dev->d_vc_pw, pws.data(), n * sizeof(ff::Fr), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_vcell_agg, dim3((unsigned)(CELLS_PER_EXT_BLOB * CELL_SIZE / 256)), dim3(256), 0, st, dev->d_rec[0],
-                           (const u32*)dev->d_vc_cells, (const u32*)dev->d_vc_cols, (const ff::Fr*)dev->d_vc_pw);
-        if (kzgamd_ntt_fr_device(dev->ntt, dev->d_rec[1], dev->d_rec[0], CELL_SIZE, CELLS_PER_EXT_BLOB, 1, st) != 0)
-            throw CkErr{C_KZG_ERROR, "ntt"};
-        hipLaunchKernelGGL(k_vcell_interp, dim3((unsigned)CELL_SIZE), dim3((unsigned)CELLS_PER_EXT_BLOB), 0, st, dev->d_rec[2],
-                           (const ff::Fr*)dev->d_rec[1], (const ff::Fr*)dev->d_roots8192);
-        CK_HIP(hipMemcpyAsync(interp.data(), dev->d_rec[2], CELL_SIZE * sizeof(ff::Fr), hipMemcpyDeviceToHost, st));
-        CK_HIP(hipStreamSynchronize(st));
-    }
-    for (size_t k = 0; k < CELL_SIZE; ++k) interp[k] = ff::to_mont(interp[k]);  // the kernels work on canonical values
-    for (size_t k = 0; k < CELL_SIZE; ++k) sc[np + n + m + k] = ff::neg(interp[k]);
-    // the MSM next to the membership test of its points, as in verify_g1_finish
-    blst_p1 out[2];
-    try {
-        std::lock_guard<std::mutex> lk(dev->mu);
-        kzgamd::DeviceGuard on_device(dev->device);
-        CK_HIP(on_device.err);
-        CK_HIP(hipEventSynchronize(dev->ev_decoded));
-        if (!dev->msm_verify) dev->msm_verify = kzgamd::msm_create(dev->d_vpts, np, true, false, true, kzgamd::G1_TRUSTED, &dev->opt);
-        else kzgamd::msm_reset_points(dev->msm_verify, dev->d_vpts, np);
-        kzgamd::msm_run_host(dev->msm_verify, out, sc.data(), np, 2);
-    } catch (...) {
-        (void)decode_points_status(dev, np);  // nothing of this call stays in flight
-        throw;
-    }
-    const std::vector<int> stat = decode_points_status(dev, np);
-    for (size_t i = 0; i < np; ++i) CK_REQUIRE(stat[i] != 1, "Invalid G1 encoding");
-    for (size_t i = 0; i < n; ++i) CK_REQUIRE(stat[i] == 0, "Proof is not valid");
-    for (size_t i = n; i < n + m; ++i) CK_REQUIRE(stat[i] == 0, "Commitment is not valid");
-    if (!have_mono) {
-        bool mono_ok = true;
-        for (size_t i = n + m; i < np; ++i) mono_ok = mono_ok && stat[i] == 0;
-        if (mono_ok) {
-            std::lock_guard<std::mutex> lk(dev->mu);
-            kzgamd::DeviceGuard on_device(dev->device);
-            CK_HIP(on_device.err);
-            AffPt* keep = nullptr;
-            CK_HIP(hipMalloc(&keep, CELL_SIZE * sizeof(AffPt)));
-            if (hipMemcpy(keep, dev->d_vpts + n + m, CELL_SIZE * sizeof(AffPt), hipMemcpyDeviceToDevice) == hipSuccess) dev->d_mono64 = keep;
-            else (void)hipFree(keep);
-        }
-    }
-    blst_p2 g2gen, g2s64;
-    const kzgamd::pairing::G2Jac gen = kzgamd::pairing::g2_generator();
-    memcpy(&g2gen, &gen, sizeof g2gen);
-    memcpy(&g2s64, &dev->g2_monomial[CELL_SIZE], sizeof g2s64);
-    *ok = kzgamd::pairing::pairings_verify(&out[1], &g2gen, &out[0], &g2s64);
-}
-
-// compute_vanishing_polynomial_from_roots (das.rs:493-518)
-std::vector<ff::Fr> vanishing_from_roots(const std::vector<ff::Fr>& rts) {
-    std::vector<ff::Fr> poly;
-    poly.push_back(ff::neg(rts[0]));
-    for (size_t i = 1; i < rts.size(); ++i) {
-        const ff::Fr nr = ff::neg(rts[i]);
-        poly.push_back(ff::add(nr, poly[i - 1]));
-        for (size_t j = i - 1; j >= 1; --j) poly[j] = ff::add(ff::mul(poly[j], nr), poly[j - 1]);
-        poly[0] = ff::mul(poly[0], nr);
-    }
-    poly.push_back(ff::Fr::one());
-    return poly;
-}
-
-// recover_cells_and_kzg_proofs (kzg/src/das.rs:101-205; recover_cells :566-657): the five 8192-point transforms, the
-// pointwise products, the coset shifts and the inversions on the GPU; the vanishing polynomial of the <= 64 missing
-// cells (65 coefficients) on the host.
-void recover_cells(Cell* recovered_cells, KZGProof* recovered_proofs, const uint64_t* cell_indices, const Cell* cells,
-                   size_t ncells, const CKZGSettings* cs, KzgAmdSettings* dev) {
-    std::vector<ff::Fr> cf;
-    CK_REQUIRE(cells_to_limbs(cf, cells, ncells), "Invalid scalar");
-    CK_REQUIRE(ncells <= CELLS_PER_EXT_BLOB, "Cell length cannot be larger than CELLS_PER_EXT_BLOB");
-    CK_REQUIRE(ncells >= CELLS_PER_EXT_BLOB / 2, "Impossible to recover");
-    std::vector<char> have(CELLS_PER_EXT_BLOB, 0);
-    std::vector<u32> idx32(ncells);
-    for (size_t i = 0; i < ncells; ++i) {
-        CK_REQUIRE(cell_indices[i] < CELLS_PER_EXT_BLOB, "Invalid cell index");
-        if (i + 1 < ncells) CK_REQUIRE(cell_indices[i + 1] > cell_indices[i], "Indices must be in strictly ascending order");
-        have[cell_indices[i]] = 1;
-        idx32[i] = (u32)cell_indices[i];
-    }
-    const ff::Fr* roots = reinterpret_cast<const ff::Fr*>(cs->roots_of_unity);
-    std::lock_guard<std::mutex> lk(dev->mu);
-    kzgamd::DeviceGuard on_device(dev->device);
-    CK_HIP(on_device.err);
-    dev->ensure(1);
-    dev->ensure_cells(1);
-    dev->ensure_recover();
-    hipStream_t st = dev->stream;
-    const size_t E = 2 * N;
-    ff::Fr *A = dev->d_rec[0], *B = dev->d_rec[1], *C = dev->d_rec[2], *D = dev->d_rec[3];
-    auto ntt = [&](ff::Fr* out, const ff::Fr* in, int inverse) {
-        if (kzgamd_ntt_fr_device(dev->ntt, out, in, E, 1, inverse, st) != 0) throw CkErr{C_KZG_ERROR, "ntt"};
-    };
-    auto mul = [&](ff::Fr* out, const ff::Fr* a, const ff::Fr* b) {
-        hipLaunchKernelGGL(k_fr_mul, dim3((unsigned)(E / 256)), dim3(256), 0, st, out, a, b, E);
-    };
-    // the provided evaluations in bit-reversed order, missing ones zero
-    CK_HIP(hipMemsetAsync(A, 0, E * sizeof(ff::Fr), st));
-    CK_HIP(hipMemcpyAsync(dev->d_rec_in, cf.data(), ncells * CELL_SIZE * 32, hipMemcpyHostToDevice, st));
-    CK_HIP(hipMemcpyAsync(dev->d_rec_idx, idx32.data(), ncells * sizeof(u32), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_rec_scatter, dim3((unsigned)((ncells * CELL_SIZE + 255) / 256)), dim3(256), 0, st, A,
-                       (const u32*)dev->d_rec_in, (const u32*)dev->d_rec_idx, ncells, ncells != CELLS_PER_EXT_BLOB);
-    std::vector<ff::Fr> vanishing;  // must outlive the copy below
-    if (ncells != CELLS_PER_EXT_BLOB) {
-        // vanishing_polynomial_for_missing_cells (:520-551): roots w^(64 * brp7(i)) for the missing cells i, short
-        // polynomial stretched by 64
-        std::vector<ff::Fr> rts;
-        for (u32 i = 0; i < CELLS_PER_EXT_BLOB; ++i)
-            if (!have[i]) rts.push_back(roots[(size_t)rbl7(i) * CELL_SIZE]);
-        const std::vector<ff::Fr> shortp = vanishing_from_roots(rts);
-        vanishing.assign(E, ff::Fr::zero());
-        for (size_t i = 0; i < shortp.size(); ++i) vanishing[i * CELL_SIZE] = shortp[i];
-        CK_HIP(hipMemcpyAsync(B, vanishing.data(), E * sizeof(ff::Fr), hipMemcpyHostToDevice, st));
-        ntt(C, B, 0);                      // vanishing_poly_eval
-        mul(A, A, C);                      // extended_evaluation_times_zero
-        ntt(D, A, 1);                      // ..._coeffs
-        mul(D, D, dev->d_pow7);            // coset_fft: shift_poly by 7, then the transform
-        ntt(A, D, 0);                      // extended_evaluations_over_coset
-        mul(B, B, dev->d_pow7);
-        ntt(C, B, 0);                      // vanishing_poly_over_coset
-        hipLaunchKernelGGL(k_fr_inverse, dim3((unsigned)(E / 64)), dim3(64), 0, st, C, E);
-        mul(A, A, C);
-        ntt(D, A, 1);                      // coset_ifft: the transform, then shift_poly by 1/7
-        mul(D, D, dev->d_pow7inv);         // reconstructed_poly_coeff
-        ntt(A, D, 0);                      // its 8192 evaluations, natural order
-        hipLaunchKernelGGL(k_cells_out, dim3((unsigned)(E / 256)), dim3(256), 0, st, reinterpret_cast<u32*>(dev->d_fr_ext),
-                           (const ff::Fr*)A, (size_t)1);
-        CK_HIP(hipMemcpyAsync(recovered_cells, dev->d_fr_ext, E * 32, hipMemcpyDeviceToHost, st));
-    } else {
-        memcpy(recovered_cells, cells, E * 32);
-        if (recovered_proofs) ntt(D, A, 1);  // poly_lagrange_to_monomial of the given cells (:186-188)
-    }
-    if (recovered_proofs) {
-        // compute_fk20_proofs reads the first 4096 coefficients (:190-200, toeplitz_coeffs_stride :659-688)
-        if (!dev->d_roots8192) {
-            CK_HIP(hipMalloc(&dev->d_roots8192, (2 * N + 1) * sizeof(ff::Fr)));
-            CK_HIP(hipMemcpy(dev->d_roots8192, cs->roots_of_unity, (2 * N + 1) * sizeof(ff::Fr), hipMemcpyHostToDevice));
-        }
-        if (!dev->msm_monomial) dev->msm_monomial = kzgamd::msm_create(dev->d_monomial, N, true, true, true, kzgamd::G1_TRUSTED, &dev->opt);
-        dev->ensure_q(1);
-        CK_HIP(hipMemcpyAsync(dev->d_fr_b, D, N * sizeof(ff::Fr), hipMemcpyDeviceToDevice, st));
-        enqueue_cell_proofs(dev, 1, st, false);
-        CK_HIP(hipMemcpyAsync(recovered_proofs, dev->d_proofs, CELLS_PER_EXT_BLOB * 48, hipMemcpyDeviceToHost, st));
-    }
-    CK_HIP(hipStreamSynchronize(st));
-}
-
-}  // namespace
-
-// c_bindings.rs:290-355 -> DAS::verify_cell_kzg_proof_batch (kzg/src/das.rs:294-389)
-extern "C" C_KZG_RET verify_cell_kzg_proof_batch(bool* ok, const Bytes48* commitments_bytes, const uint64_t* cell_indices,
-                                                 const Cell* cells, const Bytes48* proofs_bytes, uint64_t num_cells,
-                                                 const CKZGSettings* s) {
-    if (!ok) return C_KZG_BADARGS;
-    *ok = false;
-    KzgAmdSettings* dev = lookup(s);
-    if (!dev) return C_KZG_BADARGS;
-    if (num_cells == 0) {
-        *ok = true;
-        return C_KZG_OK;
-    }
-    if (!commitments_bytes || !cell_indices || !cells || !proofs_bytes) return C_KZG_BADARGS;
-    return guarded([&] { verify_cells(ok, commitments_bytes, cell_indices, cells, proofs_bytes, (size_t)num_cells, s, dev); });
-}
-
-// c_bindings.rs:202-289 -> DAS::recover_cells_and_kzg_proofs (kzg/src/das.rs:101-205); recovered_proofs may be NULL
-extern "C" C_KZG_RET recover_cells_and_kzg_proofs(Cell* recovered_cells, KZGProof* recovered_proofs, const uint64_t* cell_indices,
-                                                  const Cell* cells, uint64_t num_cells, const CKZGSettings* s) {
-    if (!recovered_cells) return C_KZG_BADARGS;
-    KzgAmdSettings* dev = lookup(s);
-    if (!dev) return C_KZG_BADARGS;
-    if (num_cells && (!cell_indices || !cells)) return C_KZG_BADARGS;
-    return guarded([&] { recover_cells(recovered_cells, recovered_proofs, cell_indices, cells, (size_t)num_cells, s, dev); });
-}
-
-// blst/src/eip_7594.rs:35-97: the Fiat-Shamir scalar of a cell batch (no settings: the inputs are only parsed —
-// FsG1::from_bytes accepts any curve point, blst/src/types/g1.rs:65-87 — and hashed)
-extern "C" C_KZG_RET compute_verify_cell_kzg_proof_batch_challenge(blst_fr* challenge_out, const Bytes48* commitment_bytes,
-                                                                   uint64_t num_commitments, const uint64_t* commitment_indices,
-                                                                   const uint64_t* cell_indices, const Cell* cells,
-                                                                   const Bytes48* proofs_bytes, uint64_t num_cells) {
-    if (!challenge_out) return C_KZG_BADARGS;
-    memset(challenge_out, 0, sizeof *challenge_out);
-    if ((num_commitments && !commitment_bytes) || (num_cells && (!commitment_indices || !cell_indices || !cells || !proofs_bytes)))
-        return C_KZG_BADARGS;
-    return guarded([&] {
-        for (size_t i = 0; i < num_commitments; ++i) {
-            blst_p1 t;
-            CK_REQUIRE(kzgamd::host_p1_uncompress(&t, commitment_bytes[i].bytes), "Invalid commitment");
-        }
-        std::vector<ff::Fr> cf;
-        CK_REQUIRE(cells_to_limbs(cf, cells, (size_t)num_cells), "Invalid scalar");
-        for (size_t i = 0; i < num_cells; ++i) {
-            blst_p1 t;
-            CK_REQUIRE(kzgamd::host_p1_uncompress(&t, proofs_bytes[i].bytes), "Invalid proof");
-        }
-        const ff::Fr r = cell_batch_challenge(commitment_bytes, (size_t)num_commitments, commitment_indices, cell_indices, cells,
-                                              proofs_bytes, (size_t)num_cells);
-        memcpy(challenge_out, &r, sizeof r);
-    });
-}
-
-// ---- host-only helpers over blst_p2 / the pairing (no GPU needed): what a binding test-suite or a caller that
-// wants to finish kzgamd_verify_*_g1 itself uses.  pairings_verify = blst/src/kzg_proofs.rs:73-100.
-extern "C" int kzgamd_pairings_verify(const blst_p1* a1, const blst_p2* a2, const blst_p1* b1, const blst_p2* b2) {
-    if (!a1 || !a2 || !b1 || !b2) return -1;
-    return kzgamd::pairing::pairings_verify(a1, a2, b1, b2) ? 1 : 0;
-}
-extern "C" int kzgamd_p2_uncompress(blst_p2* out, const uint8_t in[96]) {
-    kzgamd::pairing::G2Jac p;
-    if (!out || !in || !kzgamd::pairing::g2_uncompress(p, in)) return 1;
-    memcpy(out, &p, sizeof p);
-    return 0;
-}
-extern "C" void kzgamd_p2_compress(uint8_t out[96], const blst_p2* in) {
-    kzgamd::pairing::G2Jac p;
-    memcpy(&p, in, sizeof p);
-    kzgamd::pairing::g2_compress(out, p);
-}
-extern "C" void kzgamd_p2_generator(blst_p2* out) {
-    const kzgamd::pairing::G2Jac g = kzgamd::pairing::g2_generator();
-    memcpy(out, &g, sizeof g);
-}
-extern "C" void kzgamd_p2_mult(blst_p2* out, const blst_p2* in, const blst_fr* scalar_mont) {
-    kzgamd::pairing::G2Jac p;
-    memcpy(&p, in, sizeof p);
-    ff::Fr k;
-    memcpy(&k, scalar_mont, 32);
-    k = ff::from_mont(k);
-    const kzgamd::pairing::G2Jac r = kzgamd::pairing::g2_mul(p, k.v);
-    memcpy(out, &r, sizeof r);
-}
-extern "C" void kzgamd_p2_add(blst_p2* out, const blst_p2* a, const blst_p2* b) {
-    kzgamd::pairing::G2Jac x, y;
-    memcpy(&x, a, sizeof x);
-    memcpy(&y, b, sizeof y);
-    const kzgamd::pairing::G2Jac r = kzgamd::pairing::g2_add(x, y);
-    memcpy(out, &r, sizeof r);
-}
-
 // blst/src/eip_4844.rs:498-517.  Concurrent callers on one settings object are merged into batches (coalesced_call).
 extern "C" C_KZG_RET compute_blob_kzg_proof(KZGProof* out, const Blob* blob, const Bytes48* commitment_bytes,
                                             const CKZGSettings* s) {
@@ -3531,23 +1887,6 @@ extern "C" void bytes_from_bls_field(Bytes32* out, const blst_fr* in) {         
     fr_limbs_to_be32(out->bytes, v.v);
 }
 
-// kzg/src/eth/c_bindings.rs:356-372 (EIP-7594).  cells or proofs may be NULL, not both (das.rs:250-252).
-extern "C" C_KZG_RET compute_cells_and_kzg_proofs(Cell* cells, KZGProof* proofs, const Blob* blob, const CKZGSettings* s) {
-    if (!blob || (!cells && !proofs)) return C_KZG_BADARGS;
-    KzgAmdSettings* dev = lookup(s);
-    if (!dev) return C_KZG_BADARGS;
-    return guarded([&] { cells_and_proofs(cells ? cells->bytes : nullptr, proofs, blob, 1, s, dev); });
-}
-
-extern "C" C_KZG_RET kzgamd_compute_cells_and_kzg_proofs_batch(Cell* cells, KZGProof* proofs, const Blob* blobs, size_t n,
-                                                               const CKZGSettings* s) {
-    if (!blobs || (!cells && !proofs)) return C_KZG_BADARGS;
-    KzgAmdSettings* dev = lookup(s);
-    if (!dev) return C_KZG_BADARGS;
-    if (n == 0) return C_KZG_OK;
-    return guarded([&] { cells_and_proofs(cells ? cells->bytes : nullptr, proofs, blobs, n, s, dev); });
-}
-
 extern "C" int kzgamd_settings_table_info(const CKZGSettings* s, int which, int* window_bits, int* rows, int* wide_table) {
     KzgAmdSettings* dev = lookup(s);
     if (!dev || which < 0 || which > 2) return -1;
@@ -3569,3 +1908,4 @@ extern "C" void* kzgamd_settings_msm_handle(const CKZGSettings* s) {
     KzgAmdSettings* dev = lookup(s);
     return dev ? (void*)dev->msm : nullptr;
 }
+

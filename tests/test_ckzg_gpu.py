@@ -434,7 +434,7 @@ def test_concurrent_callers_share_one_settings_handle(kzg, settings, oracle, ora
 def test_sixteen_concurrent_callers_every_result_against_the_oracle(kzg, settings, oracle, oracle_settings, golden):
     """16 threads on ONE CKZGSettings, as the reference's rayon workers use it (kzg/src/eip_4844.rs:781-805): single
     commitments, single proofs, proofs at explicit points and small batches interleaved (the calls overlap on the
-    lanes of the settings object, see ckzg.hip), a large batch on the parent's own pipeline in the middle; every
+    lanes of the settings object, see ckzg_shared.h and ckzg.hip), a large batch on the parent's own pipeline in the middle; every
     result is compared with the oracle's, and an invalid blob in one thread fails only that call."""
     import threading
 
