@@ -712,7 +712,7 @@ def main():
                     "b1_prepared_threads_16": o16.get("b1_prepared_threads_16"),
                     "b1_prepared_threads_16_over_1": (o16.get("b1_prepared_threads_16") or 0) / max(o1.get("b1_prepared_threads_1") or 1, 1),
                     "b1_prepared_threads_16_calls_not_combined": b16nc.get("b1_prepared_threads_16"),
-                    "b1_unit": "mult_pippenger_prepared calls/s (4096 scalars each) on one shared prepared handle",
+                    "b1_unit": "mult_pippenger_prepared calls/s (4096 scalars each) on one shared prepared handle (24 GB table budget: c = 13, 20 additions per scalar)",
                     "failed_or_different_from_the_serial_results": (o16.get("failed_or_different_from_the_serial_results", 0) or 0)
                                                                    + (o1.get("failed_or_different_from_the_serial_results", 0) or 0)
                                                                    + (b16nc.get("failed_or_different_from_the_serial_results", 0) or 0),

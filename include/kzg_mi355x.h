@@ -65,7 +65,7 @@ typedef struct {
                                     * commitments, cell proofs, FK20 columns; tables after the first are built at first
                                     * use).  0 = default: 160 GB, capped by what is free less 12 GB of working room */
     const char *tuning;            /* NULL, or "key=value;key=value": the measured switches (kzgamd_tuning_keys lists
-                                    * them; DESIGN.md §12).  An unknown key or a value out of range fails the call */
+                                    * them; DESIGN.md §9).  An unknown key or a value out of range fails the call */
 } KzgAmdConfig;
 void kzgamd_config_init(KzgAmdConfig *cfg);   /* struct_size, device = -1, no budget, no tuning */
 /* the tuning keys, one per line: "name default lo hi meaning"; returns a static string */

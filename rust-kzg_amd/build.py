@@ -75,10 +75,39 @@ def _obj_stale(src, obj):
     return False
 
 
+def _content_hash(defines):
+    """sha256 over the text of every source and header of the library and the compile flags: what the objects are a
+    function of (with the pinned toolchain).  Modification times lie — an edit while a compilation runs leaves an object
+    newer than its source — so a library is only reused when the stamp written next to it names this hash."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(defines).encode())
+    names = sorted(set(SOURCES) | {f for f in os.listdir(CSRC) if f.endswith(".h")})
+    for name in names + [os.path.join("..", "..", "include", "kzg_mi355x.h")]:
+        p = os.path.join(CSRC, name)
+        if os.path.exists(p):
+            with open(p, "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read() + b"\0")
+    return h.hexdigest()
+
+
+def _stamp_path(lib):
+    return lib + ".built_from"
+
+
+def _stamp_matches(lib, defines):
+    try:
+        with open(_stamp_path(lib)) as fh:
+            return fh.read().strip() == _content_hash(defines)
+    except OSError:
+        return False
+
+
 def _compile_and_link(lib, tag, defines, force, verbose):
-    """Objects <source><tag>.o (parallel hipcc, rebuilt by their .d files) -> lib."""
+    """Objects <source><tag>.o (parallel hipcc, rebuilt by their .d files) -> lib; then the content stamp."""
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    want = _content_hash(defines)  # before compiling: an edit during the compilation makes the stamp stale, as it should
     objs = []
     procs = []
     for s in srcs:
@@ -96,14 +125,20 @@ def _compile_and_link(lib, tag, defines, force, verbose):
     if procs or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lpthread"]
         subprocess.check_call(cmd, cwd=CSRC)
+    with open(_stamp_path(lib), "w") as fh:
+        fh.write(want + "\n")
     return lib
 
 
 def build(force=False, verbose=False):
-    """The product library.  KZGAMD_REBUILD=1 in the environment forces a full recompilation (what a fresh clone does)."""
+    """The product library.  Reused only when its stamp names the content hash of the sources; objects are reused by
+    their dependency files, except that a library whose stamp names ANOTHER hash while no object looks stale (an edit
+    during a compilation) is recompiled in full.  KZGAMD_REBUILD=1 forces a full recompilation (what a fresh clone does)."""
     force = force or os.environ.get("KZGAMD_REBUILD") == "1"
-    if not force and not _stale():
+    if not force and os.path.exists(LIB) and _stamp_matches(LIB, []):
         return LIB
+    if not force and os.path.exists(LIB) and not _stale():
+        force = True  # nothing looks newer than the library, yet it was built from other text
     return _compile_and_link(LIB, "", [], force, verbose)
 
 
@@ -117,7 +152,10 @@ LIB_EXACT = os.path.join(CSRC, "libkzg_mi355x_exact.so")
 
 def build_exact(force=False, verbose=False):
     force = force or os.environ.get("KZGAMD_REBUILD") == "1"
-    return _compile_and_link(LIB_EXACT, ".exact", ["-DKZGAMD_FORCE_EXACT_TESTS"], force, verbose)
+    defines = ["-DKZGAMD_FORCE_EXACT_TESTS"]
+    if not force and os.path.exists(LIB_EXACT) and _stamp_matches(LIB_EXACT, defines):
+        return LIB_EXACT
+    return _compile_and_link(LIB_EXACT, ".exact", defines, force, verbose)
 
 
 if __name__ == "__main__":

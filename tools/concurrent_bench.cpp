@@ -49,7 +49,12 @@ int main(int argc, char** argv) {
         aff[i].x = P->x;  // the setup's points are affine (Z = 1 in Montgomery form)
         aff[i].y = P->y;
     }
-    void* msm = prepare_msm(aff.data(), NP);
+    // its table next to the settings object's (and, under bench.py, the parent process's): an explicit budget instead
+    // of "whatever is free", which would leave the lanes of the settings object nothing to allocate their workspaces from
+    KzgAmdConfig mcfg;
+    kzgamd_config_init(&mcfg);
+    mcfg.table_budget_bytes = 24000000000ull;
+    void* msm = kzgamd_prepare_msm_ex(aff.data(), NP, &mcfg);
     if (!msm) return 5;
     std::vector<std::vector<blst_fr>> sc(NB, std::vector<blst_fr>(NP));
     std::vector<std::array<uint8_t, 48>> want(NB);
