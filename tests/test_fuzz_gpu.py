@@ -15,7 +15,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 BUDGET = {"product": {"fuzz_msm.py": 120, "fuzz_ckzg.py": 120, "fuzz_g1.py": 30},
-          "exact": {"fuzz_msm.py": 45, "fuzz_ckzg.py": 45, "fuzz_g1.py": 30}}
+          "exact": {"fuzz_msm.py": 35, "fuzz_ckzg.py": 35, "fuzz_g1.py": 25}}
 
 
 @pytest.mark.parametrize("tool,seed", [("fuzz_msm.py", 11), ("fuzz_ckzg.py", 12), ("fuzz_g1.py", 13)])

@@ -191,6 +191,9 @@ def test_large_2p20_roundtrip_and_digest(kzg, oracle):
 
 def test_three_pass_2p25_matches_oracle(kzg, oracle):
     # n = 2^25 needs the third pass (stages 24..); raw random residues (< 2^254) as input
+    if kzg.LIB_PATH.endswith("_exact.so"):
+        pytest.skip("the Fr transforms contain no exact-zero test: both builds are the same kernels; the oracle's 2^25 "
+                    "transform (25 s on the host) runs once")
     import numpy as np
 
     L = oracle.lib()
