@@ -65,7 +65,7 @@ inline const TuneKey* tune_keys() {
         {"glv", 1, 0, 1, "0: no endomorphism split in the variable-base engine"},
         {"fbw_glv", 1, 0, 1, "0: the wide table never takes the GLV form (rows over 128-bit halves), whatever it would save"},
         {"combine", 1, 0, 1, "0: concurrent mult_pippenger_prepared calls queue on the handle's mutex, one launch each"},
-        {"combine_lanes", 2, 1, 2, "batches of combined calls in flight at once"},
+        {"combine_lanes", 3, 1, 4, "batches of combined calls in flight at once"},
         {"combine_gather_min", 6, 1, 32, "with a batch in flight, wait for this many queued calls ..."},
         {"combine_gather_us", 60, 0, 100000, "... but at most this long (microseconds)"},
         {"g1_wide_max", 4096, 0, 1L << 40, "G1 stages of up to this many half-butterflies run a wave each"},

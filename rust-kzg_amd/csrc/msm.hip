@@ -1832,7 +1832,7 @@ struct MsmTuning {
     bool no_wide_tail = false, no_hybrid_fold = false;
     bool one_level_sort = false, tree_tail = false, flat_digits = false, direct_scatter = false, scatter_atomics = false;
     bool combine = true;
-    int combine_lanes = 2, combine_gather_min = 6, combine_gather_us = 60;
+    int combine_lanes = 3, combine_gather_min = 6, combine_gather_us = 60;
     int tail_pieces = 0;
     static MsmTuning from(const kzgamd::Options& o) {
         using namespace kzgamd;
@@ -1860,6 +1860,17 @@ struct MsmTuning {
         return t;
     }
 };
+
+// The scalars of a combined batch stay where their callers staged them (page-locked slots, one per caller): one kernel
+// fetches them over PCIe into the batch's contiguous buffer instead of one copy operation per request on the stream.
+struct ScalarSlots {
+    const uint4* p[32];  // MsmContext::COMBINE_MAX
+};
+__global__ void __launch_bounds__(256) k_gather_scalars(uint4* __restrict__ dst, ScalarSlots slots, size_t per, size_t nreq) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nreq * per) return;
+    dst[t] = slots.p[t / per][t % per];
+}
 
 struct kzgamd::MsmContext {
     std::mutex mu;
@@ -1926,12 +1937,12 @@ struct kzgamd::MsmContext {
         bool done = false, failed = false;
         HipErr err{hipSuccess, ""};
     };
-    static constexpr size_t COMBINE_MAX = 32;
+    static constexpr size_t COMBINE_MAX = 32;  // = the pointers of ScalarSlots
     static constexpr int COMBINE_SLOTS = 48;
     // Up to COMBINE_LANES batches are in flight at once, each on a lane of its own (stream, staging, and — through
     // workspace_for(stream) — MSM workspace): the copies and launches of one batch are issued while the kernels of the
     // previous one run.  The handle's mutex is held while a batch is enqueued, not while it is awaited.
-    static constexpr int COMBINE_LANES = 2;
+    static constexpr int COMBINE_LANES = 4;
     struct CombineLane {
         hipStream_t st = nullptr;
         DevBuf<u32> scalars;
@@ -2780,9 +2791,19 @@ static void msm_run_combined_batch(MsmContext* ctx, MsmContext::CombineLane& lan
             lane.scalars.ensure(nb * np * 8 + 8);
             lane.out.ensure(nb * 3 + 3);
             try {
-                for (size_t j = 0; j < nb; ++j)
-                    HIP_TRY(hipMemcpyAsync(lane.scalars.p + j * np * 8, batch[j]->slot ? (const void*)batch[j]->slot : batch[j]->scalars,
-                                           np * 32, hipMemcpyHostToDevice, lane.st));
+                bool all_slots = true;
+                for (size_t j = 0; j < nb; ++j) all_slots = all_slots && batch[j]->slot != nullptr;
+                if (all_slots) {
+                    ScalarSlots ss;
+                    for (size_t j = 0; j < MsmContext::COMBINE_MAX; ++j) ss.p[j] = j < nb ? (const uint4*)batch[j]->slot : nullptr;
+                    const size_t per = np * 2, total = nb * per;  // 16-byte words per request
+                    hipLaunchKernelGGL(k_gather_scalars, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, lane.st,
+                                       (uint4*)lane.scalars.p, ss, per, nb);
+                } else {  // a caller found the slot pool empty: its scalars are in pageable memory
+                    for (size_t j = 0; j < nb; ++j)
+                        HIP_TRY(hipMemcpyAsync(lane.scalars.p + j * np * 8, batch[j]->slot ? (const void*)batch[j]->slot : batch[j]->scalars,
+                                               np * 32, hipMemcpyHostToDevice, lane.st));
+                }
                 msm_enqueue(ctx, lane.out.p, lane.scalars.p, np, nb, 1, lane.st, OUT_JACOBIAN);
                 HIP_TRY(hipMemcpyAsync(lane.h_out, lane.out.p, nb * 144, hipMemcpyDeviceToHost, lane.st));
             } catch (...) {
@@ -2815,7 +2836,7 @@ static void msm_run_host_combined(MsmContext* ctx, void* out, const void* scalar
         DeviceGuard on_device(ctx->device);
         q.slot_bytes = ctx->n * 32;
         if (on_device.err != hipSuccess ||
-            hipHostMalloc((void**)&q.h_slots, (size_t)MsmContext::COMBINE_SLOTS * q.slot_bytes, hipHostMallocPortable) != hipSuccess) {
+            hipHostMalloc((void**)&q.h_slots, (size_t)MsmContext::COMBINE_SLOTS * q.slot_bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
             q.h_slots = nullptr;
             q.pinned_failed = true;
             (void)hipGetLastError();

@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
         // of "whatever is free", which would leave the lanes of the settings object nothing to allocate their workspaces from
         KzgAmdConfig mcfg;
         kzgamd_config_init(&mcfg);
-        mcfg.table_budget_bytes = 24000000000ull;
+        mcfg.table_budget_bytes = getenv("B1_TABLE_GB") ? (uint64_t)(atof(getenv("B1_TABLE_GB")) * 1e9) : 24000000000ull;
         msm = kzgamd_prepare_msm_ex(aff.data(), NP, &mcfg);
         if (!msm) return 5;
         sc.assign(NB, std::vector<blst_fr>(NP));

@@ -1,4 +1,7 @@
+# 16 (and 32) threads of mult_pippenger_prepared on one prepared handle against the combining keys and the table budget
 export LD_LIBRARY_PATH=rust-kzg_amd/csrc:/opt/rocm/lib
 S=tests/golden/trusted_setup.txt
-for t in 1 16 32; do tools/concurrent_bench $S 1.0 $t 2; done
-for lanes in 1 2; do for gm in 1 6 12; do for us in 60 150; do echo "lanes $lanes gather_min $gm us $us"; KZGAMD_TUNING="combine_lanes=$lanes;combine_gather_min=$gm;combine_gather_us=$us" tools/concurrent_bench $S 0.8 16 2; done; done; done
+for gb in 24 100; do for lanes in 1 2 3 4; do for gm in 4 6; do
+  echo "table $gb GB lanes $lanes gather_min $gm"; B1_TABLE_GB=$gb KZGAMD_TUNING="combine_lanes=$lanes;combine_gather_min=$gm" tools/concurrent_bench $S 0.8 16 2
+done; done; done
+for lanes in 2 3 4; do echo "32 threads lanes $lanes"; KZGAMD_TUNING="combine_lanes=$lanes" tools/concurrent_bench $S 0.8 32 2; done
