@@ -583,13 +583,16 @@ def test_horner_exceptional_additions(oracle, kzg, sign):
         assert compressed(L, got) == b"\xc0" + bytes(47)
 
 
-def test_two_large_msms_in_one_launch(oracle, kzg):
+@pytest.mark.parametrize("nbatch", [2, 5])
+def test_several_large_msms_in_one_call(oracle, kzg, nbatch):
     """nbatch = 2 over a 40 000-point variable-base handle: 16 bucket sets of 32 768 buckets go through the tiled
-    digit reduction and the limb-parallel cell sums together (set indexing of every stage with more than one MSM)."""
+    digit reduction and the limb-parallel cell sums together (set indexing of every stage with more than one MSM).
+    nbatch = 5: more coarse bins than the two-level sort holds in one launch — the call runs as sub-batches of 2 + 2 + 1
+    (output and scalar offsets of every sub-batch)."""
     import torch
 
     L = oracle.lib()
-    n, nbatch = 40000, 2
+    n = 40000
     stream = torch.cuda.current_stream().cuda_stream
     d_pts = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
     kzg.generate_points(d_pts.data_ptr(), n, 31, stream)
