@@ -1129,7 +1129,7 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
     // (the device check is a 1.7 ms latency chain whatever the count; a host core takes ~0.2 ms per commitment with
     // 64-bit limbs, and the hashing pool does them in parallel while the GPU proves: up to 64 blobs the host wins)
     const bool host_check = derive && n <= dev->cfg_host_check_max && !commitments_checked_elsewhere;
-    // KZGAMD_DEVICE_SHA=1: the Fiat-Shamir hashes of a host-buffer batch on the GPU too (k_challenge_sha256, one lane per
+    // tuning key device_sha=1: the Fiat-Shamir hashes of a host-buffer batch on the GPU too (k_challenge_sha256, one lane per
     // blob: 2050 serial compressions, ~8 ms however many blobs) and no host threads at all.  Measured against the host
     // pool: 256 blobs 22 k vs 50 k proofs/s, 1024 blobs 47 k vs 66 k, 4096 blobs 72 k vs 78 k — the kernel only pays when
     // other batches hide it (the device-resident pipeline), so the host pool stays the default.
@@ -1525,7 +1525,7 @@ void commit_lane_batch(KzgAmdSettings* dev, const std::vector<CommitReq*>& reqs)
         CK_HIP(hipMemcpyAsync(ho, dev->d_out, n * (host_compress ? 144 : 48), hipMemcpyDeviceToHost, dev->stream));
     };
     // (Replaying this sequence as one captured graph per batch size was measured: 19.4 k vs 18.9 k commitments/s at 16
-    // threads, 3 991 vs 4 040 /s for one — nothing; the call-by-call form stays.  DESIGN.md §9.)
+    // threads, 3 991 vs 4 040 /s for one — nothing; the call-by-call form stays.  profiles/NOTES.md §9.)
     try {
         enqueue_all();
     } catch (...) {

@@ -196,7 +196,7 @@ void cells_and_proofs(uint8_t* cells, KZGProof* proofs, const Blob* blobs, size_
     // over x_ext_fft_columns, two G1 transforms of 128 points — ~25x fewer point additions than 128 MSMs of 4096, but
     // the G1 transforms are 14 serial stages of a 128-bit scalar multiplication each: tens of ms of latency whatever
     // the batch).  A few blobs: the direct form, one more fixed-base MSM per cell over the monomial table.
-    // KZGAMD_FK20 = 0 / 1 forces one or the other.
+    // Tuning key fk20 = 0 / 1 forces one or the other.
     bool fk20 = proofs && n >= FK20_MIN_BLOBS;
     if (dev->cfg_fk20 >= 0) fk20 = proofs && dev->cfg_fk20 != 0;
     if (dev->fk20_unavailable) fk20 = false;

@@ -22,7 +22,7 @@
 // -DKZGAMD_FFTG1_OUTLINE_MUL: fp28::mul / sqr as real functions in this file (a window step shrinks from 60 - 130 KB of
 // code to under 20 KB).  Measured, not adopted: the long-lane kernels run one or two waves per SIMD and might have been
 // bound by instruction fetch (64 KB instruction cache per two CUs) — they are not: FK20 of 256 blobs 23.9 -> 27.6 ms,
-// one lane per half-butterfly 31.6 -> 37.8 ms (the argument marshalling of the calls), DESIGN.md §9.
+// one lane per half-butterfly 31.6 -> 37.8 ms (the argument marshalling of the calls), profiles/NOTES.md §9.
 #ifdef KZGAMD_FFTG1_OUTLINE_MUL
 #define FP28_OUTLINE_MUL 1
 #endif
@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(256) k_g1_store(ff::Fp* __restrict__ out, cons
 // half-butterfly with the limb-parallel arithmetic of g1w.hip.h (a doubling is 3 multiplication steps deep instead of
 // 9, an addition 4 instead of 14; ~0.5 us per step), signed 4-bit windows (multiples 1..8 and their negatives in LDS),
 // and a second small kernel adds the two halves and forms x + t, x - t.  About 5x the instructions per butterfly of the
-// single-lane kernel, so it is used while the waves of a stage fit the chip a few times over (KZGAMD_G1_WIDE_MAX).
+// single-lane kernel, so it is used while the waves of a stage fit the chip a few times over (tuning key g1_wide_max).
 constexpr int WTAB = 8;
 struct WideScratch {
     u32 sh[16];              // g1w's exact zero test

@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) k_digits(DigitParams P, const u32* __rest
 // ---------------------------------------------------------------------------------------------------------
 // Two-level sort (default for one MSM up to n = 2^22).  The one-level sort above pays two global atomics' worth
 // of L2 traffic per entry (histogram with return value, then a scattered 4-byte write): 1.2 ms at n = 2^20.
-// Here a bucket id is split into a coarse bin (bucket >> fb) and a fine bucket (low fb bits; fb = 7, KZGAMD_FINE_BITS
+// Here a bucket id is split into a coarse bin (bucket >> fb) and a fine bucket (low fb bits; fb = 7, tuning key fine_bits
 // = 7..10 for experiments: fewer, larger bins make k_part_scatter's runs longer and the kernel faster — 169 vs 267 us at
 // n = 2^20 with fb = 10 — but k_bin_sort then has 256 workgroups of 65536 entries and loses the same time again;
 // 7, 8, 9 and 10 are within noise of each other end to end):
@@ -892,7 +892,7 @@ __global__ void __launch_bounds__(DIGIT_T) k_digit_sums(const Xyzz* __restrict__
 // nb / 1024 values each: few enough additions for one wave per addition (k_digit_sums_wide, k_digit_bits_wide).
 constexpr int TILE_T = 512;  // two buckets per lane and phase: a full CU (two waves per SIMD) per tile
 // Every addition is at one of TWO inlined sites, each the body of a loop whose second operand comes from
-// memory (the form that took the scratch out of the G1 stages): loop 1 folds the pieces of the lane's two
+// memory (the form that took the scratch out of the G1 stages, profiles/NOTES.md §16): loop 1 folds the pieces of the lane's two
 // buckets, loop 2 is a ten-step schedule — the pair of buckets, four row-tree levels, the pair of rows, four column-tree
 // levels — in which a step only chooses where the operand comes from and where the sum goes.  (Round 3's form had five
 // sites, each with its own never-taken doubling: 256 VGPRs, 86 of them spilled; removed in round 5.)
@@ -1580,7 +1580,7 @@ __global__ void __launch_bounds__(256) k_blocksum(const Xyzz* __restrict__ in_al
 // reset for the next call) adds the BSH_PARTS sums.  One launch, 1 + 3 single-lane and 8 + 4 + 16 limb-parallel
 // additions deep, against 1 + 8 and then 1 + 6 single-lane ones in two launches of k_blocksum.
 constexpr int BSH_PARTS = 16;
-constexpr size_t BSH_MAX = 64;   // MSMs per call folded this way by default (KZGAMD_HYBRID_MAX)
+constexpr size_t BSH_MAX = 64;   // MSMs per call folded this way by default (tuning key hybrid_max)
 constexpr size_t BSH_CAP = 128;  // ... at most
 __global__ void __launch_bounds__(256) k_blocksum_hybrid(const Xyzz* __restrict__ in_all, Xyzz* __restrict__ out,
                                                          Xyzz* __restrict__ part, u32* __restrict__ counter, size_t n) {
@@ -2063,7 +2063,7 @@ MsmContext* msm_create(const void* points, size_t n, bool points_on_device, bool
         // over table rows 2^(c j) P with one bucket set.  Measured (tools/time_prepared.py, 2^20 / 2^21 / 2^22 points):
         // 4.57 / 9.7 / 16.8 ms against 3.51 / 6.5 / 13.1 ms for the GLV-split engine on the plain bases — the rows make
         // the gathers of the accumulation miss every cache (2 GB of table) and one set of 2^19 buckets costs the reduction
-        // more than eight sets of 2^15 — so such a handle takes the variable-base shape when its bases pass
+        // more than eight sets of 2^15 (profiles/NOTES.md §9) — so such a handle takes the variable-base shape when its bases pass
         // the subgroup test.  Tuning key fixed_as_variable_min: log2 of the smallest such n (0 = never).
         bool as_variable = false;
         if (prepare && !ctx->window_forced && g1_policy != G1_NO_SPLIT) {
@@ -2261,7 +2261,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         int spl = nbatch >= 256 ? 4 : 1;
         // segment MSMs (FK20: 128 MSMs of 64 scalars per blob): from 128 blobs on, 16 scalars per lane — 320 additions
         // per lane instead of 80 and four partial sums per MSM instead of 16 for k_lane_sum (0.23 -> 0.05 ms at 256
-        // blobs); the accumulation itself takes the same 6.2 - 6.4 ms either way (measured)
+        // blobs); the accumulation itself takes the same 6.2 - 6.4 ms either way (measured, profiles/NOTES.md §16)
         if (nseg && ctx->fbw_glv && npoints % 32 == 0) {
             if (nbatch * npoints >= ((size_t)1 << 21)) spl = 16;       // 256 blobs: 131 072 lanes, two waves per SIMD
             else if (nbatch * npoints >= ((size_t)1 << 20)) spl = 8;  // 128 blobs: the same
@@ -2422,7 +2422,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     ws.lvlA[1].ensure(nsets * n2);
     ws.lvlM[1].ensure(nsets * n2);
     ws.heavy.ensure(nsets * nb);
-    // Window groups (KZGAMD_GROUPS=2..4, off by default).  The sort is bound by atomics / scattered writes, the
+    // Window groups (tuning key groups = 2..4, off by default).  The sort is bound by atomics / scattered writes, the
     // accumulation by the integer VALUs and the reduction tail by latency, so a single large MSM can be cut into
     // groups of windows that run as a pipeline on their own streams: the sort of group g+1 overlaps the accumulation
     // of group g, whose tail overlaps the accumulation of g+1; only the Horner over the window sums joins them.
@@ -2464,7 +2464,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     const bool use_top = nsets <= 64;  // many independent sets (batched MSMs) keep plain tree levels busy on their own
     // few chains: run the serial tails limb-parallel, one point operation per wave
     const bool wide_tail = use_top && !ctx->tune.no_wide_tail;
-    // few sets of many buckets: the digit-decomposed reduction instead of the (A, M) tree (KZGAMD_TREE_TAIL=1: the tree)
+    // few sets of many buckets: the digit-decomposed reduction instead of the (A, M) tree (tuning key tree_tail=1: the tree)
     // measured (same box, tree vs digits): n = 2^14 (4096 buckets) 1.20 vs 1.35 ms, 2^16 1.53 vs 1.48, 2^20 4.53 vs 4.35, 2^22 14.67 vs 14.26
     const bool digit_tail = use_top && nb >= 16384 && !ctx->tune.tree_tail;
     // the tiled form of the digit sums (k_tile_sums_loop); tuning key flat_digits: one pass over the buckets per digit
@@ -2555,7 +2555,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             // entries per scalar (windows of this launch's group x halves): the staged scatter holds 16 per scalar
             const size_t per_scalar = (size_t)(G > 1 ? ns : (size_t)nwin) * (ctx->glv ? 2 : 1);
             const bool staged = per_scalar * STAGE_T * STAGE_SCALARS <= STAGE_CAP && !ctx->tune.direct_scatter;
-            // per-workgroup histograms kept by the count pass (KZGAMD_SCATTER_ATOMICS=1: recount + one atomic per run)
+            // per-workgroup histograms kept by the count pass (tuning key scatter_atomics=1: recount + one atomic per run)
             const bool keep_hist = staged && G == 1 && !ctx->tune.scatter_atomics;
             u32 *wg_hist = nullptr, *wg_off = nullptr;
             if (keep_hist) {

@@ -1,5 +1,5 @@
-# 16-thread throughput of the coalesced entry points against the leader / gather settings (KZGAMD_LEADERS,
-# KZGAMD_GATHER_MIN, KZGAMD_GATHER_US are read once per process)
+# 16-thread throughput of the coalesced entry points against the leader / gather settings (tuning keys leaders,
+# gather_min, gather_us: read when the settings object is created)
 export LD_LIBRARY_PATH=rust-kzg_amd/csrc:/opt/rocm/lib
 for cfg in "3 6 60" "3 5 40" "3 8 100" "4 4 40" "4 5 60" "2 8 60" "2 8 120" "5 4 40" "3 6 0"; do
   set -- $cfg

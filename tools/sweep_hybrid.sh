@@ -1,5 +1,5 @@
 # host-buffer batch calls of 1 .. 256 blobs (tools/time_batches.py) against the fold switches:
-# KZGAMD_HYBRID_MAX (largest batch k_blocksum_hybrid takes), KZGAMD_WIDE_FOLD_MAX (largest batch k_wide_fold64 takes;
+# hybrid_max (largest batch k_blocksum_hybrid takes), wide_fold_max (largest batch k_wide_fold64 takes;
 # negative: never)
 export KZGAMD_FBW_MAX_GB=100
 for cfg in "KZGAMD_TUNING=wide_fold_max=1" "KZGAMD_TUNING=wide_fold_max=-1" "KZGAMD_TUNING=wide_fold_max=4;hybrid_max=16"; do
