@@ -102,8 +102,12 @@ extern "C" C_KZG_RET kzgamd_load_trusted_setup_file_multi_ex(CKZGSettings out[],
         KzgAmdConfig mine;
         kzgamd_config_init(&mine);
         if (cfg) {
-            if (cfg->struct_size != sizeof mine) return C_KZG_BADARGS;
-            mine = *cfg;
+            // field by field: a caller compiled against a later, longer struct is accepted like everywhere else (the
+            // single-device loader validates struct_size and the tuning string)
+            if (cfg->struct_size < sizeof mine) return C_KZG_BADARGS;
+            mine.struct_size = cfg->struct_size;
+            mine.table_budget_bytes = cfg->table_budget_bytes;
+            mine.tuning = cfg->tuning;
         }
         mine.device = devices ? devices[d] : (int)d;
         FILE* f = fmemopen(text.data(), len, "r");
