@@ -75,7 +75,9 @@ const char *kzgamd_tuning_keys(void);
  * B1 — GPU MSM plug-in.  Same three symbols `rust-kzg-blst` binds under feature `sppark`
  * (blst-sppark/src/lib.rs:8-62, defined today by blst-sppark/cuda/pippenger.cu:23-38).
  * Scalars are blst_fr IN MONTGOMERY FORM (blst/src/kzg_proofs.rs:47-48); out is Jacobian.
- * Thread-safe: calls on one handle serialise on an internal mutex.
+ * Thread-safe: any number of threads may call on one handle (the reference shares it through an Arc between rayon
+ * workers, kzg/src/msm/sppark.rs:24-44).  Concurrent mult_pippenger_prepared calls of the same length are combined into
+ * batched launches (up to three in flight); other calls serialise on an internal mutex.
  * Bases may be ANY points of the curve, as in the reference (FsG1::from_bytes does not test the subgroup,
  * blst/src/types/g1.rs:65-87): the result is the plain sum of k_i P_i.  The engines' endomorphism (GLV) split is an
  * identity of the r-torsion subgroup G1 only, so every handle tests its bases once at creation and runs unsplit if one
@@ -157,6 +159,9 @@ RustError kzgamd_generate_points(void *d_out_affine, size_t npoints, uint64_t se
  *   das_fft_extension: 0 ok, 1 empty, 2 not a power of two, 3 longer than max width / 2
  *   fft_g1:            as ntt_fr
  *   negative: device error
+ * Thread-safe: a handle may be shared between threads (FFTSettings is shared by reference in the reference); concurrent
+ * ntt_fr / das_fft_extension calls of the same kind and length (up to 8192 elements) are combined into batched launches,
+ * everything else serialises on the handle's mutex.
  * ------------------------------------------------------------------------------------------ */
 void *kzgamd_ntt_new(unsigned scale);           /* FsFFTSettings::new(scale), blst/src/types/fft_settings.rs:30-58 */
 void *kzgamd_ntt_new_ex(unsigned scale, const KzgAmdConfig *cfg);

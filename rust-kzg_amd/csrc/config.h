@@ -64,7 +64,7 @@ inline const TuneKey* tune_keys() {
         {"fixed_as_variable_min", 19, 0, 39, "log2 of the smallest prepared handle that, without room for a wide table, runs the variable-base engine (0 = never)"},
         {"glv", 1, 0, 1, "0: no endomorphism split in the variable-base engine"},
         {"fbw_glv", 1, 0, 1, "0: the wide table never takes the GLV form (rows over 128-bit halves), whatever it would save"},
-        {"combine", 1, 0, 1, "0: concurrent mult_pippenger_prepared calls queue on the handle's mutex, one launch each"},
+        {"combine", 1, 0, 1, "0: concurrent mult_pippenger_prepared / ntt_fr / das_fft_extension calls on one handle queue on its mutex, one launch each"},
         {"combine_lanes", 3, 1, 4, "batches of combined calls in flight at once"},
         {"combine_gather_min", 6, 1, 32, "with a batch in flight, wait for this many queued calls ..."},
         {"combine_gather_us", 60, 0, 100000, "... but at most this long (microseconds)"},

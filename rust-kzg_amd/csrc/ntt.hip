@@ -489,6 +489,7 @@ void* kzgamd::ntt_create(unsigned scale, const kzgamd::Options& opt) {
         ctx->g1_wide_max = (size_t)opt.t[kzgamd::T_G1_WIDE_MAX];
         ctx->g1_quad_max = (size_t)opt.t[kzgamd::T_G1_QUAD_MAX];
         ctx->g1_pair_max = (size_t)opt.t[kzgamd::T_G1_PAIR_MAX];
+        ctx->combine = opt.t[kzgamd::T_COMBINE] != 0;
         kzgamd::expand_roots(ctx->roots, scale);
         // device twiddles in the 2^261 domain, w*2^261 = (w*2^256) * 2^5, already sliced into the 9 x 29-bit limbs
         // the butterflies multiply with (36 bytes per root instead of 32, ~27 instructions less per butterfly)
@@ -549,11 +550,133 @@ extern "C" int kzgamd_ntt_fr_device(void* vctx, void* d_out, const void* d_in, s
     return 0;
 }
 
+namespace {
+// ---- combining of concurrent host-buffer calls on one handle (see NttCtx::Combine) ----
+struct SlotPtrs {
+    uint4* p[32];  // NttCtx::COMB_MAX
+};
+__global__ void __launch_bounds__(256) k_slots_gather(uint4* __restrict__ dst, SlotPtrs slots, size_t per, size_t nreq) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nreq * per) dst[t] = slots.p[t / per][t % per];
+}
+__global__ void __launch_bounds__(256) k_slots_scatter(SlotPtrs slots, const uint4* __restrict__ src, size_t per, size_t nreq) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nreq * per) slots.p[t / per][t % per] = src[t];
+}
+void das_enqueue(NttCtx* ctx, Fr* d_odds, const Fr* d_evens, Fr* d_tmp, size_t n, size_t nbatch, hipStream_t stream);
+
+// one batch on `lane`: every request has the same kind and length; sets rc of each
+void run_combined_batch(NttCtx* ctx, NttCtx::CombLane& lane, const std::vector<NttCtx::HostCall*>& batch) {
+    const size_t nb = batch.size(), n = batch[0]->n;
+    const int kind = batch[0]->kind;
+    int rc = 0;
+    try {
+        kzgamd::DeviceGuard on_device(ctx->device);
+        NTT_TRY(on_device.err);
+        if (!lane.st) {
+            NTT_TRY(hipStreamCreateWithFlags(&lane.st, hipStreamNonBlocking));
+            const size_t cap = NttCtx::COMB_MAX * NttCtx::COMB_NMAX * sizeof(Fr);
+            NTT_TRY(hipMalloc(&lane.d_in, cap));
+            NTT_TRY(hipMalloc(&lane.d_out, cap));
+            NTT_TRY(hipMalloc(&lane.d_tmp, cap));
+        }
+        SlotPtrs sp;
+        for (size_t j = 0; j < NttCtx::COMB_MAX; ++j) sp.p[j] = j < nb ? (uint4*)batch[j]->slot : nullptr;
+        const size_t per = n * 2, total = nb * per;  // 16-byte words per request
+        const unsigned grid = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(k_slots_gather, dim3(grid), dim3(256), 0, lane.st, (uint4*)lane.d_in, sp, per, nb);
+        if (kind == 2) das_enqueue(ctx, lane.d_out, lane.d_in, lane.d_tmp, n, nb, lane.st);
+        else ntt_enqueue(ctx, lane.d_out, lane.d_in, n, nb, kind == 1, lane.st);
+        hipLaunchKernelGGL(k_slots_scatter, dim3(grid), dim3(256), 0, lane.st, sp, (const uint4*)lane.d_out, per, nb);
+        NTT_TRY(hipGetLastError());
+        NTT_TRY(hipStreamSynchronize(lane.st));
+    } catch (const NttErr& e) {
+        if (lane.st) (void)hipStreamSynchronize(lane.st);  // nothing may still read or write the callers' slots
+        rc = -(int)e.e - 100;
+    }
+    for (auto* r : batch) r->rc = rc;
+}
+
+// returns false when the call cannot be combined (no slot): the caller takes the plain path
+bool run_host_combined(NttCtx* ctx, void* out, const void* in, size_t n, int kind, int* rc_out) {
+    NttCtx::HostCall me{out, in, n, kind};
+    auto& q = ctx->comb;
+    std::vector<NttCtx::HostCall*> batch;
+    batch.reserve(NttCtx::COMB_MAX);
+    std::unique_lock<std::mutex> lk(q.mu);
+    if (!q.h_slots && !q.pinned_failed) {
+        kzgamd::DeviceGuard on_device(ctx->device);
+        q.slot_bytes = NttCtx::COMB_NMAX * sizeof(Fr);
+        if (on_device.err != hipSuccess ||
+            hipHostMalloc((void**)&q.h_slots, (size_t)NttCtx::COMB_SLOTS * q.slot_bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+            q.h_slots = nullptr;
+            q.pinned_failed = true;
+            (void)hipGetLastError();
+        } else {
+            for (int i = NttCtx::COMB_SLOTS; i-- > 0;) q.free_slots.push_back(q.h_slots + (size_t)i * q.slot_bytes);
+        }
+    }
+    if (q.free_slots.empty()) return false;
+    me.slot = q.free_slots.back();
+    q.free_slots.pop_back();
+    lk.unlock();
+    memcpy(me.slot, in, n * sizeof(Fr));
+    lk.lock();
+    q.pending.push_back(&me);
+    while (!me.done) {
+        if (q.leaders < NttCtx::COMB_LANES && !q.pending.empty()) {
+            ++q.leaders;
+            NttCtx::CombLane* lane = nullptr;
+            for (auto& l : q.lanes)
+                if (!l.busy) {
+                    lane = &l;
+                    break;
+                }
+            lane->busy = true;
+            while (!q.pending.empty() && !me.done) {
+                batch.clear();
+                const size_t bn = q.pending.front()->n;
+                const int bk = q.pending.front()->kind;
+                for (auto it = q.pending.begin(); it != q.pending.end() && batch.size() < NttCtx::COMB_MAX;) {
+                    if ((*it)->n == bn && (*it)->kind == bk) {
+                        batch.push_back(*it);
+                        it = q.pending.erase(it);
+                    } else {
+                        ++it;
+                    }
+                }
+                lk.unlock();
+                run_combined_batch(ctx, *lane, batch);
+                lk.lock();
+                for (auto* r : batch) r->done = true;
+                q.cv.notify_all();
+            }
+            lane->busy = false;
+            --q.leaders;
+            q.cv.notify_all();
+        } else {
+            q.cv.wait(lk);
+        }
+    }
+    lk.unlock();
+    if (me.rc == 0) memcpy(out, me.slot, n * sizeof(Fr));
+    lk.lock();
+    q.free_slots.push_back(me.slot);
+    lk.unlock();
+    *rc_out = me.rc;
+    return true;
+}
+}  // namespace
+
 extern "C" int ntt_fr(void* vctx, blst_fr* out, const blst_fr* in, size_t n, int inverse) {
     NttCtx* ctx = (NttCtx*)vctx;
     if (!ctx || !out || !in) return -1;
     if (n > ctx->W) return 1;                 // "Supplied list is longer than the available max width"
     if (n == 0 || (n & (n - 1))) return 2;    // "A list with power-of-two length expected"
+    if (ctx->combine && n <= NttCtx::COMB_NMAX) {
+        int rc = 0;
+        if (run_host_combined(ctx, out, in, n, inverse != 0 ? 1 : 0, &rc)) return rc;
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
     try {
         kzgamd::DeviceGuard on_device(ctx->device);
@@ -605,6 +728,10 @@ extern "C" int das_fft_extension(void* vctx, blst_fr* odds, const blst_fr* evens
     if (n == 0) return 1;                  // "A non-zero list ab expected"
     if (n & (n - 1)) return 2;             // "A list with power-of-two length expected"
     if (n * 2 > ctx->W) return 3;          // "Supplied list is longer than the available max width"
+    if (ctx->combine && n <= NttCtx::COMB_NMAX) {
+        int rc = 0;
+        if (run_host_combined(ctx, odds, evens, n, 2, &rc)) return rc;
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
     try {
         kzgamd::DeviceGuard on_device(ctx->device);

@@ -1,4 +1,5 @@
-"""Concurrent callers on ONE B1 / B2 handle.  The reference shares its handles between rayon workers: SpparkPrecomputation
+"""Concurrent callers on ONE B1 / B2 handle (calls of the same kind and length are combined into batched launches below
+the seam: msm.hip msm_run_host_combined, ntt.hip run_host_combined).  The reference shares its handles between rayon workers: SpparkPrecomputation
 is Send + Sync and lives in an Arc (kzg/src/msm/sppark.rs:24-44), verify_blob_kzg_proof_batch calls the MSM from
 par_chunks (kzg/src/eip_4844.rs:781-805), FFT settings are shared by reference.  Sixteen threads per handle, every
 result against the oracle: mult_pippenger_prepared (whose concurrent calls are combined into one launch, msm.hip:
@@ -124,6 +125,32 @@ def test_sixteen_threads_share_one_ntt_handle(kzg, oracle):
             odds = (O.Fr * n)()
             assert L.odas_fft_extension(C.byref(ofs), odds, data, n) == 0
             assert got[(t, k, "das")] == bytes(odds), (t, k, n)
+    # the same calls with the combining off (tuning key combine=0: every call on the handle's mutex): the same bytes
+    fs2 = kzg.FFTSettings(scale, kzg.make_config(tuning={"combine": 0}))
+    got2 = {}
+
+    def work_plain(t):
+        for k in range(len(sizes)):
+            n, inv, data = inputs[(t, k)]
+            got2[(t, k)] = bytes(fs2.fft_fr(data, n, inverse=inv))[: 32 * n]
+
+    assert run_threads(work_plain) == []
+    assert all(got2[key] == got[key] for key in got2)
+    fs2.close()
+    # errors keep their codes through the combined path, and a call longer than the combining limit takes the plain one
+    with pytest.raises(kzg.KzgAmdError, match="power-of-two"):
+        fs.fft_fr(inputs[(0, 0)][2], 12)
+    big = kzg.FFTSettings(15)
+    n = 1 << 15
+    rnd = random.Random(5)
+    data = fr_bulk([rnd.randrange(O.R) for _ in range(n)])
+    ofs15 = O.FFTSettings()
+    assert L.offt_settings_new(C.byref(ofs15), 15) == 0
+    exp = (O.Fr * n)()
+    assert L.offt_fr(C.byref(ofs15), exp, data, n, 0) == 0
+    assert bytes(big.fft_fr(data, n))[: 32 * n] == bytes(exp)
+    big.close()
+    L.offt_settings_free(C.byref(ofs15))
     fs.close()
     L.offt_settings_free(C.byref(ofs))
 

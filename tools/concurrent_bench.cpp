@@ -78,6 +78,25 @@ int main(int argc, char** argv) {
         }
         return 0;
     };
+    // B2: one NTT handle shared by the threads (FFTSettings by reference from rayon workers): ntt_fr of 4096 elements
+    const size_t NTT_N = 4096;
+    void* ntt = nullptr;
+    std::vector<std::vector<blst_fr>> ntt_in, ntt_want;
+    auto prepare_b2 = [&]() -> int {
+        if (ntt) return 0;
+        ntt = kzgamd_ntt_new(13);
+        if (!ntt) return 7;
+        ntt_in.assign(NB, std::vector<blst_fr>(NTT_N));
+        ntt_want.assign(NB, std::vector<blst_fr>(NTT_N));
+        for (int i = 0; i < NB; ++i) {
+            for (auto& x : ntt_in[i]) {
+                for (int k = 0; k < 4; ++k) x.l[k] = rng();
+                x.l[3] &= 0x3fffffffffffffffull;
+            }
+            if (ntt_fr(ntt, ntt_want[i].data(), ntt_in[i].data(), NTT_N, 0) != 0) return 7;
+        }
+        return 0;
+    };
     long errors = 0;  // failed calls + results that differ from the serial ones
     printf("{");
     bool first = true;
@@ -85,9 +104,11 @@ int main(int argc, char** argv) {
     if (argc > 3) Ts = {atoi(argv[3])};
     const int only = argc > 4 ? atoi(argv[4]) : -1;  // 0 = commitments only, 1 = proofs only
     for (int T : Ts) {
-        for (int what = 0; what < 3; ++what) {
+        for (int what = 0; what < 4; ++what) {
+            if (what == 3 && only != 3) continue;  // the B2 leg only on request
             if (only >= 0 && what != only) continue;
             if (what == 2 && (b1_rc = prepare_b1()) != 0) return b1_rc;
+            if (what == 3 && prepare_b2() != 0) return 7;
             std::atomic<bool> stop{false};
             std::atomic<long> total{0};
             std::atomic<int> bad{0};
@@ -99,6 +120,14 @@ int main(int argc, char** argv) {
                     KZGProof p;
                     const int i = t % NB;
                     while (!stop.load(std::memory_order_relaxed)) {
+                        if (what == 3) {
+                            std::vector<blst_fr> o(NTT_N);
+                            if (ntt_fr(ntt, o.data(), ntt_in[i].data(), NTT_N, 0) != 0 ||
+                                memcmp(o.data(), ntt_want[i].data(), NTT_N * sizeof(blst_fr)) != 0)
+                                bad.fetch_add(1);
+                            ++n;
+                            continue;
+                        }
                         if (what == 2) {
                             blst_p1 out;
                             uint8_t got[48];
@@ -126,13 +155,14 @@ int main(int argc, char** argv) {
             stop.store(true);
             for (auto& x : th) x.join();
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            printf("%s\"%s_threads_%d\": %.0f", first ? "" : ", ", what == 0 ? "commit" : what == 1 ? "proof" : "b1_prepared", T, total.load() / dt);
+            printf("%s\"%s_threads_%d\": %.0f", first ? "" : ", ", what == 0 ? "commit" : what == 1 ? "proof" : what == 2 ? "b1_prepared" : "b2_ntt_fr_4096", T, total.load() / dt);
             first = false;
             errors += bad.load();
         }
     }
     printf(", \"failed_or_different_from_the_serial_results\": %ld}\n", errors);
     if (msm) free_msm(msm);
+    if (ntt) kzgamd_ntt_free(ntt);
     free_trusted_setup(&s);
     return 0;
 }
