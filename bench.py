@@ -710,6 +710,10 @@ def main():
                 # the kzg:: traits reaches); with and without the combining of concurrent calls into one launch
                 env_nc = dict(env, KZGAMD_TUNING="combine=0")
                 b16nc = json.loads(subprocess.run([cb, SETUP, "0.8", "16", "2"], stdout=subprocess.PIPE, env=env_nc, timeout=120).stdout.decode().strip().splitlines()[-1])
+                # B2 seam: the same for ONE NTT handle, ntt_fr of 4096 elements
+                n16 = json.loads(subprocess.run([cb, SETUP, "0.6", "16", "3"], stdout=subprocess.PIPE, env=env, timeout=120).stdout.decode().strip().splitlines()[-1])
+                n1 = json.loads(subprocess.run([cb, SETUP, "0.4", "1", "3"], stdout=subprocess.PIPE, env=env, timeout=120).stdout.decode().strip().splitlines()[-1])
+                n16nc = json.loads(subprocess.run([cb, SETUP, "0.6", "16", "3"], stdout=subprocess.PIPE, env=env_nc, timeout=120).stdout.decode().strip().splitlines()[-1])
                 res["concurrent_callers"] = {
                     "threads_16": {"blob_to_kzg_commitment_per_s": o16.get("commit_threads_16"), "compute_blob_kzg_proof_per_s": o16.get("proof_threads_16")},
                     "threads_1": {"blob_to_kzg_commitment_per_s": o1.get("commit_threads_1"), "compute_blob_kzg_proof_per_s": o1.get("proof_threads_1")},
@@ -717,10 +721,15 @@ def main():
                     "b1_prepared_threads_16": o16.get("b1_prepared_threads_16"),
                     "b1_prepared_threads_16_over_1": (o16.get("b1_prepared_threads_16") or 0) / max(o1.get("b1_prepared_threads_1") or 1, 1),
                     "b1_prepared_threads_16_calls_not_combined": b16nc.get("b1_prepared_threads_16"),
+                    "b2_ntt_fr_4096_threads_1": n1.get("b2_ntt_fr_4096_threads_1"),
+                    "b2_ntt_fr_4096_threads_16": n16.get("b2_ntt_fr_4096_threads_16"),
+                    "b2_ntt_fr_4096_threads_16_calls_not_combined": n16nc.get("b2_ntt_fr_4096_threads_16"),
+                    "b2_unit": "ntt_fr calls/s (4096 elements, host buffers) on one shared NTT handle",
                     "b1_unit": "mult_pippenger_prepared calls/s (4096 scalars each) on one shared prepared handle (24 GB table budget: c = 13, 20 additions per scalar)",
                     "failed_or_different_from_the_serial_results": (o16.get("failed_or_different_from_the_serial_results", 0) or 0)
                                                                    + (o1.get("failed_or_different_from_the_serial_results", 0) or 0)
-                                                                   + (b16nc.get("failed_or_different_from_the_serial_results", 0) or 0),
+                                                                   + (b16nc.get("failed_or_different_from_the_serial_results", 0) or 0)
+                                                                   + sum((x.get("failed_or_different_from_the_serial_results", 0) or 0) for x in (n16, n1, n16nc)),
                     "path": "native threads, one CKZGSettings, host buffers; calls are merged into batches on up to three lanes "
                             "(own process: its settings object is loaded next to this one); every result is compared with "
                             "the one a serial call gave"}
