@@ -76,8 +76,8 @@ const char *kzgamd_tuning_keys(void);
  * (blst-sppark/src/lib.rs:8-62, defined today by blst-sppark/cuda/pippenger.cu:23-38).
  * Scalars are blst_fr IN MONTGOMERY FORM (blst/src/kzg_proofs.rs:47-48); out is Jacobian.
  * Thread-safe: any number of threads may call on one handle (the reference shares it through an Arc between rayon
- * workers, kzg/src/msm/sppark.rs:24-44).  Concurrent mult_pippenger_prepared calls of the same length are combined into
- * batched launches (up to three in flight); other calls serialise on an internal mutex.
+ * workers, kzg/src/msm/sppark.rs:24-44).  Concurrent mult_pippenger_prepared calls of the same length (up to 2^16
+ * scalars) are combined into batched launches (up to three in flight); other calls serialise on an internal mutex.
  * Bases may be ANY points of the curve, as in the reference (FsG1::from_bytes does not test the subgroup,
  * blst/src/types/g1.rs:65-87): the result is the plain sum of k_i P_i.  The engines' endomorphism (GLV) split is an
  * identity of the r-torsion subgroup G1 only, so every handle tests its bases once at creation and runs unsplit if one

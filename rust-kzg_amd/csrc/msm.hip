@@ -1939,6 +1939,10 @@ struct kzgamd::MsmContext {
     };
     static constexpr size_t COMBINE_MAX = 32;  // = the pointers of ScalarSlots
     static constexpr int COMBINE_SLOTS = 48;
+    // Calls of more scalars than this take the plain path: their kernels run for a millisecond and more, next to which
+    // the per-invocation cost the combiner removes is nothing — and 48 slots of the handle's full length would pin
+    // 1.6 GB of host memory for a 2^20-point handle.
+    static constexpr size_t COMBINE_NMAX = (size_t)1 << 16;
     // Up to COMBINE_LANES batches are in flight at once, each on a lane of its own (stream, staging, and — through
     // workspace_for(stream) — MSM workspace): the copies and launches of one batch are issued while the kernels of the
     // previous one run.  The handle's mutex is held while a batch is enqueued, not while it is awaited.
@@ -2854,7 +2858,7 @@ static void msm_run_host_combined(MsmContext* ctx, void* out, const void* scalar
     std::unique_lock<std::mutex> lk(q.mu);
     if (!q.h_slots && !q.pinned_failed) {
         DeviceGuard on_device(ctx->device);
-        q.slot_bytes = ctx->n * 32;
+        q.slot_bytes = (ctx->n < MsmContext::COMBINE_NMAX ? ctx->n : MsmContext::COMBINE_NMAX) * 32;
         if (on_device.err != hipSuccess ||
             hipHostMalloc((void**)&q.h_slots, (size_t)MsmContext::COMBINE_SLOTS * q.slot_bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
             q.h_slots = nullptr;
@@ -2925,7 +2929,7 @@ static void msm_run_host_combined(MsmContext* ctx, void* out, const void* scalar
 // host buffers in, host buffers out
 void msm_run_host(MsmContext* ctx, void* out, const void* scalars, size_t npoints, size_t nbatch, size_t nseg) {
     if (npoints * (nseg ? nseg : 1) > ctx->n) throw HipErr{hipErrorInvalidValue, "npoints exceeds the prepared size"};
-    if (ctx->prepared && nbatch == 1 && npoints > 0 && ctx->tune.combine && !nseg) {
+    if (ctx->prepared && nbatch == 1 && npoints > 0 && npoints <= MsmContext::COMBINE_NMAX && ctx->tune.combine && !nseg) {
         msm_run_host_combined(ctx, out, scalars, npoints);
         return;
     }

@@ -573,13 +573,12 @@ void run_combined_batch(NttCtx* ctx, NttCtx::CombLane& lane, const std::vector<N
     try {
         kzgamd::DeviceGuard on_device(ctx->device);
         NTT_TRY(on_device.err);
-        if (!lane.st) {
-            NTT_TRY(hipStreamCreateWithFlags(&lane.st, hipStreamNonBlocking));
-            const size_t cap = NttCtx::COMB_MAX * NttCtx::COMB_NMAX * sizeof(Fr);
-            NTT_TRY(hipMalloc(&lane.d_in, cap));
-            NTT_TRY(hipMalloc(&lane.d_out, cap));
-            NTT_TRY(hipMalloc(&lane.d_tmp, cap));
-        }
+        // each on its own test: an allocation that failed is tried again by the next batch, not taken for made
+        const size_t cap = NttCtx::COMB_MAX * NttCtx::COMB_NMAX * sizeof(Fr);
+        if (!lane.st) NTT_TRY(hipStreamCreateWithFlags(&lane.st, hipStreamNonBlocking));
+        if (!lane.d_in) NTT_TRY(hipMalloc(&lane.d_in, cap));
+        if (!lane.d_out) NTT_TRY(hipMalloc(&lane.d_out, cap));
+        if (!lane.d_tmp) NTT_TRY(hipMalloc(&lane.d_tmp, cap));
         SlotPtrs sp;
         for (size_t j = 0; j < NttCtx::COMB_MAX; ++j) sp.p[j] = j < nb ? (uint4*)batch[j]->slot : nullptr;
         const size_t per = n * 2, total = nb * per;  // 16-byte words per request

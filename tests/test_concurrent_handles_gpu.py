@@ -193,3 +193,41 @@ def test_sixteen_threads_share_one_fft_g1_handle(kzg, oracle):
         assert got[(t, k)] == [compressed(L, exp[i]) for i in range(n)], (t, k, n, inv)
     fs.close()
     L.offt_settings_free(C.byref(ofs))
+
+
+def test_calls_at_and_beyond_the_combining_limit_share_one_handle(kzg, oracle):
+    """Calls of up to 2^16 scalars are combined (a page-locked slot holds exactly that many), longer ones take the
+    handle's own stream under its mutex (msm.hip: COMBINE_NMAX): both kinds at once on one handle, each against the
+    oracle's Pippenger on the same points."""
+    import torch
+
+    L = oracle.lib()
+    lim = 1 << 16
+    n = lim + 64
+    d_pts = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    kzg.generate_points(d_pts.data_ptr(), n, 21, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    pts = (O.G1Affine * n).from_buffer_copy(d_pts.cpu().numpy().tobytes())
+    h = kzg.prepare_multi_scalar_mult(pts, n, kzg.make_config(table_budget_gb=8))
+    rnd = random.Random(33)
+    want, scalars = {}, {}
+    for m in (lim, n, lim - 1):
+        vals = [rnd.randrange(O.R) for _ in range(m)]
+        vals[0], vals[-1] = 0, O.R - 1
+        exp = O.G1()
+        L.omsm_tiling_pippenger(C.byref(exp), pts, b"".join(v.to_bytes(32, "little") for v in vals), m)
+        want[m] = compressed(L, exp)
+        scalars[m] = fr_bulk(vals)  # Montgomery form, what mult_pippenger_prepared takes
+    order = [lim, n, lim - 1, n]
+    got = {}
+
+    def work(t):
+        for k in range(3):
+            m = order[(t + k) % len(order)]
+            got[(t, k)] = (m, compressed(L, kzg.multi_scalar_mult_prepared(h, scalars[m], m)))
+
+    assert run_threads(work) == []
+    assert len(got) == 3 * THREADS
+    for key, (m, c) in got.items():
+        assert c == want[m], (key, m)
+    h.close()
