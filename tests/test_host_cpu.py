@@ -437,3 +437,89 @@ def test_rust_sys_crate_declares_what_the_header_declares():
     for fn in ("g1.rs", "kzg_settings.rs", "fft_settings.rs"):
         used = set(re.findall(r"sys::(\w+)\(", open(os.path.join(ROOT, "rust-kzg_amd", "rust-backend", "src", fn)).read()))
         assert used <= sys_fns, (fn, used - sys_fns)
+
+
+def test_configuration_parser_and_its_documented_table(tmp_path):
+    """csrc/config.h on the host: the key table is well-formed, `kzgamd::Options::parse` / `resolve` accept what
+    include/kzg_mi355x.h says they accept and refuse the rest (unknown key, missing / non-numeric value, out of range,
+    a struct_size that is no version of KzgAmdConfig), the caller's struct beats the environment, and DESIGN.md §9
+    lists exactly the keys of the table with their defaults and ranges."""
+    import re
+    import shutil
+    import subprocess
+
+    cxx = shutil.which("g++") or shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    src = tmp_path / "cfgcheck.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstdlib>
+#include "config.h"
+using kzgamd::Options;
+static int fails = 0;
+#define EXPECT(c) do { if (!(c)) { printf("FAILED line %d: %s\n", __LINE__, #c); ++fails; } } while (0)
+int main() {
+    const kzgamd::TuneKey* k = kzgamd::tune_keys();
+    for (int i = 0; i < kzgamd::T_COUNT; ++i)
+        printf("KEY %s %ld %ld %ld\n", k[i].name, k[i].dflt, k[i].lo, k[i].hi);
+    std::string err;
+    Options o;
+    EXPECT(o.parse(nullptr, &err) && o.parse("", &err) && o.parse(" ; ,\n", &err));
+    EXPECT(o.parse("spl=4;glv=0, window=13 fk20=-1\n", &err));
+    EXPECT(o.t[kzgamd::T_SPL] == 4 && o.t[kzgamd::T_GLV] == 0 && o.t[kzgamd::T_WINDOW] == 13 && o.t[kzgamd::T_FK20] == -1);
+    EXPECT(o.t[kzgamd::T_LEADERS] == 3);  // untouched keys keep their defaults
+    EXPECT(!o.parse("sql=4", &err) && err.find("unknown key 'sql'") != std::string::npos);
+    EXPECT(!o.parse("spl", &err) && err.find("no value") != std::string::npos);
+    EXPECT(!o.parse("spl=", &err) && err.find("non-numeric") != std::string::npos);
+    EXPECT(!o.parse("spl=x", &err) && err.find("non-numeric") != std::string::npos);
+    EXPECT(!o.parse("spl=4x", &err));            // trailing garbage is a key without a value
+    EXPECT(!o.parse("spl=17", &err) && err.find("out of range") != std::string::npos);
+    EXPECT(!o.parse("glv=-1", &err) && !o.parse("combine_lanes=0", &err) && !o.parse("combine_lanes=5", &err));
+    EXPECT(o.parse("g1_pair_max=1099511627776", &err));   // 2^40: the long range of the G1 stage keys
+    // resolve: defaults < environment < struct
+    setenv("KZGAMD_TUNING", "spl=2;lgc=9", 1);
+    setenv("KZGAMD_FBW_MAX_GB", "24", 1);
+    Options r;
+    EXPECT(Options::resolve(r, nullptr, &err) && r.t[kzgamd::T_SPL] == 2 && r.t[kzgamd::T_LGC] == 9 && r.table_budget_gb == 24 && r.device == -1);
+    KzgAmdConfig c;
+    memset(&c, 0, sizeof c);
+    c.struct_size = sizeof c;
+    c.device = 3;
+    c.table_budget_bytes = 10000000000ull;
+    c.tuning = "spl=8";
+    EXPECT(Options::resolve(r, &c, &err) && r.t[kzgamd::T_SPL] == 8 && r.t[kzgamd::T_LGC] == 9 && r.table_budget_gb == 10 && r.device == 3);
+    c.table_budget_bytes = KZGAMD_NO_TABLES;
+    EXPECT(Options::resolve(r, &c, &err) && r.table_budget_gb == 0);
+    c.table_budget_bytes = 0;  // 0 = not given: the environment's value stays
+    EXPECT(Options::resolve(r, &c, &err) && r.table_budget_gb == 24);
+    c.tuning = "nonsense=1";
+    EXPECT(!Options::resolve(r, &c, &err));
+    c.tuning = nullptr;
+    c.struct_size = 8;
+    EXPECT(!Options::resolve(r, &c, &err) && err.find("struct_size") != std::string::npos);
+    c.struct_size = sizeof c + 16;  // a later, longer version of the struct: its known prefix is read
+    EXPECT(Options::resolve(r, &c, &err));
+    setenv("KZGAMD_TUNING", "spl=99", 1);  // a bad environment string fails the call as well
+    EXPECT(!Options::resolve(r, nullptr, &err));
+    printf("fails %d\n", fails);
+    return fails != 0;
+}
+''')
+    exe = tmp_path / "cfgcheck"
+    subprocess.check_call([cxx, "-O1", "-std=c++17", "-I", os.path.join(ROOT, "rust-kzg_amd", "csrc"), str(src), "-o", str(exe)])
+    res = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0 and "fails 0" in res.stdout, res.stdout + res.stderr
+    keys = [ln.split()[1:] for ln in res.stdout.splitlines() if ln.startswith("KEY ")]
+    names = [k[0] for k in keys]
+    assert len(names) == len(set(names)) == 39
+    for name, d, lo, hi in keys:
+        assert re.fullmatch(r"[a-z0-9_]+", name) and int(lo) <= int(d) <= int(hi), name
+    # DESIGN.md §9: one row per key, same default and range
+    design = open(os.path.join(ROOT, "DESIGN.md"), encoding="utf-8").read()
+    sec = design[design.index("## 9. Configuration and tuning keys"):]
+    sec = sec[:sec.index("\n## 10.")]
+    rows = re.findall(r"^\| `([a-z0-9_]+)` \| (-?\d+) \| (-?\d+) … (-?\d+) \|", sec, flags=re.M)
+    assert [tuple(r) for r in rows] == [tuple(k) for k in keys]
+    # and the header names the same four fields the parser reads
+    hdr = open(os.path.join(ROOT, "include", "kzg_mi355x.h")).read()
+    for field in ("struct_size", "device", "table_budget_bytes", "tuning", "KZGAMD_NO_TABLES"):
+        assert field in hdr
