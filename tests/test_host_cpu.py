@@ -523,3 +523,57 @@ int main() {
     hdr = open(os.path.join(ROOT, "include", "kzg_mi355x.h")).read()
     for field in ("struct_size", "device", "table_budget_bytes", "tuning", "KZGAMD_NO_TABLES"):
         assert field in hdr
+
+
+@pytest.mark.parametrize("portable", [False, True])
+def test_host_sha256_both_code_paths_against_hashlib(tmp_path, portable):
+    """csrc/sha256.h hashes the Fiat-Shamir transcripts of host-buffer calls (kzg/src/eip_4844.rs:236-238, :920-945): its
+    SHA-NI path is the one the GPU box's host runs, its portable path the one nothing else here would ever run — both
+    against hashlib on every padding boundary and on transcript-sized messages fed in ragged pieces."""
+    import hashlib
+    import shutil
+    import subprocess
+
+    cxx = shutil.which("g++") or shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    lengths = list(range(0, 130)) + [191, 192, 193, 4095, 4096, 16 + 131072 + 48, 16 + 8 + 8 + 64 * 144 + 7]
+    src = tmp_path / "shacheck.cpp"
+    src.write_text(("#define __builtin_cpu_supports(x) 0\n" if portable else "") + r'''
+#include <cstdio>
+#include <vector>
+#include "sha256.h"
+static uint64_t st = 88172645463325252ull;
+static uint32_t rnd() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 11); }
+int main(int argc, char** argv) {
+    for (int a = 1; a < argc; ++a) {
+        const size_t n = strtoul(argv[a], nullptr, 10);
+        std::vector<uint8_t> m(n + 1);
+        for (size_t i = 0; i < n; ++i) m[i] = (uint8_t)(i * 131 + n);
+        kzgamd::Sha256 h;
+        size_t off = 0;
+        while (off < n) {  // ragged pieces: 1 .. 200 bytes
+            size_t take = 1 + rnd() % 200;
+            if (take > n - off) take = n - off;
+            h.update(m.data() + off, take);
+            off += take;
+        }
+        uint8_t d[32];
+        h.finish(d);
+        for (int i = 0; i < 32; ++i) printf("%02x", d[i]);
+        printf("\n");
+        h.reset();  // a reused object starts clean
+        h.update(m.data(), n);
+        uint8_t d2[32];
+        h.finish(d2);
+        if (memcmp(d, d2, 32)) printf("reuse differs at %zu\n", n);
+    }
+    return 0;
+}
+''')
+    exe = tmp_path / "shacheck"
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "rust-kzg_amd", "csrc"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)] + [str(n) for n in lengths]).decode().split("\n")
+    out = [ln for ln in out if ln]
+    assert len(out) == len(lengths), out[-3:]
+    for n, got in zip(lengths, out):
+        msg = bytes((i * 131 + n) & 0xFF for i in range(n))
+        assert got == hashlib.sha256(msg).hexdigest(), n
