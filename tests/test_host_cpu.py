@@ -577,3 +577,136 @@ int main(int argc, char** argv) {
     for n, got in zip(lengths, out):
         msg = bytes((i * 131 + n) & 0xFF for i in range(n))
         assert got == hashlib.sha256(msg).hexdigest(), n
+
+
+def test_host_g1_serialisation_and_subgroup_test_against_the_oracle(tmp_path, oracle):
+    """csrc/host_g1.h (the host side of bytes_to_kzg_commitment, compute_challenge's commitment, commitment checks of
+    small proof batches, the Horner tail of variable-base host calls): uncompress / compress / batch compress, the
+    Jacobian doubling and addition with their exceptional cases, and the endomorphism subgroup test, against the oracle
+    on points of G1, curve points outside G1 and every class of invalid encoding (FsG1::from_bytes,
+    blst/src/types/g1.rs:65-87)."""
+    import random
+    import shutil
+    import subprocess
+
+    import oracle_ffi as O
+
+    L = oracle.lib()
+    rnd = random.Random(404)
+    g = O.G1()
+    L.og1_generator(C.byref(g))
+
+    def comp(p):
+        buf = C.create_string_buffer(48)
+        L.og1_compress(buf, C.byref(p))
+        return buf.raw
+
+    enc = [comp(O.G1())]  # infinity: c0 00 ... 00
+    for k in [1, 2, 3, O.R - 1] + [rnd.randrange(1, O.R) for _ in range(24)]:
+        p = O.G1()
+        kf = O.fr_from_int(k)
+        L.og1_mul(C.byref(p), C.byref(g), C.byref(kf))
+        enc.append(comp(p))
+    # on the curve, outside G1: small x with a square x^3 + 4, both signs of y
+    x = 0
+    outside = 0
+    while outside < 6:
+        x += 1
+        rhs = (pow(x, 3, O.P) + 4) % O.P
+        y = pow(rhs, (O.P + 1) // 4, O.P)
+        if y * y % O.P == rhs:
+            for sign in (0, 0x20):
+                enc.append(bytes([0x80 | sign | (x >> 376)]) + (x & ((1 << 376) - 1)).to_bytes(47, "big"))
+            outside += 1
+    valid = len(enc)
+    good = enc[5]
+    bad = [
+        bytes([good[0] & 0x7F]) + good[1:],                 # compression flag missing
+        bytes([0xC0]) + bytes(46) + b"\x01",                # infinity with a non-zero x
+        bytes([0xE0]) + bytes(47),                          # infinity with the sign flag
+        bytes([0x80 | (O.P >> 376)]) + (O.P & ((1 << 376) - 1)).to_bytes(47, "big"),  # x = p
+        bytes([0x9F]) + b"\xff" * 47,                       # x >= p
+    ]
+    x = 0
+    while len(bad) < 8:                                     # x^3 + 4 not a square: not on the curve
+        x += 1
+        rhs = (pow(x, 3, O.P) + 4) % O.P
+        if pow(rhs, (O.P - 1) // 2, O.P) != 1:
+            bad.append(bytes([0x80]) + x.to_bytes(47, "big"))
+    enc += bad
+
+    cxx = shutil.which("g++") or shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    src = tmp_path / "g1check.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <vector>
+#include "host_g1.h"
+using namespace kzgamd;
+static void hex(const uint8_t* p, size_t n) { for (size_t i = 0; i < n; ++i) printf("%02x", p[i]); }
+int main() {
+    char line[256];
+    std::vector<blst_p1> pts;
+    while (fgets(line, sizeof line, stdin)) {
+        uint8_t in[48];
+        for (int i = 0; i < 48; ++i) { unsigned v; sscanf(line + 2 * i, "%2x", &v); in[i] = (uint8_t)v; }
+        blst_p1 p;
+        if (!host_p1_uncompress(&p, in)) { printf("bad\n"); continue; }
+        uint8_t c[48];
+        host_p1_compress(c, &p);
+        printf("ok %d ", host_p1_in_g1(&p) ? 1 : 0);
+        hex(c, 48);
+        printf("\n");
+        pts.push_back(p);
+    }
+    // doublings, sums (P + P, P + (-P), P + infinity among them) through the batch compression
+    std::vector<blst_p1> out;
+    auto J = [](const blst_p1& p) { const ff::Fp* P = reinterpret_cast<const ff::Fp*>(&p); return HostJac{P[0], P[1], P[2]}; };
+    auto put = [&](const HostJac& j) { blst_p1 p; ff::Fp* P = reinterpret_cast<ff::Fp*>(&p); P[0] = j.x; P[1] = j.y; P[2] = j.z; out.push_back(p); };
+    for (size_t i = 0; i < pts.size(); ++i) {
+        const HostJac a = J(pts[i]), b = J(pts[(i + 1) % pts.size()]);
+        HostJac d = host_jac_dbl(a);
+        put(d);                       // 2a (non-trivial Z from here on)
+        put(host_jac_add(d, b));      // 2a + b
+        put(host_jac_add(a, a));      // the doubling branch of the addition
+        HostJac n = d;
+        n.y = hfp::neg(n.y);
+        put(host_jac_add(d, n));      // infinity
+        put(host_jac_mul_u64(a, 0xd201000000010000ull + i));
+    }
+    std::vector<uint8_t> c(out.size() * 48);
+    host_p1_compress_batch(c.data(), out.data(), out.size());
+    for (size_t i = 0; i < out.size(); ++i) { printf("c "); hex(c.data() + 48 * i, 48); printf("\n"); }
+    return 0;
+}
+''')
+    exe = tmp_path / "g1check"
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "rust-kzg_amd", "csrc"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], input="\n".join(e.hex() for e in enc) + "\n", capture_output=True, text=True, check=True).stdout.split("\n")
+    heads, sums = [ln for ln in out if ln and not ln.startswith("c ")], [ln[2:] for ln in out if ln.startswith("c ")]
+    assert len(heads) == len(enc)
+    pts = []
+    for i, (e, ln) in enumerate(zip(enc, heads)):
+        a = O.G1Affine()
+        ok = L.og1_uncompress(C.byref(a), e)
+        assert (ln != "bad") == bool(ok) == (i < valid), (i, e.hex(), ln)
+        if not ok:
+            continue
+        p = O.G1()
+        L.og1_from_affine(C.byref(p), C.byref(a))
+        if e[0] & 0x40:
+            p = O.G1()
+        _, in_g1, again = ln.split()
+        assert int(in_g1) == L.og1_in_subgroup(C.byref(p)), (i, e.hex())
+        assert again == e.hex() == comp(p).hex(), i
+        pts.append(p)
+    assert sum(1 for ln in heads if ln.startswith("ok 0")) == 12  # the six outside points, both signs
+    assert len(sums) == 5 * len(pts)
+    for i, a in enumerate(pts):
+        b = pts[(i + 1) % len(pts)]
+        d, s, n, m = O.G1(), O.G1(), O.G1(), O.G1()
+        L.og1_dbl(C.byref(d), C.byref(a))
+        L.og1_add_or_dbl(C.byref(s), C.byref(d), C.byref(b))
+        kf = O.fr_from_int(0xd201000000010000 + i)
+        L.og1_mul(C.byref(m), C.byref(a), C.byref(kf))
+        want = [comp(d).hex(), comp(s).hex(), comp(d).hex(), comp(O.G1()).hex(), comp(m).hex()]
+        assert sums[5 * i:5 * i + 5] == want, i
