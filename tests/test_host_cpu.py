@@ -710,3 +710,53 @@ int main() {
         L.og1_mul(C.byref(m), C.byref(a), C.byref(kf))
         want = [comp(d).hex(), comp(s).hex(), comp(d).hex(), comp(O.G1()).hex(), comp(m).hex()]
         assert sums[5 * i:5 * i + 5] == want, i
+
+
+def test_glv_split_identity_and_bounds_on_the_host(tmp_path):
+    """kzgamd::glv_split (glv.hip.h; the same function runs in the MSM's digit kernels and, on the host, for the roots
+    of fft_g1): k = s1*k1 + s2*k2*x^2 (mod r) with both halves below 2^126.5 — what lets ceil(128/c) signed windows never
+    carry out of the top one — on the boundaries of every branch-free select (0, 1, (r-1)/2 and its neighbours, r - 1,
+    multiples of x^2 and of x^2/2 and their neighbours) and on random scalars."""
+    import random
+    import shutil
+    import subprocess
+
+    R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    X = 0xd201000000010000
+    X2 = X * X
+    rnd = random.Random(77)
+    ks = [0, 1, 2, R - 1, R - 2, (R - 1) // 2, (R - 1) // 2 + 1, (R - 1) // 2 - 1, X2, X2 - 1, X2 + 1, X2 // 2, X2 // 2 + 1,
+          X2 // 2 - 1, (1 << 128) - 1, 1 << 128, (1 << 254) + 5]
+    for m in (1, 2, 3, 1 << 60, (R // 2) // X2, (R // 2) // X2 - 1):
+        for d in (-1, 0, 1):
+            ks += [(m * X2 + d) % R, (m * X2 + X2 // 2 + d) % R, (R - m * X2 + d) % R]
+    ks += [rnd.randrange(R) for _ in range(20000)]
+    cxx = shutil.which("g++") or shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    src = tmp_path / "glvcheck.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include "glv.hip.h"
+int main() {
+    char line[128];
+    while (fgets(line, sizeof line, stdin)) {
+        ff::u32 k[8], k1[8], k2[8], n1, n2;
+        for (int i = 0; i < 8; ++i) sscanf(line + 8 * (7 - i), "%8x", &k[i]);
+        kzgamd::glv_split(k, k1, k2, n1, n2);
+        for (int i = 7; i >= 0; --i) printf("%08x", k1[i]);
+        printf(" ");
+        for (int i = 7; i >= 0; --i) printf("%08x", k2[i]);
+        printf(" %u %u\n", n1, n2);
+    }
+    return 0;
+}
+''')
+    exe = tmp_path / "glvcheck"
+    subprocess.check_call([cxx, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "rust-kzg_amd", "csrc"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], input="".join("%064x\n" % k for k in ks), capture_output=True, text=True, check=True).stdout.split()
+    assert len(out) == 4 * len(ks)
+    bound = int(2 ** 126.5)
+    for i, k in enumerate(ks):
+        k1, k2, n1, n2 = int(out[4 * i], 16), int(out[4 * i + 1], 16), int(out[4 * i + 2]), int(out[4 * i + 3])
+        assert n1 in (0, 1) and n2 in (0, 1)
+        assert k1 < bound and k2 < bound, hex(k)
+        assert ((-k1 if n1 else k1) + (-k2 if n2 else k2) * X2 - k) % R == 0, hex(k)
