@@ -760,3 +760,141 @@ int main() {
         assert n1 in (0, 1) and n2 in (0, 1)
         assert k1 < bound and k2 < bound, hex(k)
         assert ((-k1 if n1 else k1) + (-k2 if n2 else k2) * X2 - k) % R == 0, hex(k)
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_fp28_primitives_at_their_documented_bounds(tmp_path, exact):
+    """fp28.hip.h states a contract per primitive (limb and value bounds of the operands, normalisation and value bound
+    of the result).  The round-4 g1::dbl bug was a caller outside such a contract; this pins the contracts themselves,
+    on the host, at the EDGES of what they allow — values k*p and k*p +- 1, values with an empty top limb, the largest
+    value a bound admits, operands with 30-bit limbs — against Python integers: mul / sqr / mul2_inline (Montgomery
+    2^392), sub<K> / sub_lazy<K> / neg<K> for every pad (no limb may wrap), is_zero_mod_p with and without its filter
+    (-DKZGAMD_FORCE_EXACT_TESTS)."""
+    import random
+    import shutil
+    import subprocess
+
+    P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    M28 = (1 << 28) - 1
+    rnd = random.Random(2828)
+    RINV = pow(1 << 392, -1, P)
+
+    def limbs_norm(v):  # normalized representation: limbs 0..12 < 2^28, the rest in the top limb
+        assert v < 1 << (364 + 32)
+        return [(v >> (28 * i)) & M28 for i in range(13)] + [v >> 364]
+
+    def value(l):
+        return sum(x << (28 * i) for i, x in enumerate(l))
+
+    def edge_values(k):  # values in [0, k*p): multiples of p and their neighbours, empty top limb, the maximum, random
+        out = [0, 1, k * P - 1, (1 << 364) - 1, 1 << 364, M28]
+        for j in range(k):
+            out += [j * P, j * P + 1, max(0, j * P - 1)]
+        out += [rnd.randrange(k * P) for _ in range(40)] + [rnd.randrange(1 << 364) for _ in range(6)]
+        return [v for v in out if v < k * P]
+
+    def lazy(maxlimb_bits):  # a representation with limbs up to maxlimb_bits wide
+        return [rnd.randrange(1 << maxlimb_bits) if rnd.random() < 0.8 else (1 << maxlimb_bits) - 1 for _ in range(14)]
+
+    cases = []  # (op, operands as limb lists, checker)
+
+    def fmt(l):
+        return " ".join("%x" % x for x in l)
+
+    def check_mont(prod):
+        def chk(out):
+            assert all(x <= M28 for x in out[:13]), "result not normalized"
+            assert value(out) < 2 * P, "result not below 2p"
+            assert (value(out) - prod * RINV) % P == 0, "wrong residue"
+        return chk
+
+    # ---- mul / sqr / mul2 ----
+    for _ in range(300):
+        ka, kb = rnd.choice([(2, 2), (10, 6), (16, 4), (32, 2), (64, 1), (8, 8)])
+        a, b = rnd.choice(edge_values(ka)), rnd.choice(edge_values(kb))
+        cases.append(("mul", [limbs_norm(a), limbs_norm(b)], check_mont(a * b)))
+        cases.append(("sqr", [limbs_norm(b)], check_mont(b * b)))
+    for _ in range(200):  # operands with 30-bit limbs: value up to ~2^394, the other operand keeps the product below 2^392 p
+        a = lazy(30)
+        bmax = ((P << 392) // max(value(a), 1)) - 1
+        b = rnd.randrange(min(bmax, 2 * P)) if bmax > 0 else 0
+        cases.append(("mul", [a, limbs_norm(b)], check_mont(value(a) * b)))
+        s = lazy(29)  # sqr of a lazy sum of two normalized values < 2^29 per limb: keep the value product in range
+        if value(s) ** 2 < (P << 392):
+            cases.append(("sqr", [s], check_mont(value(s) ** 2)))
+    for _ in range(100):  # both operands with 30-bit limbs (the value bound leaves room for that in the low half only)
+        a, b = lazy(30)[:7] + [0] * 7, lazy(30)[:7] + [0] * 7
+        cases.append(("mul", [a, b], check_mont(value(a) * value(b))))
+    for _ in range(300):  # mul2: one lazy operand (limbs < 2^28 + 2^29) per product, as its callers pass
+        a, c = limbs_norm(rnd.choice(edge_values(2))), limbs_norm(rnd.choice(edge_values(2)))
+        b = [rnd.randrange((1 << 28) + (1 << 29)) for _ in range(13)] + [rnd.randrange(0x1a0110 + 0x1a011 * 8)]
+        d = [rnd.randrange((1 << 28) + (1 << 29)) for _ in range(13)] + [rnd.randrange(0x1a0110 + 0x1a011 * 8)]
+        tot = value(a) * value(b) + value(c) * value(d)
+        if tot < (P << 392):
+            cases.append(("mul2", [a, b, c, d], check_mont(tot)))
+    # ---- sub<K>, sub_lazy<K>, neg<K> ----
+    for k in (2, 4, 8, 16, 32):
+        for bv in edge_values(k - 1):
+            for av in (0, rnd.choice(edge_values(2)), rnd.choice(edge_values(10))):
+                want = av + k * P - bv
+
+                def chk_sub(out, want=want):
+                    assert all(x <= M28 for x in out[:13]) and value(out) == want
+
+                def chk_lazy(out, want=want):
+                    assert all(x < (1 << 28) + (1 << 29) for x in out[:13]) and out[13] < 1 << 31 and value(out) == want
+
+                cases.append(("sub%d" % k, [limbs_norm(av), limbs_norm(bv)], chk_sub))
+                cases.append(("subl%d" % k, [limbs_norm(av), limbs_norm(bv)], chk_lazy))
+            cases.append(("neg%d" % k, [limbs_norm(bv)], lambda out, w=k * P - bv: (all(x <= M28 for x in out[:13]) and value(out) == w) or (_ for _ in ()).throw(AssertionError("neg"))))
+    # ---- is_zero_mod_p: normalized or lazy a with value < 64p ----
+    for j in range(64):
+        for v, want in ((j * P, 1), (j * P + 1, 0), (j * P + (1 << 364), 0), (j * P + (1 << 200), 0)):
+            if j * P <= v < 64 * P and (v != 0 or want):
+                cases.append(("iszero", [limbs_norm(v)], lambda out, w=want: out == [w] or (_ for _ in ()).throw(AssertionError("iszero"))))
+    for _ in range(200):
+        v = rnd.randrange(64 * P)
+        cases.append(("iszero", [limbs_norm(v)], lambda out, w=int(v % P == 0): out == [w] or (_ for _ in ()).throw(AssertionError("iszero"))))
+    # a lazy (unnormalized) multiple of p: sum of two normalized multiples, limb-wise
+    for _ in range(50):
+        x, y = limbs_norm(rnd.randrange(30) * P), limbs_norm(rnd.randrange(30) * P)
+        cases.append(("iszero", [[p + q for p, q in zip(x, y)]], lambda out: out == [1] or (_ for _ in ()).throw(AssertionError("iszero lazy"))))
+
+    cxx = shutil.which("g++") or shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    src = tmp_path / "fp28check.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstring>
+#include "fp28.hip.h"
+using fp28::Fe;
+static Fe rd() { Fe r; for (int i = 0; i < 14; ++i) if (scanf("%x", &r.v[i]) != 1) r.v[i] = 0; return r; }
+static void wr(const Fe& a) { for (int i = 0; i < 14; ++i) printf("%x ", a.v[i]); printf("\n"); }
+int main() {
+    char op[16];
+    while (scanf("%15s", op) == 1) {
+        if (!strcmp(op, "mul")) { Fe a = rd(), b = rd(); wr(fp28::mul(a, b)); }
+        else if (!strcmp(op, "sqr")) { Fe a = rd(); wr(fp28::sqr(a)); }
+        else if (!strcmp(op, "mul2")) { Fe a = rd(), b = rd(), c = rd(), d = rd(); wr(fp28::mul2_inline(a, b, c, d)); }
+        else if (!strcmp(op, "iszero")) { Fe a = rd(); printf("%d\n", fp28::is_zero_mod_p(a) ? 1 : 0); }
+#define SUBS(K) \
+        else if (!strcmp(op, "sub" #K)) { Fe a = rd(), b = rd(); wr(fp28::sub<K>(a, b)); } \
+        else if (!strcmp(op, "subl" #K)) { Fe a = rd(), b = rd(); wr(fp28::sub_lazy<K>(a, b)); } \
+        else if (!strcmp(op, "neg" #K)) { Fe a = rd(); wr(fp28::neg<K>(a)); }
+        SUBS(2) SUBS(4) SUBS(8) SUBS(16) SUBS(32)
+        else { printf("unknown op %s\n", op); return 1; }
+    }
+    return 0;
+}
+''')
+    exe = tmp_path / "fp28check"
+    subprocess.check_call([cxx, "-O1", "-std=c++17"] + (["-DKZGAMD_FORCE_EXACT_TESTS"] if exact else []) +
+                          ["-I", os.path.join(ROOT, "rust-kzg_amd", "csrc"), str(src), "-o", str(exe)])
+    text = "".join(op + " " + " ".join(fmt(l) for l in ops) + "\n" for op, ops, _ in cases)
+    out = subprocess.run([str(exe)], input=text, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert len(out) == len(cases) > 3000
+    for (op, ops, chk), ln in zip(cases, out):
+        got = [int(x, 16) for x in ln.split()]
+        try:
+            chk(got)
+        except AssertionError as e:
+            raise AssertionError("%s %s -> %s: %s" % (op, [hex(value(l)) for l in ops], ln, e))
