@@ -898,3 +898,150 @@ int main() {
             chk(got)
         except AssertionError as e:
             raise AssertionError("%s %s -> %s: %s" % (op, [hex(value(l)) for l in ops], ln, e))
+
+
+def test_fr29_butterfly_arithmetic_at_its_documented_bounds(tmp_path):
+    """fr29.hip.h, the arithmetic of the NTT kernels, on the host against Python integers: mul_signed (result in (-r, r)
+    with a signed top limb, for a lazy multiplicand < 64r whose own top limb may be negative), butterfly_signed /
+    butterfly_lazy / butterfly_lazy8 (value identities, no limb wraps), one radix-4 round exactly as ntt.hip's ntt_round
+    chains them (two butterfly levels, then ONE carry pass: limbs normalised, value grown by < 10r, never negative),
+    reduce_lazy on EVERY multiple of r below 64r and its neighbours (its quotient estimate is off by one there or
+    nowhere), finish, mul."""
+    import random
+    import shutil
+    import subprocess
+
+    R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    M29 = (1 << 29) - 1
+    RINV = pow(1 << 261, -1, R)
+    rnd = random.Random(2929)
+
+    def limbs(v):
+        assert 0 <= v < 1 << (232 + 31)
+        return [(v >> (29 * i)) & M29 for i in range(8)] + [v >> 232]
+
+    def sval(l):  # top limb signed
+        top = l[8] - (1 << 32) if l[8] >> 31 else l[8]
+        return sum(x << (29 * i) for i, x in enumerate(l[:8])) + (top << 232)
+
+    def edge(k):
+        out = [0, 1, k * R - 1, (1 << 232) - 1, 1 << 232]
+        for j in range(0, k, max(1, k // 8)):
+            out += [j * R, j * R + 1, max(0, j * R - 1)]
+        return [v for v in out if v < k * R] + [rnd.randrange(k * R) for _ in range(30)]
+
+    cases = []
+
+    def normalized(l):
+        return all(x <= M29 for x in l[:8]) and not l[8] >> 31
+
+    # ---- one radix-4 round, the way ntt_round<..., FIRST = false> runs it: inputs normalised, value < 51r ----
+    def chk_round(es, ws):
+        def net(e, w):
+            e = list(e)
+            for (a, b, wi) in ((0, 1, 0), (2, 3, 1), (0, 2, 2), (1, 3, 3)):
+                t = e[b] * w[wi] * RINV
+                e[a], e[b] = e[a] + t, e[a] - t
+            return e
+
+        want = net(es, ws)
+
+        def chk(out):
+            got = [out[9 * i:9 * i + 9] for i in range(4)]
+            for g, w, e in zip(got, want, es):
+                assert normalized(g), "round output not normalised"
+                assert (sval(g) - w) % R == 0, "round residue"
+                assert 0 <= sval(g) < max(es) + 10 * R + 1, "round growth"
+        return chk
+
+    for _ in range(400):
+        top = rnd.choice([1, 2, 8, 30, 51])
+        es = [rnd.choice(edge(top)) for _ in range(4)]
+        ws = [rnd.choice([0, 1, R - 1, rnd.randrange(R), rnd.randrange(R)]) for _ in range(4)]
+        cases.append(("round", [limbs(e) for e in es] + [limbs(w) for w in ws], chk_round(es, ws)))
+    # ---- mul_signed alone on lazy multiplicands: limbs up to 1.5 * 2^30, top limb down to -1 ----
+    for _ in range(400):
+        a = [rnd.randrange(3 << 29) for _ in range(8)] + [rnd.choice([0, 1, 0xFFFFFFFF, rnd.randrange(64 * 0x73eda7)])]
+        if not -R < sval(a) < 64 * R:
+            continue
+        b = rnd.choice([0, 1, R - 1, rnd.randrange(R)])
+
+        def chk(out, want=sval(a) * b):
+            assert all(x <= M29 for x in out[:8]) and -R < sval(out) < R and (sval(out) - want * RINV) % R == 0
+        cases.append(("msig", [a, limbs(b)], chk))
+    # ---- the three butterflies: values and limb growth ----
+    for _ in range(300):
+        x = rnd.choice(edge(51))
+        t = rnd.randrange(-R + 1, 2 * R)  # what mul_signed returns, or a normalised value below 2r
+        tl = [(t >> (29 * i)) & M29 for i in range(8)] + [(t >> 232) & 0xFFFFFFFF]
+
+        def chk_s(out, x=x, t=t):
+            a, b = out[:9], out[9:]
+            assert sval(a) == x + t + R and sval(b) == x + 4 * R - t
+            assert all(v < (1 << 29) + (1 << 30) for v in a[:8] + b[:8])
+        cases.append(("bfs", [limbs(x), tl], chk_s))
+        t3 = rnd.choice(edge(3))
+        cases.append(("bfl", [limbs(x), limbs(t3)], lambda out, x=x, t=t3: (sval(out[:9]) == x + t and sval(out[9:]) == x + 4 * R - t and all(v < 3 << 29 for v in out[:8] + out[9:17])) or (_ for _ in ()).throw(AssertionError("bfl"))))
+        t7 = rnd.choice(edge(7))
+        cases.append(("bfl8", [limbs(x), limbs(t7)], lambda out, x=x, t=t7: (sval(out[:9]) == x + t and sval(out[9:]) == x + 8 * R - t and all(v < 3 << 29 for v in out[:8] + out[9:17])) or (_ for _ in ()).throw(AssertionError("bfl8"))))
+    # ---- reduce_lazy / finish: every multiple of r below 64r with its neighbours, the maximum, random ----
+    vals = [64 * R - 1]
+    for j in range(64):
+        vals += [j * R, j * R + 1, j * R + R - 1, j * R + (R >> 1)]
+    vals += [rnd.randrange(64 * R) for _ in range(3000)]
+    for v in vals:
+        cases.append(("redl", [limbs(v)], lambda out, v=v: sum(x << (32 * i) for i, x in enumerate(out)) == v % R or (_ for _ in ()).throw(AssertionError("reduce_lazy %x" % v))))
+    for v in vals[:600]:
+        m = rnd.choice([1, R - 1, rnd.randrange(R)])
+        cases.append(("fin", [limbs(v), limbs(m)], lambda out, v=v, m=m: sum(x << (32 * i) for i, x in enumerate(out)) == v * m * RINV % R or (_ for _ in ()).throw(AssertionError("finish"))))
+    # ---- mul: multiplicand limbs < 2^31, multiplier normalised, a*b < 2^261 r ----
+    for _ in range(300):
+        a = [rnd.randrange(1 << 31) for _ in range(8)] + [rnd.randrange(64 * 0x73eda7)]
+        b = rnd.randrange(R)
+        if sval(a) * b < (R << 261):
+            cases.append(("mul", [a, limbs(b)], lambda out, w=sval(a) * b: (normalized(out) and sval(out) < 2 * R and (sval(out) - w * RINV) % R == 0) or (_ for _ in ()).throw(AssertionError("mul"))))
+
+    cxx = shutil.which("g++") or shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    src = tmp_path / "fr29check.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstring>
+#include "fr29.hip.h"
+using fr29::Fe;
+static Fe rd() { Fe r; for (int i = 0; i < 9; ++i) if (scanf("%x", &r.v[i]) != 1) r.v[i] = 0; return r; }
+static void wr(const Fe& a) { for (int i = 0; i < 9; ++i) printf("%x ", a.v[i]); }
+static void wr(const ff::Fr& a) { for (int i = 0; i < 8; ++i) printf("%x ", a.v[i]); }
+static void bf(Fe& x, Fe& y, const Fe& w) { const Fe t = fr29::mul_signed<true>(y, w); fr29::butterfly_signed(x, y, t); }
+int main() {
+    char op[16];
+    while (scanf("%15s", op) == 1) {
+        if (!strcmp(op, "round")) {
+            Fe e[4], w[4];
+            for (auto& x : e) x = rd();
+            for (auto& x : w) x = rd();
+            bf(e[0], e[1], w[0]); bf(e[2], e[3], w[1]); bf(e[0], e[2], w[2]); bf(e[1], e[3], w[3]);   // ntt.hip: KZG_BF x 4
+            for (auto& x : e) { fr29::norm(x); wr(x); }
+        } else if (!strcmp(op, "msig")) { Fe a = rd(), b = rd(); wr(fr29::mul_signed<true>(a, b)); }
+        else if (!strcmp(op, "bfs")) { Fe x = rd(), t = rd(), y; fr29::butterfly_signed(x, y, t); wr(x); wr(y); }
+        else if (!strcmp(op, "bfl")) { Fe x = rd(), t = rd(), y; fr29::butterfly_lazy(x, y, t); wr(x); wr(y); }
+        else if (!strcmp(op, "bfl8")) { Fe x = rd(), t = rd(), y; fr29::butterfly_lazy8(x, y, t); wr(x); wr(y); }
+        else if (!strcmp(op, "redl")) { Fe a = rd(); wr(fr29::reduce_lazy(a)); }
+        else if (!strcmp(op, "fin")) { Fe a = rd(), m = rd(); wr(fr29::finish(a, m)); }
+        else if (!strcmp(op, "mul")) { Fe a = rd(), b = rd(); wr(fr29::mul(a, b)); }
+        else { printf("unknown op %s\n", op); return 1; }
+        printf("\n");
+    }
+    return 0;
+}
+''')
+    exe = tmp_path / "fr29check"
+    subprocess.check_call([cxx, "-O1", "-std=c++17", "-I", os.path.join(ROOT, "rust-kzg_amd", "csrc"), str(src), "-o", str(exe)])
+    text = "".join(op + " " + " ".join(" ".join("%x" % x for x in l) for l in ops) + "\n" for op, ops, _ in cases)
+    out = subprocess.run([str(exe)], input=text, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert len(out) == len(cases) > 5000
+    for (op, ops, chk), ln in zip(cases, out):
+        got = [int(x, 16) for x in ln.split()]
+        try:
+            chk(got)
+        except AssertionError as e:
+            raise AssertionError("%s %s -> %s: %s" % (op, [hex(sval(l)) for l in ops], ln, e))
