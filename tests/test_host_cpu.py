@@ -1069,3 +1069,19 @@ def test_barrier_audit_on_file_is_the_audit_of_these_sources():
     inside = sorted({ln.split("inside:", 1)[1].strip() for ln in now.splitlines() if "inside:" in ln})
     for stmt in inside:
         assert not re.search(r"threadIdx|lane|tid\b|__shfl|is_zero|is_inf", stmt), stmt
+
+
+def test_the_library_reads_four_environment_variables():
+    """Configuration is an API (KzgAmdConfig, csrc/config.h), not the process environment: the library sources read the
+    four variables DESIGN.md §9 and include/kzg_mi355x.h name, each at one site, and nothing else."""
+    import glob
+
+    seen = {}
+    for path in glob.glob(os.path.join(ROOT, "rust-kzg_amd", "csrc", "*.h*")):
+        for name in re.findall(r'getenv\(\s*"([^"]*)"', open(path).read()):
+            seen[name] = seen.get(name, 0) + 1
+        assert not re.search(r"getenv\(\s*[^\"\s]", open(path).read()), path  # no computed names
+    assert seen == {"KZGAMD_TUNING": 1, "KZGAMD_FBW_MAX_GB": 1, "KZGAMD_VERBOSE": 1, "KZGAMD_DEBUG": 1}
+    design = open(os.path.join(ROOT, "DESIGN.md"), encoding="utf-8").read()
+    for name in seen:
+        assert name in design
