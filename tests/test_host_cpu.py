@@ -1085,3 +1085,111 @@ def test_the_library_reads_four_environment_variables():
     design = open(os.path.join(ROOT, "DESIGN.md"), encoding="utf-8").read()
     for name in seen:
         assert name in design
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_g1_point_formulas_against_the_oracle_on_the_host(tmp_path, oracle, exact):
+    """g1_28.hip.h (the XYZZ formulas every MSM and G1-transform kernel inlines: madd, dadd, dadd_unequal, dbl, dbl_k,
+    mul_small, to_blst_jacobian) compiled for the host and held to the oracle's point arithmetic, with the exceptional
+    cases the reference's p1_dadd_affine / p1_dadd handle (kzg/src/msm/pippenger_utils.rs:90-210): the accumulator or the
+    addend at infinity, P + P (the doubling branch of an addition), P + (-P); with and without the filter in front of the
+    exact zero test (the two builds of the library)."""
+    import random
+    import shutil
+    import subprocess
+
+    import oracle_ffi as O
+
+    L = oracle.lib()
+    rnd = random.Random(515)
+    g = O.G1()
+    L.og1_generator(C.byref(g))
+
+    def comp(p):
+        buf = C.create_string_buffer(48)
+        L.og1_compress(buf, C.byref(p))
+        return buf.raw.hex()
+
+    def mul(p, k):
+        r, kf = O.G1(), O.fr_from_int(k % O.R)
+        L.og1_mul(C.byref(r), C.byref(p), C.byref(kf))
+        return r
+
+    def add(a, b):
+        r = O.G1()
+        L.og1_add_or_dbl(C.byref(r), C.byref(a), C.byref(b))
+        return r
+
+    inf = O.G1()
+    cases = []  # (line, expected compressed)
+    for it in range(60):
+        P = mul(g, rnd.randrange(1, O.R))
+        Q = mul(g, rnd.randrange(1, O.R))
+        P2, Q2 = mul(P, 2), mul(Q, 2)
+        k = rnd.choice([0, 1, 2, 3, 15, 16, 112, 255]) if it % 2 else rnd.randrange(1, 300)
+        ks = rnd.choice([0, 1, 2, 3, 5, 64, 0xFFFF, 0x12345])
+        rows = [
+            ("madd", P, Q, 0, add(P2, Q)), ("madd", P, P2, 0, mul(P, 4)), ("madd", P, mul(P2, O.R - 1), 0, inf),
+            ("madd0", P, Q, 0, Q),
+            ("dadd", P, Q, 0, add(P2, Q2)), ("dadd", P, P, 0, mul(P, 4)), ("dadd", P, mul(P, O.R - 1), 0, inf),
+            ("dadd", inf, Q, 0, Q2), ("dadd", P, inf, 0, P2),
+            ("daddu", P, Q, 0, add(P2, Q2)), ("daddu", P, P, 0, mul(P, 4)), ("daddu", P, mul(P, O.R - 1), 0, inf),
+            ("dblk", P, inf, k, mul(P, 2 << k)), ("muls", P, inf, ks, mul(P, 2 * ks)),
+        ]
+        for op, a, b, kk, want in rows:
+            cases.append(("%s %s %s %d" % (op, comp(a), comp(b), kk), comp(want)))
+    cases.append(("dblk %s %s 7" % (comp(inf), comp(inf)), comp(inf)))
+    cases.append(("muls %s %s 9" % (comp(inf), comp(inf)), comp(inf)))
+
+    cxx = shutil.which("g++") or shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    src = tmp_path / "g1formulas.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include <cstring>
+#include "g1_28.hip.h"
+#include "host_g1.h"
+using g1::Xyzz;
+static bool rd(Xyzz& out) {  // compressed hex -> XYZZ (affine: ZZ = ZZZ = 1), infinity -> all-zero
+    char h[128];
+    if (scanf("%127s", h) != 1) return false;
+    uint8_t in[48];
+    for (int i = 0; i < 48; ++i) { unsigned v; sscanf(h + 2 * i, "%2x", &v); in[i] = (uint8_t)v; }
+    blst_p1 p;
+    if (!kzgamd::host_p1_uncompress(&p, in)) return false;
+    const ff::Fp* P = reinterpret_cast<const ff::Fp*>(&p);
+    if (P[2].is_zero()) g1::set_inf(out);
+    else g1::set_affine(out, fp28::from_blst(P[0]), fp28::from_blst(P[1]));
+    return true;
+}
+static void wr(const Xyzz& a) {
+    blst_p1 p;
+    g1::to_blst_jacobian(reinterpret_cast<ff::Fp*>(&p), a);
+    uint8_t c[48];
+    kzgamd::host_p1_compress(c, &p);
+    for (int i = 0; i < 48; ++i) printf("%02x", c[i]);
+    printf("\n");
+}
+static void twice(Xyzz& a) { if (!g1::is_inf(a)) g1::dbl(a); }   // a non-trivial ZZ on every operand
+int main() {
+    char op[16];
+    while (scanf("%15s", op) == 1) {
+        Xyzz a, b;
+        unsigned k;
+        if (!rd(a) || !rd(b) || scanf("%u", &k) != 1) { printf("input\n"); return 1; }
+        if (!strcmp(op, "madd")) { Xyzz acc = a; twice(acc); g1::madd(acc, b.x, b.y); wr(acc); }
+        else if (!strcmp(op, "madd0")) { Xyzz acc; g1::set_inf(acc); g1::madd(acc, b.x, b.y); wr(acc); }
+        else if (!strcmp(op, "dadd")) { twice(a); twice(b); g1::dadd(a, b); wr(a); }
+        else if (!strcmp(op, "daddu")) { twice(a); twice(b); if (g1::dadd_unequal(a, b)) g1::dbl(a); wr(a); }
+        else if (!strcmp(op, "dblk")) { twice(a); g1::dbl_k(a, (int)k); wr(a); }
+        else if (!strcmp(op, "muls")) { twice(a); g1::mul_small(a, k); wr(a); }
+        else { printf("unknown\n"); return 1; }
+    }
+    return 0;
+}
+''')
+    exe = tmp_path / "g1formulas"
+    subprocess.check_call([cxx, "-O1", "-std=c++17"] + (["-DKZGAMD_FORCE_EXACT_TESTS"] if exact else []) + ["-I", os.path.join(ROOT, "rust-kzg_amd", "csrc"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], input="\n".join(c[0] for c in cases) + "\n", capture_output=True, text=True, check=True).stdout.split()
+    assert len(out) == len(cases) > 800
+    for (line, want), got in zip(cases, out):
+        assert got == want, line.split()[0] + " " + line.split()[-1]
