@@ -579,20 +579,9 @@ int main(int argc, char** argv) {
         assert got == hashlib.sha256(msg).hexdigest(), n
 
 
-def test_host_g1_serialisation_and_subgroup_test_against_the_oracle(tmp_path, oracle):
-    """csrc/host_g1.h (the host side of bytes_to_kzg_commitment, compute_challenge's commitment, commitment checks of
-    small proof batches, the Horner tail of variable-base host calls): uncompress / compress / batch compress, the
-    Jacobian doubling and addition with their exceptional cases, and the endomorphism subgroup test, against the oracle
-    on points of G1, curve points outside G1 and every class of invalid encoding (FsG1::from_bytes,
-    blst/src/types/g1.rs:65-87)."""
-    import random
-    import shutil
-    import subprocess
-
-    import oracle_ffi as O
-
-    L = oracle.lib()
-    rnd = random.Random(404)
+def _g1_encodings(L, O, rnd):
+    """compressed G1 encodings for the (de)serialisation tests: infinity, points of G1, curve points outside G1 (both
+    signs), then every class of invalid encoding; returns (encodings, number of valid ones)"""
     g = O.G1()
     L.og1_generator(C.byref(g))
 
@@ -634,6 +623,32 @@ def test_host_g1_serialisation_and_subgroup_test_against_the_oracle(tmp_path, or
         if pow(rhs, (O.P - 1) // 2, O.P) != 1:
             bad.append(bytes([0x80]) + x.to_bytes(47, "big"))
     enc += bad
+    return enc, valid
+
+
+def test_host_g1_serialisation_and_subgroup_test_against_the_oracle(tmp_path, oracle):
+    """csrc/host_g1.h (the host side of bytes_to_kzg_commitment, compute_challenge's commitment, commitment checks of
+    small proof batches, the Horner tail of variable-base host calls): uncompress / compress / batch compress, the
+    Jacobian doubling and addition with their exceptional cases, and the endomorphism subgroup test, against the oracle
+    on points of G1, curve points outside G1 and every class of invalid encoding (FsG1::from_bytes,
+    blst/src/types/g1.rs:65-87)."""
+    import random
+    import shutil
+    import subprocess
+
+    import oracle_ffi as O
+
+    L = oracle.lib()
+    rnd = random.Random(404)
+    g = O.G1()
+    L.og1_generator(C.byref(g))
+
+    def comp(p):
+        buf = C.create_string_buffer(48)
+        L.og1_compress(buf, C.byref(p))
+        return buf.raw
+
+    enc, valid = _g1_encodings(L, O, rnd)
 
     cxx = shutil.which("g++") or shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
     src = tmp_path / "g1check.cpp"
@@ -1193,3 +1208,65 @@ int main() {
     assert len(out) == len(cases) > 800
     for (line, want), got in zip(cases, out):
         assert got == want, line.split()[0] + " " + line.split()[-1]
+
+
+def test_device_g1_serialisation_code_against_the_oracle_on_the_host(tmp_path, oracle):
+    """g1_io.hip.h — what k_uncompress / k_decode_check_g1 and the compressed output mode of the MSM's last kernel run per
+    point — compiled for the host: the same encodings as the host_g1.h test (valid, outside G1, every invalid class) are
+    accepted or refused as the oracle does, accepted ones compress back to themselves, and a point with non-trivial
+    ZZ / ZZZ (its double) compresses to the oracle's bytes (the inversion behind it included)."""
+    import random
+    import shutil
+    import subprocess
+
+    import oracle_ffi as O
+
+    L = oracle.lib()
+    enc, valid = _g1_encodings(L, O, random.Random(404))
+    cxx = shutil.which("g++") or shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
+    src = tmp_path / "g1io.cpp"
+    src.write_text(r'''
+#include <cstdio>
+#include "g1_28.hip.h"
+#include "g1_io.hip.h"
+static void hex(const unsigned char* p) { for (int i = 0; i < 48; ++i) printf("%02x", p[i]); }
+int main() {
+    char line[256];
+    while (fgets(line, sizeof line, stdin)) {
+        unsigned char in[48], c[48], c2[48];
+        for (int i = 0; i < 48; ++i) { unsigned v; sscanf(line + 2 * i, "%2x", &v); in[i] = (unsigned char)v; }
+        g1::AffPt a;
+        if (!g1io::uncompress(a, in)) { printf("bad\n"); continue; }
+        g1::Xyzz p;
+        if (a.flags & 1) g1::set_inf(p);
+        else g1::set_affine(p, a.x, a.y);
+        g1io::compress(c, p);
+        if (!g1::is_inf(p)) g1::dbl(p);
+        g1io::compress(c2, p);
+        printf("ok ");
+        hex(c);
+        printf(" ");
+        hex(c2);
+        printf("\n");
+    }
+    return 0;
+}
+''')
+    exe = tmp_path / "g1io"
+    subprocess.check_call([cxx, "-O1", "-std=c++17", "-I", os.path.join(ROOT, "rust-kzg_amd", "csrc"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], input="\n".join(e.hex() for e in enc) + "\n", capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert len(out) == len(enc)
+    for i, (e, ln) in enumerate(zip(enc, out)):
+        assert (ln != "bad") == (i < valid), (i, e.hex(), ln)
+        if ln == "bad":
+            continue
+        _, again, doubled = ln.split()
+        assert again == e.hex(), i
+        a, p, d = O.G1Affine(), O.G1(), O.G1()
+        assert L.og1_uncompress(C.byref(a), e)
+        if not e[0] & 0x40:
+            L.og1_from_affine(C.byref(p), C.byref(a))
+        L.og1_dbl(C.byref(d), C.byref(p))
+        buf = C.create_string_buffer(48)
+        L.og1_compress(buf, C.byref(d))
+        assert doubled == buf.raw.hex(), i
