@@ -1,8 +1,10 @@
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
+SEED=${SEED:-41}
 mkdir -p $R/gpurun_out
-LOG=$R/gpurun_out/long_fuzz3.log
+LOG=$R/gpurun_out/long_fuzz_$SEED.log
 : > $LOG
-for spec in "product libkzg_mi355x.so 150 41" "exact libkzg_mi355x_exact.so 90 41"; do
+# SEED, PB (seconds per tool, product build), EB (exact build):  SEED=51 PB=100 EB=60 bash tools/fuzz_session.sh
+for spec in "product libkzg_mi355x.so ${PB:-150} $SEED" "exact libkzg_mi355x_exact.so ${EB:-90} $SEED"; do
   set -- $spec
   s=$4
   for f in fuzz_ckzg.py fuzz_msm.py fuzz_g1.py; do
