@@ -845,7 +845,8 @@ def main():
             t_p = (time.perf_counter() - t0) / 2
             ok = ms.verify_blob_batch(host_blobs[:64 * BLOB], cmb[:64 * 48], b"".join(prs[:64]), min(64, nmb))
             res["in_process_multi"] = {
-                "devices": ms.settings_devices(), "blobs_per_call": nmb, "commitments_per_s": nmb / t_c, "proofs_per_s": nmb / t_p,
+                "devices": ms.settings_devices(), "objects": ndev, "blobs_per_call": nmb, "commitments_per_s": nmb / t_c, "proofs_per_s": nmb / t_p,
+                "host_read_GBps": nmb * BLOB / t_c / 1e9,
                 "first_64_proofs_verify": bool(ok),
                 "path": "kzgamd_blob_to_kzg_commitment_batch_multi / kzgamd_compute_blob_kzg_proof_batch_multi: one process, "
                         "%d settings object(s), slabs of the batch per device on one host thread each, host buffers in and out "
@@ -853,6 +854,55 @@ def main():
             ms.close()
         except Exception as e:  # noqa: BLE001
             res["in_process_multi"] = {"error": repr(e)}
+        if world == 1:
+            # ---- the N = 8 host side on the hardware there is: EIGHT settings objects on this one GPU (8 GB per table), fed by
+            # the library's eight host threads from pageable memory and from page-locked memory (kzgamd_pin_host_buffer).  The
+            # GPU is shared eight ways, so commitments/s says nothing about eight GPUs; what the leg shows is what ONE host
+            # process sustains reading caller buffers through eight slab threads — the first wall an 8-GPU node would meet
+            # (8 x ~87 k blobs/s = ~90 GB/s of host reads).
+            try:
+                import ctypes as C
+
+                ms8 = kzg.MultiKZGSettings(SETUP, [0] * 8, kzg.make_config(table_budget_gb=8))
+                nmb = len(host_blobs) // BLOB
+                L = kzg.lib()
+                rows = {}
+                # pageable: the bytes object as it is; pinned: a page-locked copy of it (and of the output)
+                pin_in = C.create_string_buffer(host_blobs, len(host_blobs))
+                pin_out = C.create_string_buffer(nmb * 48)
+                for mode in ("pageable", "pinned"):
+                    if mode == "pinned":
+                        assert L.kzgamd_pin_host_buffer(pin_in, len(pin_in)) == 0 and L.kzgamd_pin_host_buffer(pin_out, len(pin_out)) == 0
+                    src = host_blobs if mode == "pageable" else pin_in
+                    out = C.create_string_buffer(nmb * 48) if mode == "pageable" else pin_out
+                    assert L.kzgamd_blob_to_kzg_commitment_batch_multi(out, src, nmb, ms8.ptrs, 8) == 0
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        assert L.kzgamd_blob_to_kzg_commitment_batch_multi(out, src, nmb, ms8.ptrs, 8) == 0
+                    t_c8 = (time.perf_counter() - t0) / 3
+                    cm8 = out.raw
+                    pout = C.create_string_buffer(nmb * 48)
+                    assert L.kzgamd_compute_blob_kzg_proof_batch_multi(pout, src, cm8, nmb, ms8.ptrs, 8) == 0
+                    t0 = time.perf_counter()
+                    for _ in range(2):
+                        assert L.kzgamd_compute_blob_kzg_proof_batch_multi(pout, src, cm8, nmb, ms8.ptrs, 8) == 0
+                    t_p8 = (time.perf_counter() - t0) / 2
+                    rows[mode] = {"commitments_per_s": nmb / t_c8, "proofs_per_s": nmb / t_p8,
+                                  "host_read_GBps_commit": nmb * BLOB / t_c8 / 1e9, "host_read_GBps_prove": nmb * BLOB / t_p8 / 1e9,
+                                  "equals_one_object": cm8 == b"".join(cms)}
+                L.kzgamd_unpin_host_buffer(pin_in)
+                L.kzgamd_unpin_host_buffer(pin_out)
+                # 256 blobs, 32 per object: BASELINE configs[4]'s shape
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    ms8.proof_batch(host_blobs[:256 * BLOB], cm8[:256 * 48], 256)
+                rows["configs4_256_blobs_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+                res["in_process_multi"]["eight_objects_one_gpu"] = dict(rows, objects=8, blobs_per_call=nmb,
+                    path="8 settings objects on GPU 0 (table_budget_bytes = 8 GB each), kzgamd_*_batch_multi: one host thread per "
+                         "object; the GPU is shared eight ways — the figure of interest is the host-side feed rate")
+                ms8.close()
+            except Exception as e:  # noqa: BLE001
+                res["in_process_multi"]["eight_objects_one_gpu"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_extras:
         # ---- what a smaller commitment table costs (KzgAmdConfig.table_budget_bytes): device-resident commitments/s per HBM budget ----

@@ -11,6 +11,12 @@ HEADERS = ["ff.hip.h", "fp28.hip.h", "g1_28.hip.h", "g1_io.hip.h", "msm_internal
            os.path.join("..", "..", "include", "kzg_mi355x.h")]
 
 
+# what the last build() / build_exact() / build_prefixed() of this process did, per library file name: "reused (content stamp
+# matches the sources)" or "compiled: <sources>; linked" — __graft_entry__.build() prints it, so that a build record says
+# whether hipcc ran
+REPORT = {}
+
+
 def _stale():
     if not os.path.exists(LIB):
         return True
@@ -51,6 +57,7 @@ def build_prefixed(verbose=False):
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PREFIXED] + objs + ["-lpthread"], cwd=CSRC)
     for o in objs:
         os.remove(o)
+    REPORT[os.path.basename(LIB_PREFIXED)] = "relinked from the product library's objects (symbols renamed with llvm-objcopy)"
     return LIB_PREFIXED
 
 
@@ -122,9 +129,14 @@ def _compile_and_link(lib, tag, defines, force, verbose):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + s)
+    compiled = [s for s, _ in procs]
+    linked = False
     if procs or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lpthread"]
         subprocess.check_call(cmd, cwd=CSRC)
+        linked = True
+    REPORT[os.path.basename(lib)] = ("compiled with hipcc --offload-arch=gfx950: %s; " % (", ".join(compiled) if compiled else "nothing (objects up to date)")) + \
+        ("linked" if linked else "library up to date")
     with open(_stamp_path(lib), "w") as fh:
         fh.write(want + "\n")
     return lib
@@ -136,6 +148,7 @@ def build(force=False, verbose=False):
     during a compilation) is recompiled in full.  KZGAMD_REBUILD=1 forces a full recompilation (what a fresh clone does)."""
     force = force or os.environ.get("KZGAMD_REBUILD") == "1"
     if not force and os.path.exists(LIB) and _stamp_matches(LIB, []):
+        REPORT[os.path.basename(LIB)] = "reused (content stamp matches the sources: nothing to compile)"
         return LIB
     if not force and os.path.exists(LIB) and not _stale():
         force = True  # nothing looks newer than the library, yet it was built from other text
@@ -154,6 +167,7 @@ def build_exact(force=False, verbose=False):
     force = force or os.environ.get("KZGAMD_REBUILD") == "1"
     defines = ["-DKZGAMD_FORCE_EXACT_TESTS"]
     if not force and os.path.exists(LIB_EXACT) and _stamp_matches(LIB_EXACT, defines):
+        REPORT[os.path.basename(LIB_EXACT)] = "reused (content stamp matches the sources: nothing to compile)"
         return LIB_EXACT
     return _compile_and_link(LIB_EXACT, ".exact", defines, force, verbose)
 

@@ -631,10 +631,18 @@ def test_device_entry_point_on_two_streams(kzg, settings):
         assert [got[48 * i:48 * i + 48] for i in range(nb)] == want[k]
 
 
-def test_device_resident_blob_proofs_match_the_host_buffer_path(kzg, settings, golden, blob_loader):
+@pytest.mark.parametrize("sha_lanes", [4, 1])
+def test_device_resident_blob_proofs_match_the_host_buffer_path(kzg, settings, golden, blob_loader, sha_lanes):
     """kzgamd_compute_blob_kzg_proof_device (SHA-256 challenge on the GPU) against the reference vectors and against
-    the host-buffer entry point on random blobs; bad blobs / commitments only flag their own slot."""
+    the host-buffer entry point on random blobs; bad blobs / commitments only flag their own slot.  Both forms of the
+    device hash (tuning key sha_lanes): four lanes per blob — the message schedules of four blocks side by side, the
+    default — and one lane per blob; 72 blobs = four full waves of the four-lane form and half of a fifth."""
     import torch
+
+    module_settings = settings
+    if sha_lanes != 4:
+        settings = kzg.KZGSettings.from_file(os.path.join(GOLDEN, "trusted_setup.txt"),
+                                             kzg.make_config(table_budget_gb=8, tuning={"sha_lanes": sha_lanes}))
 
     dev = torch.device("cuda", 0)
     cases = [c for c in golden["compute_blob_kzg_proof"] if c["output"] is not None]
@@ -650,9 +658,9 @@ def test_device_resident_blob_proofs_match_the_host_buffer_path(kzg, settings, g
             b[i] = 0
         blobs.append(bytes(b))
     extra = blobs[len(cases):]
-    ecm = kzg.blob_to_kzg_commitment_batch(b"".join(extra), len(extra), settings)
+    ecm = kzg.blob_to_kzg_commitment_batch(b"".join(extra), len(extra), module_settings)
     cms += ecm
-    want += kzg.compute_blob_kzg_proof_batch(b"".join(extra), b"".join(ecm), len(extra), settings)
+    want += kzg.compute_blob_kzg_proof_batch(b"".join(extra), b"".join(ecm), len(extra), module_settings)  # host SHA-256
     n = len(blobs)
     # slot n: blob with an element == r; slot n + 1: commitment that is no G1 element
     bad_blob = bytearray(blobs[-1])
@@ -676,6 +684,8 @@ def test_device_resident_blob_proofs_match_the_host_buffer_path(kzg, settings, g
     assert stat[:n] == [0] * n and stat[n] != 0 and stat[n + 1] != 0
     for i in range(n):
         assert out[48 * i:48 * i + 48] == want[i], i
+    if settings is not module_settings:
+        settings.close()
 
 
 def test_settings_fk20_columns_match_oracle(kzg, settings, oracle, oracle_settings):

@@ -475,18 +475,24 @@ int main() {
     EXPECT(!o.parse("spl=17", &err) && err.find("out of range") != std::string::npos);
     EXPECT(!o.parse("glv=-1", &err) && !o.parse("combine_lanes=0", &err) && !o.parse("combine_lanes=5", &err));
     EXPECT(o.parse("g1_pair_max=1099511627776", &err));   // 2^40: the long range of the G1 stage keys
+    // inside the range but not a value any engine honours: refused, not remapped
+    EXPECT(!o.parse("spl=3", &err) && err.find("out of range") != std::string::npos);
+    EXPECT(!o.parse("spl=5", &err) && !o.parse("blocksum_threads=100", &err) && !o.parse("fine_bits=6", &err));
+    EXPECT(!o.parse("lgc=1", &err) && !o.parse("lgc=9", &err) && !o.parse("window=1", &err) && !o.parse("window_prepared=1", &err));
+    EXPECT(!o.parse("sha_lanes=2", &err) && !o.parse("wide_fold_max=-1", &err));
+    EXPECT(o.parse("spl=16;blocksum_threads=128;fine_bits=10;lgc=2;window=2;sha_lanes=1;sub_streams=0", &err));
     // resolve: defaults < environment < struct
-    setenv("KZGAMD_TUNING", "spl=2;lgc=9", 1);
+    setenv("KZGAMD_TUNING", "spl=2;lgc=8", 1);
     setenv("KZGAMD_FBW_MAX_GB", "24", 1);
     Options r;
-    EXPECT(Options::resolve(r, nullptr, &err) && r.t[kzgamd::T_SPL] == 2 && r.t[kzgamd::T_LGC] == 9 && r.table_budget_gb == 24 && r.device == -1);
+    EXPECT(Options::resolve(r, nullptr, &err) && r.t[kzgamd::T_SPL] == 2 && r.t[kzgamd::T_LGC] == 8 && r.table_budget_gb == 24 && r.device == -1);
     KzgAmdConfig c;
     memset(&c, 0, sizeof c);
     c.struct_size = sizeof c;
     c.device = 3;
     c.table_budget_bytes = 10000000000ull;
     c.tuning = "spl=8";
-    EXPECT(Options::resolve(r, &c, &err) && r.t[kzgamd::T_SPL] == 8 && r.t[kzgamd::T_LGC] == 9 && r.table_budget_gb == 10 && r.device == 3);
+    EXPECT(Options::resolve(r, &c, &err) && r.t[kzgamd::T_SPL] == 8 && r.t[kzgamd::T_LGC] == 8 && r.table_budget_gb == 10 && r.device == 3);
     c.table_budget_bytes = KZGAMD_NO_TABLES;
     EXPECT(Options::resolve(r, &c, &err) && r.table_budget_gb == 0);
     c.table_budget_bytes = 0;  // 0 = not given: the environment's value stays
@@ -510,7 +516,7 @@ int main() {
     assert res.returncode == 0 and "fails 0" in res.stdout, res.stdout + res.stderr
     keys = [ln.split()[1:] for ln in res.stdout.splitlines() if ln.startswith("KEY ")]
     names = [k[0] for k in keys]
-    assert len(names) == len(set(names)) == 39
+    assert len(names) == len(set(names)) == 41
     for name, d, lo, hi in keys:
         assert re.fullmatch(r"[a-z0-9_]+", name) and int(lo) <= int(d) <= int(hi), name
     # one row per key, same default and range

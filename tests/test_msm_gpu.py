@@ -60,6 +60,60 @@ def test_small_sizes_with_and_without_precomputation(oracle, kzg):
     h.close()
 
 
+def test_every_size_up_to_128_into_a_garbage_filled_output(oracle, kzg):
+    """The reference's exhaustive small sweep (kzg-bench/src/tests/bls12_381.rs:314-387): EVERY n in 0..=128 — without
+    precomputation, with ONE handle prepared for all 128 points, and with a handle prepared for exactly n points — each
+    time into an output the caller filled with a random point first (`let mut res = TG1::rand()`): the result must not
+    depend on what the output held.  Expected values are the oracle's running sums of [s_i]P_i."""
+    L = oracle.lib()
+    rnd = random.Random(2024)
+    N = 128
+    pts = gen_points(L, N, rnd)
+    sc = O.fr_array([rnd.randrange(O.R) for _ in range(N)])
+    # results[i] = sum of the first i terms, as the reference builds them (point by point)
+    results = [bytes([0xC0]) + bytes(47)]
+    cur = O.G1()
+    C.memset(C.byref(cur), 0, C.sizeof(cur))
+    for i in range(N):
+        pj = O.G1()
+        L.og1_from_affine(C.byref(pj), C.byref(pts[i]))
+        term = O.G1()
+        L.og1_mul(C.byref(term), C.byref(pj), C.byref(sc[i]))
+        nxt = O.G1()
+        L.og1_add_or_dbl(C.byref(nxt), C.byref(cur), C.byref(term))
+        cur = nxt
+        results.append(compressed(L, cur))
+    garbage = [gen_points(L, 1, rnd)[0] for _ in range(4)]
+
+    def garbage_out(k):
+        # a valid random point in blst's Jacobian layout (x, y, z = R mod p): what TG1::rand() leaves in `res`
+        g = O.G1()
+        L.og1_from_affine(C.byref(g), C.byref(garbage[k % 4]))
+        out = kzg.BlstP1()
+        C.memmove(C.byref(out), C.byref(g), 144)
+        return out
+
+    lib = kzg.lib()
+    whole = kzg.prepare_multi_scalar_mult(pts, N)
+    for n in range(N + 1):
+        out = garbage_out(n)
+        err = lib.mult_pippenger(C.byref(out), pts, n, sc)
+        assert err.code == 0, (n, err.code)
+        assert compressed(L, as_oracle_g1(out)) == results[n], ("unprepared", n)
+        out = garbage_out(n + 1)
+        err = lib.mult_pippenger_prepared(whole.handle, C.byref(out), n, sc)
+        assert err.code == 0, (n, err.code)
+        assert compressed(L, as_oracle_g1(out)) == results[n], ("prepared for 128", n)
+        if n > 0:  # prepare_msm of no points has no handle to return (the reference's precompute yields None there)
+            own = kzg.prepare_multi_scalar_mult(pts, n)
+            out = garbage_out(n + 2)
+            err = lib.mult_pippenger_prepared(own.handle, C.byref(out), n, sc)
+            assert err.code == 0, (n, err.code)
+            assert compressed(L, as_oracle_g1(out)) == results[n], ("prepared for n", n)
+            own.close()
+    whole.close()
+
+
 def test_edge_scalars_and_points(oracle, kzg):
     L = oracle.lib()
     rnd = random.Random(12)
@@ -352,9 +406,10 @@ def test_msm_2p20_matches_oracle(oracle, kzg):
         h.close()
 
 
-@pytest.mark.parametrize("logn", [22, 23, 24])
+@pytest.mark.parametrize("logn", [16, 18, 19, 21, 22, 23, 24])
 def test_msm_2p22_split_property(oracle, kzg, logn):
-    # BASELINE configs[2] upper size (n = 2^22) and beyond: a size-independent property instead of a CPU recomputation:
+    # BASELINE configs[2] (n = 2^16 … 2^22: every size bench.py times, 2^20 has its own oracle test above) and beyond: a
+    # size-independent property instead of a CPU recomputation:
     # MSM over all points == MSM(first half) + MSM(second half), plus one oracle-checked small prefix.
     # 2^23 is the largest size of the two-level sort (24-bit point indices for P_i and [x^2]P_i), 2^24 runs the
     # one-level sort again.
@@ -583,12 +638,15 @@ def test_horner_exceptional_additions(oracle, kzg, sign):
         assert compressed(L, got) == b"\xc0" + bytes(47)
 
 
-@pytest.mark.parametrize("nbatch", [2, 5])
-def test_several_large_msms_in_one_call(oracle, kzg, nbatch):
-    """nbatch = 2 over a 40 000-point variable-base handle: 16 bucket sets of 32 768 buckets go through the tiled
-    digit reduction and the limb-parallel cell sums together (set indexing of every stage with more than one MSM).
-    nbatch = 5: more coarse bins than the two-level sort holds in one launch — the call runs as sub-batches of 2 + 2 + 1
-    (output and scalar offsets of every sub-batch)."""
+@pytest.mark.parametrize("nbatch,sub_streams", [(2, 0), (5, 0), (2, 3), (5, 3), (7, 2), (9, 1)])
+def test_several_large_msms_in_one_call(oracle, kzg, nbatch, sub_streams):
+    """Batches of MSMs over a 40 000-point variable-base handle.  With sub_streams = 0 (everything on the caller's stream,
+    round 5's form): nbatch = 2 — 16 bucket sets of 32 768 buckets go through the tiled digit reduction and the
+    limb-parallel cell sums together (set indexing of every stage with more than one MSM); nbatch = 5 — more coarse bins
+    than the two-level sort holds in one launch: sub-batches of 2 + 2 + 1 (output and scalar offsets of every sub-batch).
+    With side streams (the default is 3): the batch is always cut (1 + 1; 2 + 2 + 1; 2 + 2 + 2 + 1 over two side streams;
+    2 + 2 + 2 + 2 + 1 over one), the accumulations chained on the caller's stream, sorts and reductions on the
+    high-priority side streams with their own workspaces; two calls back to back reuse streams, events and workspaces."""
     import torch
 
     L = oracle.lib()
@@ -603,16 +661,19 @@ def test_several_large_msms_in_one_call(oracle, kzg, nbatch):
     sc[n + 5:n + 3000, 4:] = 0  # the second MSM has a run of short scalars
     d_sc = sc.cuda()
     d_out = torch.zeros(144 * nbatch, dtype=torch.uint8, device="cuda")
-    h = kzg.DeviceMsm(d_pts.data_ptr(), n, False)
+    h = kzg.DeviceMsm(d_pts.data_ptr(), n, False, kzg.make_config(tuning={"sub_streams": sub_streams}))
+    d_out2 = torch.zeros(144 * nbatch, dtype=torch.uint8, device="cuda")
     kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr(), n, nbatch, False, stream)
+    kzg.msm_prepared_batch_device(h, d_out2.data_ptr(), d_sc.data_ptr(), n, nbatch, False, stream)  # no sync in between
     torch.cuda.synchronize()
-    out = d_out.cpu().numpy().tobytes()
+    out, out2 = d_out.cpu().numpy().tobytes(), d_out2.cpu().numpy().tobytes()
     pts = (O.G1Affine * n).from_buffer_copy(d_pts.cpu().numpy().tobytes())
     for b in range(nbatch):
-        got = O.G1()
-        C.memmove(C.byref(got), out[144 * b:144 * b + 144], 144)
         exp = O.G1()
         L.omsm_tiling_pippenger(C.byref(exp), pts, sc[b * n:(b + 1) * n].numpy().tobytes(), n)
-        assert compressed(L, got) == compressed(L, exp), b
+        for o in (out, out2):
+            got = O.G1()
+            C.memmove(C.byref(got), o[144 * b:144 * b + 144], 144)
+            assert compressed(L, got) == compressed(L, exp), b
     h.close()
 

@@ -240,6 +240,81 @@ def test_two_ranks_share_one_gpu_with_the_gpu_engine(kzg):
         assert "rank %d ok" % rank in o
 
 
+RCCL_ONE_RANK_WORKER = r'''
+import ctypes as C, os, sys, random, importlib.util
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, torch.distributed as dist
+from importlib import util
+spec = util.spec_from_file_location("sharding", os.path.join(ROOT, "rust-kzg_amd", "sharding.py"))
+sh = util.module_from_spec(spec); spec.loader.exec_module(sh)
+torch.cuda.set_device(0)
+path = os.path.join(ROOT, "rust-kzg_amd", "__init__.py")
+spec = importlib.util.spec_from_file_location("rust_kzg_amd", path, submodule_search_locations=[os.path.dirname(path)])
+kzg = importlib.util.module_from_spec(spec); sys.modules["rust_kzg_amd"] = kzg; spec.loader.exec_module(kzg)
+import oracle_ffi as O
+L = O.lib()
+# backend "nccl" IS RCCL on ROCm; one rank is what a one-GPU box can form (RCCL refuses two ranks on one device)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % PORT, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+s = kzg.KZGSettings.from_file(os.path.join(ROOT, "tests", "golden", "trusted_setup.txt"),
+                              kzg.make_config(table_budget_gb=40))
+with open(os.path.join(ROOT, "tests", "golden", "trusted_setup.txt"), "rb") as f:
+    rc, os_ = O.load_settings(f.read())
+assert rc == 0
+rnd = random.Random(3)
+n = 9
+raw = bytearray(rnd.randbytes(n * 131072))
+for i in range(0, len(raw), 32):
+    raw[i] = 0
+dev = torch.device("cuda", 0)
+stream = torch.cuda.current_stream().cuda_stream
+d_blobs = torch.frombuffer(raw, dtype=torch.uint8).to(dev)
+# this rank's slab through the device-resident pipeline: commitments and proofs never leave HBM before the collective
+d_cm = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
+d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+d_cs = torch.empty(n * 131072, dtype=torch.uint8, device=dev)
+kzg.blob_to_kzg_commitment_device(d_cm.data_ptr(), d_st.data_ptr(), d_cs.data_ptr(), d_blobs.data_ptr(), n, s, stream)
+d_pr = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
+d_ps = torch.zeros(n, dtype=torch.int32, device=dev)
+scr = torch.empty(n * kzg.PROOF_SCRATCH_BYTES, dtype=torch.uint8, device=dev)
+kzg.compute_blob_kzg_proof_device(d_pr.data_ptr(), d_ps.data_ptr(), scr.data_ptr(), d_blobs.data_ptr(), d_cm.data_ptr(), n, s, stream)
+torch.cuda.synchronize()
+assert int(d_st.abs().sum()) == 0 and int(d_ps.abs().sum()) == 0
+# the one collective of a sharded batch, on device tensors: ncclAllGather (all_gather_into_tensor) through RCCL
+all_c = sh.gather_results(d_cm, n, 48, dist)
+all_p = sh.gather_results(d_pr, n, 48, dist)
+assert all_c.is_cuda and all_p.is_cuda
+# and the timing collectives bench.py uses (barrier + MAX all_reduce over ranks)
+t = torch.tensor([1.5], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); dist.barrier()
+assert float(t) == 1.5
+cb, pb = all_c.cpu().numpy().tobytes(), all_p.cpu().numpy().tobytes()
+for i in range(n):
+    b = bytes(raw[i * 131072:(i + 1) * 131072])
+    o = C.create_string_buffer(48)
+    assert L.oblob_to_kzg_commitment(o, b, C.byref(os_)) == 0 and o.raw == cb[48 * i:48 * i + 48], i
+    q = C.create_string_buffer(48)
+    assert L.ocompute_blob_kzg_proof(q, b, o.raw, C.byref(os_)) == 0 and q.raw == pb[48 * i:48 * i + 48], i
+dist.destroy_process_group()
+s.close()
+print("rccl single rank ok")
+'''
+
+
+@pytest.mark.gpu
+def test_gather_results_runs_over_rccl_on_device_tensors(kzg):
+    """SURVEY 8(e): the one collective of a sharded batch (sharding.gather_results -> all_gather_into_tensor ->
+    ncclAllGather) and bench.py's barrier / MAX all-reduce EXECUTE through RCCL on device tensors — as a world of one
+    rank, which is what a one-GPU box can form.  The slab comes from the device-resident commitment and proof pipelines,
+    the gathered bytes are held to the oracle."""
+    port = 32100 + (os.getpid() % 500)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    code = "ROOT=%r\nPORT=%d\n" % (ROOT, port) + RCCL_ONE_RANK_WORKER
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=900)
+    o = p.stdout.decode()
+    assert p.returncode == 0, o[-3000:]
+    assert "rccl single rank ok" in o
+
+
 @pytest.mark.gpu
 def test_sharded_commit_gpu_engine_two_ranks(kzg):
     if kzg.device_count() < 2:
@@ -387,6 +462,86 @@ def test_in_process_multi_two_settings_objects_on_gpu0(kzg, oracle, oracle_setti
     # the in-library multi-GPU path on the hardware there is: two settings objects on GPU 0 (40 GB per table through
     # KzgAmdConfig.table_budget_bytes so that both fit — no environment variable), every result against the oracle
     _in_process_multi(kzg, oracle, oracle_settings, [0, 0], kzg.make_config(table_budget_gb=40))
+
+
+_EIGHT_CACHE = {}
+
+
+def _oracle_commitments_and_proofs(oracle, oracle_settings, blobs):
+    """(commitments, proofs) of the oracle for `blobs`, computed once per session (both library flavours reuse them)."""
+    import ctypes as C
+
+    key = hash(blobs[0][:64]) ^ len(blobs)
+    if key not in _EIGHT_CACHE:
+        L = oracle.lib()
+        cs, ps = [], []
+        for b in blobs:
+            o = C.create_string_buffer(48)
+            assert L.oblob_to_kzg_commitment(o, b, C.byref(oracle_settings)) == 0
+            p = C.create_string_buffer(48)
+            assert L.ocompute_blob_kzg_proof(p, b, o.raw, C.byref(oracle_settings)) == 0
+            cs.append(o.raw)
+            ps.append(p.raw)
+        _EIGHT_CACHE[key] = (cs, ps)
+    return _EIGHT_CACHE[key]
+
+
+@pytest.mark.gpu
+def test_in_process_multi_eight_settings_objects_on_gpu0(kzg, oracle, oracle_settings):
+    """BASELINE configs[4] in its exact shape — compute_blob_kzg_proof_batch over 256 blobs cut into EIGHT slabs of 32 —
+    on the hardware there is: eight settings objects on GPU 0 (8 GB per table through KzgAmdConfig.table_budget_bytes),
+    one host thread per object inside the library (csrc/multi.hip), the reference's batch parallelism
+    (kzg/src/eip_4844.rs:770-816) with settings objects in the place of rayon workers.  Commitments, proofs, cells + cell
+    proofs and batched verification of 256 blobs, then 257 (uneven slabs: 33 + 7 x 32), 7 and 3 blobs (fewer blobs than
+    objects: empty slabs), every result against the oracle (cells: against ONE object's batch entry point, which the
+    reference's cell vectors pin); one blob with an element >= r in slab 5 fails every call with C_KZG_BADARGS."""
+    import ctypes as C
+
+    NDEV, N = 8, 257
+    blobs = _random_blobs(86, N)
+    want_c, want_p = _oracle_commitments_and_proofs(oracle, oracle_settings, blobs)
+    ms = kzg.MultiKZGSettings(SETUP, [0] * NDEV, kzg.make_config(table_budget_gb=8))
+    try:
+        assert ms.settings_devices() == [0] * NDEV
+        infos = [ms.table_info(d) for d in range(NDEV)]
+        assert all(i["rc"] == 0 and i["wide_table"] >= 1 for i in infos), infos  # every object got its own wide table (2: GLV form)
+        one = kzg.KZGSettings()  # a borrowed view of the first object for the single-object reference calls
+        C.memmove(C.byref(one.c), C.byref(ms.arr[0]), C.sizeof(kzg.CKZGSettings))
+        for n in (256, 257, 7, 3):
+            joined, cj, pj = b"".join(blobs[:n]), b"".join(want_c[:n]), b"".join(want_p[:n])
+            assert ms.commit_batch(joined, n) == want_c[:n], n
+            assert ms.proof_batch(joined, cj, n) == want_p[:n], n
+            assert ms.verify_blob_batch(joined, cj, pj, n) is True, n
+            cells, proofs = ms.cells_and_proofs_batch(joined, n)
+            c1, p1 = kzg.compute_cells_and_kzg_proofs_batch(joined, n, one)
+            assert cells == c1 and proofs == p1, n
+            if n == 3:  # and the single-blob (direct) form, blob by blob
+                for i in range(n):
+                    cs, ps = kzg.compute_cells_and_kzg_proofs(blobs[i], one)
+                    assert cells[i * 262144:(i + 1) * 262144] == cs and proofs[i * 6144:(i + 1) * 6144] == ps, i
+        # the slabs of 256 blobs over 8 objects are 32 each: blob 170 lies in slab 5
+        lo, hi = C.c_size_t(), C.c_size_t()
+        assert kzg.lib().kzgamd_shard_range(256, NDEV, 5, C.byref(lo), C.byref(hi)) == 0
+        assert (lo.value, hi.value) == (160, 192)
+        bad = bytearray(blobs[170])
+        bad[32 * 77:32 * 78] = bytes.fromhex("73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001")  # = r
+        spoiled = b"".join(blobs[:170] + [bytes(bad)] + blobs[171:256])
+        cj = b"".join(want_c[:256])
+        with pytest.raises(kzg.KzgAmdError, match="C_KZG_RET 1"):
+            ms.commit_batch(spoiled, 256)
+        with pytest.raises(kzg.KzgAmdError, match="C_KZG_RET 1"):
+            ms.proof_batch(spoiled, cj, 256)
+        with pytest.raises(kzg.KzgAmdError, match="C_KZG_RET 1"):
+            ms.cells_and_proofs_batch(spoiled, 256)
+        with pytest.raises(kzg.KzgAmdError, match="C_KZG_RET 1"):
+            ms.verify_blob_batch(spoiled, cj, b"".join(want_p[:256]), 256)
+        # a wrong proof in slab 7 only: the ANDed verdict is false
+        swapped = want_p[:254] + [want_p[255], want_p[254]]
+        assert ms.verify_blob_batch(b"".join(blobs[:256]), cj, b"".join(swapped), 256) is False
+        # the objects are still good after the failed calls
+        assert ms.commit_batch(b"".join(blobs[:256]), 256) == want_c[:256]
+    finally:
+        ms.close()
 
 
 @pytest.mark.gpu

@@ -67,6 +67,47 @@ def test_fft_matches_oracle(kzg, oracle, logn):
     fs.close()
 
 
+def test_every_length_on_one_long_lived_handle(kzg, oracle):
+    """Stride invariance (kzg-bench/src/tests/fft_fr.rs:87-106: `stride_fft`, a 2^9-point transform on settings of scale
+    9 and of scale 12 gives the same values): ONE handle of scale 15 serves every power-of-two length up to its
+    max_width — forward, inverse and the DAS extension (whose lists are at most half the width) — each against the
+    oracle on settings of the SAME scale (the reference's stride = max_width / n walk over one table of roots) and against
+    the oracle on settings made for exactly that length."""
+    L = oracle.lib()
+    SCALE = 15
+    fs = kzg.FFTSettings(SCALE)
+    ofs = O.FFTSettings()
+    assert L.offt_settings_new(C.byref(ofs), SCALE) == 0
+    rnd = random.Random(1509)
+    for logn in range(0, SCALE + 1):
+        n = 1 << logn
+        data = fr_bulk([rnd.randrange(O.R) for _ in range(n)])
+        ofs_n = O.FFTSettings()
+        assert L.offt_settings_new(C.byref(ofs_n), max(logn, 1)) == 0
+        for inv in (False, True):
+            exp = (O.Fr * n)()
+            assert L.offt_fr(C.byref(ofs), exp, data, n, 1 if inv else 0) == 0
+            exp_n = (O.Fr * n)()
+            assert L.offt_fr(C.byref(ofs_n), exp_n, data, n, 1 if inv else 0) == 0
+            assert bytes(exp) == bytes(exp_n), (logn, inv)  # the oracle itself is stride-invariant
+            got = fs.fft_fr(data, n, inverse=inv)
+            assert bytes(got)[: 32 * n] == bytes(exp), (logn, inv)
+        if logn < SCALE:  # das_fft_extension of n evens needs 2n <= max_width
+            exp = (O.Fr * n)()
+            assert L.odas_fft_extension(C.byref(ofs), exp, data, n) == 0
+            got = fs.das_fft_extension(data, n)
+            assert bytes(got)[: 32 * n] == bytes(exp), logn
+        L.offt_settings_free(C.byref(ofs_n))
+    # and the reference's own case: 2^9 points of 0, 1, 2, ... on scale 9 and scale 12 handles
+    data = fr_bulk(list(range(512)))
+    a, b = kzg.FFTSettings(9), kzg.FFTSettings(12)
+    assert bytes(a.fft_fr(data, 512)) == bytes(b.fft_fr(data, 512)) == bytes(fs.fft_fr(data, 512))
+    a.close()
+    b.close()
+    L.offt_settings_free(C.byref(ofs))
+    fs.close()
+
+
 @pytest.mark.parametrize("logn,nbatch", [(0, 5), (1, 3), (3, 1000), (7, 3), (7, 64), (8, 17), (10, 5), (11, 3), (12, 3), (13, 3), (14, 2)])
 def test_device_batches_match_oracle(kzg, oracle, logn, nbatch):
     # kzgamd_ntt_fr_device: nbatch contiguous transforms in one call, partial tiles included (4096 does not divide
