@@ -31,16 +31,31 @@ pub struct MiKZGSettings {
     pub precomputation: Option<Arc<MiPrecomputation>>,
     pub x_ext_fft_columns: Vec<Vec<MiG1>>,
     pub cell_size: usize,
+    /// whether the FK20 matrix table was attached; `false` = it did not fit its budget (or the device refused) and
+    /// `g1_lincomb_batch` runs row by row — correct, two orders of magnitude slower; callers that care can look
+    pub matrix_table_attached: bool,
 }
 
-fn prepare(points: &[MiG1], matrix: &[Vec<MiG1>]) -> Option<Arc<MiPrecomputation>> {
+/// HBM each of the two fixed-base tables of ONE settings object may take.  The library's default (160 GB per table,
+/// capped by what is free) is right for a process that owns a GPU and one settings object; the rust-kzg test and bench
+/// suites create several `KZGSettings` side by side (and in parallel), and two tables at the default would leave a
+/// second object with tiny tables or none.  24 GB buys window c = 13 (20 additions per scalar: 80 % of the default
+/// table's commitments/s, DESIGN.md §6 "throughput per table budget"); 16 GB holds the 128 x 64 FK20 matrix at c = 13.
+/// [`MiKZGSettings::set_table_budgets`] rebuilds the tables with other values (0 = the library's default).
+pub const LAGRANGE_TABLE_BUDGET_BYTES: u64 = 24 << 30;
+pub const MATRIX_TABLE_BUDGET_BYTES: u64 = 16 << 30;
+
+fn prepare(points: &[MiG1], matrix: &[Vec<MiG1>], lagrange_budget: u64, matrix_budget: u64) -> (Option<Arc<MiPrecomputation>>, bool) {
     let mut affines: Vec<MiG1Affine> = alloc::vec![MiG1Affine::default(); points.len()];
     MiG1Affine::into_affines_loc(&mut affines, points);
     let raw = unsafe { core::slice::from_raw_parts(affines.as_ptr() as *const blst_p1_affine, affines.len()) };
-    let handle = sys::prepare_raw(raw);
+    let mut cfg = sys::KzgAmdConfig::default();
+    cfg.table_budget_bytes = lagrange_budget;
+    let handle = sys::prepare_raw_with(raw, &cfg);
     if handle.is_null() {
-        return None;
+        return (None, false);
     }
+    let mut attached = false;
     // the matrix rows, flattened row-major (every row has the same length: cell_size)
     let rows = matrix.len();
     let cols = matrix.first().map_or(0, |r| r.len());
@@ -49,10 +64,38 @@ fn prepare(points: &[MiG1], matrix: &[Vec<MiG1>]) -> Option<Arc<MiPrecomputation
         let mut flat_aff: Vec<MiG1Affine> = alloc::vec![MiG1Affine::default(); flat.len()];
         MiG1Affine::into_affines_loc(&mut flat_aff, &flat);
         let flat_raw = unsafe { core::slice::from_raw_parts(flat_aff.as_ptr() as *const blst_p1_affine, flat_aff.len()) };
-        // a matrix that does not fit the HBM budget is not an error: g1_lincomb_batch then runs row by row
-        let _ = unsafe { sys::attach_matrix_raw(handle, flat_raw, rows, cols, None) };
+        // a matrix that does not fit the HBM budget is not an error — g1_lincomb_batch then runs row by row — but it is
+        // recorded (MiKZGSettings::matrix_table_attached) and, with KZGAMD_VERBOSE set, said on stderr
+        let mut mcfg = sys::KzgAmdConfig::default();
+        mcfg.table_budget_bytes = matrix_budget;
+        match unsafe { sys::attach_matrix_raw(handle, flat_raw, rows, cols, Some(&mcfg)) } {
+            Ok(()) => attached = true,
+            Err(_e) => {
+                #[cfg(feature = "std")]
+                if std::env::var_os("KZGAMD_VERBOSE").is_some() {
+                    eprintln!("rust-kzg-mi355x: FK20 matrix table not attached ({} x {}, budget {} bytes): {}", rows, cols, matrix_budget, _e);
+                }
+            }
+        }
     }
-    Some(Arc::new(MiPrecomputation::from_ptr(handle)))
+    (Some(Arc::new(MiPrecomputation::from_ptr(handle))), attached)
+}
+
+impl MiKZGSettings {
+    /// Rebuilds the two device tables with other HBM budgets (bytes per table; 0 = the library's default of 160 GB
+    /// capped by the free HBM — for a process with ONE settings object on a GPU of its own).  The old tables are
+    /// released first if this object is their last owner (otherwise when the last clone that shares them goes away).
+    pub fn set_table_budgets(&mut self, lagrange_budget_bytes: u64, matrix_budget_bytes: u64) {
+        // free the old tables first (they may hold most of the HBM) — if this object is their last owner
+        if let Some(old) = self.precomputation.take() {
+            if let Ok(old) = Arc::try_unwrap(old) {
+                unsafe { sys::free_raw(old.table) };
+            }
+        }
+        let (pre, attached) = prepare(&self.g1_values_lagrange_brp, &self.x_ext_fft_columns, lagrange_budget_bytes, matrix_budget_bytes);
+        self.precomputation = pre;
+        self.matrix_table_attached = attached;
+    }
 }
 
 impl KZGSettings<FsFr, MiG1, FsG2, MiFFTSettings, FsPoly, FsFp, MiG1Affine, MiG1ProjAddAffine> for MiKZGSettings {
@@ -87,7 +130,8 @@ impl KZGSettings<FsFr, MiG1, FsG2, MiFFTSettings, FsPoly, FsFp, MiG1Affine, MiG1
                 x_ext_fft_columns[row][offset] = value;
             }
         }
-        let precomputation = prepare(g1_lagrange_brp, &x_ext_fft_columns);
+        let (precomputation, matrix_table_attached) =
+            prepare(g1_lagrange_brp, &x_ext_fft_columns, LAGRANGE_TABLE_BUDGET_BYTES, MATRIX_TABLE_BUDGET_BYTES);
         Ok(Self {
             g1_values_monomial: g1_monomial.to_vec(),
             g1_values_lagrange_brp: g1_lagrange_brp.to_vec(),
@@ -96,6 +140,7 @@ impl KZGSettings<FsFr, MiG1, FsG2, MiFFTSettings, FsPoly, FsFp, MiG1Affine, MiG1
             precomputation,
             x_ext_fft_columns,
             cell_size,
+            matrix_table_attached,
         })
     }
 
