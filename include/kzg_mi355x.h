@@ -109,11 +109,11 @@ RustError kzgamd_mult_pippenger_matrix(void *msm, blst_p1 out[], const blst_fr s
  * PrecomputationTable is ONE object built from (points, matrix) (precompute(), kzg/src/msm/bgmw.rs:206-304) and the sppark
  * flavour of it has room for one pointer (kzg/src/msm/sppark.rs:5-22) — after this call kzgamd_mult_pippenger_matrix on
  * `msm` multiplies by the attached matrix, mult_pippenger_prepared by its own points as before; free_msm frees both.
- * cfg: the matrix table's budget and tuning (its device is the handle's).  A set-up step: attach (or re-attach, which
- * frees the previous matrix) before the handle is shared between threads, not while matrix calls are in flight. */
+ * cfg: the matrix table's budget and tuning (its device is the handle's).  A handle takes ONE matrix, once: a second
+ * attach fails (code 1) and leaves the first in place, so a matrix call in flight never sees its table freed. */
+RustError kzgamd_msm_attach_matrix(void *msm, const blst_p1_affine points[], size_t rows, size_t cols, const KzgAmdConfig *cfg);
 /* rows and columns of the matrix a handle holds or has attached; 1 when it has none */
 int kzgamd_msm_matrix_shape(void *msm, size_t *rows, size_t *cols);
-RustError kzgamd_msm_attach_matrix(void *msm, const blst_p1_affine points[], size_t rows, size_t cols, const KzgAmdConfig *cfg);
 
 /* Device-resident form used by the batched blob pipeline and bench.py: d_scalars / d_out are
  * device pointers, work is enqueued on `stream` (a hipStream_t, NULL = default stream) and NOT

@@ -394,6 +394,11 @@ __global__ void __launch_bounds__(QT) k_quotient_b(u32* __restrict__ q_out, u32*
 // streams (the hash of one batch runs under the MSM of another) and when host cores are scarce (eight ranks per node);
 // the host-buffer entry points keep hashing small batches on the host's SHA units, where one blob takes 75 us.
 __device__ __forceinline__ u32 sha_rotr(u32 x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+// gfx950's three-input bit operation (v_bitop3_b32, truth table in the immediate): a ^ b ^ c, Ch and Maj are ONE
+// instruction each — 14 instead of 18 per compression round (the compiler finds Ch and Maj by itself, not the xors)
+__device__ __forceinline__ u32 sha_xor3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ u32 sha_ch(u32 e, u32 f, u32 g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xca); }   // e ? f : g
+__device__ __forceinline__ u32 sha_maj(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xe8); }
 __device__ __forceinline__ void sha256_block(u32 h[8], u32 w[16]) {
     constexpr u32 K[64] = {
         0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u,
@@ -409,15 +414,15 @@ __device__ __forceinline__ void sha256_block(u32 h[8], u32 w[16]) {
     for (int t = 0; t < 64; ++t) {
         if (t >= 16) {
             const u32 w15 = w[(t - 15) & 15], w2 = w[(t - 2) & 15];
-            const u32 s0 = sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3);
-            const u32 s1 = sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10);
+            const u32 s0 = sha_xor3(sha_rotr(w15, 7), sha_rotr(w15, 18), w15 >> 3);
+            const u32 s1 = sha_xor3(sha_rotr(w2, 17), sha_rotr(w2, 19), w2 >> 10);
             w[t & 15] += s0 + w[(t - 7) & 15] + s1;
         }
-        const u32 S1 = sha_rotr(e, 6) ^ sha_rotr(e, 11) ^ sha_rotr(e, 25);
-        const u32 ch = (e & f) ^ (~e & g);
+        const u32 S1 = sha_xor3(sha_rotr(e, 6), sha_rotr(e, 11), sha_rotr(e, 25));
+        const u32 ch = sha_ch(e, f, g);
         const u32 t1 = hh + S1 + ch + K[t] + w[t & 15];
-        const u32 S0 = sha_rotr(a, 2) ^ sha_rotr(a, 13) ^ sha_rotr(a, 22);
-        const u32 maj = (a & b) ^ (a & c) ^ (b & c);
+        const u32 S0 = sha_xor3(sha_rotr(a, 2), sha_rotr(a, 13), sha_rotr(a, 22));
+        const u32 maj = sha_maj(a, b, c);
         const u32 t2 = S0 + maj;
         hh = g;
         g = f;
@@ -497,6 +502,146 @@ __global__ void __launch_bounds__(64) k_challenge_sha256(u32* __restrict__ z_be,
     const ff::Fr red = ff::from_mont(ff::mul(v, ff::Fr::r2()));
 #pragma unroll
     for (int i = 0; i < 8; ++i) z_be[b * 8 + i] = __builtin_bswap32(red.v[7 - i]);
+}
+
+// The same hash with FOUR lanes per blob (16 blobs per wave).  SHA-256 has two halves: the message schedule of a block
+// (W[16..63], 48 steps that depend on the block's words only) and the compression (64 rounds that depend on the
+// previous block's state).  Only the compression is a chain.  The four lanes of a blob take the next four blocks, each
+// expands ITS block's schedule and leaves W[t] + K[t] in LDS — one pass of the schedule code serves four blocks — and
+// then lane 0 of the four runs the 4 x 64 rounds with one LDS operand per round.  Per block the wave issues ~150 + 980
+// instructions instead of ~2000, so the chain is about half as long (a lone wave issues an instruction every ~5 cycles
+// whatever its lane count), on four times the waves: 64 waves per 1024 blobs, ~3 % of what the batch's MSM issues.
+// (One blob per WAVE would shorten the chain no further — the compression rounds are the chain — and cost 16 x more.)
+constexpr int SHA_Q = 4;                 // lanes (= blocks in flight) per blob
+constexpr int SHA_BLOBS = 64 / SHA_Q;    // blobs per wave
+constexpr int SHA_BLOCKS = 2050;         // (32 + 131072 + 48 + 1 + 8 bytes) rounded up to 64-byte blocks
+__device__ __forceinline__ void sha256_rounds_wk(u32 h[8], const uint4* __restrict__ wk) {
+    u32 a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+#pragma unroll
+    for (int t4 = 0; t4 < 16; ++t4) {
+        const uint4 v = wk[t4];
+        const u32 x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u32 S1 = sha_xor3(sha_rotr(e, 6), sha_rotr(e, 11), sha_rotr(e, 25));
+            const u32 ch = sha_ch(e, f, g);
+            const u32 t1 = hh + S1 + ch + x[k];
+            const u32 S0 = sha_xor3(sha_rotr(a, 2), sha_rotr(a, 13), sha_rotr(a, 22));
+            const u32 maj = sha_maj(a, b, c);
+            hh = g;
+            g = f;
+            f = e;
+            e = d + t1;
+            d = c;
+            c = b;
+            b = a;
+            a = t1 + S0 + maj;
+        }
+    }
+    h[0] += a;
+    h[1] += b;
+    h[2] += c;
+    h[3] += d;
+    h[4] += e;
+    h[5] += f;
+    h[6] += g;
+    h[7] += hh;
+}
+// word m (0 .. 16 * SHA_BLOCKS - 1) of the padded message, big-endian
+__device__ __forceinline__ u32 sha_msg_word(int m, const u32* __restrict__ blob, const u32* __restrict__ cm) {
+    constexpr int NB = N * 8;  // words of a blob
+    if (m < 8) return m == 0 ? 0x4653424cu : m == 1 ? 0x4f425645u : m == 2 ? 0x52494659u : m == 3 ? 0x5f56315fu : m == 7 ? (u32)N : 0u;
+    if (m < 8 + NB) return __builtin_bswap32(blob[m - 8]);
+    if (m < 8 + NB + 12) return __builtin_bswap32(cm[m - 8 - NB]);
+    if (m == 8 + NB + 12) return 0x80000000u;
+    if (m == 16 * SHA_BLOCKS - 1) return (u32)((32 + BYTES_PER_BLOB + 48) * 8);
+    return 0u;
+}
+__global__ void __launch_bounds__(64) k_challenge_sha256_quad(u32* __restrict__ z_be, const u32* __restrict__ blobs,
+                                                              const u32* __restrict__ commitments, size_t n) {
+    // per blob: SHA_Q blocks x 16 uint4 of W + K, padded by one uint4 so that the 16 lanes that compress read 64 banks
+    __shared__ uint4 wk[SHA_BLOBS][SHA_Q * 16 + 1];
+    constexpr u32 K[64] = {
+        0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u,
+        0x12835b01u, 0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u,
+        0x0fc19dc6u, 0x240ca1ccu, 0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u,
+        0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u, 0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u,
+        0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u, 0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u,
+        0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u, 0x1e376c08u, 0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au,
+        0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u, 0x90befffau, 0xa4506cebu, 0xbef9a3f7u,
+        0xc67178f2u};
+    const int lane = threadIdx.x, q = lane / SHA_Q, j = lane % SHA_Q;
+    const size_t b_raw = (size_t)blockIdx.x * SHA_BLOBS + q;
+    const bool live = b_raw < n;
+    const size_t b = live ? b_raw : n - 1;  // lanes past the end hash the last blob again and store nothing
+    __builtin_amdgcn_s_setprio(3);  // a handful of long serial waves next to throughput kernels: never starve them
+    const u32* blob = blobs + b * (N * 8);
+    const u32* cm = commitments + b * 12;
+    u32 h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    constexpr int GROUPS = (SHA_BLOCKS + SHA_Q - 1) / SHA_Q;
+#pragma unroll 1
+    for (int g = 0; g < GROUPS; ++g) {
+        const int blk = g * SHA_Q + j;
+        u32 w[16];
+        if (blk >= 1 && blk < 2048) {  // sixteen words of the blob: words 16 blk - 8 .. 16 blk + 7
+            const uint4* src = reinterpret_cast<const uint4*>(blob + 16 * blk - 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint4 v = src[k];
+                w[4 * k] = __builtin_bswap32(v.x);
+                w[4 * k + 1] = __builtin_bswap32(v.y);
+                w[4 * k + 2] = __builtin_bswap32(v.z);
+                w[4 * k + 3] = __builtin_bswap32(v.w);
+            }
+        } else {  // the header block, the two blocks with the commitment and the padding, blocks past the end (unused)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) w[k] = blk < SHA_BLOCKS ? sha_msg_word(16 * blk + k, blob, cm) : 0u;
+        }
+        fpw::wave_sync();  // the compression of the previous group has read its operands
+        uint4* dst = &wk[q][j * 16];
+#pragma unroll
+        for (int t4 = 0; t4 < 16; ++t4) {
+            u32 x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int t = 4 * t4 + k;
+                if (t >= 16) {
+                    const u32 w15 = w[(t - 15) & 15], w2 = w[(t - 2) & 15];
+                    const u32 s0 = sha_xor3(sha_rotr(w15, 7), sha_rotr(w15, 18), w15 >> 3);
+                    const u32 s1 = sha_xor3(sha_rotr(w2, 17), sha_rotr(w2, 19), w2 >> 10);
+                    w[t & 15] += s0 + w[(t - 7) & 15] + s1;
+                }
+                x[k] = w[t & 15] + K[t];
+            }
+            dst[t4] = make_uint4(x[0], x[1], x[2], x[3]);
+        }
+        fpw::wave_sync();
+        if (j == 0) {
+            const int left = SHA_BLOCKS - g * SHA_Q;
+#pragma unroll 1
+            for (int jj = 0; jj < SHA_Q && jj < left; ++jj) sha256_rounds_wk(h, &wk[q][jj * 16]);
+        }
+    }
+    if (j != 0 || !live) return;
+    // hash_to_bls_field: the digest as a big-endian integer, reduced mod r
+    ff::Fr v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v.v[i] = h[7 - i];
+    const ff::Fr red = ff::from_mont(ff::mul(v, ff::Fr::r2()));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z_be[b * 8 + i] = __builtin_bswap32(red.v[7 - i]);
+}
+// launch of the challenge hashes of n blobs on `st`.  Tuning key sha_lanes: 4 = four lanes per blob (the chain ~0.6 as
+// long, 2.4 x the instructions), 1 = one lane per blob, 0 (default) = by batch size: four lanes up to 512 blobs — a call
+// that waits for its hashes — one lane for the large batches of a pipelined caller, whose hashes run under other
+// batches' MSMs and only cost what they issue (measured, 1024 blobs on four streams: 77.7 k proofs/s against 73.5 k).
+static inline void launch_challenge_sha256(u32* z_be, const u32* blobs, const u32* commitments, size_t n, int lanes, hipStream_t st) {
+    if (lanes == 0) lanes = n <= 512 ? 4 : 1;
+    if (lanes == 1)
+        hipLaunchKernelGGL(k_challenge_sha256, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, z_be, blobs, commitments, n);
+    else
+        hipLaunchKernelGGL(k_challenge_sha256_quad, dim3((unsigned)((n + SHA_BLOBS - 1) / SHA_BLOBS)), dim3(64), 0, st, z_be, blobs,
+                           commitments, n);
 }
 
 // the r-torsion test of a decoded point: phi(P) == -[x^2]P, phi(x,y) = (beta*x, y), x the BLS parameter (the in-tree
@@ -1180,9 +1325,8 @@ void prove_batch(KZGProof* proofs, Bytes32* ys, const Blob* blobs, const Bytes32
             hipStream_t cs = dev->pipe_stream(k);
             CK_HIP(hipMemcpyAsync(dev->d_blobs + off * BYTES_PER_BLOB, blobs + off, cn * BYTES_PER_BLOB, hipMemcpyHostToDevice, cs));
             if (k < (size_t)KzgAmdSettings::NPIPE) CK_HIP(hipStreamWaitEvent(cs, dev->ev_commit, 0));
-            hipLaunchKernelGGL(k_challenge_sha256, dim3((unsigned)((cn + 63) / 64)), dim3(64), 0, cs, (u32*)(dev->d_z + off * 8),
-                               (const u32*)(dev->d_blobs + off * BYTES_PER_BLOB),
-                               (const u32*)(dev->d_commit + off * 48), cn);
+            launch_challenge_sha256((u32*)(dev->d_z + off * 8), (const u32*)(dev->d_blobs + off * BYTES_PER_BLOB),
+                                    (const u32*)(dev->d_commit + off * 48), cn, dev->cfg_sha_lanes, cs);
             prove_enqueue(dev, off, cn, cs, proofs == nullptr, out_mode);
         }
         dev->pipe_join();  // dev->stream now waits for every chunk
@@ -1697,8 +1841,7 @@ extern "C" C_KZG_RET kzgamd_compute_blob_kzg_proof_device(void* d_proofs, void* 
         u32* y = z + n * 8;
         int* stat = (int*)d_status;
         CK_HIP(hipMemsetAsync(stat, 0, n * sizeof(int), st));
-        hipLaunchKernelGGL(k_challenge_sha256, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, z, (const u32*)d_blobs,
-                           (const u32*)d_commitments, n);
+        launch_challenge_sha256(z, (const u32*)d_blobs, (const u32*)d_commitments, n, dev->cfg_sha_lanes, st);
         hipLaunchKernelGGL(k_check_commitments, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, stat,
                            (const unsigned char*)d_commitments, n);
         hipLaunchKernelGGL(k_quotient, dim3((unsigned)n), dim3(QT), 0, st, scal, y, stat, (const u32*)d_blobs, (const u32*)z,

@@ -223,6 +223,7 @@ struct KzgAmdSettings {
     kzgamd::Options opt;
     CoalesceQueue q_commit, q_blob_proof, q_proof;
     bool cfg_device_sha = false;
+    int cfg_sha_lanes = 0;  // lanes per blob of the device Fiat-Shamir hash (tuning key sha_lanes; 0 = by batch size)
     size_t cfg_host_check_max = 64;  // see HOST_CHECK_MAX
     size_t cfg_prove_chunk = 0;
     bool cfg_wide_check = true;      // false: single-lane tests
@@ -237,6 +238,7 @@ struct KzgAmdSettings {
             q->gather_us = (int)o.t[T_GATHER_US];
         }
         cfg_device_sha = o.t[T_DEVICE_SHA] != 0;
+        cfg_sha_lanes = (int)o.t[T_SHA_LANES];
         cfg_host_check_max = (size_t)o.t[T_HOST_CHECK_MAX];
         cfg_prove_chunk = (size_t)o.t[T_PROVE_CHUNK];
         cfg_wide_check = o.t[T_WIDE_CHECK] != 0;

@@ -20,9 +20,9 @@ namespace kzgamd {
 
 enum TuneId {
     // wide-table (fixed-base) path of the MSM
-    T_SPL, T_NO_WIDE_TAIL, T_NO_HYBRID_FOLD, T_HYBRID_MAX, T_WIDE_FOLD_MAX, T_SPL1_MAX, T_BLOCKSUM_THREADS,
+    T_SPL, T_NO_WIDE_TAIL, T_NO_HYBRID_FOLD, T_NO_WIDE_TREE, T_QUAD_ACCUM_MAX, T_HYBRID_MAX, T_WIDE_FOLD_MAX, T_SPL1_MAX, T_BLOCKSUM_THREADS,
     // bucket engine
-    T_LGC, T_GROUPS, T_TAIL_PIECES, T_FINE_BITS, T_ONE_LEVEL_SORT, T_TREE_TAIL, T_FLAT_DIGITS, T_DIRECT_SCATTER, T_SCATTER_ATOMICS,
+    T_LGC, T_GROUPS, T_TAIL_PIECES, T_SUB_STREAMS, T_SUB_PRIO, T_SUB_LARGE, T_TILE_ROWS, T_FINE_BITS, T_ONE_LEVEL_SORT, T_TREE_TAIL, T_FLAT_DIGITS, T_DIRECT_SCATTER, T_SCATTER_ATOMICS,
     // shape of a handle
     T_WINDOW, T_WINDOW_PREPARED, T_FIXED_AS_VARIABLE_MIN, T_GLV, T_FBW_GLV,
     // concurrent host-buffer callers of one prepared handle (B1)
@@ -30,7 +30,7 @@ enum TuneId {
     // G1 transforms: which stage form by the number of half-butterflies
     T_G1_WIDE_MAX, T_G1_QUAD_MAX, T_G1_PAIR_MAX,
     // c-kzg surface
-    T_FK20, T_DEVICE_SHA, T_HOST_CHECK_MAX, T_WIDE_CHECK, T_PROVE_CHUNK, T_PROVE_FIRST, T_COMMIT_CHUNK, T_COMMIT_FIRST,
+    T_FK20, T_DEVICE_SHA, T_SHA_LANES, T_HOST_CHECK_MAX, T_WIDE_CHECK, T_PROVE_CHUNK, T_PROVE_FIRST, T_COMMIT_CHUNK, T_COMMIT_FIRST,
     T_LEADERS, T_GATHER_MIN, T_GATHER_US,
     T_COUNT
 };
@@ -46,21 +46,27 @@ inline const TuneKey* tune_keys() {
         {"spl", 0, 0, 16, "scalars per lane of the wide-table accumulation (0 = by batch size; 1, 2, 4, 8, 16)"},
         {"no_wide_tail", 0, 0, 1, "1: single-lane instead of limb-parallel tails and folds"},
         {"no_hybrid_fold", 0, 0, 1, "1: two launches of k_blocksum instead of k_blocksum_hybrid for 5..16 MSMs per call"},
+        {"no_wide_tree", 0, 0, 1, "1: a lone commitment's partial sums folded by two launches of k_wide_fold64 instead of the one-launch tree k_wide_tree"},
+        {"quad_accum_max", 4, 0, 64, "commitments per call whose accumulation runs four lanes per (scalar, half) chain (k_fbw_accum_quad; 0 = never; only calls that get a lane per (scalar, half), see spl1_max)"},
         {"hybrid_max", 0, 0, 1 << 20, "MSMs per call folded by k_blocksum_hybrid (0 = built-in)"},
-        {"wide_fold_max", 0, 0, 1 << 20, "MSMs per call folded limb-parallel (0 = built-in)"},
+        {"wide_fold_max", 0, 0, 1 << 20, "MSMs per call folded limb-parallel by k_wide_tree (0 = built-in: 4)"},
         {"spl1_max", 0, 0, 1 << 20, "MSMs per call that get a lane per (scalar, half) (0 = 8)"},
-        {"blocksum_threads", 0, 0, 256, "threads of k_blocksum: 64 / 128 / 256 (0 = by batch size)"},
-        {"lgc", 0, 0, 16, "log2 of the accumulation chunk of the bucket engine (0 = by size)"},
+        {"blocksum_threads", 0, 0, 256, "threads of k_blocksum: 64, 128 or 256 (0 = by batch size)"},
+        {"lgc", 0, 0, 8, "log2 of the accumulation chunk of the bucket engine (0 = by size; 2 ... 8)"},
         {"groups", 0, 0, 4, "window groups of the bucket engine on their own streams (0 = one)"},
         {"tail_pieces", 0, 0, 4, "a single large MSM accumulates its window sets in this many pieces, the reduction of a piece beside the accumulation of the next (0, 1 = one piece; measured: nothing gained)"},
-        {"fine_bits", 0, 0, 16, "width of the second sort level (0 = default)"},
+        {"sub_streams", 6, 0, 6, "a batch of large MSMs runs as sub-batches whose accumulations stay on the caller's stream while the sort and the reduction chains of each run on one of this many high-priority side streams (own workspaces) beside another sub-batch's accumulation (0 = one stream, one workspace); MSMs below 2^18 points unless sub_large = 1"},
+        {"sub_prio", 1, 0, 1, "1: the side streams of sub_streams are created with the device's highest stream priority, 0: with the default priority"},
+        {"sub_large", 0, 0, 1, "1: the side streams of sub_streams also for batches of MSMs of 2^18 points and more (measured slower: nothing runs well beside a chip-filling accumulation)"},
+        {"tile_rows", 0, 0, 32, "rows of 32 buckets per tile of the tiled bucket reduction: 32 (a 512-lane workgroup, a CU each) or 16 (256 lanes, a wave per SIMD); 0 = 32"},
+        {"fine_bits", 0, 0, 10, "width of the second sort level (0 = default; 7 ... 10)"},
         {"one_level_sort", 0, 0, 1, "1: the one-level sort at every size (it is the form small bucket counts take anyway)"},
         {"tree_tail", 0, 0, 1, "1: the tree reduction at every size (the form of fewer than 16384 buckets)"},
         {"flat_digits", 0, 0, 1, "1: untiled digit sums (the form bucket counts that are no multiple of 1024 take)"},
         {"direct_scatter", 0, 0, 1, "1: scatter without the LDS staging (the form of very long scalars per tile)"},
         {"scatter_atomics", 0, 0, 1, "1: ranks from global atomics instead of the kept histogram"},
-        {"window", 0, 0, 22, "window bits of a variable-base handle (0 = by size)"},
-        {"window_prepared", 0, 0, 22, "window bits of a prepared handle: bucket engine over table rows, no wide table (0 = by size)"},
+        {"window", 0, 0, 22, "window bits of a variable-base handle (0 = by size; 2 ... 22)"},
+        {"window_prepared", 0, 0, 22, "window bits of a prepared handle: bucket engine over table rows, no wide table (0 = by size; 2 ... 22)"},
         {"fixed_as_variable_min", 19, 0, 39, "log2 of the smallest prepared handle that, without room for a wide table, runs the variable-base engine (0 = never)"},
         {"glv", 1, 0, 1, "0: no endomorphism split in the variable-base engine"},
         {"fbw_glv", 1, 0, 1, "0: the wide table never takes the GLV form (rows over 128-bit halves), whatever it would save"},
@@ -73,6 +79,7 @@ inline const TuneKey* tune_keys() {
         {"g1_pair_max", 32768, 0, 1L << 40, "... up to this many, two lanes each; above, one lane each"},
         {"fk20", -1, -1, 1, "cell proofs by FK20 (1), by one fixed-base MSM per cell (0), or by batch size (-1)"},
         {"device_sha", 0, 0, 1, "1: Fiat-Shamir SHA-256 of host-buffer batches on the GPU"},
+        {"sha_lanes", 0, 0, 4, "lanes per blob of the device Fiat-Shamir hash: 4 (the message schedules of four blocks side by side, the compression chain 0.6 as long, 2.4 x the instructions), 1, or 0 = 4 up to 512 blobs per launch and 1 above"},
         {"host_check_max", 64, 0, 1 << 20, "commitments of a proof batch up to this many are validated on the host pool"},
         {"wide_check", 1, 0, 1, "0: single-lane commitment checks"},
         {"prove_chunk", 0, 0, 1 << 20, "blobs per pipelined chunk of a large proof batch (0 = by size)"},
@@ -84,6 +91,21 @@ inline const TuneKey* tune_keys() {
         {"gather_us", 60, 0, 100000, "... but at most this long (microseconds)"},
     };
     return k;
+}
+
+// values inside a key's range that no engine would honour: rejected like a value outside it
+inline bool tune_value_allowed(int id, long v) {
+    switch (id) {
+        case T_SPL: return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16;
+        case T_BLOCKSUM_THREADS: return v == 0 || v == 64 || v == 128 || v == 256;
+        case T_FINE_BITS: return v == 0 || (v >= 7 && v <= 10);
+        case T_LGC: return v == 0 || (v >= 2 && v <= 8);
+        case T_WINDOW:
+        case T_WINDOW_PREPARED: return v == 0 || (v >= 2 && v <= 22);
+        case T_SHA_LANES: return v == 0 || v == 1 || v == 4;
+        case T_TILE_ROWS: return v == 0 || v == 16 || v == 32;
+        default: return true;
+    }
 }
 
 struct Options {
@@ -123,7 +145,7 @@ struct Options {
                 if (err) *err = "tuning: unknown key '" + name + "'";
                 return false;
             }
-            if (v < k[id].lo || v > k[id].hi) {
+            if (v < k[id].lo || v > k[id].hi || !tune_value_allowed(id, v)) {
                 if (err) *err = "tuning: '" + name + "' out of range";
                 return false;
             }

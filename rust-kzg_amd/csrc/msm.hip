@@ -31,6 +31,7 @@
 #include "../../include/kzg_mi355x.h"
 #include "g1_io.hip.h"
 #include "g1w.hip.h"
+#include "g1grp.hip.h"
 #include "glv.hip.h"
 #include "host_g1.h"
 #include "config.h"
@@ -795,6 +796,13 @@ __device__ __forceinline__ void load_bucket(Xyzz& v, const Xyzz* __restrict__ pa
 // fill the chip, since it also sums each bucket's pieces):  A = sum A_j,  M = sum M_j + S * sum_j j*A_j  with S = buckets per child
 // (a power of two -> doublings).  Level 0 reads the buckets themselves (M_j = 0, S = 1).
 // Every level is a short chain (<= ~3*GRP adds) over many lanes instead of one long running sum.
+// Registers (hipcc 7.2, code-object metadata): three live XYZZ points and four inlined additions put k_level<true> at
+// 388 VGPRs + 132 AGPRs and k_level<false> at 441 + 185 with FOUR spilled VGPRs (16 B of scratch per lane, touched once
+// per folded child).  It stays: the kernel runs one wave per SIMD either way (launch bound 128, > 256 registers), it is
+// the many-sets path only (batches of small variable-base MSMs, nsets > 64: throughput work of thousands of
+// workgroups), and the spilled registers are four of ~630 (a store and a load of 16 B per lane next to ~13 000
+// arithmetic instructions per folded child).  The remedy that took the spills out of k_tile_sums — one addition site in
+// a loop whose operand comes from memory — has not been applied here.
 template <bool FIRST>
 __global__ void __launch_bounds__(128) k_level(const Xyzz* __restrict__ inA, const Xyzz* __restrict__ inM,
                                                Xyzz* __restrict__ outA, Xyzz* __restrict__ outM, size_t nin, size_t nsets,
@@ -890,21 +898,32 @@ __global__ void __launch_bounds__(DIGIT_T) k_digit_sums(const Xyzz* __restrict__
 // bucket instead of J = 3, every bucket's pieces folded exactly once in the same kernel, and nsets * nb / 1024 =
 // 256 workgroups of eight waves at n = 2^20 (a chain of ~15 additions).  The (digit, value) cells that are left have
 // nb / 1024 values each: few enough additions for one wave per addition (k_digit_sums_wide, k_digit_bits_wide).
-constexpr int TILE_T = 512;  // two buckets per lane and phase: a full CU (two waves per SIMD) per tile
+constexpr int TILE_T = 512;  // ROWS = 32: two buckets per lane and phase, a full CU (two waves per SIMD) per tile
 // Every addition is at one of TWO inlined sites, each the body of a loop whose second operand comes from
 // memory (the form that took the scratch out of the G1 stages, profiles/NOTES.md §16): loop 1 folds the pieces of the lane's two
-// buckets, loop 2 is a ten-step schedule — the pair of buckets, four row-tree levels, the pair of rows, four column-tree
+// buckets, loop 2 is a schedule of steps — the pair of buckets, four row-tree levels, the pair of rows, the column-tree
 // levels — in which a step only chooses where the operand comes from and where the sum goes.  (Round 3's form had five
 // sites, each with its own never-taken doubling: 256 VGPRs, 86 of them spilled; removed in round 5.)
-__global__ void __launch_bounds__(TILE_T) k_tile_sums_loop(const Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
-                                                           const unsigned char* __restrict__ heavy, Xyzz* __restrict__ dense,
-                                                           Xyzz* __restrict__ Gs, Xyzz* __restrict__ Cp, size_t nb,
-                                                           size_t nchunk, ChunkSel cs) {
+//
+// ROWS = 32 (tiles of 1024 buckets, 512 lanes: the default) or 16 (tiles of 512 buckets, 256 lanes; tuning key tile_rows).
+// The kernel needs 240 VGPRs, so a 512-lane workgroup wants ALL registers of all four SIMDs of a CU; a 256-lane one is a
+// wave per SIMD and could take the place of one retiring workgroup of a running accumulation (230 VGPRs, four waves).
+// Round 6 built the 16-row form for that — the reduction of one MSM under the accumulation of the next — and measured
+// that it does not happen: beside an accumulation the tiles still wait (2.9 ms instead of 0.32) whatever the stream
+// priority, and alone the 16-row form is slower (0.936 vs 0.889 ms at 2^16, 3.52 vs 3.42 at 2^20: twice the tiles, twice
+// the values per S[0][d] cell).  profiles/NOTES.md §20.
+template <int ROWS>
+__global__ void __launch_bounds__(ROWS * 16) k_tile_sums_loop(const Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
+                                                              const unsigned char* __restrict__ heavy, Xyzz* __restrict__ dense,
+                                                              Xyzz* __restrict__ Gs, Xyzz* __restrict__ Cp, size_t nb,
+                                                              size_t nchunk, ChunkSel cs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ts[];
     Xyzz* sh = (Xyzz*)smem_ts;
-    const size_t ntiles = nb >> 10;
+    constexpr int T = ROWS * 16;
+    constexpr int CL = ROWS == 32 ? 4 : 3;  // column-tree levels: ROWS / 2 row pairs -> 1
+    const size_t ntiles = nb / (size_t)(ROWS * 32);
     const size_t set = blockIdx.x / ntiles, tile = blockIdx.x % ntiles;
-    const size_t k0 = tile << 10;
+    const size_t k0 = tile * (size_t)(ROWS * 32);
     const int t = threadIdx.x;
     const int r = t >> 4, q = t & 15;   // rows: buckets 32 r + 2 q, + 1
     const int c = t & 31, rg = t >> 5;  // columns: rows 2 rg, 2 rg + 1 of column c
@@ -936,9 +955,10 @@ __global__ void __launch_bounds__(TILE_T) k_tile_sums_loop(const Xyzz* __restric
     }
     // acc = bucket kb + 1; step 0 adds bucket kb (this lane wrote it)
 #pragma unroll 1
-    for (int s = 0; s < 10; ++s) {
-        const int lvl = s < 5 ? s - 1 : s - 6;         // tree steps 1..4 / 6..9: strides 8, 4, 2, 1
-        const int stride = lvl >= 0 ? 8 >> lvl : 0;
+    for (int s = 0; s < 6 + CL; ++s) {
+        const int lvl = s < 5 ? s - 1 : s - 6;                        // tree steps 1..4 / 6..: strides 8, 4, 2, 1 / ROWS/4 .. 1
+        const int stride = lvl >= 0 ? (s < 5 ? 8 >> lvl : (ROWS / 4) >> lvl) : 0;
+        const int unit = s < 5 ? ROWS : 32;                           // slots between the operands of a tree step, per stride
         bool active = true;
         Xyzz v;
         if (s == 0) {
@@ -946,14 +966,14 @@ __global__ void __launch_bounds__(TILE_T) k_tile_sums_loop(const Xyzz* __restric
         } else if (s == 5) {
             v = dn[k0 + (size_t)(32 * (2 * rg + 1) + c)];
         } else {
-            active = s < 5 ? t < 32 * stride : rg < stride;
-            if (active) v = sh[t + 32 * stride];
+            active = t < unit * stride;
+            if (active) v = sh[t + unit * stride];
         }
         if (active && g1::dadd_unequal(acc, v)) g1::dbl(acc);
         if (s == 0) {
-            // the row tree runs q-major (slot 32 q + r): the lanes still adding at a level are the first 32 * stride of
+            // the row tree runs q-major (slot ROWS q + r): the lanes still adding at a level are the first ROWS * stride of
             // the workgroup, whole waves drop out level by level
-            sh[32 * q + r] = acc;
+            sh[ROWS * q + r] = acc;
             __syncthreads();
             acc = sh[t];  // slot t is only ever written by lane t from here on
         } else {
@@ -961,7 +981,7 @@ __global__ void __launch_bounds__(TILE_T) k_tile_sums_loop(const Xyzz* __restric
             __syncthreads();
         }
         if (s == 4) {
-            if (t < 32) Gs[set * (nb >> 5) + (k0 >> 5) + t] = acc;
+            if (t < ROWS) Gs[set * (nb >> 5) + (k0 >> 5) + t] = acc;
             __threadfence();  // the folded buckets this workgroup wrote are read back by other lanes
             __syncthreads();
             acc = dn[k0 + (size_t)(32 * (2 * rg) + c)];
@@ -973,12 +993,12 @@ __global__ void __launch_bounds__(TILE_T) k_tile_sums_loop(const Xyzz* __restric
 // S[set][0][d] = sum over the tiles of Cp[set][tile][d];  S[set][j][d], j >= 1, = sum of the groups whose digit j - 1
 // (base 32, of the group index) equals d.  One 64-thread workgroup per cell, nb / 1024 values each (32 at 2^15 buckets).
 __global__ void __launch_bounds__(64) k_digit_sums2(const Xyzz* __restrict__ Gs, const Xyzz* __restrict__ Cp,
-                                                    Xyzz* __restrict__ S, size_t nb, int logNb, int J) {
+                                                    Xyzz* __restrict__ S, size_t nb, int logNb, int J, size_t ntiles) {
     __shared__ Xyzz sh[64];
     const int per_set = J << DIGIT_BITS;
     const size_t set = blockIdx.x / per_set;
     const int jd = (int)(blockIdx.x % per_set), j = jd >> DIGIT_BITS, d = jd & ((1 << DIGIT_BITS) - 1);
-    const size_t ntiles = nb >> 10, ng = nb >> 5;
+    const size_t ng = nb >> 5;
     const int lane = threadIdx.x;
     Xyzz acc;
     g1::set_inf(acc);
@@ -1254,7 +1274,7 @@ __device__ __forceinline__ void wide_cell_finish(g1w::WPt& acc, Xyzz* __restrict
 // k_digit_sums2 with limb-parallel additions: grid = cells * WSPLIT waves
 __global__ void __launch_bounds__(64) k_digit_sums_wide(const Xyzz* __restrict__ Gs, const Xyzz* __restrict__ Cp,
                                                         Xyzz* __restrict__ S, Xyzz* __restrict__ part,
-                                                        u32* __restrict__ counter, size_t nb, int logNb, int J) {
+                                                        u32* __restrict__ counter, size_t nb, int logNb, int J, size_t ntiles) {
     __shared__ u32 sh[16];
     __shared__ u32 last_s;
     const int lane = threadIdx.x;
@@ -1263,7 +1283,7 @@ __global__ void __launch_bounds__(64) k_digit_sums_wide(const Xyzz* __restrict__
     const int per_set = J << DIGIT_BITS;
     const size_t set = cell / per_set;
     const int jd = (int)(cell % per_set), j = jd >> DIGIT_BITS, d = jd & ((1 << DIGIT_BITS) - 1);
-    const size_t ntiles = nb >> 10, ng = nb >> 5;
+    const size_t ng = nb >> 5;
     const fpw::Lane lc = fpw::lane_consts(lane);
     g1w::WPt acc;
     g1w::set_inf(acc);
@@ -1309,8 +1329,9 @@ __global__ void __launch_bounds__(64) k_digit_bits_wide(const Xyzz* __restrict__
 // one to finish adds the eight partial sums (the fold of a single commitment's partial sums: two launches instead of
 // the 13 single-lane tree levels of k_blocksum)
 constexpr int WFOLD = 8;
-constexpr size_t WIDE_FOLD_MAX = 1;  // MSMs per launch folded this way (2 .. 4: k_blocksum_hybrid is faster, 0.27 / 0.28 / 0.29 ms per
-                                     // commitment call against 0.29 / 0.33 / 0.37; 8 and 16 were slower than k_blocksum already)
+constexpr size_t WIDE_FOLD_MAX = 4;  // MSMs per launch folded limb-parallel (k_wide_tree).  Round 6, host-buffer commitment calls of
+                                     // 1 / 2 / 3 / 4 / 8 blobs, ms: 1 -> 0.185 / 0.227 / 0.269 / 0.277 / 0.309, 4 -> 0.182 / 0.186 / 0.230 /
+                                     // 0.244 / 0.301, 8 -> . / 0.193 / 0.230 / 0.252 / 0.381 (k_blocksum_hybrid beyond 4)
 __global__ void __launch_bounds__(64) k_wide_fold64(const Xyzz* __restrict__ in, Xyzz* __restrict__ out, Xyzz* __restrict__ part,
                                                     u32* __restrict__ counter, int per_wave) {
     __shared__ u32 sh[16];
@@ -1324,6 +1345,82 @@ __global__ void __launch_bounds__(64) k_wide_fold64(const Xyzz* __restrict__ in,
     const Xyzz* src = in + (cell * WFOLD + (size_t)sub) * per_wave;  // a cell = WFOLD * per_wave consecutive points
     for (int e = 0; e < per_wave; ++e) g1w::dadd(acc, g1w::load(src + e, lane), lc, sh, lane);
     wide_cell_finish<WFOLD>(acc, part, out, counter, cell, sub, lc, sh, &last_s, lane);
+}
+
+// The fold of a few commitments' partial sums in one launch of limb-parallel additions (round 6).  A limb-parallel addition
+// is ~2.2 us for a wave that has its SIMD to itself, so the shape is: never more than one wave per SIMD while the chip
+// has room, and as few device-wide hand-overs as the depth allows (a hand-over — store, fence, atomic, fence, reload
+// across the XCDs' L2s — costs ~10 us, as much as four additions).
+//   stage 0: a workgroup of FOUR waves (one per SIMD of its CU) takes 32 consecutive partial sums: every wave adds 8,
+//            wave 0 adds the four results through LDS                                       (7 + 3 additions)
+//   stage 1: the LAST of 16 neighbouring workgroups to finish (a counter per group) adds their 16 sums the same way:
+//            four per wave, then the four                                                    (3 + 3)
+//   stage 2: the last group of an MSM to finish (a counter per MSM) adds the group sums     (3 + 3 for 8192 partial sums)
+// 22 additions and two hand-overs deep for 8192 partial sums.  Measured under the profiler (one commitment): 0.085 ms for a
+// first form with 16-wave workgroups (four waves per SIMD on a quarter of the chip) and one hand-over, 0.098 ms for a form
+// with a hand-over per radix-4 level, 0.116 ms for the two launches of k_wide_fold64 with their memsets (round 5).
+// Counters are zero between launches (the wave that takes a group or an MSM resets its counter).
+constexpr int WTREE_PER_WG = 32, WTREE_GROUP = 16;
+__global__ void __launch_bounds__(256) k_wide_tree(const Xyzz* __restrict__ in, Xyzz* __restrict__ out, Xyzz* __restrict__ part,
+                                                   u32* __restrict__ counter, size_t n, u32 nwg) {
+    __shared__ Xyzz shp[4];
+    __shared__ u32 scr[4][16];
+    __shared__ u32 seen_s;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t set = blockIdx.x / nwg;
+    const u32 wg = blockIdx.x % nwg;
+    const u32 ngroups = nwg / WTREE_GROUP;
+    const fpw::Lane lc = fpw::lane_consts(lane);
+    u32* sh = scr[wave];
+    // per MSM: nwg workgroup sums, then ngroups group sums; counters: ngroups, then one
+    Xyzz* p1 = part + set * (size_t)(nwg + ngroups);
+    Xyzz* p2 = p1 + nwg;
+    u32* cnt = counter + set * (size_t)(ngroups + 1);
+    g1w::WPt acc;
+    // acc of the four waves -> wave 0's acc (workgroup-uniform control flow)
+    auto fold4 = [&]() {
+        g1w::store(shp + wave, acc, lc, lane);
+        __syncthreads();
+        if (wave == 0) {
+            g1w::set_inf(acc);
+            for (int k = 0; k < 4; ++k) g1w::dadd(acc, g1w::load(shp + k, lane), lc, sh, lane);
+        }
+        __syncthreads();  // shp is free again
+    };
+    // wave 0 publishes acc at `slot` and counts this workgroup at `c`; true for the last of `expect` to arrive
+    auto hand_over = [&](Xyzz* slot, u32* c, u32 expect) {
+        if (wave == 0) {
+            g1w::store(slot, acc, lc, lane);
+            __threadfence();
+            if (lane == 0) seen_s = atomicAdd(c, 1u);
+        }
+        __syncthreads();
+        const bool last = seen_s == expect - 1;
+        __syncthreads();
+        if (last) {
+            __threadfence();
+            if (threadIdx.x == 0) *c = 0;  // ready for the next launch
+        }
+        return last;
+    };
+    g1w::set_inf(acc);
+    {
+        const Xyzz* src = in + set * n + ((size_t)wg * 4 + wave) * (WTREE_PER_WG / 4);
+        for (int k = 0; k < WTREE_PER_WG / 4; ++k) g1w::dadd(acc, g1w::load(src + k, lane), lc, sh, lane);
+    }
+    fold4();
+    const u32 group = wg / WTREE_GROUP;
+    if (!hand_over(p1 + wg, cnt + group, WTREE_GROUP)) return;
+    g1w::set_inf(acc);
+    for (int k = 0; k < WTREE_GROUP / 4; ++k) g1w::dadd(acc, g1w::load(p1 + (size_t)group * WTREE_GROUP + wave * (WTREE_GROUP / 4) + k, lane), lc, sh, lane);
+    fold4();
+    if (ngroups > 1) {
+        if (!hand_over(p2 + group, cnt + ngroups, ngroups)) return;
+        g1w::set_inf(acc);
+        for (u32 k = wave; k < ngroups; k += 4) g1w::dadd(acc, g1w::load(p2 + k, lane), lc, sh, lane);
+        fold4();
+    }
+    if (wave == 0) g1w::store(out + set, acc, lc, lane);
 }
 
 // ============================ wide fixed-base table ("FBW") ============================
@@ -1545,6 +1642,47 @@ __global__ void __launch_bounds__(256) k_fbw_accum(DigitParams P, const u32* __r
         acc.y = fp28::mul(fp28::neg<8>(acc.y), fp28::one());    // -Y, back under the 2p bound
     }
     partial[t] = acc;
+}
+
+// k_fbw_accum<1, true> with FOUR lanes per (scalar, half) chain (g1grp.hip.h): the eight mixed additions of a chain are
+// 4 multiplications deep instead of 10, on four times the lanes — for the few commitments of a latency-bound call
+// (8192 chains per commitment: 128 waves leave most of the chip idle, 512 waves still do).  ONE loop with ONE inlined
+// addition in its body.  Role 0 of a group writes the chain's sum.
+__global__ void __launch_bounds__(256) k_fbw_accum_quad(DigitParams P, const u32* __restrict__ digits,
+                                                        const WidePt* __restrict__ wide, Xyzz* __restrict__ partial,
+                                                        size_t lanes_per_msm) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = (int)(threadIdx.x & 3);
+    const size_t chain = t >> 2;
+    if (chain >= lanes_per_msm * P.nbatch) return;  // a whole group leaves: chains never straddle a quad
+    const size_t b = chain / lanes_per_msm;
+    const size_t l = chain % lanes_per_msm;
+    const u32 part = (u32)(l & 1);
+    const size_t i = l >> 1;
+    Xyzz acc;
+    g1::set_inf(acc);
+    const int sh = P.c - 1;
+    const size_t seg0 = P.nseg ? (b % P.nseg) * P.n : 0;
+    const int DW = (P.nwin + 3) & ~3;
+    const uint4* dg = reinterpret_cast<const uint4*>(digits + ((b * P.n + i) * 2 + part) * DW);
+    uint4 v = make_uint4(FBW_SKIP, FBW_SKIP, FBW_SKIP, FBW_SKIP);
+#pragma unroll 1
+    for (int w = 0; w < DW; ++w) {
+        if ((w & 3) == 0) v = dg[w >> 2];
+        const int k = w & 3;
+        const u32 e = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+        if (e == FBW_SKIP) continue;
+        const WidePt pk = wide[(((size_t)w * P.row_stride + seg0 + i) << sh) + (e & 0x7fffffffu)];
+        if (pk.pad[0]) continue;  // multiple of a base at infinity
+        fp28::Fe x = pk.x, y = pk.y;
+        if (e >> 31) y = fp28::neg<2>(y);
+        grp::madd_body4(acc, x, y, r);
+    }
+    if (part && !g1::is_inf(acc)) {
+        acc.x = fp28::mul(acc.x, beta28());                     // psi(X, Y, ZZ, ZZZ) = (beta X, -Y, ZZ, ZZZ)
+        acc.y = fp28::mul(fp28::neg<8>(acc.y), fp28::one());    // -Y, back under the 2p bound
+    }
+    if (r == 0) partial[chain] = acc;
 }
 
 // one workgroup per MSM: plain sum of its n partial sums
@@ -1829,17 +1967,20 @@ struct Workspace {
 // up); every variant computes the same result a different way.
 struct MsmTuning {
     int spl = 0, hybrid_max = 0, wide_fold_max = 0, spl1_max = 0, blocksum_threads = 0, lgc = 0, groups = 0, fine_bits = 0;
-    bool no_wide_tail = false, no_hybrid_fold = false;
+    bool no_wide_tail = false, no_hybrid_fold = false, no_wide_tree = false;
+    int quad_accum_max = 4;
     bool one_level_sort = false, tree_tail = false, flat_digits = false, direct_scatter = false, scatter_atomics = false;
     bool combine = true;
     int combine_lanes = 3, combine_gather_min = 6, combine_gather_us = 60;
-    int tail_pieces = 0;
+    int tail_pieces = 0, sub_streams = 6, tile_rows = 0, sub_prio = 1, sub_large = 0;
     static MsmTuning from(const kzgamd::Options& o) {
         using namespace kzgamd;
         MsmTuning t;
         t.spl = (int)o.t[T_SPL];
         t.no_wide_tail = o.t[T_NO_WIDE_TAIL] != 0;
         t.no_hybrid_fold = o.t[T_NO_HYBRID_FOLD] != 0;
+        t.no_wide_tree = o.t[T_NO_WIDE_TREE] != 0;
+        t.quad_accum_max = (int)o.t[T_QUAD_ACCUM_MAX];
         t.hybrid_max = (int)o.t[T_HYBRID_MAX];
         t.wide_fold_max = (int)o.t[T_WIDE_FOLD_MAX];
         t.spl1_max = (int)o.t[T_SPL1_MAX];
@@ -1857,6 +1998,10 @@ struct MsmTuning {
         t.combine_gather_min = (int)o.t[T_COMBINE_GATHER_MIN];
         t.combine_gather_us = (int)o.t[T_COMBINE_GATHER_US];
         t.tail_pieces = (int)o.t[T_TAIL_PIECES];
+        t.sub_streams = (int)o.t[T_SUB_STREAMS];
+        t.tile_rows = (int)o.t[T_TILE_ROWS];
+        t.sub_prio = (int)o.t[T_SUB_PRIO];
+        t.sub_large = (int)o.t[T_SUB_LARGE];
         return t;
     }
 };
@@ -1910,6 +2055,21 @@ struct kzgamd::MsmContext {
         return *ws_extra.back().second;
     }
     hipStream_t stream = nullptr;
+    // A batch of large MSMs runs as sub-batches (tuning key sub_streams).  The accumulations — VALU throughput, the chip
+    // full — stay on the caller's stream, one after the other; everything else of a sub-batch (its sort before, its
+    // reduction chains and Horner after: atomics / latency, a fraction of the chip) runs on one of these side streams,
+    // which rotate over the sub-batches, each with its own workspace.  The side streams have the highest priority the
+    // device offers: at equal priority the accumulation's waves hold every register of every SIMD and a reduction
+    // kernel launched beside it waits for slots (traced in round 6: k_tile_sums_loop 2.8 ms instead of 0.32, the next
+    // sub-batch's accumulation waiting behind it).  accum_on / ev_sorted / ev_accd are what msm_enqueue's k_accum launch
+    // site reads.
+    static constexpr int MAXSUB = 6;
+    hipStream_t sub_stream[MAXSUB] = {};
+    hipEvent_t ev_sub_fork = nullptr, ev_sub_join[MAXSUB] = {}, ev_sorted[MAXSUB] = {}, ev_accd[MAXSUB] = {};
+    bool accum_redirect = false;     // set by the sub-batch loop: this enqueue's k_accum goes to accum_on ...
+    hipStream_t accum_on = nullptr;  // ... the caller's stream (which may be the null stream)
+    hipEvent_t accum_ready = nullptr, accum_done = nullptr;
+    bool in_sub_batch = false;  // the enqueue in progress is a sub-batch: it is not cut again
     // window-group pipeline of the variable-base engine: one auxiliary stream per group, events to fork from /
     // join into the caller's stream and to order the digit and accumulation kernels across groups
     static constexpr int MAXG = 4;
@@ -1960,14 +2120,18 @@ struct kzgamd::MsmContext {
         std::deque<HostCall*> pending;
         int leaders = 0;
         CombineLane lanes[COMBINE_LANES];
-        unsigned char* h_slots = nullptr;  // COMBINE_SLOTS x slot_bytes, page-locked
+        // page-locked staging slots, allocated in chunks as callers need them (4, 4, 8, 16, 16): a handle that one thread
+        // uses at a time pins four slots (a single caller keeps the fast staging path: a copy from a page-locked slot
+        // instead of the runtime's staging of pageable memory), sixteen concurrent callers grow the pool to what they use
+        std::vector<unsigned char*> slot_chunks;
+        int slots_allocated = 0;
         size_t slot_bytes = 0;
         bool pinned_failed = false;
         std::vector<unsigned char*> free_slots;
     } comb;
     ~MsmContext() {
         delete matrix;
-        if (comb.h_slots) (void)hipHostFree(comb.h_slots);
+        for (auto* c : comb.slot_chunks) (void)hipHostFree(c);
         for (auto& l : comb.lanes) {
             if (l.h_out) (void)hipHostFree(l.h_out);
             l.scalars.release();
@@ -1984,6 +2148,13 @@ struct kzgamd::MsmContext {
         for (auto& e : ev)
             if (e) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_sub_fork) (void)hipEventDestroy(ev_sub_fork);
+        for (int k = 0; k < MAXSUB; ++k) {
+            if (ev_sub_join[k]) (void)hipEventDestroy(ev_sub_join[k]);
+            if (ev_sorted[k]) (void)hipEventDestroy(ev_sorted[k]);
+            if (ev_accd[k]) (void)hipEventDestroy(ev_accd[k]);
+            if (sub_stream[k]) (void)hipStreamDestroy(sub_stream[k]);
+        }
         for (int g = 0; g < MAXG; ++g) {
             if (ev_dig[g]) (void)hipEventDestroy(ev_dig[g]);
             if (ev_acc[g]) (void)hipEventDestroy(ev_acc[g]);
@@ -2294,15 +2465,23 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                 bcount_new = true;
             }
         }
-        const size_t wf_max = ctx->tune.wide_fold_max > 0 ? (size_t)ctx->tune.wide_fold_max
-                              : (ctx->tune.wide_fold_max < 0 ? (size_t)0 : WIDE_FOLD_MAX);  // negative: never
+        const size_t wf_max = ctx->tune.wide_fold_max > 0 ? (size_t)ctx->tune.wide_fold_max : WIDE_FOLD_MAX;
         const bool wide_fold = nbatch <= wf_max && (lanes == 4096 || lanes == 8192) && !ctx->tune.no_wide_tail;
+        bool wcount_new = false;
         if (wide_fold) {
-            ws.wpart.ensure((nbatch * 128 + nbatch) * (size_t)WFOLD);
-            ws.wcount.ensure(nbatch * 128 + nbatch);
+            // k_wide_tree: lanes / 32 workgroup sums + lanes / 512 group sums per MSM, a counter per group and one per MSM
+            // (zeroed when allocated, left at zero by every launch); k_wide_fold64 (tuning key no_wide_tree): 129 cells x
+            // WFOLD parts, a counter per cell — which is more of both
+            const size_t need_p = (nbatch * 128 + nbatch) * (size_t)WFOLD, need_c = nbatch * 128 + nbatch;
+            ws.wpart.ensure(need_p);
+            if (ws.wcount.cap < need_c) {
+                ws.wcount.ensure(need_c);
+                wcount_new = true;
+            }
         }
         if (ctx->fbw_glv) ws.digits.ensure(nbatch * npoints * 2 * (size_t)((nwin + 3) & ~3));
         if (bcount_new) HIP_TRY(hipMemsetAsync(ws.bcount.p, 0, BSH_CAP * sizeof(u32), stream));
+        if (wcount_new) HIP_TRY(hipMemsetAsync(ws.wcount.p, 0, ws.wcount.cap * sizeof(u32), stream));
         if (reserve_only) return;
         WsUse ws_use(ws, stream, &ws == &ctx->ws);
         DigitParams P{npoints, nbatch, c, nwin, 1, mont, nb, ctx->n, 0, 0, nwin, (u32)nseg};
@@ -2327,7 +2506,11 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
 #define KZG_FBW_LAUNCH(SPL_, GLV_)                                                                           \
     hipLaunchKernelGGL((k_fbw_accum<SPL_, GLV_>), grid, dim3(256), 0, stream, P, acc_in,                         \
                        (const WidePt*)ctx->wide.p, ws.buckets.p, lanes)
-        if (ctx->fbw_glv) {
+        if (ctx->fbw_glv && spl == 1 && nbatch <= (size_t)ctx->tune.quad_accum_max) {
+            // a lane per (scalar, half) AND four lanes per chain: the few-commitments form
+            hipLaunchKernelGGL(k_fbw_accum_quad, dim3((unsigned)((lanes * nbatch * 4 + 255) / 256)), dim3(256), 0, stream, P, acc_in,
+                               (const WidePt*)ctx->wide.p, ws.buckets.p, lanes);
+        } else if (ctx->fbw_glv) {
             if (spl == 1) KZG_FBW_LAUNCH(1, true);
             else if (spl == 2) KZG_FBW_LAUNCH(2, true);
             else if (spl == 4) KZG_FBW_LAUNCH(4, true);
@@ -2346,6 +2529,11 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             // many small MSMs (segments of a table): one lane adds the few partial sums of an MSM
             hipLaunchKernelGGL(k_lane_sum, dim3((unsigned)((nbatch + 63) / 64)), dim3(64), 0, stream, (const Xyzz*)ws.buckets.p,
                                sums, lanes, nbatch);
+        } else if (wide_fold && !ctx->tune.no_wide_tree) {
+            // a few commitments (wide_fold_max): one launch of limb-parallel additions, 32 partial sums per workgroup
+            const u32 nwg = (u32)(lanes / WTREE_PER_WG);
+            hipLaunchKernelGGL(k_wide_tree, dim3((unsigned)(nbatch * nwg)), dim3(256), 0, stream, (const Xyzz*)ws.buckets.p, sums,
+                               ws.wpart.p, ws.wcount.p, lanes, nwg);
         } else if (wide_fold) {
             // one or two commitments: the partial sums folded 64 : 1, then 64 : 1 or 128 : 1, with limb-parallel additions
             const int pw2 = (int)(lanes / 64 / WFOLD);  // 8 or 16 points per wave in the second launch
@@ -2387,20 +2575,85 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     }
     // A batch of large MSMs whose sets together have more coarse bins than the two-level sort's LDS counters hold
     // (MAX_BINS) would take the one-level sort — 1.2 ms instead of 0.3 per 2^20-point MSM (measured: 4 x 2^20 in one call
-    // 4.2 ms per MSM against 3.4 for one).  Such a batch runs as consecutive sub-batches that fit, on the same stream and
-    // workspace; each is still thousands of workgroups.
-    if (nbatch > 1 && !ctx->tune.one_level_sort && npoints >= ((size_t)1 << 15)) {
+    // 4.2 ms per MSM against 3.4 for one).  Such a batch runs as sub-batches that fit.  Round 6: ANY batch of large MSMs is
+    // cut into sub-batches, and only their accumulations stay on the caller's stream; the sort and the reduction of a
+    // sub-batch run on a high-priority side stream beside another sub-batch's accumulation (MsmContext::sub_stream;
+    // tuning key sub_streams = how many rotate, 0 = everything on the caller's stream and workspace as in round 5).
+    if (nbatch > 1 && !ctx->in_sub_batch && !ctx->tune.one_level_sort && npoints >= ((size_t)1 << 15)) {
         const int fb0 = ctx->tune.fine_bits >= FINE_BITS_MIN && ctx->tune.fine_bits <= FINE_BITS_MAX ? ctx->tune.fine_bits : FINE_BITS_MIN;
         const size_t bins_per_msm = (nb >> fb0) * (ctx->prepared ? (size_t)1 : (size_t)nwin);
-        const size_t per = bins_per_msm ? MAX_BINS / bins_per_msm : 0;
+        size_t per = bins_per_msm ? MAX_BINS / bins_per_msm : 0;
+        // Measured (tools/ab_batched.py, profiles/NOTES.md §20): 4 or 8 x 2^16 in one call 0.70 -> 0.645 ms per MSM with six side
+        // streams (three: 0.70), 4 x 2^17 0.87 -> 0.82 — there the reduction chains of the sub-batches (0.7 ms each, a
+        // fraction of the chip) overlap each other.  From
+        // 2^18 points on an accumulation fills every register of every SIMD for milliseconds and whatever is launched
+        // beside it, at any stream priority, crawls (k_tile_sums_loop 2.9 ms instead of 0.32, k_digit_sums_wide 1.6 instead
+        // of 0.09) and delays the next sub-batch: 4 x 2^20 3.26 ms per MSM on one stream, 3.3 - 3.5 with side streams.
+        // So the side streams serve batches of MSMs below 2^18 points; tuning key sub_large = 1 lifts the limit.
+        int nside = ctx->tune.sub_streams < 0 ? 0 : ctx->tune.sub_streams > MsmContext::MAXSUB ? MsmContext::MAXSUB : ctx->tune.sub_streams;
+        if (npoints >= ((size_t)1 << 18) && !ctx->tune.sub_large) nside = 0;
+        if (nside > 0 && per >= 1) {
+            // at least two sub-batches; from 2^18 points an MSM's accumulation alone fills the chip for a millisecond
+            const size_t cap = npoints >= ((size_t)1 << 18) ? (size_t)1 : (nbatch + 1) / 2;
+            if (per > cap) per = cap;
+        }
         if (nb >= ((size_t)1 << fb0) && per >= 1 && per < nbatch) {
             const size_t out_stride = out_mode == OUT_COMPRESSED ? 48 : out_mode == OUT_WINDOWS ? (size_t)nwin * 144 : 144;
-            for (size_t b0 = 0; b0 < nbatch; b0 += per) {
+            const size_t nsub = (nbatch + per - 1) / per;
+            const int lanes = nside > 0 ? (int)(nsub < (size_t)nside ? nsub : (size_t)nside) : 0;  // side streams in use
+            if (lanes > 0 && !ctx->sub_stream[lanes - 1]) {
+                int least = 0, greatest = 0;
+                HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                const int prio = ctx->tune.sub_prio ? greatest : 0;
+                for (int k = 0; k < lanes; ++k) {
+                    if (!ctx->sub_stream[k]) HIP_TRY(hipStreamCreateWithPriority(&ctx->sub_stream[k], hipStreamNonBlocking, prio));
+                    if (!ctx->ev_sub_join[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_sub_join[k], hipEventDisableTiming));
+                    if (!ctx->ev_sorted[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_sorted[k], hipEventDisableTiming));
+                    if (!ctx->ev_accd[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_accd[k], hipEventDisableTiming));
+                }
+            }
+            struct SubReset {  // an exception below must not leave the next enqueue in sub-batch mode
+                MsmContext* c;
+                ~SubReset() {
+                    c->accum_redirect = false;
+                    c->accum_on = nullptr;
+                    c->accum_ready = c->accum_done = nullptr;
+                    c->in_sub_batch = false;
+                }
+            } sub_reset{ctx};
+            ctx->in_sub_batch = true;
+            if (reserve_only) {  // the first sub-batch is the largest; every stream of the rotation gets its workspace
+                if (lanes == 0) msm_enqueue(ctx, nullptr, nullptr, npoints, per, mont, stream, out_mode, true, nseg);
+                for (int k = 0; k < lanes; ++k)
+                    msm_enqueue(ctx, nullptr, nullptr, npoints, per, mont, ctx->sub_stream[k], out_mode, true, nseg);
+                return;
+            }
+            if (lanes > 0) {
+                if (!ctx->ev_sub_fork) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_sub_fork, hipEventDisableTiming));
+                // whatever produced the scalars (and last used the outputs) on the caller's stream comes first
+                HIP_TRY(hipEventRecord(ctx->ev_sub_fork, stream));
+                for (int k = 0; k < lanes; ++k) HIP_TRY(hipStreamWaitEvent(ctx->sub_stream[k], ctx->ev_sub_fork, 0));
+            }
+            size_t k = 0;
+            for (size_t b0 = 0; b0 < nbatch; b0 += per, ++k) {
                 const size_t nbp = b0 + per <= nbatch ? per : nbatch - b0;
+                hipStream_t st = stream;
+                if (lanes > 0) {
+                    const int lane = (int)(k % (size_t)lanes);
+                    st = ctx->sub_stream[lane];
+                    ctx->accum_redirect = true;
+                    ctx->accum_on = stream;
+                    ctx->accum_ready = ctx->ev_sorted[lane];
+                    ctx->accum_done = ctx->ev_accd[lane];
+                }
                 msm_enqueue(ctx, d_out ? (unsigned char*)d_out + b0 * out_stride : nullptr,
-                            d_scalars ? (const unsigned char*)d_scalars + b0 * npoints * 32 : nullptr, npoints, nbp, mont, stream,
-                            out_mode, reserve_only, nseg);
-                if (reserve_only) break;  // the first sub-batch is the largest
+                            d_scalars ? (const unsigned char*)d_scalars + b0 * npoints * 32 : nullptr, npoints, nbp, mont, st,
+                            out_mode, false, nseg);
+            }
+            ctx->accum_redirect = false;
+            for (int j = 0; j < lanes; ++j) {
+                HIP_TRY(hipEventRecord(ctx->ev_sub_join[j], ctx->sub_stream[j]));
+                HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_sub_join[j], 0));
             }
             return;
         }
@@ -2472,7 +2725,10 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     // measured (same box, tree vs digits): n = 2^14 (4096 buckets) 1.20 vs 1.35 ms, 2^16 1.53 vs 1.48, 2^20 4.53 vs 4.35, 2^22 14.67 vs 14.26
     const bool digit_tail = use_top && nb >= 16384 && !ctx->tune.tree_tail;
     // the tiled form of the digit sums (k_tile_sums_loop); tuning key flat_digits: one pass over the buckets per digit
-    const bool tiled_digits = digit_tail && nb % 1024 == 0 && !ctx->tune.flat_digits;
+    // tile rows: 32 (tiles of 1024 buckets, a CU per workgroup); 16 (512 buckets, a wave per SIMD) by tuning key
+    const int tile_rows = ctx->tune.tile_rows ? ctx->tune.tile_rows : 32;  // 16: measured slower alone (3.52 vs 3.42 ms at 2^20) and no help beside an accumulation
+    const bool tiled_digits = digit_tail && nb % ((size_t)tile_rows * 32) == 0 && !ctx->tune.flat_digits;
+    const size_t ntiles = nb / ((size_t)tile_rows * 32);
     // shape of the tree (the same for every group: level 0 folds by the group size): k_top stride B + 2
     size_t top_stride = 0;
     {
@@ -2496,7 +2752,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             ws.dense.ensure(nsets * nb);
             if (tiled_digits) {
                 ws.lvlA[1].ensure(nsets * (nb >> 5));  // group sums
-                ws.lvlM[1].ensure(nsets * (nb >> 5));  // per-tile column sums: (nb / 1024) tiles x 32
+                ws.lvlM[1].ensure(nsets * (nb >> 4));  // per-tile column sums: ntiles x 32 (16-row tiles: nb / 16)
                 const size_t cells = nsets * (size_t)(((logNb + DIGIT_BITS - 1) / DIGIT_BITS) * 32 + logNb + 2);
                 ws.wpart.ensure(cells * WSPLIT);
                 ws.wcount.ensure(cells);
@@ -2508,6 +2764,10 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         }
     }
     if (reserve_only) return;
+    // sub-batch of a batch of large MSMs: the accumulation goes to the caller's stream (see MsmContext::sub_stream)
+    const bool accum_redirect = ctx->accum_redirect;
+    const hipStream_t accum_on = ctx->accum_on;
+    const hipEvent_t accum_ready = ctx->accum_ready, accum_done = ctx->accum_done;
     WsUse ws_use(ws, stream, &ws == &ctx->ws);
     hipEvent_t* pev = nullptr;
     if (ctx->profile && ctx->ev_used + 4 <= MsmContext::EV_MAX) {
@@ -2614,9 +2874,19 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         const u32* p_off = offsets + (ps0 - set0) * (nb + 1);
         Xyzz* p_buckets = buckets + (ps0 - set0) * (nb + nchunk);
         const unsigned char* p_heavy = heavy + (ps0 - set0) * nb;
-        hipLaunchKernelGGL(k_accum, dim3((unsigned)((pns * nchunk + 255) / 256)), dim3(256), 0, ast, p_off,
+        hipStream_t kst = ast;
+        if (accum_redirect) {  // sorted on ast; accumulated on accum_on, behind the previous sub-batch's accumulation
+            HIP_TRY(hipEventRecord(accum_ready, ast));
+            HIP_TRY(hipStreamWaitEvent(accum_on, accum_ready, 0));
+            kst = accum_on;
+        }
+        hipLaunchKernelGGL(k_accum, dim3((unsigned)((pns * nchunk + 255) / 256)), dim3(256), 0, kst, p_off,
                            (const u32*)(ws.sorted.p + ps0 * set_cap), (const AffPt*)ctx->table.p, p_buckets, nb, pns, set_cap,
                            nchunk, pcs);
+        if (accum_redirect) {
+            HIP_TRY(hipEventRecord(accum_done, accum_on));
+            HIP_TRY(hipStreamWaitEvent(ast, accum_done, 0));
+        }
         if (tst != ast) {
             HIP_TRY(hipEventRecord(ctx->ev_acc[piece], ast));
             HIP_TRY(hipStreamWaitEvent(tst, ctx->ev_acc[piece], 0));
@@ -2638,10 +2908,13 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             Xyzz* dense = ws.dense.p + ps0 * nb;
             if (tiled_digits) {
                 Xyzz* Gs = ws.lvlA[1].p + ps0 * (nb >> 5);
-                Xyzz* Cp = ws.lvlM[1].p + ps0 * (nb >> 5);
-                hipLaunchKernelGGL(k_tile_sums_loop, dim3((unsigned)(pns * (nb >> 10))),
-                                   dim3(TILE_T), TILE_T * sizeof(Xyzz), st, (const Xyzz*)p_buckets, p_off,
-                                   p_heavy, dense, Gs, Cp, nb, nchunk, pcs);
+                Xyzz* Cp = ws.lvlM[1].p + ps0 * (ntiles * 32);
+                if (tile_rows == 16)
+                    hipLaunchKernelGGL(k_tile_sums_loop<16>, dim3((unsigned)(pns * ntiles)), dim3(256), 256 * sizeof(Xyzz), st,
+                                       (const Xyzz*)p_buckets, p_off, p_heavy, dense, Gs, Cp, nb, nchunk, pcs);
+                else
+                    hipLaunchKernelGGL(k_tile_sums_loop<32>, dim3((unsigned)(pns * ntiles)), dim3(TILE_T), TILE_T * sizeof(Xyzz), st,
+                                       (const Xyzz*)p_buckets, p_off, p_heavy, dense, Gs, Cp, nb, nchunk, pcs);
                 if (wide_tail) {
                     // cells of this group: [0, pns * J * 32) digit sums, then pns * (logNb + 2) bit sums
                     const size_t c1 = pns * (size_t)(J * 32), c2 = pns * (size_t)(logNb + 2);
@@ -2650,12 +2923,12 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                     Xyzz* part = ws.wpart.p + cbase * WSPLIT;  // WSPLIT >= WSPLIT_S slots per cell
                     HIP_TRY(hipMemsetAsync(cnt, 0, (c1 + c2) * sizeof(u32), st));
                     hipLaunchKernelGGL(k_digit_sums_wide, dim3((unsigned)(c1 * WSPLIT_S)), dim3(64), 0, st, (const Xyzz*)Gs,
-                                       (const Xyzz*)Cp, S, part, cnt, nb, logNb, J);
+                                       (const Xyzz*)Cp, S, part, cnt, nb, logNb, J, ntiles);
                     hipLaunchKernelGGL(k_digit_bits_wide, dim3((unsigned)(c2 * WSPLIT)), dim3(64), 0, st, (const Xyzz*)S, top,
                                        part + c1 * WSPLIT, cnt + c1, logNb, J);
                 } else {
                     hipLaunchKernelGGL(k_digit_sums2, dim3((unsigned)(pns * (size_t)(J * 32))), dim3(64), 0, st, (const Xyzz*)Gs,
-                                       (const Xyzz*)Cp, S, nb, logNb, J);
+                                       (const Xyzz*)Cp, S, nb, logNb, J, ntiles);
                 }
             } else {
                 hipLaunchKernelGGL(k_fold_buckets, dim3((unsigned)((pns * nb + 127) / 128)), dim3(128), 0, st,
@@ -2856,16 +3129,20 @@ static void msm_run_host_combined(MsmContext* ctx, void* out, const void* scalar
     std::vector<MsmContext::HostCall*> batch;
     batch.reserve(MsmContext::COMBINE_MAX);  // everything that can throw happens before the request is visible
     std::unique_lock<std::mutex> lk(q.mu);
-    if (!q.h_slots && !q.pinned_failed) {
+    if (q.free_slots.empty() && !q.pinned_failed && q.slots_allocated < MsmContext::COMBINE_SLOTS) {
         DeviceGuard on_device(ctx->device);
         q.slot_bytes = (ctx->n < MsmContext::COMBINE_NMAX ? ctx->n : MsmContext::COMBINE_NMAX) * 32;
+        int grow = q.slots_allocated < 8 ? 4 : q.slots_allocated < 16 ? 8 : 16;
+        if (grow > MsmContext::COMBINE_SLOTS - q.slots_allocated) grow = MsmContext::COMBINE_SLOTS - q.slots_allocated;
+        unsigned char* chunk = nullptr;
         if (on_device.err != hipSuccess ||
-            hipHostMalloc((void**)&q.h_slots, (size_t)MsmContext::COMBINE_SLOTS * q.slot_bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
-            q.h_slots = nullptr;
-            q.pinned_failed = true;
+            hipHostMalloc((void**)&chunk, (size_t)grow * q.slot_bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
+            q.pinned_failed = true;  // callers without a slot hand their own (pageable) buffer to the batch
             (void)hipGetLastError();
         } else {
-            for (int i = MsmContext::COMBINE_SLOTS; i-- > 0;) q.free_slots.push_back(q.h_slots + (size_t)i * q.slot_bytes);
+            q.slot_chunks.push_back(chunk);
+            q.slots_allocated += grow;
+            for (int i = grow; i-- > 0;) q.free_slots.push_back(chunk + (size_t)i * q.slot_bytes);
         }
     }
     if (!q.free_slots.empty()) {
@@ -3058,11 +3335,19 @@ extern "C" RustError kzgamd_msm_attach_matrix(void* msm, const blst_p1_affine po
     kzgamd_config_init(&inherited);
     if (cfg) inherited = *cfg;
     inherited.device = ctx->device;  // the matrix lives where its handle lives
+    {
+        // a handle takes ONE matrix, once: matrix calls read ctx->matrix without the handle's lock (they run on the
+        // matrix's own), so replacing it under them would free a table in use
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        if (ctx->matrix) return make_error(1, "kzgamd_msm_attach_matrix: the handle already has a matrix attached");
+    }
     void* m = kzgamd_prepare_msm_matrix(points, rows, cols, &inherited);
     if (!m) return make_error(1, "kzgamd_msm_attach_matrix: the matrix handle could not be built (see stderr)");
     std::lock_guard<std::mutex> lk(ctx->mu);
-    kzgamd::DeviceGuard on_device(ctx->device);
-    delete ctx->matrix;
+    if (ctx->matrix) {  // another thread attached meanwhile
+        free_msm(m);
+        return make_error(1, "kzgamd_msm_attach_matrix: the handle already has a matrix attached");
+    }
     ctx->matrix = (MsmContext*)m;
     return ok_error();
 }

@@ -603,16 +603,20 @@ bool run_host_combined(NttCtx* ctx, void* out, const void* in, size_t n, int kin
     std::vector<NttCtx::HostCall*> batch;
     batch.reserve(NttCtx::COMB_MAX);
     std::unique_lock<std::mutex> lk(q.mu);
-    if (!q.h_slots && !q.pinned_failed) {
+    if (q.free_slots.empty() && !q.pinned_failed && q.slots_allocated < NttCtx::COMB_SLOTS) {
         kzgamd::DeviceGuard on_device(ctx->device);
         q.slot_bytes = NttCtx::COMB_NMAX * sizeof(Fr);
+        int grow = q.slots_allocated < 8 ? 4 : q.slots_allocated < 16 ? 8 : 16;
+        if (grow > NttCtx::COMB_SLOTS - q.slots_allocated) grow = NttCtx::COMB_SLOTS - q.slots_allocated;
+        unsigned char* chunk = nullptr;
         if (on_device.err != hipSuccess ||
-            hipHostMalloc((void**)&q.h_slots, (size_t)NttCtx::COMB_SLOTS * q.slot_bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
-            q.h_slots = nullptr;
+            hipHostMalloc((void**)&chunk, (size_t)grow * q.slot_bytes, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
             q.pinned_failed = true;
             (void)hipGetLastError();
         } else {
-            for (int i = NttCtx::COMB_SLOTS; i-- > 0;) q.free_slots.push_back(q.h_slots + (size_t)i * q.slot_bytes);
+            q.slot_chunks.push_back(chunk);
+            q.slots_allocated += grow;
+            for (int i = grow; i-- > 0;) q.free_slots.push_back(chunk + (size_t)i * q.slot_bytes);
         }
     }
     if (q.free_slots.empty()) return false;

@@ -77,7 +77,9 @@ struct NttCtx {
         std::deque<HostCall*> pending;
         int leaders = 0;
         CombLane lanes[COMB_LANES];
-        unsigned char* h_slots = nullptr;  // COMB_SLOTS x slot_bytes, page-locked and mapped
+        // page-locked, mapped staging slots, allocated in chunks as callers need them (4, 4, 8, ...): see msm.hip's pool
+        std::vector<unsigned char*> slot_chunks;
+        int slots_allocated = 0;
         size_t slot_bytes = 0;
         bool pinned_failed = false;
         std::vector<unsigned char*> free_slots;
@@ -85,7 +87,7 @@ struct NttCtx {
     bool combine = true;  // tuning key combine
 
     ~NttCtx() {
-        if (comb.h_slots) (void)hipHostFree(comb.h_slots);
+        for (auto* c : comb.slot_chunks) (void)hipHostFree(c);
         for (auto& l : comb.lanes) {
             if (l.d_in) (void)hipFree(l.d_in);
             if (l.d_out) (void)hipFree(l.d_out);

@@ -631,16 +631,16 @@ def test_device_entry_point_on_two_streams(kzg, settings):
         assert [got[48 * i:48 * i + 48] for i in range(nb)] == want[k]
 
 
-@pytest.mark.parametrize("sha_lanes", [4, 1])
+@pytest.mark.parametrize("sha_lanes", [0, 4, 1])
 def test_device_resident_blob_proofs_match_the_host_buffer_path(kzg, settings, golden, blob_loader, sha_lanes):
     """kzgamd_compute_blob_kzg_proof_device (SHA-256 challenge on the GPU) against the reference vectors and against
     the host-buffer entry point on random blobs; bad blobs / commitments only flag their own slot.  Both forms of the
     device hash (tuning key sha_lanes): four lanes per blob — the message schedules of four blocks side by side, the
-    default — and one lane per blob; 72 blobs = four full waves of the four-lane form and half of a fifth."""
+    what a batch of this size takes by default (sha_lanes = 0) — and one lane per blob; 72 blobs = four full waves of the four-lane form and half of a fifth."""
     import torch
 
     module_settings = settings
-    if sha_lanes != 4:
+    if sha_lanes != 0:
         settings = kzg.KZGSettings.from_file(os.path.join(GOLDEN, "trusted_setup.txt"),
                                              kzg.make_config(table_budget_gb=8, tuning={"sha_lanes": sha_lanes}))
 

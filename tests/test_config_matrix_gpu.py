@@ -81,6 +81,8 @@ def test_matrix_handle_fk20_shape_against_the_oracle_and_separate_calls(kzg, ora
     # the same handle then answers both g1_lincomb and g1_lincomb_batch
     both = kzg.prepare_multi_scalar_mult(s.g1_lagrange_affine(), 4096, kzg.make_config(table_budget_gb=8))
     both.attach_matrix(aff, rows, cols, kzg.make_config(table_budget_gb=16))
+    with pytest.raises(kzg.KzgAmdError):  # one matrix per handle, once: a re-attach would free a table matrix calls may be using
+        both.attach_matrix(aff, rows, cols, kzg.make_config(table_budget_gb=16))
     got = both.multiply_batch(sc, 1)
     assert [compressed(L, got[k]) for k in range(rows)] == want[:rows]
     lag = s.g1_lagrange_affine()

@@ -479,7 +479,7 @@ int main() {
     EXPECT(!o.parse("spl=3", &err) && err.find("out of range") != std::string::npos);
     EXPECT(!o.parse("spl=5", &err) && !o.parse("blocksum_threads=100", &err) && !o.parse("fine_bits=6", &err));
     EXPECT(!o.parse("lgc=1", &err) && !o.parse("lgc=9", &err) && !o.parse("window=1", &err) && !o.parse("window_prepared=1", &err));
-    EXPECT(!o.parse("sha_lanes=2", &err) && !o.parse("wide_fold_max=-1", &err));
+    EXPECT(!o.parse("sha_lanes=2", &err) && !o.parse("wide_fold_max=-1", &err) && !o.parse("tile_rows=8", &err));
     EXPECT(o.parse("spl=16;blocksum_threads=128;fine_bits=10;lgc=2;window=2;sha_lanes=1;sub_streams=0", &err));
     // resolve: defaults < environment < struct
     setenv("KZGAMD_TUNING", "spl=2;lgc=8", 1);
@@ -516,7 +516,7 @@ int main() {
     assert res.returncode == 0 and "fails 0" in res.stdout, res.stdout + res.stderr
     keys = [ln.split()[1:] for ln in res.stdout.splitlines() if ln.startswith("KEY ")]
     names = [k[0] for k in keys]
-    assert len(names) == len(set(names)) == 41
+    assert len(names) == len(set(names)) == 46
     for name, d, lo, hi in keys:
         assert re.fullmatch(r"[a-z0-9_]+", name) and int(lo) <= int(d) <= int(hi), name
     # one row per key, same default and range

@@ -95,6 +95,7 @@ def test_every_size_up_to_128_into_a_garbage_filled_output(oracle, kzg):
 
     lib = kzg.lib()
     whole = kzg.prepare_multi_scalar_mult(pts, N)
+    small = kzg.make_config(table_budget_gb=0.25)  # 128 handles are built below: a table of c = 10, not the default 160 GB budget's
     for n in range(N + 1):
         out = garbage_out(n)
         err = lib.mult_pippenger(C.byref(out), pts, n, sc)
@@ -105,7 +106,7 @@ def test_every_size_up_to_128_into_a_garbage_filled_output(oracle, kzg):
         assert err.code == 0, (n, err.code)
         assert compressed(L, as_oracle_g1(out)) == results[n], ("prepared for 128", n)
         if n > 0:  # prepare_msm of no points has no handle to return (the reference's precompute yields None there)
-            own = kzg.prepare_multi_scalar_mult(pts, n)
+            own = kzg.prepare_multi_scalar_mult(pts, n, small)
             out = garbage_out(n + 2)
             err = lib.mult_pippenger_prepared(own.handle, C.byref(out), n, sc)
             assert err.code == 0, (n, err.code)
@@ -404,6 +405,20 @@ def test_msm_2p20_matches_oracle(oracle, kzg):
             C.memmove(C.byref(got), d_out.cpu().numpy().tobytes(), 144)
             assert compressed(L, got) == compressed(L, exp), pieces
         h.close()
+    # round 6's forms of the reduction: 16-row tiles (k_tile_sums_loop<16>) for a lone MSM, and a batch of two with the side
+    # streams forced on at this size (sub_large: accumulations on the caller's stream, sort and reduction on side streams)
+    d_sc2 = torch.cat([d_sc, d_sc])
+    for tuning, nb in (({"tile_rows": 16}, 1), ({"sub_large": 1, "sub_streams": 2, "tile_rows": 16}, 2), ({"sub_large": 1, "sub_prio": 0}, 2)):
+        d_out = torch.zeros(144 * nb, dtype=torch.uint8, device="cuda")
+        h = kzg.DeviceMsm(d_pts.data_ptr(), n, False, kzg.make_config(tuning=tuning))
+        kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc2.data_ptr(), n, nb, False, stream)
+        torch.cuda.synchronize()
+        raw = d_out.cpu().numpy().tobytes()
+        for b in range(nb):
+            got = O.G1()
+            C.memmove(C.byref(got), raw[144 * b:144 * b + 144], 144)
+            assert compressed(L, got) == compressed(L, exp), (tuning, b)
+        h.close()
 
 
 @pytest.mark.parametrize("logn", [16, 18, 19, 21, 22, 23, 24])
@@ -465,6 +480,50 @@ def test_prepared_bucket_path_without_wide_table(oracle, kzg):
         exp = O.G1()
         L.omsm_affine(C.byref(exp), pts, O.fr_array(v), n)
         assert compressed(L, as_oracle_g1(got[b])) == compressed(L, exp), b
+    h.close()
+
+
+@pytest.mark.parametrize("tuning", [{}, {"quad_accum_max": 0}, {"no_wide_tree": 1}, {"quad_accum_max": 0, "no_wide_tree": 1},
+                                    {"quad_accum_max": 8, "wide_fold_max": 8}, {"spl1_max": 1, "wide_fold_max": 1, "quad_accum_max": 1}],
+                         ids=lambda t: ";".join("%s=%d" % kv for kv in t.items()) or "default")
+def test_few_commitments_every_accumulation_and_fold_form(oracle, oracle_settings, kzg, tuning):
+    """One to eight MSMs per call over the 4096-point setup (the call shape of every c-kzg consumer: a handful of
+    blobs): a lane per (scalar, half) with one lane or FOUR lanes per chain (k_fbw_accum_quad, tuning key quad_accum_max),
+    folded by the one-launch tree of limb-parallel additions (k_wide_tree), by the two launches of k_wide_fold64
+    (no_wide_tree) or by k_blocksum_hybrid, in every combination the keys select — against the oracle.  Scalars include
+    zeros (skipped windows, chains that stay at infinity), r - 1, small values and a batch member that is all zero."""
+    L = oracle.lib()
+    pts = oracle_settings.g1_lagrange_brp
+    n = 4096
+    h = kzg.prepare_multi_scalar_mult(pts, n, kzg.make_config(table_budget_gb=8.0, tuning=tuning))  # c = 11: 6.4 GB
+    info = h.info()
+    assert info["wide_table"] and info["wide_glv"]
+    rnd = random.Random(4096)
+    sets = []
+    for k in range(8):
+        vals = [rnd.randrange(O.R) for _ in range(n)]
+        if k == 1:
+            vals = [0] * n
+        if k == 2:
+            vals[:2048] = [0] * 2048
+            vals[4000:] = [O.R - 1] * 96
+        if k == 3:
+            vals = [rnd.randrange(1 << 16) for _ in range(n)]
+        sets.append(vals)
+    want = []
+    for vals in sets:
+        exp = O.G1()
+        L.omsm_affine(C.byref(exp), pts, O.fr_array(vals), n)
+        want.append(compressed(L, exp))
+    for nbatch in (1, 2, 3, 8):
+        flat = O.fr_array([x for vals in sets[:nbatch] for x in vals])
+        for _ in range(2):  # the second call finds the counters where the first left them
+            got = kzg.multi_scalar_mult_prepared_batch(h, flat, n, nbatch)
+            assert [compressed(L, as_oracle_g1(got[b])) for b in range(nbatch)] == want[:nbatch], nbatch
+    # single calls on every set (k = 1: all-zero scalars -> the point at infinity)
+    for k in (1, 2, 3):
+        assert compressed(L, as_oracle_g1(kzg.multi_scalar_mult_prepared(h, O.fr_array(sets[k]), n))) == want[k], k
+    assert want[1] == b"\xc0" + bytes(47)
     h.close()
 
 
@@ -638,15 +697,16 @@ def test_horner_exceptional_additions(oracle, kzg, sign):
         assert compressed(L, got) == b"\xc0" + bytes(47)
 
 
-@pytest.mark.parametrize("nbatch,sub_streams", [(2, 0), (5, 0), (2, 3), (5, 3), (7, 2), (9, 1)])
+@pytest.mark.parametrize("nbatch,sub_streams", [(2, 0), (5, 0), (2, 3), (5, 3), (7, 2), (9, 1), (5, 6)])
 def test_several_large_msms_in_one_call(oracle, kzg, nbatch, sub_streams):
     """Batches of MSMs over a 40 000-point variable-base handle.  With sub_streams = 0 (everything on the caller's stream,
     round 5's form): nbatch = 2 — 16 bucket sets of 32 768 buckets go through the tiled digit reduction and the
     limb-parallel cell sums together (set indexing of every stage with more than one MSM); nbatch = 5 — more coarse bins
     than the two-level sort holds in one launch: sub-batches of 2 + 2 + 1 (output and scalar offsets of every sub-batch).
-    With side streams (the default is 3): the batch is always cut (1 + 1; 2 + 2 + 1; 2 + 2 + 2 + 1 over two side streams;
-    2 + 2 + 2 + 2 + 1 over one), the accumulations chained on the caller's stream, sorts and reductions on the
-    high-priority side streams with their own workspaces; two calls back to back reuse streams, events and workspaces."""
+    With side streams (the default, 3, for MSMs below 2^18 points): the batch is always cut (1 + 1; 2 + 2 + 1; 2 + 2 + 2 + 1
+    over two side streams; 2 + 2 + 2 + 2 + 1 over one; 2 + 2 + 1 with six streams on offer), the accumulations chained on
+    the caller's stream, sorts and reductions on the high-priority side streams with their own workspaces; two calls back to
+    back reuse streams, events and workspaces."""
     import torch
 
     L = oracle.lib()
