@@ -2,7 +2,7 @@
 """Every __syncthreads() of the library with the function it is in and the control statements that enclose it (brace
 matching on the source text): the raw material of the barrier audit in DESIGN.md — a workgroup barrier is only safe where
 every wave of the workgroup reaches it, i.e. where the enclosing conditions are uniform over the workgroup.
-  python tools/barrier_audit.py > profiles/r05_barrier_audit.txt"""
+  python tools/barrier_audit.py > profiles/r06_barrier_audit.txt"""
 import os
 import re
 import sys
