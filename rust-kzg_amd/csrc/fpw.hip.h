@@ -94,12 +94,29 @@ __device__ __forceinline__ u32 rows4(int row, u32 a0, u32 a1, u32 a2, u32 a3) {
 // a * b * 2^-392 mod p, independently in each of the four rows.  14 steps of
 //     acc += a_i * b_j (b_j by a DPP row broadcast) ; m = acc_0 * p' ; acc += p_i * m ;
 //     acc_i <- low28(acc_{i+1}) + (acc_i >> 28)            (one DPP row shift folded into the add)
+// A step is one dependency chain of eight instructions, ~80 cycles for a lone wave (tools/lone_wave_issue.hip: a
+// dependent v_mad_u64_u32 follows its producer after 12.7 cycles, a DPP read of a fresh result after 16.4, a plain
+// instruction after 8.3; independent ones issue 5 apart).  KZGAMD_WMUL_DIGIT_AHEAD (round 6, measured, not adopted) takes
+// the quotient digit off the first multiply-add — m = acc_0 * p' + (a_0 * p') * b_j mod 2^28, the second product known
+// before the chain starts: six instructions on the chain, but nine issued, and in-order issue puts the three others on
+// the path: 1.48 us per doubling against 1.40 (tools/wmul_bench.hip; same checksums: the digits are the same digits).
 __device__ __forceinline__ u32 wmul4(u32 a, u32 b, const Lane& c) {
     u32 acc = 0;
     // the 14 broadcasts of b do not depend on the accumulator chain: taken up front, they leave the chain
     // mad -> broadcast of lane 0 -> quotient digit -> mad -> shift down
     const u32 bb[14] = {row_lane<0>(b), row_lane<1>(b), row_lane<2>(b),  row_lane<3>(b),  row_lane<4>(b),  row_lane<5>(b),  row_lane<6>(b),
                         row_lane<7>(b), row_lane<8>(b), row_lane<9>(b), row_lane<10>(b), row_lane<11>(b), row_lane<12>(b), row_lane<13>(b)};
+#if defined(KZGAMD_WMUL_DIGIT_AHEAD)
+    const u32 a0p = row_lane<0>(a) * fp28::P0INV;  // only its low 28 bits matter below
+#define KZG_WSTEP(J)                                                                            \
+    {                                                                                           \
+        const u32 m = (u32)((u64)row_lane<0>(acc) * fp28::P0INV + (u64)(a0p * bb[J])) & MASK;   \
+        u64 t = (u64)a * bb[J] + acc;                                                           \
+        asm("" : "+v"(t)); /* keeps acc inside this multiply-add: re-associated, it comes back as a 64-bit add on the chain */ \
+        t += (u64)c.p * m;                                                                      \
+        acc = from_next((u32)t & MASK) + (u32)(t >> 28);                                        \
+    }
+#else
 #define KZG_WSTEP(J)                                               \
     {                                                              \
         const u32 bj = bb[J];                                      \
@@ -108,6 +125,7 @@ __device__ __forceinline__ u32 wmul4(u32 a, u32 b, const Lane& c) {
         t += (u64)c.p * m;                                         \
         acc = from_next((u32)t & MASK) + (u32)(t >> 28);           \
     }
+#endif
     KZG_WSTEP(0) KZG_WSTEP(1) KZG_WSTEP(2) KZG_WSTEP(3) KZG_WSTEP(4) KZG_WSTEP(5) KZG_WSTEP(6)
     KZG_WSTEP(7) KZG_WSTEP(8) KZG_WSTEP(9) KZG_WSTEP(10) KZG_WSTEP(11) KZG_WSTEP(12) KZG_WSTEP(13)
 #undef KZG_WSTEP

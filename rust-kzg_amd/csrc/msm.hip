@@ -912,7 +912,17 @@ constexpr int TILE_T = 512;  // ROWS = 32: two buckets per lane and phase, a ful
 // that it does not happen: beside an accumulation the tiles still wait (2.9 ms instead of 0.32) whatever the stream
 // priority, and alone the 16-row form is slower (0.936 vs 0.889 ms at 2^16, 3.52 vs 3.42 at 2^20: twice the tiles, twice
 // the values per S[0][d] cell).  profiles/NOTES.md §20.
-template <int ROWS>
+// sh[g] += sh[g + off] on the four lanes of group g (roles 0..3).  A function of its own: inlined as a third site of the
+// step loop it took the kernel to 256 VGPRs with 184 spilled; called, its registers are allocated apart from the loop's
+// (the caller keeps nothing live across the call: the sums go through the tile's slots).
+static __device__ __noinline__ void tile_quad_add(Xyzz* sh, int g, int off, int role) {
+    Xyzz a = sh[g];
+    const Xyzz v = sh[g + off];
+    if (grp::dadd_body<4>(a, v, role)) grp::dbl_body<4>(a, role);
+    if (role == 0) sh[g] = a;
+}
+
+template <int ROWS, bool QUAD>
 __global__ void __launch_bounds__(ROWS * 16) k_tile_sums_loop(const Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
                                                               const unsigned char* __restrict__ heavy, Xyzz* __restrict__ dense,
                                                               Xyzz* __restrict__ Gs, Xyzz* __restrict__ Cp, size_t nb,
@@ -961,6 +971,20 @@ __global__ void __launch_bounds__(ROWS * 16) k_tile_sums_loop(const Xyzz* __rest
         const int unit = s < 5 ? ROWS : 32;                           // slots between the operands of a tree step, per stride
         bool active = true;
         Xyzz v;
+        if (QUAD && lvl >= 0 && unit * stride * 4 <= T) {
+            // a tree level with at most T / 4 additions left: four neighbouring lanes per addition (g1grp.hip.h: an
+            // addition 4 multiplications deep instead of 14), operands and sum in the slots the single-lane levels use
+            if ((t >> 2) < unit * stride) tile_quad_add(sh, t >> 2, unit * stride, t & 3);
+            __syncthreads();
+            acc = sh[t];  // lanes below the next level's width read their sum back (others: unused)
+            if (s == 4) {
+                if (t < ROWS) Gs[set * (nb >> 5) + (k0 >> 5) + t] = acc;
+                __threadfence();
+                __syncthreads();
+                acc = dn[k0 + (size_t)(32 * (2 * rg) + c)];
+            }
+            continue;
+        }
         if (s == 0) {
             v = dn[kb];
         } else if (s == 5) {
@@ -1972,7 +1996,7 @@ struct MsmTuning {
     bool one_level_sort = false, tree_tail = false, flat_digits = false, direct_scatter = false, scatter_atomics = false;
     bool combine = true;
     int combine_lanes = 3, combine_gather_min = 6, combine_gather_us = 60;
-    int tail_pieces = 0, sub_streams = 6, tile_rows = 0, sub_prio = 1, sub_large = 0;
+    int tail_pieces = 0, sub_streams = 6, tile_rows = 0, tile_quad = 1, sub_prio = 1, sub_large = 0;
     static MsmTuning from(const kzgamd::Options& o) {
         using namespace kzgamd;
         MsmTuning t;
@@ -2000,6 +2024,7 @@ struct MsmTuning {
         t.tail_pieces = (int)o.t[T_TAIL_PIECES];
         t.sub_streams = (int)o.t[T_SUB_STREAMS];
         t.tile_rows = (int)o.t[T_TILE_ROWS];
+        t.tile_quad = (int)o.t[T_TILE_QUAD];
         t.sub_prio = (int)o.t[T_SUB_PRIO];
         t.sub_large = (int)o.t[T_SUB_LARGE];
         return t;
@@ -2909,12 +2934,17 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             if (tiled_digits) {
                 Xyzz* Gs = ws.lvlA[1].p + ps0 * (nb >> 5);
                 Xyzz* Cp = ws.lvlM[1].p + ps0 * (ntiles * 32);
-                if (tile_rows == 16)
-                    hipLaunchKernelGGL(k_tile_sums_loop<16>, dim3((unsigned)(pns * ntiles)), dim3(256), 256 * sizeof(Xyzz), st,
-                                       (const Xyzz*)p_buckets, p_off, p_heavy, dense, Gs, Cp, nb, nchunk, pcs);
-                else
-                    hipLaunchKernelGGL(k_tile_sums_loop<32>, dim3((unsigned)(pns * ntiles)), dim3(TILE_T), TILE_T * sizeof(Xyzz), st,
-                                       (const Xyzz*)p_buckets, p_off, p_heavy, dense, Gs, Cp, nb, nchunk, pcs);
+#define KZG_TILE_SUMS(R, Q)                                                                                                          \
+    hipLaunchKernelGGL((k_tile_sums_loop<R, Q>), dim3((unsigned)(pns * ntiles)), dim3(R * 16), (R * 16) * sizeof(Xyzz), st, \
+                       (const Xyzz*)p_buckets, p_off, p_heavy, dense, Gs, Cp, nb, nchunk, pcs)
+                if (tile_rows == 16) {
+                    if (ctx->tune.tile_quad) KZG_TILE_SUMS(16, true);
+                    else KZG_TILE_SUMS(16, false);
+                } else {
+                    if (ctx->tune.tile_quad) KZG_TILE_SUMS(32, true);
+                    else KZG_TILE_SUMS(32, false);
+                }
+#undef KZG_TILE_SUMS
                 if (wide_tail) {
                     // cells of this group: [0, pns * J * 32) digit sums, then pns * (logNb + 2) bit sums
                     const size_t c1 = pns * (size_t)(J * 32), c2 = pns * (size_t)(logNb + 2);

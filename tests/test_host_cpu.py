@@ -516,7 +516,7 @@ int main() {
     assert res.returncode == 0 and "fails 0" in res.stdout, res.stdout + res.stderr
     keys = [ln.split()[1:] for ln in res.stdout.splitlines() if ln.startswith("KEY ")]
     names = [k[0] for k in keys]
-    assert len(names) == len(set(names)) == 46
+    assert len(names) == len(set(names)) == 47
     for name, d, lo, hi in keys:
         assert re.fullmatch(r"[a-z0-9_]+", name) and int(lo) <= int(d) <= int(hi), name
     # one row per key, same default and range
@@ -1083,8 +1083,8 @@ def test_barrier_audit_on_file_is_the_audit_of_these_sources():
         return [re.sub(r":\d+", "", ln).rstrip() for ln in text.splitlines() if ln.strip()]
 
     assert shape(now) == shape(filed), "regenerate profiles/r06_barrier_audit.txt (tools/barrier_audit.py) and re-read it"
-    assert shape(now)[-1] == "75 barriers"
-    assert "75 `__syncthreads()`" in open(os.path.join(ROOT, "DESIGN.md"), encoding="utf-8").read()
+    assert shape(now)[-1] == "77 barriers"
+    assert "77 `__syncthreads()`" in open(os.path.join(ROOT, "DESIGN.md"), encoding="utf-8").read()
     # the enclosing statements the audit found uniform: loops over compile-time or kernel-parameter bounds, conditions
     # on kernel parameters / plan constants / values broadcast through shared memory after a barrier
     inside = sorted({ln.split("inside:", 1)[1].strip() for ln in now.splitlines() if "inside:" in ln})

@@ -408,7 +408,9 @@ def test_msm_2p20_matches_oracle(oracle, kzg):
     # round 6's forms of the reduction: 16-row tiles (k_tile_sums_loop<16>) for a lone MSM, and a batch of two with the side
     # streams forced on at this size (sub_large: accumulations on the caller's stream, sort and reduction on side streams)
     d_sc2 = torch.cat([d_sc, d_sc])
-    for tuning, nb in (({"tile_rows": 16}, 1), ({"sub_large": 1, "sub_streams": 2, "tile_rows": 16}, 2), ({"sub_large": 1, "sub_prio": 0}, 2)):
+    # ... and the tiles' upper tree levels with one lane per addition (tile_quad = 0; the default runs them four lanes each)
+    for tuning, nb in (({"tile_rows": 16}, 1), ({"sub_large": 1, "sub_streams": 2, "tile_rows": 16}, 2), ({"sub_large": 1, "sub_prio": 0}, 2),
+                       ({"tile_quad": 0}, 1), ({"tile_quad": 0, "tile_rows": 16}, 1)):
         d_out = torch.zeros(144 * nb, dtype=torch.uint8, device="cuda")
         h = kzg.DeviceMsm(d_pts.data_ptr(), n, False, kzg.make_config(tuning=tuning))
         kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc2.data_ptr(), n, nb, False, stream)
