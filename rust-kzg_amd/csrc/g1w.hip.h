@@ -110,6 +110,20 @@ __device__ __forceinline__ void dadd(WPt& acc, const WPt& b, const Lane& c, u32*
     acc.zzz = row_all(t, 2, lane);
 }
 
+// acc += src[0] + src[stride] + ... (n points): the operand of the NEXT addition is loaded before the current one starts
+// (four registers per lane), so that a chain fed from memory other CUs have just written waits for one round trip, not n.
+// A rolled loop on purpose: unrolled over an array of operands the body (an inlined addition per element) is too large
+// for the unroller and the array lands in scratch.
+__device__ __forceinline__ void add_n(WPt& acc, const g1::Xyzz* src, size_t stride, int n, const Lane& c, u32* sh, int lane) {
+    WPt nx = load(src, lane);
+#pragma unroll 1
+    for (int k = 0; k < n; ++k) {
+        const WPt cur = nx;
+        if (k + 1 < n) nx = load(src + (size_t)(k + 1) * stride, lane);
+        dadd(acc, cur, c, sh, lane);
+    }
+}
+
 // acc = 2^k * acc through Jacobian doublings (3 multiplication steps each)
 __device__ __forceinline__ void dbl_k(WPt& acc, int k, const Lane& c, int lane) {
     using namespace fpw;

@@ -1290,7 +1290,7 @@ __device__ __forceinline__ void wide_cell_finish(g1w::WPt& acc, Xyzz* __restrict
     __threadfence();
     g1w::WPt tot;
     g1w::set_inf(tot);
-    for (int k = 0; k < NSPLIT; ++k) g1w::dadd(tot, g1w::load(part + cell * NSPLIT + k, lane), lc, sh, lane);
+    g1w::add_n(tot, part + cell * NSPLIT, 1, NSPLIT, lc, sh, lane);
     g1w::store(out + cell, tot, lc, lane);
     if (lane == 0) counter[cell] = 0;  // ready for the next launch
 }
@@ -1311,16 +1311,34 @@ __global__ void __launch_bounds__(64) k_digit_sums_wide(const Xyzz* __restrict__
     const fpw::Lane lc = fpw::lane_consts(lane);
     g1w::WPt acc;
     g1w::set_inf(acc);
+    // the operand of the NEXT addition is loaded before the current one starts: the values come from other CUs' tiles
+    // (another XCD's L2 or HBM), and a load issued when its addition is due leaves the chain waiting for it every time
     if (j == 0) {
-        for (size_t e = sub; e < ntiles; e += WSPLIT_S) g1w::dadd(acc, g1w::load(Cp + (set * ntiles + e) * 32 + d, lane), lc, sh, lane);
+        const Xyzz* src = Cp + set * ntiles * 32 + d;
+        g1w::WPt nx;
+        g1w::set_inf(nx);
+        if ((size_t)sub < ntiles) nx = g1w::load(src + (size_t)sub * 32, lane);
+        for (size_t e = sub; e < ntiles; e += WSPLIT_S) {
+            const g1w::WPt cur = nx;
+            if (e + WSPLIT_S < ntiles) nx = g1w::load(src + (e + WSPLIT_S) * 32, lane);
+            g1w::dadd(acc, cur, lc, sh, lane);
+        }
     } else {
         const int logNg = logNb - DIGIT_BITS, lo_bits = DIGIT_BITS * (j - 1);
         const int w = logNg - lo_bits < DIGIT_BITS ? logNg - lo_bits : DIGIT_BITS;  // width of this digit
         if (d < (1 << w)) {
             const size_t cnt = ng >> w;
+            auto group_of = [&](size_t m) {
+                return ((m >> lo_bits) << (lo_bits + w)) | ((size_t)d << lo_bits) | (m & (((size_t)1 << lo_bits) - 1));
+            };
+            const Xyzz* src = Gs + set * ng;
+            g1w::WPt nx;
+            g1w::set_inf(nx);
+            if ((size_t)sub < cnt) nx = g1w::load(src + group_of(sub), lane);
             for (size_t m = sub; m < cnt; m += WSPLIT_S) {
-                const size_t g = ((m >> lo_bits) << (lo_bits + w)) | ((size_t)d << lo_bits) | (m & (((size_t)1 << lo_bits) - 1));
-                g1w::dadd(acc, g1w::load(Gs + set * ng + g, lane), lc, sh, lane);
+                const g1w::WPt cur = nx;
+                if (m + WSPLIT_S < cnt) nx = g1w::load(src + group_of(m + WSPLIT_S), lane);
+                g1w::dadd(acc, cur, lc, sh, lane);
             }
         }
     }
@@ -1343,8 +1361,17 @@ __global__ void __launch_bounds__(64) k_digit_bits_wide(const Xyzz* __restrict__
     g1w::set_inf(acc);
     if (q <= logNb) {
         const int j = q < logNb ? q / DIGIT_BITS : 0, b = q % DIGIT_BITS;
-        for (int d = sub * (32 / WSPLIT); d < (sub + 1) * (32 / WSPLIT); ++d)
-            if (q == logNb || ((d >> b) & 1)) g1w::dadd(acc, g1w::load(S + (set * J + j) * 32 + d, lane), lc, sh, lane);
+        // every digit sum of the part is loaded an addition ahead of its use, taken or not (they were written by other CUs
+        // a kernel ago)
+        constexpr int PER = 32 / WSPLIT;
+        const Xyzz* src = S + (set * J + j) * 32 + sub * PER;
+        g1w::WPt nx = g1w::load(src, lane);
+#pragma unroll 1
+        for (int k = 0; k < PER; ++k) {
+            const g1w::WPt cur = nx;
+            if (k + 1 < PER) nx = g1w::load(src + k + 1, lane);
+            if (q == logNb || (((sub * PER + k) >> b) & 1)) g1w::dadd(acc, cur, lc, sh, lane);
+        }
     }
     wide_cell_finish<WSPLIT>(acc, part, top, counter, cell, sub, lc, sh, &last_s, lane);
 }
@@ -1367,7 +1394,7 @@ __global__ void __launch_bounds__(64) k_wide_fold64(const Xyzz* __restrict__ in,
     g1w::WPt acc;
     g1w::set_inf(acc);
     const Xyzz* src = in + (cell * WFOLD + (size_t)sub) * per_wave;  // a cell = WFOLD * per_wave consecutive points
-    for (int e = 0; e < per_wave; ++e) g1w::dadd(acc, g1w::load(src + e, lane), lc, sh, lane);
+    g1w::add_n(acc, src, 1, per_wave, lc, sh, lane);
     wide_cell_finish<WFOLD>(acc, part, out, counter, cell, sub, lc, sh, &last_s, lane);
 }
 
@@ -1430,18 +1457,27 @@ __global__ void __launch_bounds__(256) k_wide_tree(const Xyzz* __restrict__ in, 
     g1w::set_inf(acc);
     {
         const Xyzz* src = in + set * n + ((size_t)wg * 4 + wave) * (WTREE_PER_WG / 4);
-        for (int k = 0; k < WTREE_PER_WG / 4; ++k) g1w::dadd(acc, g1w::load(src + k, lane), lc, sh, lane);
+        g1w::add_n(acc, src, 1, WTREE_PER_WG / 4, lc, sh, lane);
     }
     fold4();
     const u32 group = wg / WTREE_GROUP;
     if (!hand_over(p1 + wg, cnt + group, WTREE_GROUP)) return;
     g1w::set_inf(acc);
-    for (int k = 0; k < WTREE_GROUP / 4; ++k) g1w::dadd(acc, g1w::load(p1 + (size_t)group * WTREE_GROUP + wave * (WTREE_GROUP / 4) + k, lane), lc, sh, lane);
+    g1w::add_n(acc, p1 + (size_t)group * WTREE_GROUP + wave * (WTREE_GROUP / 4), 1, WTREE_GROUP / 4, lc, sh, lane);
     fold4();
     if (ngroups > 1) {
         if (!hand_over(p2 + group, cnt + ngroups, ngroups)) return;
         g1w::set_inf(acc);
-        for (u32 k = wave; k < ngroups; k += 4) g1w::dadd(acc, g1w::load(p2 + k, lane), lc, sh, lane);
+        {
+            g1w::WPt nx;
+            g1w::set_inf(nx);
+            if ((u32)wave < ngroups) nx = g1w::load(p2 + wave, lane);
+            for (u32 k = wave; k < ngroups; k += 4) {
+                const g1w::WPt cur = nx;
+                if (k + 4 < ngroups) nx = g1w::load(p2 + k + 4, lane);
+                g1w::dadd(acc, cur, lc, sh, lane);
+            }
+        }
         fold4();
     }
     if (wave == 0) g1w::store(out + set, acc, lc, lane);
