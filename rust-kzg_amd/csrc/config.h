@@ -22,7 +22,7 @@ enum TuneId {
     // wide-table (fixed-base) path of the MSM
     T_SPL, T_NO_WIDE_TAIL, T_NO_HYBRID_FOLD, T_NO_WIDE_TREE, T_QUAD_ACCUM_MAX, T_HYBRID_MAX, T_WIDE_FOLD_MAX, T_SPL1_MAX, T_BLOCKSUM_THREADS,
     // bucket engine
-    T_LGC, T_GROUPS, T_TAIL_PIECES, T_SUB_STREAMS, T_SUB_PRIO, T_SUB_LARGE, T_TILE_ROWS, T_TILE_QUAD, T_FINE_BITS, T_ONE_LEVEL_SORT, T_TREE_TAIL, T_FLAT_DIGITS, T_DIRECT_SCATTER, T_SCATTER_ATOMICS,
+    T_LGC, T_GROUPS, T_TAIL_PIECES, T_SUB_STREAMS, T_SUB_PRIO, T_SUB_LARGE, T_TILE_ROWS, T_TILE_QUAD, T_DIGIT_MIN_LOG, T_FINE_BITS, T_ONE_LEVEL_SORT, T_TREE_TAIL, T_FLAT_DIGITS, T_DIRECT_SCATTER, T_SCATTER_ATOMICS,
     // shape of a handle
     T_WINDOW, T_WINDOW_PREPARED, T_FIXED_AS_VARIABLE_MIN, T_GLV, T_FBW_GLV,
     // concurrent host-buffer callers of one prepared handle (B1)
@@ -60,6 +60,7 @@ inline const TuneKey* tune_keys() {
         {"sub_large", 0, 0, 1, "1: the side streams of sub_streams also for batches of MSMs of 2^18 points and more (measured slower: nothing runs well beside a chip-filling accumulation)"},
         {"tile_rows", 0, 0, 32, "rows of 32 buckets per tile of the tiled bucket reduction: 32 (a 512-lane workgroup, a CU each) or 16 (256 lanes, a wave per SIMD); 0 = 32"},
         {"tile_quad", 1, 0, 1, "1: the tree levels of the tiled bucket reduction that keep at most a quarter of the lanes busy run four lanes per addition (an addition 4 multiplications deep instead of 14); 0: one lane per addition throughout"},
+        {"digit_min_log", 14, 10, 30, "log2 of the smallest bucket count per set that takes the digit-decomposed (tiled) bucket reduction instead of the (sum, weighted sum) tree (round 6 measured 10 ... 13 on 2^10 ... 2^18 points: the tree is faster below 2^14 buckets)"},
         {"fine_bits", 0, 0, 10, "width of the second sort level (0 = default; 7 ... 10)"},
         {"one_level_sort", 0, 0, 1, "1: the one-level sort at every size (it is the form small bucket counts take anyway)"},
         {"tree_tail", 0, 0, 1, "1: the tree reduction at every size (the form of fewer than 16384 buckets)"},

@@ -183,6 +183,63 @@ FF_HD Fe mul_signed(const Fe& a, const Fe& b) {
     return r;
 }
 
+// Two products side by side: the multiply-adds of r0 = a0 * b0 and r1 = a1 * b1 alternate, each on its own accumulator
+// chain.  Same instructions as two calls of mul_signed, but no multiply-add follows the one it depends on: back to back,
+// a dependent v_mad_u64_u32 needs a wait state (the compiler's s_nop 0 after every one of them), and at four waves per
+// SIMD such streams issue a multiply-add per 6.2 cycles where two interleaved chains issue one per 4.4
+// (tools/lone_wave_issue.hip, profiles/r06_lone_wave_issue.log).
+template <bool CHAIN = true>
+FF_HD void mul_signed2(Fe& r0, Fe& r1, const Fe& a0, const Fe& b0, const Fe& a1, const Fe& b1) {
+    u32 m0[L], m1[L];
+    u64 acc0 = 0, acc1 = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) {
+            if (i == L - 1) {
+                mad_ii<CHAIN>(acc0, a0.v[i], (int)b0.v[k - i]);
+                mad_ii<CHAIN>(acc1, a1.v[i], (int)b1.v[k - i]);
+            } else {
+                mad_uu<CHAIN>(acc0, a0.v[i], b0.v[k - i]);
+                mad_uu<CHAIN>(acc1, a1.v[i], b1.v[k - i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+            mad_ii<CHAIN>(acc0, m0[i], -(int)rl(k - i));
+            mad_ii<CHAIN>(acc1, m1[i], -(int)rl(k - i));
+        }
+        m0[k] = (u32)acc0 & MASK;
+        m1[k] = (u32)acc1 & MASK;
+        acc0 = (u64)((long long)acc0 >> 29);
+        acc1 = (u64)((long long)acc1 >> 29);
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L - 1; ++k) {
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) {
+            if (i == L - 1) {
+                mad_ii<CHAIN>(acc0, a0.v[i], (int)b0.v[k - i]);
+                mad_ii<CHAIN>(acc1, a1.v[i], (int)b1.v[k - i]);
+            } else {
+                mad_uu<CHAIN>(acc0, a0.v[i], b0.v[k - i]);
+                mad_uu<CHAIN>(acc1, a1.v[i], b1.v[k - i]);
+            }
+        }
+#pragma unroll
+        for (int i = k - L + 1; i < L; ++i) {
+            mad_ii<CHAIN>(acc0, m0[i], -(int)rl(k - i));
+            mad_ii<CHAIN>(acc1, m1[i], -(int)rl(k - i));
+        }
+        r0.v[k - L] = (u32)acc0 & MASK;
+        r1.v[k - L] = (u32)acc1 & MASK;
+        acc0 = (u64)((long long)acc0 >> 29);
+        acc1 = (u64)((long long)acc1 >> 29);
+    }
+    r0.v[L - 1] = (u32)acc0;
+    r1.v[L - 1] = (u32)acc1;
+}
+
 // x + t + r  and  x + 4r - t  for t = mul_signed(..) in (-r, 2r): the +r that makes the first one positive rides in a
 // three-operand addition, the second is |4r_i - t_i| + x_i in one instruction for the normalised limbs (4r's limbs
 // 0..7 are >= 2^29 - 1 >= t_i) and an ordinary add/sub for the signed top limb.  Limbs grow by < 2^30 per call, the

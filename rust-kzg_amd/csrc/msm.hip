@@ -2032,7 +2032,7 @@ struct MsmTuning {
     bool one_level_sort = false, tree_tail = false, flat_digits = false, direct_scatter = false, scatter_atomics = false;
     bool combine = true;
     int combine_lanes = 3, combine_gather_min = 6, combine_gather_us = 60;
-    int tail_pieces = 0, sub_streams = 6, tile_rows = 0, tile_quad = 1, sub_prio = 1, sub_large = 0;
+    int tail_pieces = 0, sub_streams = 6, tile_rows = 0, tile_quad = 1, digit_min_log = 14, sub_prio = 1, sub_large = 0;
     static MsmTuning from(const kzgamd::Options& o) {
         using namespace kzgamd;
         MsmTuning t;
@@ -2061,6 +2061,7 @@ struct MsmTuning {
         t.sub_streams = (int)o.t[T_SUB_STREAMS];
         t.tile_rows = (int)o.t[T_TILE_ROWS];
         t.tile_quad = (int)o.t[T_TILE_QUAD];
+        t.digit_min_log = (int)o.t[T_DIGIT_MIN_LOG];
         t.sub_prio = (int)o.t[T_SUB_PRIO];
         t.sub_large = (int)o.t[T_SUB_LARGE];
         return t;
@@ -2784,7 +2785,7 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     const bool wide_tail = use_top && !ctx->tune.no_wide_tail;
     // few sets of many buckets: the digit-decomposed reduction instead of the (A, M) tree (tuning key tree_tail=1: the tree)
     // measured (same box, tree vs digits): n = 2^14 (4096 buckets) 1.20 vs 1.35 ms, 2^16 1.53 vs 1.48, 2^20 4.53 vs 4.35, 2^22 14.67 vs 14.26
-    const bool digit_tail = use_top && nb >= 16384 && !ctx->tune.tree_tail;
+    const bool digit_tail = use_top && nb >= ((size_t)1 << ctx->tune.digit_min_log) && !ctx->tune.tree_tail;
     // the tiled form of the digit sums (k_tile_sums_loop); tuning key flat_digits: one pass over the buckets per digit
     // tile rows: 32 (tiles of 1024 buckets, a CU per workgroup); 16 (512 buckets, a wave per SIMD) by tuning key
     const int tile_rows = ctx->tune.tile_rows ? ctx->tune.tile_rows : 32;  // 16: measured slower alone (3.52 vs 3.42 ms at 2^20) and no help beside an accumulation

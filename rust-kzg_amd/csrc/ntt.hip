@@ -48,6 +48,10 @@ constexpr int PLAN_DAS = 3;          // plan-cache key of the fused DAS plans (n
 #define KZGAMD_NTT_NT_STORES 1
 #endif
 constexpr bool nt_stores = KZGAMD_NTT_NT_STORES != 0;
+#ifndef KZGAMD_NTT_DUAL_CHAINS
+#define KZGAMD_NTT_DUAL_CHAINS 1
+#endif
+constexpr bool dual_chains = KZGAMD_NTT_DUAL_CHAINS != 0;  // the two products of a butterfly pair interleaved (fr29::mul_signed2)
 
 // LDS holds the tile in the 9 x 29-bit form, limb-major: sh[limb * TILE + swz(idx)] (144 KiB of the 160 KiB).
 __device__ __forceinline__ Fe lds_get(const u32* sh, u32 sidx) {  // sidx already swizzled
@@ -172,6 +176,19 @@ __device__ __forceinline__ void ntt_round(u32* sh, Fr* __restrict__ out, const F
             fr29::butterfly_signed(e[K0], e[K1], tt_);         \
         }                                                      \
     }
+/* two butterflies whose products run side by side (fr29::mul_signed2) */
+#define KZG_BF2(A0, A1, WA, B0, B1, WB)                                       \
+    {                                                                        \
+        if constexpr (V == 1 && dual_chains) {                               \
+            Fe ta_, tb_;                                                     \
+            fr29::mul_signed2<true>(ta_, tb_, e[A1], WA, e[B1], WB);         \
+            fr29::butterfly_signed(e[A0], e[A1], ta_);                       \
+            fr29::butterfly_signed(e[B0], e[B1], tb_);                       \
+        } else {                                                             \
+            KZG_BF(A0, A1, WA)                                               \
+            KZG_BF(B0, B1, WB)                                               \
+        }                                                                    \
+    }
 /* twiddle w^0 = 1 on a normalised operand */
 #define KZG_BF1(K0, K1)                                  \
     {                                                    \
@@ -212,18 +229,17 @@ __device__ __forceinline__ void ntt_round(u32* sh, Fr* __restrict__ out, const F
             // M = 2: both pairs share the twiddle (idxB = idxA | 2 << pos); M = 1: two unrelated pairs
             const Fe w = tw[G.tw_ent(rd.pos, iA)];
             const Fe w2 = tw[G.tw_ent(rd.pos, iB)];
-            KZG_BF(0, 1, w)
-            KZG_BF(2, 3, w2)
+            KZG_BF2(0, 1, w, 2, 3, w2)
         }
         if (rd.M == 2) {
+            const Fe w1 = tw[G.tw_ent(rd.pos + 1, iA | rd.bit)];
             if (unit) {
                 KZG_BF1N(0, 2)
+                KZG_BF(1, 3, w1)
             } else {
                 const Fe w0 = tw[G.tw_ent(rd.pos + 1, iA)];
-                KZG_BF(0, 2, w0)
+                KZG_BF2(0, 2, w0, 1, 3, w1)
             }
-            const Fe w1 = tw[G.tw_ent(rd.pos + 1, iA | rd.bit)];
-            KZG_BF(1, 3, w1)
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) fr29::norm(e[k]);
@@ -282,6 +298,7 @@ __device__ __forceinline__ void ntt_round(u32* sh, Fr* __restrict__ out, const F
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
+#undef KZG_BF2
 #undef KZG_BF
 #undef KZG_BF1
 #undef KZG_BF1N

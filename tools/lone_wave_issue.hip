@@ -23,6 +23,11 @@ __global__ void __launch_bounds__(64) k(u32* out, int iters) {
         } else if (MODE == 3) {  // 64 mad64 on 4 independent chains
             REP8(REP8(asm volatile("v_mad_u64_u32 %0, vcc, %4, %4, %0\n v_mad_u64_u32 %1, vcc, %4, %4, %1\n v_mad_u64_u32 %2, vcc, %4, %4, %2\n v_mad_u64_u32 %3, vcc, %4, %4, %3"
                                    : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3) : "v"(c) : "vcc");))
+        } else if (MODE == 6) {  // 64 mad64 on 2 interleaved chains: no hazard, no s_nop
+            REP8(REP8(asm volatile("v_mad_u64_u32 %0, vcc, %2, %2, %0\n v_mad_u64_u32 %1, vcc, %2, %2, %1" : "+v"(m0), "+v"(m1) : "v"(c) : "vcc");))
+        } else if (MODE == 7) {  // 2 interleaved chains, with two plain instructions per four multiply-adds
+            REP8(REP8(asm volatile("v_mad_u64_u32 %0, vcc, %4, %4, %0\n v_mad_u64_u32 %1, vcc, %4, %4, %1\n v_mad_u64_u32 %0, vcc, %4, %4, %0\n v_mad_u64_u32 %1, vcc, %4, %4, %1\n"
+                                   "v_add_u32 %2, %2, %4\n v_add_u32 %3, %3, %4" : "+v"(m0), "+v"(m1), "+v"(a1), "+v"(a2) : "v"(c) : "vcc");))
         } else if (MODE == 4) {  // 64 dependent DPP moves (row_shl:1), two wait states each
             REP8(REP8(asm volatile("s_nop 1\n v_mov_b32_dpp %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a0));))
         } else if (MODE == 5) {  // dependent: add -> dpp -> add -> dpp ...
@@ -39,10 +44,10 @@ int main() {
     hipEventCreate(&a);
     hipEventCreate(&b);
     const int iters = 20000;
-    const char* names[6] = {"v_add_u32 dependent", "v_add_u32 8 chains", "v_mad_u64_u32 dependent (+s_nop 0)", "v_mad_u64_u32 4 chains", "v_mov_dpp dependent (+s_nop 1)", "add -> dpp chain"};
-    const int per[6] = {64, 64, 64, 256, 64, 128};
-    for (int waves : {1, 1024, 2048, 4096}) {
-        for (int mode = 0; mode < 6; ++mode) {
+    const char* names[8] = {"v_add_u32 dependent", "v_add_u32 8 chains", "v_mad_u64_u32 dependent (+s_nop 0)", "v_mad_u64_u32 4 chains", "v_mov_dpp dependent (+s_nop 1)", "add -> dpp chain", "v_mad_u64_u32 2 interleaved chains", "2 chains x 2 mads + 2 adds"};
+    const int per[8] = {64, 64, 64, 256, 64, 128, 128, 384};
+    for (int waves : {1, 1024, 2048, 3072, 4096}) {
+        for (int mode = 0; mode < 8; ++mode) {
             float best = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
                 hipEventRecord(a);
@@ -53,6 +58,8 @@ int main() {
                     case 3: hipLaunchKernelGGL(k<3>, dim3(waves), dim3(64), 0, 0, d, iters); break;
                     case 4: hipLaunchKernelGGL(k<4>, dim3(waves), dim3(64), 0, 0, d, iters); break;
                     case 5: hipLaunchKernelGGL(k<5>, dim3(waves), dim3(64), 0, 0, d, iters); break;
+                    case 6: hipLaunchKernelGGL(k<6>, dim3(waves), dim3(64), 0, 0, d, iters); break;
+                    case 7: hipLaunchKernelGGL(k<7>, dim3(waves), dim3(64), 0, 0, d, iters); break;
                 }
                 hipEventRecord(b);
                 hipEventSynchronize(b);
