@@ -41,7 +41,7 @@ VALU_PEAK_MODEL = ("1 wave64 instruction / SIMD / 4 cycles at 2.4 GHz: the issue
                    "three-operand or 64-bit opcode; 2.9-3.0 for two-operand 32-bit ones)")
 # MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction issues over 2 cycles (the FP32 vector rate, 157.3 TFLOP/s)
 VALU_PEAK_GUIDE_NOMINAL = 1024 * 2.4e9 / 2
-ISA_HISTOGRAM = os.path.join(ROOT, "profiles", "r05_isa_histogram.json")  # tools/isa_histogram.py
+ISA_HISTOGRAM = os.path.join(ROOT, "profiles", "r06_isa_histogram.json")  # tools/isa_histogram.py
 
 
 def opcode_weighted_peak(kernel_substr, path=None):
@@ -63,8 +63,8 @@ def opcode_weighted_peak(kernel_substr, path=None):
 
 ALG_BYTES_PER_COMMIT = 128 * N             # 96 B point + 32 B scalar per pair
 ALG_ADDS_PER_COMMIT = 20 * N + 8192        # BGMW count for the fixed-base 4096 case
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
-PMC_FALLBACK = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_pmc_summary.json")
+PMC_FALLBACK = os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
 CSRC = os.path.join(ROOT, "rust-kzg_amd", "csrc")
 # the sources a kernel family is compiled from: counters collected from another text of these files are not printed
 KERNEL_SOURCES = {
@@ -626,7 +626,7 @@ def main():
                     "frac": winstr / (ms * 1e-3) / VALU_PEAK, "wave_instructions_per_call": winstr,
                     "peak_model": VALU_PEAK_MODEL, "frac_vs_guide_nominal": winstr / (ms * 1e-3) / VALU_PEAK_GUIDE_NOMINAL,
                     "opcode_weighted": (lambda ow: None if ow is None else dict(ow, frac=winstr / (ms * 1e-3) / ow["peak"]))(
-                        opcode_weighted_peak("k_ntt_passILi%d" % (0 if n <= 4096 else 2), os.path.join(ROOT, "profiles", "r05_isa_histogram_ntt.json"))),
+                        opcode_weighted_peak("k_ntt_passILi%d" % (0 if n <= 4096 else 2), os.path.join(ROOT, "profiles", "r06_isa_histogram_ntt.json"))),
                     "instructions_per_butterfly": winstr * 64 / muls,
                     "floor_us_at_nominal_clock": winstr / VALU_PEAK * 1e6,
                     "busy_frac_at_sustained_clock": pk.get("valu_busy_frac"), "scratch_bytes_per_lane": pk.get("scratch", 0),

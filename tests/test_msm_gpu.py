@@ -699,6 +699,44 @@ def test_horner_exceptional_additions(oracle, kzg, sign):
         assert compressed(L, got) == b"\xc0" + bytes(47)
 
 
+@pytest.mark.parametrize("tuning", [{}, {"tile_quad": 0}, {"tile_rows": 16}])
+def test_tile_tree_exceptional_additions(oracle, kzg, tuning):
+    """The tiled bucket reduction on ONE repeated point: every bucket sum is a small multiple m * P (m = 0 included: P and
+    -P meet through the signed digits), so the row and column trees of k_tile_sums_loop add equal operands (the doubling
+    branch), opposite ones (infinity) and infinities at every level — the four-lane levels (grp::dadd_body<4> /
+    dbl_body<4>) and the single-lane ones alike.  Expected value without any MSM: (sum of the scalars) * P."""
+    import torch
+
+    L = oracle.lib()
+    rnd = random.Random(77)
+    n = 1 << 15  # 16-bit windows, 2^15 buckets per set: the tiled digit reduction
+    one = gen_points(L, 1, rnd)
+    pts = (O.G1Affine * n)(*[one[0]] * n)
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(78)
+    sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, generator=gen)
+    sc[:, 31] &= 0x3F
+    raw = sc.numpy().tobytes()
+    total = sum(int.from_bytes(raw[32 * i:32 * i + 32], "little") for i in range(n)) % O.R
+    p = O.G1()
+    L.og1_from_affine(C.byref(p), C.byref(pts[0]))
+    exp = O.G1()
+    k = O.fr_from_int(total)
+    L.og1_mul(C.byref(exp), C.byref(p), C.byref(k))
+    stream = torch.cuda.current_stream().cuda_stream
+    d_pts = torch.frombuffer(bytearray(bytes(pts)), dtype=torch.uint8).cuda()
+    d_sc = sc.cuda()
+    d_out = torch.ones(144, dtype=torch.uint8, device="cuda")
+    h = kzg.DeviceMsm(d_pts.data_ptr(), n, False, kzg.make_config(tuning=tuning))
+    assert h.info()["window_bits"] == 16
+    kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr(), n, 1, False, stream)
+    torch.cuda.synchronize()
+    h.close()
+    got = O.G1()
+    C.memmove(C.byref(got), d_out.cpu().numpy().tobytes(), 144)
+    assert compressed(L, got) == compressed(L, exp), tuning
+
+
 @pytest.mark.parametrize("nbatch,sub_streams", [(2, 0), (5, 0), (2, 3), (5, 3), (7, 2), (9, 1), (5, 6)])
 def test_several_large_msms_in_one_call(oracle, kzg, nbatch, sub_streams):
     """Batches of MSMs over a 40 000-point variable-base handle.  With sub_streams = 0 (everything on the caller's stream,
