@@ -22,7 +22,7 @@ enum TuneId {
     // wide-table (fixed-base) path of the MSM
     T_SPL, T_NO_WIDE_TAIL, T_NO_HYBRID_FOLD, T_NO_WIDE_TREE, T_QUAD_ACCUM_MAX, T_HYBRID_MAX, T_WIDE_FOLD_MAX, T_SPL1_MAX, T_BLOCKSUM_THREADS,
     // bucket engine
-    T_LGC, T_GROUPS, T_TAIL_PIECES, T_SUB_STREAMS, T_SUB_PRIO, T_SUB_LARGE, T_TILE_ROWS, T_TILE_QUAD, T_DIGIT_MIN_LOG, T_FINE_BITS, T_ONE_LEVEL_SORT, T_TREE_TAIL, T_FLAT_DIGITS, T_DIRECT_SCATTER, T_SCATTER_ATOMICS,
+    T_LGC, T_GROUPS, T_TAIL_PIECES, T_SUB_STREAMS, T_SUB_PRIO, T_SUB_LARGE, T_SORT_AHEAD, T_TILE_ROWS, T_TILE_QUAD, T_DIGIT_MIN_LOG, T_FINE_BITS, T_ONE_LEVEL_SORT, T_TREE_TAIL, T_FLAT_DIGITS, T_DIRECT_SCATTER, T_SCATTER_ATOMICS,
     // shape of a handle
     T_WINDOW, T_WINDOW_PREPARED, T_FIXED_AS_VARIABLE_MIN, T_GLV, T_FBW_GLV,
     // concurrent host-buffer callers of one prepared handle (B1)
@@ -58,6 +58,7 @@ inline const TuneKey* tune_keys() {
         {"sub_streams", 6, 0, 6, "a batch of large MSMs runs as sub-batches whose accumulations stay on the caller's stream while the sort and the reduction chains of each run on one of this many high-priority side streams (own workspaces) beside another sub-batch's accumulation (0 = one stream, one workspace); MSMs below 2^18 points unless sub_large = 1"},
         {"sub_prio", 1, 0, 1, "1: the side streams of sub_streams are created with the device's highest stream priority, 0: with the default priority"},
         {"sub_large", 0, 0, 1, "1: the side streams of sub_streams also for batches of MSMs of 2^18 points and more (measured slower: nothing runs well beside a chip-filling accumulation)"},
+        {"sort_ahead", 0, 0, 1, "1: a batch of MSMs of 2^18 points and more runs as sub-batches whose SORT runs on one of two side streams beside the limb-parallel chains of the previous sub-batch's reduction (after its tile sums; nothing beside an accumulation); measured +-1 %: off"},
         {"tile_rows", 0, 0, 32, "rows of 32 buckets per tile of the tiled bucket reduction: 32 (a 512-lane workgroup, a CU each) or 16 (256 lanes, a wave per SIMD); 0 = 32"},
         {"tile_quad", 1, 0, 1, "1: the tree levels of the tiled bucket reduction that keep at most a quarter of the lanes busy run four lanes per addition (an addition 4 multiplications deep instead of 14); 0: one lane per addition throughout"},
         {"digit_min_log", 14, 10, 30, "log2 of the smallest bucket count per set that takes the digit-decomposed (tiled) bucket reduction instead of the (sum, weighted sum) tree (round 6 measured 10 ... 13 on 2^10 ... 2^18 points: the tree is faster below 2^14 buckets)"},

@@ -2032,7 +2032,7 @@ struct MsmTuning {
     bool one_level_sort = false, tree_tail = false, flat_digits = false, direct_scatter = false, scatter_atomics = false;
     bool combine = true;
     int combine_lanes = 3, combine_gather_min = 6, combine_gather_us = 60;
-    int tail_pieces = 0, sub_streams = 6, tile_rows = 0, tile_quad = 1, digit_min_log = 14, sub_prio = 1, sub_large = 0;
+    int tail_pieces = 0, sub_streams = 6, tile_rows = 0, tile_quad = 1, digit_min_log = 14, sub_prio = 1, sub_large = 0, sort_ahead = 0;
     static MsmTuning from(const kzgamd::Options& o) {
         using namespace kzgamd;
         MsmTuning t;
@@ -2064,6 +2064,7 @@ struct MsmTuning {
         t.digit_min_log = (int)o.t[T_DIGIT_MIN_LOG];
         t.sub_prio = (int)o.t[T_SUB_PRIO];
         t.sub_large = (int)o.t[T_SUB_LARGE];
+        t.sort_ahead = (int)o.t[T_SORT_AHEAD];
         return t;
     }
 };
@@ -2127,10 +2128,12 @@ struct kzgamd::MsmContext {
     // site reads.
     static constexpr int MAXSUB = 6;
     hipStream_t sub_stream[MAXSUB] = {};
-    hipEvent_t ev_sub_fork = nullptr, ev_sub_join[MAXSUB] = {}, ev_sorted[MAXSUB] = {}, ev_accd[MAXSUB] = {};
+    hipEvent_t ev_sub_fork = nullptr, ev_sub_join[MAXSUB] = {}, ev_sorted[MAXSUB] = {}, ev_accd[MAXSUB] = {}, ev_gate[MAXSUB] = {};
     bool accum_redirect = false;     // set by the sub-batch loop: this enqueue's k_accum goes to accum_on ...
+    bool tail_on_accum = false;      // ... and so does everything after it (sort-ahead form: only the SORT stays on the side stream)
     hipStream_t accum_on = nullptr;  // ... the caller's stream (which may be the null stream)
     hipEvent_t accum_ready = nullptr, accum_done = nullptr;
+    hipEvent_t sort_gate = nullptr;  // sort-ahead form: recorded where the NEXT sub-batch's sort may start (after this one's tile sums)
     bool in_sub_batch = false;  // the enqueue in progress is a sub-batch: it is not cut again
     // window-group pipeline of the variable-base engine: one auxiliary stream per group, events to fork from /
     // join into the caller's stream and to order the digit and accumulation kernels across groups
@@ -2215,6 +2218,7 @@ struct kzgamd::MsmContext {
             if (ev_sub_join[k]) (void)hipEventDestroy(ev_sub_join[k]);
             if (ev_sorted[k]) (void)hipEventDestroy(ev_sorted[k]);
             if (ev_accd[k]) (void)hipEventDestroy(ev_accd[k]);
+            if (ev_gate[k]) (void)hipEventDestroy(ev_gate[k]);
             if (sub_stream[k]) (void)hipStreamDestroy(sub_stream[k]);
         }
         for (int g = 0; g < MAXG; ++g) {
@@ -2653,8 +2657,21 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
         // of 0.09) and delays the next sub-batch: 4 x 2^20 3.26 ms per MSM on one stream, 3.3 - 3.5 with side streams.
         // So the side streams serve batches of MSMs below 2^18 points; tuning key sub_large = 1 lifts the limit.
         int nside = ctx->tune.sub_streams < 0 ? 0 : ctx->tune.sub_streams > MsmContext::MAXSUB ? MsmContext::MAXSUB : ctx->tune.sub_streams;
-        if (npoints >= ((size_t)1 << 18) && !ctx->tune.sub_large) nside = 0;
-        if (nside > 0 && per >= 1) {
+        // Sort ahead (round 6, second form; key sort_ahead): from 2^18 points on NOTHING runs beside an accumulation, but
+        // the sort of sub-batch k + 1 — scattered 4-byte traffic and LDS histograms, 40-odd registers — runs on a side
+        // stream beside the REDUCTION of sub-batch k, whose chains leave most of the chip idle:
+        //     caller's stream:  accumulate(0)  reduce(0)  accumulate(1)  reduce(1) ...
+        //     side streams:     sort(0)        sort(1) [after accumulate(0)]       sort(2) [after accumulate(1)] ...
+        // Two side streams / workspaces alternate (sort(k + 2) starts after accumulate(k + 1), i.e. after reduce(k) is done
+        // with the workspace they share).
+        // Measured (tools/ab_batched.py, one box, ms per MSM; off / on with high-priority side streams / on with default
+        // priority): 4 x 2^20 3.296 / 3.312 / 3.281, 8 x 2^20 3.318 / 3.376 / 3.283, 8 x 2^18 1.194 / 1.283 / 1.179.  A first
+        // form that let the sort start right after the accumulation — beside the tile sums — lost 2.5 % (3.42 vs 3.34): the
+        // tile sums of two MSMs are 512 workgroups on every register of the chip, and k_part_scan (ONE workgroup) waited
+        // 250 us for a slot.  +-1 % is not a reason for two more streams in a call: off by default.
+        const bool sort_ahead = npoints >= ((size_t)1 << 18) && !ctx->tune.sub_large && ctx->tune.sort_ahead && nside >= 2;
+        if (npoints >= ((size_t)1 << 18) && !ctx->tune.sub_large) nside = sort_ahead ? 2 : 0;
+        if (nside > 0 && per >= 1 && !sort_ahead) {
             // at least two sub-batches; from 2^18 points an MSM's accumulation alone fills the chip for a millisecond
             const size_t cap = npoints >= ((size_t)1 << 18) ? (size_t)1 : (nbatch + 1) / 2;
             if (per > cap) per = cap;
@@ -2672,14 +2689,16 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                     if (!ctx->ev_sub_join[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_sub_join[k], hipEventDisableTiming));
                     if (!ctx->ev_sorted[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_sorted[k], hipEventDisableTiming));
                     if (!ctx->ev_accd[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_accd[k], hipEventDisableTiming));
+                    if (!ctx->ev_gate[k]) HIP_TRY(hipEventCreateWithFlags(&ctx->ev_gate[k], hipEventDisableTiming));
                 }
             }
             struct SubReset {  // an exception below must not leave the next enqueue in sub-batch mode
                 MsmContext* c;
                 ~SubReset() {
                     c->accum_redirect = false;
+                    c->tail_on_accum = false;
                     c->accum_on = nullptr;
-                    c->accum_ready = c->accum_done = nullptr;
+                    c->accum_ready = c->accum_done = c->sort_gate = nullptr;
                     c->in_sub_batch = false;
                 }
             } sub_reset{ctx};
@@ -2704,15 +2723,22 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                     const int lane = (int)(k % (size_t)lanes);
                     st = ctx->sub_stream[lane];
                     ctx->accum_redirect = true;
+                    ctx->tail_on_accum = sort_ahead;
                     ctx->accum_on = stream;
                     ctx->accum_ready = ctx->ev_sorted[lane];
                     ctx->accum_done = ctx->ev_accd[lane];
+                    // sort ahead: this sub-batch's sort waits for the previous sub-batch's accumulation (recorded on the
+                    // caller's stream by that enqueue) and for its tile sums — throughput work on every register of the chip, like the
+                    // accumulation — so that it runs beside the limb-parallel chains of the reduction only
+                    ctx->sort_gate = sort_ahead ? ctx->ev_gate[lane] : nullptr;
+                    if (sort_ahead && k > 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_gate[(int)((k - 1) % (size_t)lanes)], 0));
                 }
                 msm_enqueue(ctx, d_out ? (unsigned char*)d_out + b0 * out_stride : nullptr,
                             d_scalars ? (const unsigned char*)d_scalars + b0 * npoints * 32 : nullptr, npoints, nbp, mont, st,
                             out_mode, false, nseg);
             }
             ctx->accum_redirect = false;
+            ctx->tail_on_accum = false;
             for (int j = 0; j < lanes; ++j) {
                 HIP_TRY(hipEventRecord(ctx->ev_sub_join[j], ctx->sub_stream[j]));
                 HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_sub_join[j], 0));
@@ -2828,6 +2854,9 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
     if (reserve_only) return;
     // sub-batch of a batch of large MSMs: the accumulation goes to the caller's stream (see MsmContext::sub_stream)
     const bool accum_redirect = ctx->accum_redirect;
+    const hipEvent_t sort_gate = ctx->sort_gate;
+    bool gate_recorded = false;
+    const bool tail_on_accum = accum_redirect && ctx->tail_on_accum;  // sort-ahead form: the reduction follows its accumulation on the caller's stream
     const hipStream_t accum_on = ctx->accum_on;
     const hipEvent_t accum_ready = ctx->accum_ready, accum_done = ctx->accum_done;
     WsUse ws_use(ws, stream, &ws == &ctx->ws);
@@ -2947,9 +2976,10 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                            nchunk, pcs);
         if (accum_redirect) {
             HIP_TRY(hipEventRecord(accum_done, accum_on));
-            HIP_TRY(hipStreamWaitEvent(ast, accum_done, 0));
+            if (!tail_on_accum) HIP_TRY(hipStreamWaitEvent(ast, accum_done, 0));
         }
-        if (tst != ast) {
+        if (tail_on_accum) tst = accum_on;  // (pieces and groups are forms of a lone MSM: never together with sub-batches)
+        else if (tst != ast) {
             HIP_TRY(hipEventRecord(ctx->ev_acc[piece], ast));
             HIP_TRY(hipStreamWaitEvent(tst, ctx->ev_acc[piece], 0));
         } else if (G > 1) {
@@ -2982,6 +3012,10 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
                     else KZG_TILE_SUMS(32, false);
                 }
 #undef KZG_TILE_SUMS
+                if (tail_on_accum && sort_gate && !gate_recorded) {
+                    HIP_TRY(hipEventRecord(sort_gate, st));
+                    gate_recorded = true;
+                }
                 if (wide_tail) {
                     // cells of this group: [0, pns * J * 32) digit sums, then pns * (logNb + 2) bit sums
                     const size_t c1 = pns * (size_t)(J * 32), c2 = pns * (size_t)(logNb + 2);
@@ -3102,12 +3136,14 @@ void msm_enqueue(MsmContext* ctx, void* d_out, const void* d_scalars, size_t npo
             }
         }
     }
+    const hipStream_t fin_stream = tail_on_accum ? accum_on : stream;
+    if (tail_on_accum && sort_gate && !gate_recorded) HIP_TRY(hipEventRecord(sort_gate, fin_stream));  // reduction forms without tiles
     if (wide_tail && !ctx->prepared && out_mode == OUT_JACOBIAN && nwin > 1) {
         // few independent Horner chains: one wave each, limb-parallel doublings
-        hipLaunchKernelGGL(k_final_wide, dim3((unsigned)nbatch), dim3(64), 0, stream, finM, d_out, nwin, c);
+        hipLaunchKernelGGL(k_final_wide, dim3((unsigned)nbatch), dim3(64), 0, fin_stream, finM, d_out, nwin, c);
     } else {
         const size_t nfinal = out_mode == OUT_WINDOWS ? nbatch * (size_t)nwin : nbatch;
-        hipLaunchKernelGGL(k_final, dim3((unsigned)((nfinal + 63) / 64)), dim3(64), 0, stream, finA, finM, d_out, nbatch, nwin,
+        hipLaunchKernelGGL(k_final, dim3((unsigned)((nfinal + 63) / 64)), dim3(64), 0, fin_stream, finA, finM, d_out, nbatch, nwin,
                            c, ctx->prepared ? 1 : 0, out_mode);
     }
     if (pev) {

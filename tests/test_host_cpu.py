@@ -516,7 +516,7 @@ int main() {
     assert res.returncode == 0 and "fails 0" in res.stdout, res.stdout + res.stderr
     keys = [ln.split()[1:] for ln in res.stdout.splitlines() if ln.startswith("KEY ")]
     names = [k[0] for k in keys]
-    assert len(names) == len(set(names)) == 48
+    assert len(names) == len(set(names)) == 49
     for name, d, lo, hi in keys:
         assert re.fullmatch(r"[a-z0-9_]+", name) and int(lo) <= int(d) <= int(hi), name
     # one row per key, same default and range

@@ -777,3 +777,42 @@ def test_several_large_msms_in_one_call(oracle, kzg, nbatch, sub_streams):
             assert compressed(L, got) == compressed(L, exp), b
     h.close()
 
+
+def test_batch_of_large_msms_sorts_ahead(oracle, kzg):
+    """Five MSMs of 2^18 points in one call: sub-batches of 2 + 2 + 1 whose sorts run on two alternating side streams beside
+    the previous sub-batch's reduction while accumulations and reductions stay on the caller's stream (tuning key
+    sort_ahead = 1), two calls back to back without a synchronisation (the third sub-batch and
+    the second call reuse streams, events and workspaces), against the same call in the default form (sub-batches one after the other on one stream) and
+    against the oracle."""
+    import torch
+
+    L = oracle.lib()
+    n, nbatch = 1 << 18, 5
+    stream = torch.cuda.current_stream().cuda_stream
+    d_pts = torch.empty(n * 96, dtype=torch.uint8, device="cuda")
+    kzg.generate_points(d_pts.data_ptr(), n, 41, stream)
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(42)
+    sc = torch.randint(0, 256, (nbatch * n, 32), dtype=torch.uint8, generator=gen)
+    sc[:, 31] &= 0x3F
+    sc[3 * n + 7:3 * n + 5000, 6:] = 0  # the fourth MSM has a run of short scalars
+    d_sc = sc.cuda()
+    pts = (O.G1Affine * n).from_buffer_copy(d_pts.cpu().numpy().tobytes())
+    want = []
+    for b in range(nbatch):
+        exp = O.G1()
+        L.omsm_tiling_pippenger(C.byref(exp), pts, sc[b * n:(b + 1) * n].numpy().tobytes(), n)
+        want.append(compressed(L, exp))
+    for tuning in ({"sort_ahead": 1}, {}, {"sort_ahead": 1, "sub_streams": 2, "sub_prio": 0}):
+        h = kzg.DeviceMsm(d_pts.data_ptr(), n, False, kzg.make_config(tuning=tuning))
+        d_out = torch.zeros(144 * nbatch, dtype=torch.uint8, device="cuda")
+        d_out2 = torch.ones(144 * nbatch, dtype=torch.uint8, device="cuda")
+        kzg.msm_prepared_batch_device(h, d_out.data_ptr(), d_sc.data_ptr(), n, nbatch, False, stream)
+        kzg.msm_prepared_batch_device(h, d_out2.data_ptr(), d_sc.data_ptr(), n, nbatch, False, stream)
+        torch.cuda.synchronize()
+        for o in (d_out.cpu().numpy().tobytes(), d_out2.cpu().numpy().tobytes()):
+            for b in range(nbatch):
+                got = O.G1()
+                C.memmove(C.byref(got), o[144 * b:144 * b + 144], 144)
+                assert compressed(L, got) == want[b], (tuning, b)
+        h.close()
