@@ -157,12 +157,21 @@ struct Options {
         }
         return true;
     }
-    // defaults < environment < cfg; false (with *err) when a string does not parse or cfg is malformed
+    // keys that do not combine: each is a form of the same stretch of the engine (how a batch, or a lone MSM, is cut)
+    bool consistent(std::string* err) const {
+        if (t[T_SORT_AHEAD] && (t[T_GROUPS] > 1 || t[T_TAIL_PIECES] > 1 || t[T_SUB_LARGE])) {
+            if (err) *err = "tuning: sort_ahead does not combine with groups, tail_pieces or sub_large";
+            return false;
+        }
+        return true;
+    }
+    // defaults < environment < cfg; false (with *err) when a string does not parse, the keys contradict each other or cfg
+    // is malformed
     static bool resolve(Options& o, const KzgAmdConfig* cfg, std::string* err) {
         o = Options();
         if (!o.parse(getenv("KZGAMD_TUNING"), err)) return false;
         if (const char* e = getenv("KZGAMD_FBW_MAX_GB")) o.table_budget_gb = atof(e);
-        if (!cfg) return true;
+        if (!cfg) return o.consistent(err);
         if (cfg->struct_size < offsetof(KzgAmdConfig, tuning) + sizeof(cfg->tuning)) {
             if (err) *err = "KzgAmdConfig.struct_size is not that of any version of the struct";
             return false;
@@ -170,7 +179,7 @@ struct Options {
         o.device = cfg->device;
         if (cfg->table_budget_bytes == KZGAMD_NO_TABLES) o.table_budget_gb = 0;
         else if (cfg->table_budget_bytes) o.table_budget_gb = (double)cfg->table_budget_bytes / 1e9;
-        return o.parse(cfg->tuning, err);
+        return o.parse(cfg->tuning, err) && o.consistent(err);
     }
 };
 

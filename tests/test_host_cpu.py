@@ -481,6 +481,14 @@ int main() {
     EXPECT(!o.parse("lgc=1", &err) && !o.parse("lgc=9", &err) && !o.parse("window=1", &err) && !o.parse("window_prepared=1", &err));
     EXPECT(!o.parse("sha_lanes=2", &err) && !o.parse("wide_fold_max=-1", &err) && !o.parse("tile_rows=8", &err));
     EXPECT(o.parse("spl=16;blocksum_threads=128;fine_bits=10;lgc=2;window=2;sha_lanes=1;sub_streams=0", &err));
+    {   // keys that are forms of the same stretch of the engine do not combine
+        Options x;
+        EXPECT(x.parse("sort_ahead=1;groups=2", &err) && !x.consistent(&err) && err.find("sort_ahead") != std::string::npos);
+        Options y;
+        EXPECT(y.parse("sort_ahead=1;sub_streams=2;sub_prio=0", &err) && y.consistent(&err));
+        Options z;
+        EXPECT(z.parse("sort_ahead=1;tail_pieces=2", &err) && !z.consistent(&err));
+    }
     // resolve: defaults < environment < struct
     setenv("KZGAMD_TUNING", "spl=2;lgc=8", 1);
     setenv("KZGAMD_FBW_MAX_GB", "24", 1);
