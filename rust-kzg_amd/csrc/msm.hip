@@ -912,16 +912,8 @@ constexpr int TILE_T = 512;  // ROWS = 32: two buckets per lane and phase, a ful
 // that it does not happen: beside an accumulation the tiles still wait (2.9 ms instead of 0.32) whatever the stream
 // priority, and alone the 16-row form is slower (0.936 vs 0.889 ms at 2^16, 3.52 vs 3.42 at 2^20: twice the tiles, twice
 // the values per S[0][d] cell).  profiles/NOTES.md §20.
-// sh[g] += sh[g + off] on the four lanes of group g (roles 0..3).  A function of its own: inlined as a third site of the
-// step loop it took the kernel to 256 VGPRs with 184 spilled; called, its registers are allocated apart from the loop's
-// (the caller keeps nothing live across the call: the sums go through the tile's slots).
-static __device__ __noinline__ void tile_quad_add(Xyzz* sh, int g, int off, int role) {
-    Xyzz a = sh[g];
-    const Xyzz v = sh[g + off];
-    if (grp::dadd_body<4>(a, v, role)) grp::dbl_body<4>(a, role);
-    if (role == 0) sh[g] = a;
-}
-
+// QUAD (the default, tuning key tile_quad): the tree levels with at most a quarter of the lanes busy run four lanes per
+// addition — 237 VGPRs, no scratch in either form (hipcc 7.2, code-object metadata).
 template <int ROWS, bool QUAD>
 __global__ void __launch_bounds__(ROWS * 16) k_tile_sums_loop(const Xyzz* __restrict__ partials, const u32* __restrict__ offsets,
                                                               const unsigned char* __restrict__ heavy, Xyzz* __restrict__ dense,
@@ -964,6 +956,59 @@ __global__ void __launch_bounds__(ROWS * 16) k_tile_sums_loop(const Xyzz* __rest
         }
     }
     // acc = bucket kb + 1; step 0 adds bucket kb (this lane wrote it)
+    if constexpr (QUAD) {
+        // Two halves of the same shape — rows, then columns: the pair step and tree level 0 with one lane per addition
+        // (every lane, then half of them, busy), the remaining levels (at most T / 4 additions) with four lanes per
+        // addition (g1grp.hip.h: an addition 4 multiplications deep instead of 14).  Two loops, two inlined sites: as a
+        // third branch of ONE step loop the four-lane site took the kernel to 256 VGPRs with 184 spilled.
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            const int unit = half ? 32 : ROWS;     // slots between the operands of a tree step, per stride
+            const int st0 = half ? ROWS / 4 : 8;   // stride of tree level 0
+            const int nlev = half ? CL : 4;
+#pragma unroll 1
+            for (int j = 0; j < 2; ++j) {
+                bool active = true;
+                Xyzz v;
+                if (j == 0) {
+                    v = half ? dn[k0 + (size_t)(32 * (2 * rg + 1) + c)] : dn[kb];
+                } else {
+                    active = t < unit * st0;
+                    if (active) v = sh[t + unit * st0];
+                }
+                if (active && g1::dadd_unequal(acc, v)) g1::dbl(acc);
+                if (j == 0 && half == 0) {
+                    // the row tree runs q-major (slot ROWS q + r): the lanes still adding at a level are the first
+                    // ROWS * stride of the workgroup, whole waves drop out level by level
+                    sh[ROWS * q + r] = acc;
+                    __syncthreads();
+                    acc = sh[t];  // slot t is only ever written by lane t from here on
+                } else {
+                    if (active) sh[t] = acc;
+                    __syncthreads();
+                }
+            }
+#pragma unroll 1
+            for (int lvl = 1; lvl < nlev; ++lvl) {
+                const int n = unit * (st0 >> lvl);  // additions of this level: slots [0, n) += slots [n, 2 n)
+                const int g = t >> 2, role = t & 3;
+                if (g < n) {
+                    Xyzz a = sh[g];
+                    const Xyzz b = sh[g + n];
+                    if (grp::dadd_body<4>(a, b, role)) grp::dbl_body<4>(a, role);
+                    if (role == 0) sh[g] = a;
+                }
+                __syncthreads();
+            }
+            acc = sh[t];  // lanes below ROWS / 32 hold a row sum / a column sum of the tile
+            if (half == 0) {
+                if (t < ROWS) Gs[set * (nb >> 5) + (k0 >> 5) + t] = acc;
+                __threadfence();  // the folded buckets this workgroup wrote are read back by other lanes
+                __syncthreads();
+                acc = dn[k0 + (size_t)(32 * (2 * rg) + c)];
+            }
+        }
+    } else {
 #pragma unroll 1
     for (int s = 0; s < 6 + CL; ++s) {
         const int lvl = s < 5 ? s - 1 : s - 6;                        // tree steps 1..4 / 6..: strides 8, 4, 2, 1 / ROWS/4 .. 1
@@ -971,20 +1016,6 @@ __global__ void __launch_bounds__(ROWS * 16) k_tile_sums_loop(const Xyzz* __rest
         const int unit = s < 5 ? ROWS : 32;                           // slots between the operands of a tree step, per stride
         bool active = true;
         Xyzz v;
-        if (QUAD && lvl >= 0 && unit * stride * 4 <= T) {
-            // a tree level with at most T / 4 additions left: four neighbouring lanes per addition (g1grp.hip.h: an
-            // addition 4 multiplications deep instead of 14), operands and sum in the slots the single-lane levels use
-            if ((t >> 2) < unit * stride) tile_quad_add(sh, t >> 2, unit * stride, t & 3);
-            __syncthreads();
-            acc = sh[t];  // lanes below the next level's width read their sum back (others: unused)
-            if (s == 4) {
-                if (t < ROWS) Gs[set * (nb >> 5) + (k0 >> 5) + t] = acc;
-                __threadfence();
-                __syncthreads();
-                acc = dn[k0 + (size_t)(32 * (2 * rg) + c)];
-            }
-            continue;
-        }
         if (s == 0) {
             v = dn[kb];
         } else if (s == 5) {
@@ -1010,6 +1041,7 @@ __global__ void __launch_bounds__(ROWS * 16) k_tile_sums_loop(const Xyzz* __rest
             __syncthreads();
             acc = dn[k0 + (size_t)(32 * (2 * rg) + c)];
         }
+    }
     }
     if (rg == 0) Cp[(set * ntiles + tile) * 32 + c] = acc;
 }
